@@ -1,0 +1,1 @@
+"""rc-mvsnet_amd: MI355X-native plane-sweep hot path of RC-MVSNet (import as ``rc_mvsnet_amd``)."""

@@ -1,0 +1,184 @@
+"""Seeded synthetic DTU-shaped inputs and non-degenerate weights (no dataset / checkpoint
+is reachable here).  Shapes, camera model and depth range follow SURVEY.md section 8d:
+
+  K(1/4 res) = [[361.54125*W/640, 0, 82.900625*W/640], [0, 360.3975*H/512, 66.383875*H/512], [0,0,1]]
+  view v: rotation about y by 0.08*v rad, centre C = (60v, 10v, 0) mm, E = [R | -R C]
+  proj[:, v, 0] = E, proj[:, v, 1, :3, :3] = K (x1, x2, x4 for stages 1..3, as
+  datasets/dtu_test.py:215-224 builds them);  depth_values = 425 + 2.65*arange(192).
+
+Everything is generated on the CPU with fixed seeds so that the golden generator, the
+oracle, the tests and bench.py all see bit-identical tensors.
+"""
+import math
+
+import numpy as np
+import torch
+
+NUM_DEPTH_VALUES = 192
+
+
+def cameras(V, H, W):
+    """Returns K_quarter (3,3) float64 and a list of V extrinsics (4,4) float64."""
+    K = np.array([[361.54125 * W / 640.0, 0.0, 82.900625 * W / 640.0],
+                  [0.0, 360.3975 * H / 512.0, 66.383875 * H / 512.0],
+                  [0.0, 0.0, 1.0]])
+    Es = []
+    for v in range(V):
+        a = 0.08 * v
+        R = np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+        C = np.array([60.0 * v, 10.0 * v, 0.0])
+        E = np.eye(4)
+        E[:3, :3] = R
+        E[:3, 3] = -R @ C
+        Es.append(E)
+    return K, Es
+
+
+def proj_matrices(B, V, H, W):
+    """{'stage1','stage2','stage3'}: (B,V,2,4,4) float32."""
+    K, Es = cameras(V, H, W)
+    out = {}
+    for s, mul in (("stage1", 1.0), ("stage2", 2.0), ("stage3", 4.0)):
+        p = np.zeros((V, 2, 4, 4), dtype=np.float32)
+        for v in range(V):
+            p[v, 0] = Es[v]
+            Ks = K.copy()
+            Ks[:2] *= mul
+            p[v, 1, :3, :3] = Ks
+        out[s] = torch.from_numpy(np.broadcast_to(p, (B, V, 2, 4, 4)).copy())
+    return out
+
+
+def depth_values(B):
+    return (425.0 + 2.65 * torch.arange(NUM_DEPTH_VALUES, dtype=torch.float32)).reshape(1, -1).repeat(B, 1)
+
+
+def images(B, V, H, W, seed=0):
+    """Smooth-ish seeded images, roughly ImageNet-normalised range: (B,V,3,H,W) float32."""
+    g = torch.Generator().manual_seed(seed)
+    out = torch.zeros(B * V, 3, H, W)
+    for div, amp in ((16, 1.0), (4, 0.5), (1, 0.25)):
+        n = torch.randn(B * V, 3, max(H // div, 1), max(W // div, 1), generator=g)
+        out += amp * torch.nn.functional.interpolate(n, size=(H, W), mode="bilinear", align_corners=False)
+    return out.reshape(B, V, 3, H, W).contiguous()
+
+
+def cascade_inputs(B=1, V=3, H=512, W=640, seed=0):
+    """(imgs, proj_matrices, depth_values) of CascadeMVSNet[_eval].forward."""
+    return images(B, V, H, W, seed), proj_matrices(B, V, H, W), depth_values(B)
+
+
+# ----------------------------------------------------------------------------------------
+# weights with the reference's state_dict names
+# ----------------------------------------------------------------------------------------
+def _bn(sd, rng, name, c):
+    sd[name + ".weight"] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+    sd[name + ".bias"] = torch.from_numpy((0.1 * rng.standard_normal(c)).astype(np.float32))
+    sd[name + ".running_mean"] = torch.from_numpy((0.1 * rng.standard_normal(c)).astype(np.float32))
+    sd[name + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+    sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+
+def _w(rng, shape, fan_in, gain=1.0):
+    bound = gain * math.sqrt(3.0 / fan_in)
+    return torch.from_numpy(rng.uniform(-bound, bound, shape).astype(np.float32))
+
+
+def cost_reg_specs(cin, base=8):
+    """(name, kind, cin, cout) of CostRegNet (models/modules.py:470-489)."""
+    b = base
+    return [("conv0", "conv", cin, b), ("conv1", "conv", b, 2 * b), ("conv2", "conv", 2 * b, 2 * b),
+            ("conv3", "conv", 2 * b, 4 * b), ("conv4", "conv", 4 * b, 4 * b), ("conv5", "conv", 4 * b, 8 * b),
+            ("conv6", "conv", 8 * b, 8 * b), ("conv7", "deconv", 8 * b, 4 * b), ("conv9", "deconv", 4 * b, 2 * b),
+            ("conv11", "deconv", 2 * b, b)]
+
+
+def cascade_state_dict(seed=0, feat_channels=(32, 16, 8), prob_gain=20.0):
+    """238 tensors named like CascadeMVSNet[_eval].state_dict() (fpn, 3 stages, cr base 8).
+    BN statistics are randomised and prob.weight is scaled so that the probability volume
+    is peaked instead of flat."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+    b = 8
+    for name, ci, co, k in (("conv0.0", 3, b, 3), ("conv0.1", b, b, 3), ("conv1.0", b, 2 * b, 5), ("conv1.1", 2 * b, 2 * b, 3),
+                            ("conv1.2", 2 * b, 2 * b, 3), ("conv2.0", 2 * b, 4 * b, 5), ("conv2.1", 4 * b, 4 * b, 3),
+                            ("conv2.2", 4 * b, 4 * b, 3)):
+        sd[f"feature.{name}.conv.weight"] = _w(rng, (co, ci, k, k), ci * k * k, math.sqrt(2.0))
+        _bn(sd, rng, f"feature.{name}.bn", co)
+    sd["feature.out1.weight"] = _w(rng, (4 * b, 4 * b, 1, 1), 4 * b)
+    sd["feature.inner1.weight"] = _w(rng, (4 * b, 2 * b, 1, 1), 2 * b)
+    sd["feature.inner1.bias"] = torch.from_numpy((0.1 * rng.standard_normal(4 * b)).astype(np.float32))
+    sd["feature.inner2.weight"] = _w(rng, (4 * b, b, 1, 1), b)
+    sd["feature.inner2.bias"] = torch.from_numpy((0.1 * rng.standard_normal(4 * b)).astype(np.float32))
+    sd["feature.out2.weight"] = _w(rng, (2 * b, 4 * b, 3, 3), 4 * b * 9)
+    sd["feature.out3.weight"] = _w(rng, (b, 4 * b, 3, 3), 4 * b * 9)
+    for s, cin in enumerate(feat_channels):
+        sd.update(cost_reg_state_dict(rng, f"cost_regularization.{s}", cin, prob_gain=prob_gain))
+    return sd
+
+
+def cost_reg_state_dict(rng, prefix, cin, base=8, prob_gain=20.0):
+    sd = {}
+    for name, kind, ci, co in cost_reg_specs(cin, base):
+        shape = (co, ci, 3, 3, 3) if kind == "conv" else (ci, co, 3, 3, 3)
+        sd[f"{prefix}.{name}.conv.weight"] = _w(rng, shape, ci * 27, math.sqrt(2.0))
+        _bn(sd, rng, f"{prefix}.{name}.bn", co)
+    sd[f"{prefix}.prob.weight"] = _w(rng, (1, base, 3, 3, 3), base * 27, prob_gain)
+    return sd
+
+
+def render_state_dict(seed=1, n_src=3):
+    """82 tensors named like Rendering_Consistency_Net.state_dict() (netdepth 6, width 128)."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+    p = "MVSNet.cost_reg_2"
+    for name, kind, ci, co in cost_reg_specs(32 + 3 * n_src, 8):
+        if kind == "conv":
+            sd[f"{p}.{name}.conv.weight"] = _w(rng, (co, ci, 3, 3, 3), ci * 27)
+            _bn(sd, rng, f"{p}.{name}.bn", co)
+        else:
+            sd[f"{p}.{name}.0.weight"] = _w(rng, (ci, co, 3, 3, 3), ci * 27 / 8.0)
+            _bn(sd, rng, f"{p}.{name}.1", co)
+    q = "network_fn.nerf"
+
+    def lin(name, ci, co, gain=math.sqrt(2.0)):
+        sd[f"{q}.{name}.weight"] = _w(rng, (co, ci), ci, gain)
+        sd[f"{q}.{name}.bias"] = torch.from_numpy((0.05 * rng.standard_normal(co)).astype(np.float32))
+    lin("pts_linears.0", 63, 128)
+    for i in range(1, 5):
+        lin(f"pts_linears.{i}", 128, 128)
+    lin("pts_linears.5", 191, 128)
+    lin("pts_bias", 8 + 4 * n_src, 128, 1.0)
+    lin("views_linears.0", 131, 64)
+    lin("feature_linear", 128, 128, 1.0)
+    lin("alpha_linear", 128, 1, 1.0)
+    lin("rgb_linear", 64, 3, 1.0)
+    # pts_bias centred on 1 so that the multiplicative bias does not kill the trunk
+    sd[f"{q}.pts_bias.bias"] = sd[f"{q}.pts_bias.bias"] + 1.0
+    return sd
+
+
+# ----------------------------------------------------------------------------------------
+# rendering-branch batch (keys of datasets/dtu_train.py:344-364 that the renderer reads)
+# ----------------------------------------------------------------------------------------
+def render_batch(V, H, W, seed=0):
+    K, Es = cameras(V, H, W)
+    Kfull = K.copy()
+    Kfull[:2] *= 4.0
+    w2cs = np.stack(Es).astype(np.float32)
+    c2ws = np.stack([np.linalg.inv(E) for E in Es]).astype(np.float32)
+    intr = np.stack([Kfull] * V).astype(np.float32)
+    nf = np.stack([np.array([425.0, 425.0 + 2.65 * 191], dtype=np.float32)] * V)
+    return {"imgs": images(1, V, H, W, seed), "w2cs": torch.from_numpy(w2cs)[None], "c2ws": torch.from_numpy(c2ws)[None],
+            "intrinsics": torch.from_numpy(intr)[None], "near_fars": torch.from_numpy(nf)[None],
+            "depths_h": torch.zeros(1, V, H, W), "proj_mats": torch.zeros(1, V, 3, 4)}
+
+
+def render_randoms(H, W, n_rays=1024, n_samples=128, seed=0):
+    """The injected random draws of the sampler: pix (2,N) int64 rows (x, y); eps; u."""
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.randint(0, W, (n_rays,), generator=g)
+    ys = torch.randint(0, H, (n_rays,), generator=g)
+    eps = torch.randn(n_rays, n_samples, generator=g)
+    u = torch.rand(n_rays // 2, n_samples, generator=g)
+    return torch.stack((xs, ys)), eps, u
