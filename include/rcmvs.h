@@ -1,0 +1,142 @@
+/*
+ * rcmvs.h -- C ABI of librcmvs_hip.so: the MI355X (gfx950) plane-sweep hot path of RC-MVSNet.
+ *
+ * The reference (Boese0601/RC-MVSNet) has no FFI layer: its hot path is a composition of ATen
+ * ops inside Python nn.Modules.  Each entry point below replaces one
+ * such composition; the reference call site it replaces is cited (paths relative to the
+ * reference repository root).  The Python modules in rc-mvsnet_amd/ bind these with ctypes.
+ *
+ * Conventions
+ *   - every function is extern "C", returns int: 0 = ok, <0 = bad argument (see
+ *     rcmvs_last_error_string), >0 = a hipError_t from the launch;
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked [host]; nothing is
+ *     allocated, freed or synchronised inside; kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream); calls are re-entrant;
+ *   - all tensors are dense fp32.  Feature maps and volumes are CHANNELS-LAST inside the
+ *     library:  maps (B,h,w,C), volumes (B,D,h,w,C)  ("NHWC"/"NDHWC"); the layout entry
+ *     points convert from/to the reference's NCHW / NCDHW at the module boundary;
+ *   - `planes` is the per-pixel hypothesis-plane table (B,h,w,2) = {d_0, delta}: plane k of a
+ *     pixel lies at depth d_0 + k*delta (what models/modules.py:549-588 materialises as a
+ *     (B,D,H,W) tensor).
+ */
+#ifndef RCMVS_H
+#define RCMVS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCMVS_VERSION 100          /* 0.1.0 */
+#define RCMVS_MAX_SRC_VIEWS 10     /* V-1 */
+
+int         rcmvs_version(void);
+const char* rcmvs_last_error_string(void);   /* thread-local, valid until the next failing call */
+
+/* ---- layout (module boundary) -------------------------------------------------------- */
+/* (N,C,S) -> (N,S,C) with S = h*w or D*h*w, and back. */
+int rcmvs_nchw_to_nhwc(const float* src, float* dst, int N, int C, long long S, void* stream);
+int rcmvs_nhwc_to_nchw(const float* src, float* dst, int N, int C, long long S, void* stream);
+
+/* ---- homography  (models/casmvsnet.py:267-270, models/modules.py:314-316) ------------- */
+/* proj (B,V,2,4,4): [..,0,:,:] extrinsic, [..,1,:3,:3] intrinsic.  For every source view
+ * v=1..V-1:  P = (K_v E_v) * inverse(K_0 E_0)  (4x4 with last row 0,0,0,1), evaluated in fp64
+ * on the device and rounded to fp32:  rot (B,V-1,9) row-major 3x3, trans (B,V-1,3). */
+int rcmvs_compose_homography(const float* proj, float* rot, float* trans, int B, int V, void* stream);
+
+/* ---- hypothesis planes  (models/casmvsnet.py:357-359,383-404; modules.py:549-588) ------ */
+/* Stage 1 (prev_depth == NULL): d_0 = depth_values[b,0], delta = (dv[b,ND-1]-dv[b,0])/(D-1).
+ * Later stages: prev_depth (B,hp,wp) is bilinearly up-sampled to (H,W) (align_corners=False),
+ * the range  c -/+ D/2 * ratio * (dv[0,ND-1]-dv[0,0])/ND  is formed per full-res pixel and
+ * averaged over the scale x scale block of each stage pixel (the reference's trilinear
+ * down-sampling with integer scale 1 or 2).  planes (B,H/scale,W/scale,2). */
+int rcmvs_hypothesis_planes(const float* prev_depth, const float* depth_values, float* planes,
+                            int B, int hp, int wp, int H, int W, int scale,
+                            int D, float ratio, int ND, void* stream);
+
+/* ---- K1: fused warp + variance cost volume --------------------------------------------- */
+/* replaces homo_warping (models/modules.py:304-339) x (V-1) plus the sum / square-sum /
+ * variance chain of DepthNet_eval.forward (models/casmvsnet.py:257-288).
+ *   feats (B,V,h,w,C) channels-last, view 0 = reference;  rot/trans from
+ *   rcmvs_compose_homography;  planes (B,h,w,2);  var (B,D,h,w,C) = sum(x^2)/V - (sum(x)/V)^2.
+ * C in {8,16,32}. */
+int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
+                            const float* planes, float* var,
+                            int B, int V, int C, int D, int h, int w, void* stream);
+
+/* train-variant extra (models/casmvsnet.py:59,82,89-101): volume_feature_no_ref, NCDHW like
+ * the reference returns it: out (B, 3(V-1)+C, D, h, w) = warped RGB of each source view
+ * (imgs (B,V,h,w,3) channels-last, already resized to the stage) then the source-only
+ * variance divided by V.  square_first != 0 reproduces the eval-mode quirk (:92-96). */
+int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot, const float* trans,
+                         const float* planes, float* out,
+                         int B, int V, int C, int D, int h, int w, int square_first, void* stream);
+
+/* ---- K2/K3: 3-D convolution family, channels-last, fused epilogue ----------------------- */
+/* weight packing (host-visible layout change, done once per weight update):
+ *   conv   w (Co,Ci,3,3,3) -> packed [27][Ci][Co]      (nn.Conv3d,          modules.py:145)
+ *   deconv w (Ci,Co,3,3,3) -> packed [27][Ci][Co]      (nn.ConvTranspose3d, modules.py:189) */
+int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream);
+
+/* y = epilogue(conv3d(x, w, k=3, pad=1, stride)),  x (B,D,H,W,Ci) -> y (B,Do,Ho,Wo,Co),
+ * Do = (D-1)/stride+1 ...;   epilogue(v) = [relu](v*scale[co] + shift[co]) + residual
+ * (scale/shift/residual may be NULL).  Replaces Conv3d.forward = conv+BN(eval)+ReLU
+ * (models/modules.py:149-157) and the skip adds of CostRegNet.forward (:497-499). */
+int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                     const float* residual, float* y,
+                     int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream);
+
+/* y = epilogue(conv_transpose3d(x, w, k=3, stride=2, pad=1, output_pad=1)),
+ * x (B,D,H,W,Ci) -> y (B,2D,2H,2W,Co).  Replaces Deconv3d.forward (models/modules.py:196-204). */
+int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                       const float* residual, float* y,
+                       int B, int D, int H, int W, int Ci, int Co, int relu, void* stream);
+
+/* ---- K4: prob conv + softmax + soft-argmin + photometric confidence ---------------------- */
+/* replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression and the
+ * confidence gather of DepthNet_eval.forward (models/casmvsnet.py:293-309).
+ *   x (B,D,h,w,8) channels-last, w_prob packed [27][8][1];  depth, conf (B,h,w);
+ *   prob (B,D,h,w) optional (NULL to skip). */
+int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
+                         float* depth, float* conf, float* prob,
+                         int B, int D, int h, int w, void* stream);
+
+/* ---- rendering-consistency branch --------------------------------------------------------- */
+/* F.interpolate(size=[Do,h,w], trilinear, align_corners=True) along the plane axis only
+ * (models/render_models.py:756), NCDHW in -> NDHWC out:  x (B,C,D,h,w) -> y (B,Do,h,w,C). */
+int rcmvs_resize_planes_fwd(const float* x, float* y, int B, int C, int D, int Do, int h, int w, void* stream);
+
+/* Gaussian-Uniform ray sampler + world/NDC points (models/render_utils.py:86-108,149-243,
+ * 112-146).  Random draws are inputs: pix (2,N) int32 rows x,y; eps (N,S); u (N/2,S).
+ * cam = [K(9) | c2w(16) | w2c_ref(16) | K_ref(9) | near | far]  (52 floats, device).
+ * Outputs: z (N,S) sorted Gaussian / stratified-uniform depths, pts (N,S,3), ndc (N,S,3),
+ * dirs (N,3), rays_depth (N), target (N,3) from img0 (3,H,W) un-normalised. */
+int rcmvs_gu_sample_fwd(const float* pseudo_depth, const float* img0, const int* pix,
+                        const float* eps, const float* u, const float* cam,
+                        float* z, float* pts, float* ndc, float* dirs, float* rays_depth, float* target,
+                        int N, int S, int H, int W, void* stream);
+
+/* point features (models/renderer.py:154-166, render_utils.py:247-279,304-330):
+ * feat (N,S,8+4*nimg) = trilinear(volume (Dv,hv,wv,8) channels-last at ndc*2-1, zeros pad,
+ * align_corners) ++ per image i: bilinear border RGB of imgs (nimg,3,H,W) at the projection
+ * with poses (nimg,25) = [w2c(16) | K(9)], ++ strict in-bounds mask. */
+int rcmvs_point_feats_fwd(const float* volume, const float* imgs, const float* poses,
+                          const float* pts, const float* ndc, float* feat,
+                          int M, int Dv, int hv, int wv, int nimg, int H, int W, void* stream);
+
+/* NeRF MLP (models/render_models.py:45-49,192-220): positional encoding of ndc (10 freqs),
+ * 6x128 trunk with multiplicative feature bias, skip after layer 4, sigma/rgb heads.
+ * weights: one packed device blob laid out by rcmvs_nerf_weight_floats()/python packer.
+ * ndc (M,3), feat (M,20), dirs (N,3) with M = N*S  ->  raw (M,4) = [rgb(3), sigma]. */
+int rcmvs_nerf_mlp_fwd(const float* ndc, const float* feat, const float* dirs, const float* weights,
+                       float* raw, int N, int S, void* stream);
+long long rcmvs_nerf_weight_floats(void);
+
+/* compositing (models/renderer.py:18-26,65-93): alpha = 1-exp(-sigma), T = exclusive cumprod
+ * of (1-alpha+1e-10), w = alpha*T;  rgb (N,3), depth (N), weights (N,S), alpha (N,S). */
+int rcmvs_composite_fwd(const float* raw, const float* z, float* rgb, float* depth,
+                        float* weights, float* alpha, int N, int S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCMVS_H */

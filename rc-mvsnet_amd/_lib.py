@@ -1,0 +1,90 @@
+"""ctypes binding of librcmvs_hip.so (C ABI declared in include/rcmvs.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+There is no fallback: if the shared object is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librcmvs_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "rcmvs.h")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_ll = ctypes.c_longlong
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/rcmvs.h
+SIGNATURES = {
+    "rcmvs_version": [],
+    "rcmvs_last_error_string": [],
+    "rcmvs_nchw_to_nhwc": [_p, _p, _i, _i, _ll, _p],
+    "rcmvs_nhwc_to_nchw": [_p, _p, _i, _i, _ll, _p],
+    "rcmvs_compose_homography": [_p, _p, _p, _i, _i, _p],
+    "rcmvs_hypothesis_planes": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_warp_noref_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_pack_conv3d_weight": [_p, _p, _i, _i, _i, _p],
+    "rcmvs_conv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_deconv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_depth_head_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_resize_planes_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_gu_sample_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_point_feats_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_nerf_mlp_fwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "rcmvs_nerf_weight_floats": [],
+    "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+}
+_RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll}
+
+_lib = None
+
+
+class RcmvsError(RuntimeError):
+    pass
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into librcmvs_hip.so for gfx950 (cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (raises RcmvsError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RcmvsError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    if lib.rcmvs_version() < 100:
+        raise RcmvsError("librcmvs_hip.so is older than this package")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rcmvs_last_error_string()
+        raise RcmvsError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

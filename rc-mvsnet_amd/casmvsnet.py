@@ -1,0 +1,456 @@
+"""Drop-in modules for the reference's ``models.casmvsnet`` / ``models.modules`` surface:
+``CascadeMVSNet``, ``CascadeMVSNet_eval`` (+ ``FeatureNet``, ``CostRegNet``, ``Conv3d`` ...).
+
+Same constructor kwargs, forward signatures, output dict keys and ``state_dict`` names as
+models/casmvsnet.py:126-231,313-417 and models/modules.py:28-210,363-501, so the reference's
+``train_rcmvsnet.py`` / ``eval_rcmvsnet_*.py`` run unchanged and its checkpoints load strict.
+
+Execution:
+  * inference (module in eval mode under ``torch.no_grad()``) runs the plane-sweep hot path on
+    the hand-written HIP kernels of librcmvs_hip.so: fused warp+variance (K1), 3-D conv family
+    with folded BatchNorm (K2/K3), fused prob-conv/softmax/regression/confidence (K4), all in
+    channels-last layout, no host synchronisation anywhere in forward();
+  * the 2-D feature pyramid is delegated to PyTorch-ROCm (MIOpen), as SURVEY.md section 2 row 6
+    scopes it;
+  * anything that needs autograd or batch statistics (training) currently goes through the
+    modules' own nn.Conv3d / BatchNorm3d children on PyTorch-ROCm -- an explicit, logged
+    delegation (set RCMVS_STRICT=1 to make it an error), never a CPU path.
+"""
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import RcmvsError
+
+Align_Corners_Range = False
+
+
+# ----------------------------------------------------------------------------------------------
+# 2-D blocks (models/modules.py:28-116) -- delegated to PyTorch-ROCm
+# ----------------------------------------------------------------------------------------------
+class Conv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        if self.relu:
+            x = F.relu(x, inplace=True)
+        return x
+
+
+class FeatureNet(nn.Module):
+    """models/modules.py:363-464, arch_mode='fpn'."""
+
+    def __init__(self, base_channels, num_stage=3, stride=4, arch_mode="fpn"):
+        super().__init__()
+        if arch_mode != "fpn":
+            raise NotImplementedError("only arch_mode='fpn' (the reference's shipped configuration) is provided")
+        self.arch_mode = arch_mode
+        self.stride = stride
+        self.base_channels = base_channels
+        self.num_stage = num_stage
+        b = base_channels
+        self.conv0 = nn.Sequential(Conv2d(3, b, 3, 1, padding=1), Conv2d(b, b, 3, 1, padding=1))
+        self.conv1 = nn.Sequential(Conv2d(b, b * 2, 5, stride=2, padding=2), Conv2d(b * 2, b * 2, 3, 1, padding=1),
+                                   Conv2d(b * 2, b * 2, 3, 1, padding=1))
+        self.conv2 = nn.Sequential(Conv2d(b * 2, b * 4, 5, stride=2, padding=2), Conv2d(b * 4, b * 4, 3, 1, padding=1),
+                                   Conv2d(b * 4, b * 4, 3, 1, padding=1))
+        self.out1 = nn.Conv2d(b * 4, b * 4, 1, bias=False)
+        self.out_channels = [4 * b]
+        final_chs = b * 4
+        if num_stage == 3:
+            self.inner1 = nn.Conv2d(b * 2, final_chs, 1, bias=True)
+            self.inner2 = nn.Conv2d(b * 1, final_chs, 1, bias=True)
+            self.out2 = nn.Conv2d(final_chs, b * 2, 3, padding=1, bias=False)
+            self.out3 = nn.Conv2d(final_chs, b, 3, padding=1, bias=False)
+            self.out_channels += [b * 2, b]
+        elif num_stage == 2:
+            self.inner1 = nn.Conv2d(b * 2, final_chs, 1, bias=True)
+            self.out2 = nn.Conv2d(final_chs, b, 3, padding=1, bias=False)
+            self.out_channels.append(b)
+
+    def forward(self, x):
+        conv0 = self.conv0(x)
+        conv1 = self.conv1(conv0)
+        conv2 = self.conv2(conv1)
+        intra = conv2
+        outputs = {"stage1": self.out1(intra)}
+        if self.num_stage >= 2:
+            intra = F.interpolate(intra, scale_factor=2, mode="nearest") + self.inner1(conv1)
+            outputs["stage2"] = self.out2(intra)
+        if self.num_stage == 3:
+            intra = F.interpolate(intra, scale_factor=2, mode="nearest") + self.inner2(conv0)
+            outputs["stage3"] = self.out3(intra)
+        return outputs
+
+
+# ----------------------------------------------------------------------------------------------
+# 3-D blocks (models/modules.py:118-210) -- parameter holders + PyTorch-ROCm forward for autograd
+# ----------------------------------------------------------------------------------------------
+class Conv3d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1, **kwargs):
+        super().__init__()
+        assert stride in [1, 2]
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum)
+        self.gn = None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class Deconv3d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1, **kwargs):
+        super().__init__()
+        assert stride in [1, 2]
+        self.out_channels = out_channels
+        self.stride = stride
+        self.conv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum)
+        self.gn = None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+def _bn_fold(bn):
+    """eval-mode BatchNorm as (scale, shift), computed on the device without a sync."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+class CostRegNet(nn.Module):
+    """models/modules.py:470-501.  ``forward`` keeps the reference contract ((B,C,D,h,w) ->
+    (B,1,D,h,w) logits); the cascade uses ``features_cl`` + the fused depth head instead."""
+
+    _LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")
+
+    def __init__(self, in_channels, base_channels):
+        super().__init__()
+        b = base_channels
+        self.conv0 = Conv3d(in_channels, b, padding=1)
+        self.conv1 = Conv3d(b, b * 2, stride=2, padding=1)
+        self.conv2 = Conv3d(b * 2, b * 2, padding=1)
+        self.conv3 = Conv3d(b * 2, b * 4, stride=2, padding=1)
+        self.conv4 = Conv3d(b * 4, b * 4, padding=1)
+        self.conv5 = Conv3d(b * 4, b * 8, stride=2, padding=1)
+        self.conv6 = Conv3d(b * 8, b * 8, padding=1)
+        self.conv7 = Deconv3d(b * 8, b * 4, stride=2, padding=1, output_padding=1)
+        self.conv9 = Deconv3d(b * 4, b * 2, stride=2, padding=1, output_padding=1)
+        self.conv11 = Deconv3d(b * 2, b * 1, stride=2, padding=1, output_padding=1)
+        self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1, bias=False)
+        self._plan = None
+        self._plan_key = None
+
+    # -- HIP execution plan: packed weights + folded BN, rebuilt only when a tensor changes -----
+    def _tensors(self):
+        ts = []
+        for n in self._LAYERS:
+            m = getattr(self, n)
+            ts += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+        return ts + [self.prob.weight]
+
+    def hip_plan(self):
+        key = tuple((t.data_ptr(), t._version) for t in self._tensors())
+        if self._plan is None or key != self._plan_key:
+            plan = {}
+            for n in self._LAYERS:
+                m = getattr(self, n)
+                w = ops.pack_conv3d_weight(m.conv.weight, transposed=isinstance(m, Deconv3d))
+                s, b = _bn_fold(m.bn)
+                plan[n] = (w, s, b)
+            plan["prob"] = ops.pack_conv3d_weight(self.prob.weight)
+            self._plan, self._plan_key = plan, key
+        return self._plan
+
+    def features_cl(self, x):
+        """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8)."""
+        B, D, h, w, _ = x.shape
+        if D % 8 or h % 8 or w % 8:
+            raise RcmvsError(f"CostRegNet: volume {D}x{h}x{w} must be divisible by 8 in every axis "
+                             "(three stride-2 levels with skip connections, models/modules.py:492-499)")
+        p = self.hip_plan()
+        conv0 = ops.conv3d(x, *p["conv0"], relu=True)
+        conv2 = ops.conv3d(ops.conv3d(conv0, *p["conv1"], stride=2, relu=True), *p["conv2"], relu=True)
+        conv4 = ops.conv3d(ops.conv3d(conv2, *p["conv3"], stride=2, relu=True), *p["conv4"], relu=True)
+        t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)
+        t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True)
+        t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True)
+        return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True)
+
+    def forward(self, x):
+        if _hip_inference(self, x):
+            feat = self.features_cl(ops.to_channels_last(x.contiguous().float()))
+            logits = ops.conv3d(feat, self.hip_plan()["prob"])
+            return ops.to_channels_first(logits)
+        _note_delegation("CostRegNet")
+        conv0 = self.conv0(x)
+        conv2 = self.conv2(self.conv1(conv0))
+        conv4 = self.conv4(self.conv3(conv2))
+        t = self.conv6(self.conv5(conv4))
+        t = conv4 + self.conv7(t)
+        t = conv2 + self.conv9(t)
+        t = conv0 + self.conv11(t)
+        return self.prob(t)
+
+
+# ----------------------------------------------------------------------------------------------
+_delegation_noted = set()
+
+
+def _hip_inference(module, *tensors):
+    """The native path is taken for inference: eval mode, autograd off, tensors on the GPU."""
+    return (not module.training) and (not torch.is_grad_enabled()) and all(t.is_cuda for t in tensors)
+
+
+def _note_delegation(what):
+    if os.environ.get("RCMVS_STRICT", "0") == "1":
+        raise RcmvsError(f"{what}: this call needs autograd / batch statistics / a CPU tensor, which the HIP path does "
+                         "not provide yet (RCMVS_STRICT=1 forbids delegating it to PyTorch ops)")
+    if what not in _delegation_noted:
+        _delegation_noted.add(what)
+        warnings.warn(f"rc_mvsnet_amd: {what} is running through PyTorch-ROCm ops (autograd / training path); "
+                      "the hand-written HIP kernels cover inference (eval() under torch.no_grad()).")
+
+
+def depth_regression(p, depth_values):
+    if depth_values.dim() <= 2:
+        depth_values = depth_values.view(*depth_values.shape, 1, 1)
+    return torch.sum(p * depth_values, 1)
+
+
+def homo_warping(src_fea, src_proj, ref_proj, depth_values):
+    """Reference-contract warp (models/modules.py:304-339) through PyTorch ops -- used only by the
+    delegated (autograd) path below; inference uses the fused HIP kernel."""
+    batch, channels = src_fea.shape[0], src_fea.shape[1]
+    num_depth = depth_values.shape[1]
+    height, width = src_fea.shape[2], src_fea.shape[3]
+    with torch.no_grad():
+        proj = torch.matmul(src_proj, torch.inverse(ref_proj))
+        rot, trans = proj[:, :3, :3], proj[:, :3, 3:4]
+        y, x = torch.meshgrid([torch.arange(0, height, dtype=torch.float32, device=src_fea.device),
+                               torch.arange(0, width, dtype=torch.float32, device=src_fea.device)], indexing="ij")
+        xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(height * width, device=src_fea.device)))
+        rot_xyz = torch.matmul(rot, xyz.unsqueeze(0).repeat(batch, 1, 1))
+        rot_depth_xyz = rot_xyz.unsqueeze(2).repeat(1, 1, num_depth, 1) * depth_values.reshape(batch, 1, num_depth, -1)
+        proj_xyz = rot_depth_xyz + trans.view(batch, 3, 1, 1)
+        proj_xy = proj_xyz[:, :2] / proj_xyz[:, 2:3]
+        gx = proj_xy[:, 0] / ((width - 1) / 2) - 1
+        gy = proj_xy[:, 1] / ((height - 1) / 2) - 1
+        grid = torch.stack((gx, gy), dim=3)
+    warped = F.grid_sample(src_fea, grid.view(batch, num_depth * height, width, 2), mode="bilinear", padding_mode="zeros",
+                           align_corners=True)
+    return warped.view(batch, channels, num_depth, height, width)
+
+
+def get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth=192.0, min_depth=0.0):
+    cur_depth_min = cur_depth - ndepth / 2 * depth_inteval_pixel
+    cur_depth_max = cur_depth + ndepth / 2 * depth_inteval_pixel
+    new_interval = (cur_depth_max - cur_depth_min) / (ndepth - 1)
+    k = torch.arange(0, ndepth, device=cur_depth.device, dtype=cur_depth.dtype).reshape(1, -1, 1, 1)
+    return cur_depth_min.unsqueeze(1) + k * new_interval.unsqueeze(1)
+
+
+def get_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, device, dtype, shape, max_depth=192.0, min_depth=0.0):
+    if cur_depth.dim() == 2:
+        cur_depth_min, cur_depth_max = cur_depth[:, 0], cur_depth[:, -1]
+        new_interval = (cur_depth_max - cur_depth_min) / (ndepth - 1)
+        s = cur_depth_min.unsqueeze(1) + torch.arange(0, ndepth, device=device, dtype=dtype).reshape(1, -1) * new_interval.unsqueeze(1)
+        return s.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, shape[1], shape[2])
+    return get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth, min_depth)
+
+
+class DepthNet(nn.Module):
+    """Per-stage cost volume + depth head (models/casmvsnet.py:45-124 / :234-311).  Parameter-free,
+    kept as a child module for API compatibility; `train_variant` adds volume_feature_no_ref."""
+
+    def __init__(self, train_variant):
+        super().__init__()
+        self.train_variant = train_variant
+
+    # delegated (autograd) path: reference op graph on PyTorch-ROCm
+    def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, imgs, pad=0, prob_volume_init=None):
+        _note_delegation("DepthNet")
+        proj_matrices = torch.unbind(proj_matrices, 1)
+        assert len(features) == len(proj_matrices), "Different number of images and projection matrices"
+        assert depth_values.shape[1] == num_depth
+        V = len(features)
+        B = imgs.shape[0]
+        _, C, H, W = features[0].shape
+        ref_feature, src_features = features[0], features[1:]
+        ref_proj, src_projs = proj_matrices[0], proj_matrices[1:]
+        ref_new = ref_proj[:, 0].clone()
+        ref_new[:, :3, :4] = torch.matmul(ref_proj[:, 1, :3, :3], ref_proj[:, 0, :3, :4])
+        vs = ref_feature.unsqueeze(2).repeat(1, 1, num_depth, 1, 1)
+        vq = vs ** 2
+        out_noref = None
+        if self.train_variant:
+            small = F.interpolate(imgs.view(B * V, *imgs.shape[2:]), (H, W), mode="bilinear", align_corners=False)
+            small = small.view(B, V, -1, H, W).permute(1, 0, 2, 3, 4)
+            out_noref = torch.empty((B, 3 * (V - 1) + C, num_depth, H, W), device=imgs.device, dtype=torch.float)
+            s_nr, q_nr = 0, 0
+        for i, (src_fea, src_proj) in enumerate(zip(src_features, src_projs)):
+            src_new = src_proj[:, 0].clone()
+            src_new[:, :3, :4] = torch.matmul(src_proj[:, 1, :3, :3], src_proj[:, 0, :3, :4])
+            warped = homo_warping(src_fea, src_new, ref_new, depth_values)
+            vs = vs + warped
+            vq = vq + warped ** 2
+            if self.train_variant:
+                out_noref[:, i * 3:(i + 1) * 3] = homo_warping(small[i + 1], src_new, ref_new, depth_values)
+                wn = warped if self.training else warped ** 2      # eval-mode quirk, casmvsnet.py:92-96
+                s_nr = s_nr + wn
+                q_nr = q_nr + wn ** 2
+        var = vq.div(V).sub((vs.div(V)) ** 2)
+        if self.train_variant:
+            out_noref[:, -C:] = q_nr.div(V).sub((s_nr.div(V)) ** 2)
+        pre = cost_regularization(var).squeeze(1)
+        if prob_volume_init is not None:
+            pre = pre + prob_volume_init
+        prob = F.softmax(pre, dim=1)
+        depth = depth_regression(prob, depth_values=depth_values)
+        with torch.no_grad():
+            sum4 = 4 * F.avg_pool3d(F.pad(prob.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1, padding=0).squeeze(1)
+            idx = depth_regression(prob, depth_values=torch.arange(num_depth, device=prob.device, dtype=torch.float)).long()
+            idx = idx.clamp(min=0, max=num_depth - 1)
+            conf = torch.gather(sum4, 1, idx.unsqueeze(1)).squeeze(1)
+        out = {"depth": depth, "photometric_confidence": conf}
+        if self.train_variant:
+            out["volume_feature_no_ref"] = out_noref
+        return out
+
+
+class _CascadeBase(nn.Module):
+    TRAIN_VARIANT = False
+
+    def __init__(self, refine=False, ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1], share_cr=False,
+                 grad_method="detach", arch_mode="fpn", cr_base_chs=[8, 8, 8]):
+        super().__init__()
+        if refine:
+            raise NotImplementedError("refine=True: the reference's RefineNet is not runnable (models/modules.py:511 calls F.cat)")
+        self.refine = refine
+        self.share_cr = share_cr
+        self.ndepths = ndepths
+        self.depth_interals_ratio = depth_interals_ratio
+        self.grad_method = grad_method
+        self.arch_mode = arch_mode
+        self.cr_base_chs = cr_base_chs
+        self.num_stage = len(ndepths)
+        assert len(ndepths) == len(depth_interals_ratio)
+        self.stage_infos = {"stage1": {"scale": 4.0}, "stage2": {"scale": 2.0}, "stage3": {"scale": 1.0}}
+        self.feature = FeatureNet(base_channels=8, stride=4, num_stage=self.num_stage, arch_mode=self.arch_mode)
+        if self.share_cr:
+            self.cost_regularization = CostRegNet(in_channels=self.feature.out_channels, base_channels=8)
+        else:
+            self.cost_regularization = nn.ModuleList([CostRegNet(in_channels=self.feature.out_channels[i],
+                                                                 base_channels=self.cr_base_chs[i])
+                                                      for i in range(self.num_stage)])
+        self.DepthNet = DepthNet(self.TRAIN_VARIANT)
+
+    def _cr(self, s):
+        return self.cost_regularization if self.share_cr else self.cost_regularization[s]
+
+    # ---------------------------------------------------------------- native inference path
+    def _forward_hip(self, imgs, proj_matrices, depth_values):
+        B, V, _, H, W = imgs.shape
+        imgs = imgs.float()
+        depth_values = depth_values.contiguous().float()
+        feats = self.feature(imgs.reshape(B * V, 3, H, W))          # eval-mode BN: batching over views is exact
+        outputs = {}
+        depth = None
+        for s in range(self.num_stage):
+            key = "stage{}".format(s + 1)
+            scale = int(self.stage_infos[key]["scale"])
+            D = self.ndepths[s]
+            f = feats[key]
+            C, h, w = f.shape[1:]
+            f_cl = ops.to_channels_last(f.contiguous()).view(B, V, h, w, C)
+            rot, trans = ops.compose_homography(proj_matrices[key].contiguous().float())
+            planes = ops.hypothesis_planes(depth, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
+            var = ops.warp_variance(f_cl, rot, trans, planes, D)
+            cr = self._cr(s)
+            x8 = cr.features_cl(var)
+            depth, conf = ops.depth_head(x8, cr.hip_plan()["prob"], planes)
+            out = {"depth": depth, "photometric_confidence": conf}
+            if self.TRAIN_VARIANT:
+                small = F.interpolate(imgs.reshape(B * V, 3, H, W), (h, w), mode="bilinear", align_corners=False)
+                small_cl = ops.to_channels_last(small.contiguous()).view(B, V, h, w, 3)
+                # module is in eval mode on this path -> the reference's in-place pow_ quirk applies
+                out["volume_feature_no_ref"] = ops.warp_noref(f_cl, small_cl, rot, trans, planes, D, square_first=True)
+            outputs[key] = out
+            outputs.update(out)
+        return outputs
+
+    # ---------------------------------------------------------------- delegated (autograd) path
+    def _forward_aten(self, imgs, proj_matrices, depth_values):
+        depth_min = depth_values[0, 0]
+        depth_max = depth_values[0, -1]
+        depth_interval = (depth_max.double() - depth_min.double()) / depth_values.size(1)
+        features = [self.feature(imgs[:, v]) for v in range(imgs.size(1))]
+        img = imgs[:, 0]
+        outputs = {}
+        depth = None
+        for s in range(self.num_stage):
+            key = "stage{}".format(s + 1)
+            features_stage = [f[key] for f in features]
+            scale = int(self.stage_infos[key]["scale"])
+            if depth is not None:
+                cur = depth.detach() if self.grad_method == "detach" else depth
+                cur = F.interpolate(cur.unsqueeze(1), [img.shape[2], img.shape[3]], mode="bilinear",
+                                    align_corners=Align_Corners_Range).squeeze(1)
+            else:
+                cur = depth_values
+            itv = self.depth_interals_ratio[s] * depth_interval        # 0-dim double, like the reference's python float
+            samples = get_depth_range_samples(cur_depth=cur, ndepth=self.ndepths[s], depth_inteval_pixel=itv,
+                                              dtype=img[0].dtype, device=img[0].device,
+                                              shape=[img.shape[0], img.shape[2], img.shape[3]])
+            samples = F.interpolate(samples.unsqueeze(1), [self.ndepths[s], img.shape[2] // scale, img.shape[3] // scale],
+                                    mode="trilinear", align_corners=Align_Corners_Range).squeeze(1)
+            out = self.DepthNet(features_stage, proj_matrices[key], depth_values=samples, num_depth=self.ndepths[s],
+                                cost_regularization=self._cr(s), imgs=imgs)
+            depth = out["depth"]
+            outputs[key] = out
+            outputs.update(out)
+        return outputs
+
+    def _run(self, imgs, proj_matrices, depth_values):
+        if _hip_inference(self, imgs, depth_values):
+            return self._forward_hip(imgs, proj_matrices, depth_values)
+        return self._forward_aten(imgs, proj_matrices, depth_values)
+
+
+class CascadeMVSNet_eval(_CascadeBase):
+    """models/casmvsnet.py:313-417."""
+    TRAIN_VARIANT = False
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        return self._run(imgs, proj_matrices, depth_values)
+
+
+class CascadeMVSNet(_CascadeBase):
+    """models/casmvsnet.py:126-231: returns (outputs, stage-1 volume_feature_no_ref)."""
+    TRAIN_VARIANT = True
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        outputs = self._run(imgs, proj_matrices, depth_values)
+        return outputs, outputs["stage1"]["volume_feature_no_ref"]

@@ -1,0 +1,175 @@
+// K2/K3: 3-D convolution family (3x3x3, pad 1; stride 1 / stride 2 / transposed stride 2),
+// channels-last, with the BatchNorm(eval) scale/shift, ReLU and skip-add fused in the epilogue.
+// Replaces Conv3d.forward / Deconv3d.forward (models/modules.py:149-157,196-204) and the
+// additions of CostRegNet.forward (:497-499).
+//
+// Two code paths:
+//   * conv3d_direct_kernel  -- generic: one thread per output voxel, all Co accumulators in
+//     registers, 16-byte channel-vector loads of the input, weights through wave-uniform
+//     (scalar-cache) loads.  Handles every mode, any size; used for the strided / transposed
+//     layers and as the fallback.
+//   * conv3d_mfma_kernel (conv3d_mfma.hip) -- stride-1 layers on v_mfma_f32_16x16x4_f32.
+#include "common.h"
+
+namespace rcmvs {
+
+enum ConvMode { CONV_S1 = 0, CONV_S2 = 1, CONV_T2 = 2 };
+
+struct ConvDims {
+    int B, D, H, W;        // input
+    int Do, Ho, Wo;        // output
+};
+
+template <int CI, int CO, int MODE>
+__global__ __launch_bounds__(256) void conv3d_direct_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+    ConvDims dm, int relu) {
+    constexpr int VW = (CI % 4 == 0) ? 4 : 1;      // input channel vector width
+    const long long nvox = (long long)dm.B * dm.Do * dm.Ho * dm.Wo;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvox) return;
+    int ow = (int)(t % dm.Wo);
+    long long r = t / dm.Wo;
+    int oh = (int)(r % dm.Ho); r /= dm.Ho;
+    int od = (int)(r % dm.Do);
+    int b = (int)(r / dm.Do);
+
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+
+    const float* xb = x + (long long)b * dm.D * dm.H * dm.W * CI;
+    for (int kd = 0; kd < 3; ++kd) {
+        int id;
+        bool vd;
+        if (MODE == CONV_T2) { int n = od + 1 - kd; id = n >> 1; vd = (n >= 0) && !(n & 1) && id < dm.D; }
+        else { id = (MODE == CONV_S2 ? 2 * od : od) + kd - 1; vd = id >= 0 && id < dm.D; }
+        if (!vd) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+            int ih;
+            bool vh;
+            if (MODE == CONV_T2) { int n = oh + 1 - kh; ih = n >> 1; vh = (n >= 0) && !(n & 1) && ih < dm.H; }
+            else { ih = (MODE == CONV_S2 ? 2 * oh : oh) + kh - 1; vh = ih >= 0 && ih < dm.H; }
+            if (!vh) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                int iw;
+                bool vw;
+                if (MODE == CONV_T2) { int n = ow + 1 - kw; iw = n >> 1; vw = (n >= 0) && !(n & 1) && iw < dm.W; }
+                else { iw = (MODE == CONV_S2 ? 2 * ow : ow) + kw - 1; vw = iw >= 0 && iw < dm.W; }
+                if (!vw) continue;
+                const float* xp = xb + (((long long)id * dm.H + ih) * dm.W + iw) * CI;
+                const float* wt = wp + (long long)((kd * 3 + kh) * 3 + kw) * CI * CO;
+#pragma unroll 2
+                for (int c0 = 0; c0 < CI; c0 += VW) {
+                    float xv[VW];
+                    if (VW == 4) {
+                        float4 v4 = *reinterpret_cast<const float4*>(xp + c0);
+                        xv[0] = v4.x; xv[1 % VW] = v4.y; xv[2 % VW] = v4.z; xv[3 % VW] = v4.w;
+                    } else {
+                        xv[0] = xp[c0];
+                    }
+#pragma unroll
+                    for (int j = 0; j < VW; ++j)
+#pragma unroll
+                        for (int co = 0; co < CO; ++co)
+                            acc[co] = fmaf(xv[j], wt[(c0 + j) * CO + co], acc[co]);
+                }
+            }
+        }
+    }
+    float* yp = y + t * CO;
+    const float* rp = res ? res + t * CO : nullptr;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        float v = acc[co];
+        if (scale) v = v * scale[co] + shift[co];
+        if (relu) v = fmaxf(v, 0.0f);
+        if (rp) v += rp[co];
+        acc[co] = v;
+    }
+    if (CO % 4 == 0) {
+#pragma unroll
+        for (int co = 0; co < CO; co += 4)
+            *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+    } else {
+#pragma unroll
+        for (int co = 0; co < CO; ++co) yp[co] = acc[co];
+    }
+}
+
+// weight repack: conv (Co,Ci,27) / deconv (Ci,Co,27) -> [27][Ci][Co]
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int transposed) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = 27 * Ci * Co;
+    if (t >= n) return;
+    int co = t % Co, ci = (t / Co) % Ci, tap = t / (Co * Ci);
+    long long src = transposed ? ((long long)ci * Co + co) * 27 + tap : ((long long)co * Ci + ci) * 27 + tap;
+    packed[t] = w[src];
+}
+
+template <int MODE>
+static int direct_dispatch(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                           float* y, const ConvDims& dm, int Ci, int Co, int relu, hipStream_t st) {
+    const long long nvox = (long long)dm.B * dm.Do * dm.Ho * dm.Wo;
+    dim3 grid((unsigned)cdiv(nvox, 256)), block(256);
+#define RCMVS_CONV_CASE(CI, CO)                                                                                   \
+    if (Ci == CI && Co == CO) {                                                                                   \
+        hipLaunchKernelGGL((conv3d_direct_kernel<CI, CO, MODE>), grid, block, 0, st, x, wp, scale, shift, res, y, \
+                           dm, relu);                                                                             \
+        return launch_status("conv3d_direct");                                                                    \
+    }
+    // CostRegNet (base 8) with 8/16/32-channel inputs, and the renderer's CostReg (41 -> 8)
+    RCMVS_CONV_CASE(8, 8) RCMVS_CONV_CASE(16, 8) RCMVS_CONV_CASE(32, 8) RCMVS_CONV_CASE(41, 8)
+    RCMVS_CONV_CASE(8, 16) RCMVS_CONV_CASE(16, 16) RCMVS_CONV_CASE(16, 32) RCMVS_CONV_CASE(32, 32)
+    RCMVS_CONV_CASE(32, 64) RCMVS_CONV_CASE(64, 64) RCMVS_CONV_CASE(64, 32) RCMVS_CONV_CASE(32, 16)
+    RCMVS_CONV_CASE(8, 1)
+#undef RCMVS_CONV_CASE
+    return fail(-1, "conv3d: unsupported channel pair Ci=%d Co=%d", Ci, Co);
+}
+
+int conv3d_mfma_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                       float* y, int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);  // conv3d_mfma.hip
+bool conv3d_mfma_supported(int Ci, int Co, int D, int H, int W);
+
+}  // namespace rcmvs
+
+using namespace rcmvs;
+
+extern "C" {
+
+int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream) {
+    RCMVS_REQUIRE(w && packed && Co > 0 && Ci > 0, "pack_conv3d_weight: bad arguments");
+    int n = 27 * Ci * Co;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, packed, Co, Ci, transposed);
+    return launch_status("pack_conv3d_weight");
+}
+
+int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                     const float* residual, float* y,
+                     int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream) {
+    RCMVS_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad sizes");
+    RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_fwd: stride must be 1 or 2");
+    RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3d_fwd: scale and shift go together");
+    ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
+    hipStream_t st = as_stream(stream);
+    if (stride == 1) {
+        if (conv3d_mfma_supported(Ci, Co, D, H, W))
+            return conv3d_mfma_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
+        return direct_dispatch<CONV_S1>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
+    }
+    return direct_dispatch<CONV_S2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
+}
+
+int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                       const float* residual, float* y,
+                       int B, int D, int H, int W, int Ci, int Co, int relu, void* stream) {
+    RCMVS_REQUIRE(x && w_packed && y, "deconv3d_fwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
+    RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
+    ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
+    return direct_dispatch<CONV_T2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, as_stream(stream));
+}
+
+}  // extern "C"

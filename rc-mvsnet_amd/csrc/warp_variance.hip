@@ -1,0 +1,247 @@
+// K1: fused plane-sweep homography warp + variance cost volume (gfx950).
+//
+// Replaces, per stage, (V-1) x homo_warping (models/modules.py:304-339: ~15 materialised
+// [B,3,D,hw] intermediates + grid_sample) and the sum / square-sum / variance chain of
+// DepthNet_eval.forward (models/casmvsnet.py:257-288).  One launch reads the V feature maps and
+// the plane table and writes the variance volume exactly once.
+//
+// Mapping (wave = 64 lanes): channels-last everywhere.  A pixel's C channels are handled by
+// C/4 adjacent lanes (one float4 each), a wave covers 1024 B of contiguous output per plane
+// (256/C pixels of one image row), a 256-thread block covers a 4-row tile, and each thread keeps
+// DK = 8 planes x 4 channels of {sum, square-sum} in registers while it loops over the source
+// views -- so every bilinear tap is a 16-byte load of 4 channels and the output store of a wave
+// is one fully coalesced 1 KiB line.
+//
+// Numerics: the coordinate chain and the accumulation are compiled with fp contraction OFF and
+// IEEE division, in the operation order of oracle/warp.py (itself the reference's op order), so
+// the kernel is bit-comparable with the oracle; taps outside the source image, and non-finite
+// coordinates (z == 0), contribute zero (grid_sample zeros padding, CUDA/HIP semantics).
+#include "common.h"
+
+namespace rcmvs {
+
+constexpr int DK = 8;   // planes per thread
+
+struct WarpCoord {
+    int off[4];     // element offsets (pixel index * C) of the 4 taps, clamped in-bounds
+    float wgt[4];   // tap weights, 0 where the tap is outside the image
+};
+
+__device__ __forceinline__ WarpCoord warp_taps(float rx, float ry, float rz, float tx, float ty, float tz,
+                                               float d, float half_w, float half_h, float wm1, float hm1,
+                                               int w, int h, int C) {
+#pragma clang fp contract(off)
+    // models/modules.py:326-331, then grid_sample's align_corners=True un-normalisation
+    float px = rx * d + tx;
+    float py = ry * d + ty;
+    float pz = rz * d + tz;
+    float u = px / pz;
+    float v = py / pz;
+    float gx = u / half_w - 1.0f;
+    float gy = v / half_h - 1.0f;
+    float ix = ((gx + 1.0f) / 2.0f) * wm1;
+    float iy = ((gy + 1.0f) / 2.0f) * hm1;
+    float x0 = floorf(ix), y0 = floorf(iy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    float wx1 = ix - x0, wx0 = x1 - ix;
+    float wy1 = iy - y0, wy0 = y1 - iy;
+    // validity in the float domain (NaN / inf compare false)
+    bool vx0 = (x0 >= 0.0f) && (x0 <= wm1);
+    bool vx1 = (x1 >= 0.0f) && (x1 <= wm1);
+    bool vy0 = (y0 >= 0.0f) && (y0 <= hm1);
+    bool vy1 = (y1 >= 0.0f) && (y1 <= hm1);
+    // clamp before the int conversion so huge / non-finite values cannot overflow
+    int xi0 = (int)fminf(fmaxf(x0, 0.0f), wm1);
+    int xi1 = (int)fminf(fmaxf(x1, 0.0f), wm1);
+    int yi0 = (int)fminf(fmaxf(y0, 0.0f), hm1);
+    int yi1 = (int)fminf(fmaxf(y1, 0.0f), hm1);
+    WarpCoord t;
+    t.off[0] = (yi0 * w + xi0) * C;
+    t.off[1] = (yi0 * w + xi1) * C;
+    t.off[2] = (yi1 * w + xi0) * C;
+    t.off[3] = (yi1 * w + xi1) * C;
+    t.wgt[0] = (vx0 && vy0) ? wx0 * wy0 : 0.0f;
+    t.wgt[1] = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
+    t.wgt[2] = (vx0 && vy1) ? wx0 * wy1 : 0.0f;
+    t.wgt[3] = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
+    return t;
+}
+
+__device__ __forceinline__ float4 bilerp4(const float* __restrict__ src, const WarpCoord& t, int q4) {
+#pragma clang fp contract(off)
+    float4 a = *reinterpret_cast<const float4*>(src + t.off[0] + q4);
+    float4 b = *reinterpret_cast<const float4*>(src + t.off[1] + q4);
+    float4 c = *reinterpret_cast<const float4*>(src + t.off[2] + q4);
+    float4 d = *reinterpret_cast<const float4*>(src + t.off[3] + q4);
+    float4 r;
+    r.x = ((a.x * t.wgt[0] + b.x * t.wgt[1]) + c.x * t.wgt[2]) + d.x * t.wgt[3];
+    r.y = ((a.y * t.wgt[0] + b.y * t.wgt[1]) + c.y * t.wgt[2]) + d.y * t.wgt[3];
+    r.z = ((a.z * t.wgt[0] + b.z * t.wgt[1]) + c.z * t.wgt[2]) + d.z * t.wgt[3];
+    r.w = ((a.w * t.wgt[0] + b.w * t.wgt[1]) + c.w * t.wgt[2]) + d.w * t.wgt[3];
+    return r;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void warp_variance_kernel(
+    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int tiles_y) {
+#pragma clang fp contract(off)
+    constexpr int LPP = C / 4;          // lanes per pixel
+    constexpr int TW = 256 / C;         // pixels per wave = tile width  (1 KiB of output per plane)
+    constexpr int TH = 4;               // one wave per tile row
+    const int b = blockIdx.z;
+    const int k0 = blockIdx.y * DK;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int q4 = (threadIdx.x % LPP) * 4;
+    const int x = tx * TW + (threadIdx.x / LPP) % TW;
+    const int y = ty * TH + threadIdx.x / (LPP * TW);
+    if (x >= w || y >= h) return;
+    const long long hw = (long long)h * w;
+    const float fx = (float)x, fy = (float)y;
+    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
+    const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
+    const float2 pl = reinterpret_cast<const float2*>(planes)[(long long)b * hw + (long long)y * w + x];
+
+    const float* fb = feats + (long long)b * V * hw * C;
+    const float4 ref = *reinterpret_cast<const float4*>(fb + ((long long)y * w + x) * C + q4);
+    float4 s[DK], sq[DK];
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+        s[k] = ref;
+        sq[k] = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+    }
+    for (int v = 1; v < V; ++v) {
+        const float* r = rot + ((long long)b * (V - 1) + (v - 1)) * 9;
+        const float* t = trans + ((long long)b * (V - 1) + (v - 1)) * 3;
+        const float rx = (r[0] * fx + r[1] * fy) + r[2];
+        const float ry = (r[3] * fx + r[4] * fy) + r[5];
+        const float rz = (r[6] * fx + r[7] * fy) + r[8];
+        const float t0 = t[0], t1 = t[1], t2 = t[2];
+        const float* src = fb + (long long)v * hw * C;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+            const float d = pl.x + (float)(k0 + k) * pl.y;
+            WarpCoord tc = warp_taps(rx, ry, rz, t0, t1, t2, d, half_w, half_h, wm1, hm1, w, h, C);
+            float4 val = bilerp4(src, tc, q4);
+            s[k].x = s[k].x + val.x; s[k].y = s[k].y + val.y; s[k].z = s[k].z + val.z; s[k].w = s[k].w + val.w;
+            sq[k].x = sq[k].x + val.x * val.x; sq[k].y = sq[k].y + val.y * val.y;
+            sq[k].z = sq[k].z + val.z * val.z; sq[k].w = sq[k].w + val.w * val.w;
+        }
+    }
+    const float fV = (float)V;
+    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + q4;
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+        if (k0 + k < D) {
+            float4 m, o;
+            m.x = s[k].x / fV; m.y = s[k].y / fV; m.z = s[k].z / fV; m.w = s[k].w / fV;
+            o.x = sq[k].x / fV - m.x * m.x;
+            o.y = sq[k].y / fV - m.y * m.y;
+            o.z = sq[k].z / fV - m.z * m.z;
+            o.w = sq[k].w / fV - m.w * m.w;
+            *reinterpret_cast<float4*>(ob + (long long)(k0 + k) * hw * C) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// train-variant extra: warped RGB of every source view ++ source-only variance / V, written in
+// the reference's NCDHW layout because the tensor crosses the module boundary
+// (CascadeMVSNet.forward returns it, models/casmvsnet.py:231).  One thread per (pixel, plane).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_noref_kernel(
+    const float* __restrict__ feats, const float* __restrict__ imgs, const float* __restrict__ rot,
+    const float* __restrict__ trans, const float* __restrict__ planes, float* __restrict__ out,
+    int V, int C, int D, int h, int w, int square_first) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.z, k = blockIdx.y;
+    const long long hw = (long long)h * w;
+    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const int y = (int)(p / w), x = (int)(p % w);
+    const float fx = (float)x, fy = (float)y;
+    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
+    const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
+    const float2 pl = reinterpret_cast<const float2*>(planes)[(long long)b * hw + p];
+    const float d = pl.x + (float)k * pl.y;
+    const int CT = 3 * (V - 1) + C;
+    float* ob = out + (((long long)b * CT) * D + k) * hw + p;      // channel stride = D*hw
+    const long long cs = (long long)D * hw;
+    const float fV = (float)V;
+    // channel loop outermost over 4-channel groups keeps registers small; taps are recomputed
+    // per view only once (they do not depend on the channel)
+    for (int v = 1; v < V; ++v) {
+        const float* r = rot + ((long long)b * (V - 1) + (v - 1)) * 9;
+        const float* t = trans + ((long long)b * (V - 1) + (v - 1)) * 3;
+        const float rx = (r[0] * fx + r[1] * fy) + r[2];
+        const float ry = (r[3] * fx + r[4] * fy) + r[5];
+        const float rz = (r[6] * fx + r[7] * fy) + r[8];
+        WarpCoord tc = warp_taps(rx, ry, rz, t[0], t[1], t[2], d, half_w, half_h, wm1, hm1, w, h, 1);
+        const float* im = imgs + ((long long)b * V + v) * hw * 3;
+        for (int c = 0; c < 3; ++c) {
+            float val = ((im[tc.off[0] * 3 + c] * tc.wgt[0] + im[tc.off[1] * 3 + c] * tc.wgt[1]) +
+                         im[tc.off[2] * 3 + c] * tc.wgt[2]) + im[tc.off[3] * 3 + c] * tc.wgt[3];
+            ob[(long long)((v - 1) * 3 + c) * cs] = val;
+        }
+    }
+    for (int c = 0; c < C; ++c) {
+        float s = 0.0f, sq = 0.0f;
+        for (int v = 1; v < V; ++v) {
+            const float* r = rot + ((long long)b * (V - 1) + (v - 1)) * 9;
+            const float* t = trans + ((long long)b * (V - 1) + (v - 1)) * 3;
+            const float rx = (r[0] * fx + r[1] * fy) + r[2];
+            const float ry = (r[3] * fx + r[4] * fy) + r[5];
+            const float rz = (r[6] * fx + r[7] * fy) + r[8];
+            WarpCoord tc = warp_taps(rx, ry, rz, t[0], t[1], t[2], d, half_w, half_h, wm1, hm1, w, h, 1);
+            const float* src = feats + ((long long)b * V + v) * hw * C + c;
+            float val = ((src[(long long)tc.off[0] * C] * tc.wgt[0] + src[(long long)tc.off[1] * C] * tc.wgt[1]) +
+                         src[(long long)tc.off[2] * C] * tc.wgt[2]) + src[(long long)tc.off[3] * C] * tc.wgt[3];
+            if (square_first) val = val * val;
+            s = s + val;
+            sq = sq + val * val;
+        }
+        float m = s / fV;
+        ob[(long long)(3 * (V - 1) + c) * cs] = sq / fV - m * m;
+    }
+}
+
+}  // namespace rcmvs
+
+using namespace rcmvs;
+
+extern "C" {
+
+int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
+                            const float* planes, float* var,
+                            int B, int V, int C, int D, int h, int w, void* stream) {
+    RCMVS_REQUIRE(feats && rot && trans && planes && var, "warp_variance_fwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
+    RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
+    RCMVS_REQUIRE((long long)h * w * C < (1LL << 31), "warp_variance_fwd: feature map too large for 32-bit offsets");
+    const int TW = 256 / C, TH = 4;
+    const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+    dim3 grid(tiles_x * tiles_y, (D + DK - 1) / DK, B);
+    hipStream_t st = as_stream(stream);
+    switch (C) {
+        case 8:  hipLaunchKernelGGL(warp_variance_kernel<8>,  grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y); break;
+        case 16: hipLaunchKernelGGL(warp_variance_kernel<16>, grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y); break;
+        case 32: hipLaunchKernelGGL(warp_variance_kernel<32>, grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y); break;
+        default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+    }
+    return launch_status("warp_variance_fwd");
+}
+
+int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot, const float* trans,
+                         const float* planes, float* out,
+                         int B, int V, int C, int D, int h, int w, int square_first, void* stream) {
+    RCMVS_REQUIRE(feats && imgs && rot && trans && planes && out, "warp_noref_fwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1 && C > 0, "warp_noref_fwd: bad sizes");
+    RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_noref_fwd: V=%d unsupported", V);
+    dim3 grid((unsigned)cdiv((long long)h * w, 256), D, B);
+    hipLaunchKernelGGL(warp_noref_kernel, grid, dim3(256), 0, as_stream(stream), feats, imgs, rot, trans, planes, out,
+                       V, C, D, h, w, square_first);
+    return launch_status("warp_noref_fwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""Thin tensor-level wrappers over the C ABI (include/rcmvs.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every function
+below checks its inputs, allocates the outputs with torch.empty and enqueues exactly one
+library call on the current stream.  Layout convention inside the library is channels-last
+(maps (B,h,w,C), volumes (B,D,h,w,C)).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+# bench.py sets this to a list to have every K1 launch bracketed by HIP events recorded on the
+# launch stream (torch's current stream); None = no instrumentation.
+K1_EVENTS = None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.RcmvsError(f"{name}: expected a tensor on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.RcmvsError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.RcmvsError(f"{name}: expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _opt(t, name):
+    return ctypes.c_void_p(0) if t is None else _chk(t, name)
+
+
+# ------------------------------------------------------------------------------- layout
+def to_channels_last(x):
+    """(N,C,*spatial) -> (N,*spatial,C)."""
+    N, C = x.shape[:2]
+    S = x[0, 0].numel()
+    out = torch.empty((N, *x.shape[2:], C), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_nchw_to_nhwc(_chk(x, "x"), _chk(out, "out"), N, C, S, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def to_channels_first(x):
+    """(N,*spatial,C) -> (N,C,*spatial)."""
+    N, C = x.shape[0], x.shape[-1]
+    S = x[0, ..., 0].numel()
+    out = torch.empty((N, C, *x.shape[1:-1]), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_nhwc_to_nchw(_chk(x, "x"), _chk(out, "out"), N, C, S, _stream()), "nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------------------- geometry
+def compose_homography(proj):
+    """proj (B,V,2,4,4) -> rot (B,V-1,9), trans (B,V-1,3)."""
+    B, V = proj.shape[:2]
+    rot = torch.empty((B, V - 1, 9), device=proj.device, dtype=torch.float32)
+    trans = torch.empty((B, V - 1, 3), device=proj.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_compose_homography(_chk(proj, "proj"), _chk(rot, "rot"), _chk(trans, "trans"), B, V, _stream()),
+               "compose_homography")
+    return rot, trans
+
+
+def hypothesis_planes(prev_depth, depth_values, full_hw, scale, ndepth, ratio):
+    """-> planes (B, H/scale, W/scale, 2) = {d_0, delta}."""
+    B, ND = depth_values.shape
+    H, W = full_hw
+    planes = torch.empty((B, H // scale, W // scale, 2), device=depth_values.device, dtype=torch.float32)
+    hp, wp = (prev_depth.shape[-2:] if prev_depth is not None else (0, 0))
+    _lib.check(_lib.load().rcmvs_hypothesis_planes(_opt(prev_depth, "prev_depth"), _chk(depth_values, "depth_values"),
+                                                   _chk(planes, "planes"), B, hp, wp, H, W, scale, ndepth, float(ratio), ND,
+                                                   _stream()), "hypothesis_planes")
+    return planes
+
+
+# ------------------------------------------------------------------------------- K1
+def warp_variance(feats, rot, trans, planes, ndepth):
+    """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C)."""
+    B, V, h, w, C = feats.shape
+    var = torch.empty((B, ndepth, h, w, C), device=feats.device, dtype=torch.float32)
+    ev = None
+    if K1_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _lib.check(_lib.load().rcmvs_warp_variance_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                   _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, _stream()),
+               "warp_variance_fwd")
+    if ev is not None:
+        ev[1].record()
+        K1_EVENTS.append(ev)
+    return var
+
+
+def warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first):
+    """feats (B,V,h,w,C), imgs (B,V,h,w,3) -> (B, 3(V-1)+C, D, h, w) in the reference's NCDHW."""
+    B, V, h, w, C = feats.shape
+    out = torch.empty((B, 3 * (V - 1) + C, ndepth, h, w), device=feats.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_warp_noref_fwd(_chk(feats, "feats"), _chk(imgs, "imgs"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                _chk(planes, "planes"), _chk(out, "out"), B, V, C, ndepth, h, w,
+                                                int(bool(square_first)), _stream()), "warp_noref_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------- K2/K3
+def pack_conv3d_weight(w, transposed=False):
+    """conv (Co,Ci,3,3,3) / deconv (Ci,Co,3,3,3) -> packed (27,Ci,Co)."""
+    w = w.detach().contiguous().float()
+    Ci, Co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    packed = torch.empty((27, Ci, Co), device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_pack_conv3d_weight(_chk(w, "w"), _chk(packed, "packed"), Co, Ci, int(transposed), _stream()),
+               "pack_conv3d_weight")
+    return packed
+
+
+def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False):
+    """x (B,D,H,W,Ci) -> (B,Do,Ho,Wo,Co) with fused [relu](v*scale+shift) + residual."""
+    B, D, H, W, Ci = x.shape
+    Co = w_packed.shape[2]
+    if w_packed.shape[1] != Ci:
+        raise _lib.RcmvsError(f"conv3d: input has {Ci} channels, weight expects {w_packed.shape[1]}")
+    y = torch.empty((B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1, Co), device=x.device,
+                    dtype=torch.float32)
+    if residual is not None and residual.shape != y.shape:
+        raise _lib.RcmvsError(f"conv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
+    _lib.check(_lib.load().rcmvs_conv3d_fwd(_chk(x, "x"), _chk(w_packed, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                            _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
+                                            _stream()), "conv3d_fwd")
+    return y
+
+
+def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
+    """x (B,D,H,W,Ci) -> (B,2D,2H,2W,Co)."""
+    B, D, H, W, Ci = x.shape
+    Co = w_packed.shape[2]
+    if w_packed.shape[1] != Ci:
+        raise _lib.RcmvsError(f"deconv3d: input has {Ci} channels, weight expects {w_packed.shape[1]}")
+    y = torch.empty((B, 2 * D, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
+    if residual is not None and residual.shape != y.shape:
+        raise _lib.RcmvsError(f"deconv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)} "
+                              "(volume sizes must be divisible by 8, as in the reference)")
+    _lib.check(_lib.load().rcmvs_deconv3d_fwd(_chk(x, "x"), _chk(w_packed, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                              _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
+                                              _stream()), "deconv3d_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------- K4
+def depth_head(x8, w_prob_packed, planes, want_prob=False):
+    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)]."""
+    B, D, h, w, C = x8.shape
+    if C != 8:
+        raise _lib.RcmvsError("depth_head: the prob conv takes 8 channels")
+    depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
+    conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
+    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32) if want_prob else None
+    _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed, "w_prob"), _chk(planes, "planes"),
+                                                _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
+                                                _stream()), "depth_head_fwd")
+    return (depth, conf, prob) if want_prob else (depth, conf)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, bench, rocprofv3 kernel stats.  Logs -> gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+echo "== rocm-smi" ; rocm-smi --showproductname 2>/dev/null | head -8
+echo "== pytest -m gpu"
+timeout 900 python -m pytest tests -q -m gpu -s -p no:cacheprovider 2>&1 | tail -60 | tee gpurun_out/pytest_gpu.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
+echo "== bench"
+timeout 600 python bench.py --steps 30 --warmup 5 2>&1 | tail -3 | tee gpurun_out/bench.log
+echo "== rocprof"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1 )
+ls -R gpurun_out/prof | head -20
+f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -40 "$f"
