@@ -35,6 +35,20 @@ NDEPTHS, RATIOS = (48, 32, 8), (4, 2, 1)
 FEAT_C = (32, 16, 8)
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may really use (affinity mask and
+    cgroup CPU quota), capped at 32 -- PyTorch-CPU does not scale past that on this workload and
+    oversubscribing a quota-limited container is pathological."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def k1_algorithmic_bytes():
     """read (V-1) source maps + the reference map + the plane table, write the variance volume once
     (planes counted as the reference does: one (D,h,w) fp32 tensor)."""
@@ -52,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed on the CPU baseline (bounded sample)")
+    ap.add_argument("--cpu-scenes", type=int, default=3, help="scenes timed on the CPU baseline (bounded sample)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,23 +163,30 @@ def main():
     # ---- CPU baseline (oracle, ATen op graph of the reference) + parity on the same inputs -----
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cascade
-        nthreads = os.cpu_count() or 1
+        nthreads = host_threads()
         torch.set_num_threads(nthreads)
         imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, 0)
+        times = []
         with torch.no_grad():
-            ref = cascade.forward_eval(imgs, pm, dv, sd, NDEPTHS, RATIOS, impl="aten")     # warm-up
-            c0 = time.perf_counter()
-            for _ in range(args.cpu_scenes):
+            budget_t0 = time.perf_counter()
+            for i in range(1 + args.cpu_scenes):              # first pass = warm-up unless it is all we can afford
+                c0 = time.perf_counter()
                 ref = cascade.forward_eval(imgs, pm, dv, sd, NDEPTHS, RATIOS, impl="aten")
-            cpu_s = (time.perf_counter() - c0) / args.cpu_scenes
+                times.append(time.perf_counter() - c0)
+                if time.perf_counter() - budget_t0 > 25.0:    # bounded sample: ~10-30 s of CPU work
+                    break
             hip = model(*scenes[0])
+        timed = times[1:] if len(times) > 1 else times
+        cpu_s = sorted(timed)[len(timed) // 2]
         rng = float(dv[0, -1] - dv[0, 0])
         dd = (hip["depth"].cpu() - ref["depth"]).abs()
         result["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "ref-scenes/s", "cores": nthreads, "kind": "port",
-                                  "sample": f"{args.cpu_scenes} scenes of the same config-2 workload after 1 warm-up, "
+                                  "sample": f"median of {len(timed)} scene(s) of the same config-2 workload"
+                                            f"{' after 1 warm-up' if len(times) > 1 else ' (cold, no warm-up fit the time bound)'}, "
                                             f"oracle impl='aten' (reference op graph on PyTorch-CPU), {nthreads} threads"}
         result["parity"] = {"depth_l1_over_range": float(dd.mean()) / rng, "depth_l1_mm": float(dd.mean()),
-                            "depth_max_abs_mm": float(dd.max()), "tolerance": 1e-4}
+                            "depth_max_abs_mm": float(dd.max()), "frac_pixels_over_0.1mm": float((dd > 0.1).float().mean()),
+                            "tolerance": 1e-4}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -4,6 +4,12 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 echo "== rocm-smi" ; rocm-smi --showproductname 2>/dev/null | head -8
+python - <<PY
+import os
+print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
+try: print("cpu.max", open("/sys/fs/cgroup/cpu.max").read().strip())
+except Exception as e: print("no cpu.max", e)
+PY
 echo "== pytest -m gpu"
 timeout 900 python -m pytest tests -q -m gpu -s -p no:cacheprovider 2>&1 | tail -60 | tee gpurun_out/pytest_gpu.log
 echo "== smoke"
@@ -11,7 +17,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== bench"
 timeout 600 python bench.py --steps 30 --warmup 5 2>&1 | tail -3 | tee gpurun_out/bench.log
 echo "== rocprof"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1 )
 ls -R gpurun_out/prof | head -20
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -40 "$f"
