@@ -63,6 +63,9 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
                             const float* planes, float* var,
                             int B, int V, int C, int D, int h, int w, void* stream);
 
+/* profiling hook: select the K1 code variant (0 = default; see warp_variance.hip) */
+void rcmvs_debug_k1_variant(int variant);
+
 /* train-variant extra (models/casmvsnet.py:59,82,89-101): volume_feature_no_ref, NCDHW like
  * the reference returns it: out (B, 3(V-1)+C, D, h, w) = warped RGB of each source view
  * (imgs (B,V,h,w,3) channels-last, already resized to the stage) then the source-only
@@ -74,8 +77,13 @@ int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot
 /* ---- K2/K3: 3-D convolution family, channels-last, fused epilogue ----------------------- */
 /* weight packing (host-visible layout change, done once per weight update):
  *   conv   w (Co,Ci,3,3,3) -> packed [27][Ci][Co]      (nn.Conv3d,          modules.py:145)
- *   deconv w (Ci,Co,3,3,3) -> packed [27][Ci][Co]      (nn.ConvTranspose3d, modules.py:189) */
+ *   deconv w (Ci,Co,3,3,3) -> packed [27][Ci][Co]      (nn.ConvTranspose3d, modules.py:189)
+ * followed, for channel pairs served by the MFMA kernels (Co a multiple of 16), by the
+ * fragment-ordered image [27][Ci/(4*VEC)][Co/16][64 lanes][VEC] those kernels read. */
+long long rcmvs_packed_weight_floats(int Co, int Ci);   /* size of `packed` in floats ([27][Ci][Co] + MFMA image) */
 int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream);
+/* test/bench hook: 1 = route every layer through the direct (non-MFMA) kernels */
+void rcmvs_debug_force_direct_conv(int on);
 
 /* y = epilogue(conv3d(x, w, k=3, pad=1, stride)),  x (B,D,H,W,Ci) -> y (B,Do,Ho,Wo,Co),
  * Do = (D-1)/stride+1 ...;   epilogue(v) = [relu](v*scale[co] + shift[co]) + residual

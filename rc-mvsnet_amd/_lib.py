@@ -26,8 +26,11 @@ SIGNATURES = {
     "rcmvs_compose_homography": [_p, _p, _p, _i, _i, _p],
     "rcmvs_hypothesis_planes": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_debug_k1_variant": [_i],
     "rcmvs_warp_noref_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_packed_weight_floats": [_i, _i],
     "rcmvs_pack_conv3d_weight": [_p, _p, _i, _i, _i, _p],
+    "rcmvs_debug_force_direct_conv": [_i],
     "rcmvs_conv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_deconv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_depth_head_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -38,7 +41,8 @@ SIGNATURES = {
     "rcmvs_nerf_weight_floats": [],
     "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
 }
-_RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll}
+_RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll,
+             "rcmvs_packed_weight_floats": _ll, "rcmvs_debug_force_direct_conv": None, "rcmvs_debug_k1_variant": None}
 
 _lib = None
 

@@ -128,21 +128,42 @@ static int direct_dispatch(const float* x, const float* wp, const float* scale, 
     return fail(-1, "conv3d: unsupported channel pair Ci=%d Co=%d", Ci, Co);
 }
 
-int conv3d_mfma_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                       float* y, int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);  // conv3d_mfma.hip
-bool conv3d_mfma_supported(int Ci, int Co, int D, int H, int W);
+// conv3d_mfma.hip
+int conv3d_mfma_launch(const float* x, const float* wm, const float* scale, const float* shift, const float* res,
+                       float* y, int B, int D, int H, int W, int Ci, int Co, int mode, int relu, hipStream_t st);
+bool conv3d_mfma_supported(int Ci, int Co, int mode);
+int pack_weight_mfma_launch(const float* w, float* packed, int Co, int Ci, int transposed, hipStream_t st);
+long long mfma_weight_floats_host(int Ci, int Co);
+
+// packed weight blob = [27][Ci][Co] (direct kernels) followed by the MFMA image when the pair has one
+static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
 
 }  // namespace rcmvs
 
 using namespace rcmvs;
 
+static int g_force_direct = 0;   // test/bench hook: route everything through the direct kernels
+
 extern "C" {
+
+void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on; }
+
+long long rcmvs_packed_weight_floats(int Co, int Ci) {
+    if (Co <= 0 || Ci <= 0) return -1;
+    long long n = direct_weight_floats(Ci, Co);
+    if (conv3d_mfma_supported(Ci, Co, 0)) n += mfma_weight_floats_host(Ci, Co);
+    return n;
+}
 
 int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream) {
     RCMVS_REQUIRE(w && packed && Co > 0 && Ci > 0, "pack_conv3d_weight: bad arguments");
     int n = 27 * Ci * Co;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, packed, Co, Ci, transposed);
-    return launch_status("pack_conv3d_weight");
+    int rc = launch_status("pack_conv3d_weight");
+    if (rc) return rc;
+    if (conv3d_mfma_supported(Ci, Co, 0))
+        return pack_weight_mfma_launch(w, packed + direct_weight_floats(Ci, Co), Co, Ci, transposed, as_stream(stream));
+    return 0;
 }
 
 int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
@@ -154,11 +175,11 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
     RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3d_fwd: scale and shift go together");
     ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
-    if (stride == 1) {
-        if (conv3d_mfma_supported(Ci, Co, D, H, W))
-            return conv3d_mfma_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
-        return direct_dispatch<CONV_S1>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
-    }
+    const int mode = stride == 1 ? CONV_S1 : CONV_S2;
+    if (conv3d_mfma_supported(Ci, Co, mode) && !g_force_direct)
+        return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
+                                  mode, relu, st);
+    if (stride == 1) return direct_dispatch<CONV_S1>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
     return direct_dispatch<CONV_S2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
 }
 
@@ -169,6 +190,9 @@ int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
     RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
     ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
+    if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !g_force_direct)
+        return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
+                                  CONV_T2, relu, as_stream(stream));
     return direct_dispatch<CONV_T2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, as_stream(stream));
 }
 

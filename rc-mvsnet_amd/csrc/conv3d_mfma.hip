@@ -1,14 +1,225 @@
-// stride-1 3x3x3 convolution on v_mfma_f32_16x16x4_f32 (placeholder: dispatch disabled until the
-// kernel lands; rcmvs_conv3d_fwd falls through to the direct kernel).
+// 3x3x3 convolution family as an implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32: the MFMA is
+// a k-ordered fmaf chain, cdna_hip_programming.md section 3), channels-last, for the layers with
+// Cout >= 16 (conv1..conv9 of the 3-D U-Nets).  gfx950 only.
+//
+// GEMM view:  M = output channels (16 per m-tile), N = output "cells" (16 per n-tile),
+//             K = (tap, input channel).
+//   A[m][k] = weight, lane l supplies row m = l & 15, k-slot kq = l >> 4;
+//   B[k][n] = input activation of cell n at the tap's offset, lane l supplies column n = l & 15,
+//             k-slot kq = l >> 4;
+//   D[m][n]: lane l holds rows (l >> 4) * 4 + r (r = 0..3) of column n = l & 15, i.e. FOUR
+//             CONSECUTIVE OUTPUT CHANNELS of one cell -> the epilogue (BN scale/shift, ReLU,
+//             skip-add) and the store are one float4 per lane.
+// k-permutation: a lane loads VEC (= 4, or 2 when Cin = 8) consecutive input channels
+//   cin = chunk*4*VEC + kq*VEC + j  with one 16/8-byte load and feeds component j to MFMA j; the
+//   packed weights use the same order, so each (tap, chunk) costs one vector load per operand.
+// A "cell" is an output voxel (conv) or an input-grid voxel (transposed conv, where the 8 output
+//   parity classes 2*cell + p are separate grid.z slices so that the tap set is wave-uniform).
+// One wave = NT n-tiles x one m-tile; grid.y = m-tiles.  Cells are flattened over (b, d, h, w), so
+//   small deep-level volumes (e.g. 6x16x20) still fill whole tiles.
 #include "common.h"
 
 namespace rcmvs {
 
-bool conv3d_mfma_supported(int, int, int, int, int) { return false; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-int conv3d_mfma_launch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
-                       int, int, int, hipStream_t) {
-    return fail(-2, "conv3d_mfma: not built");
+enum { MF_S1 = 0, MF_S2 = 1, MF_T2 = 2 };
+
+struct MfmaDims {
+    int B, D, H, W;      // input volume
+    int Dg, Hg, Wg;      // cell grid (= output volume for conv, input volume for transposed)
+    int Do, Ho, Wo;      // output volume
+    long long cells;     // B*Dg*Hg*Wg
+};
+
+// floats of the MFMA weight image for (Ci, Co):  [27][chunks][mtiles][64 lanes][VEC]
+__host__ __device__ inline int mfma_vec(int Ci) { return Ci >= 16 ? 4 : 2; }
+__host__ __device__ inline long long mfma_weight_floats(int Ci, int Co) {
+    int vec = mfma_vec(Ci);
+    int chunks = Ci / (4 * vec), mtiles = (Co + 15) / 16;
+    return 27LL * chunks * mtiles * 64 * vec;
 }
+
+__global__ void pack_weight_mfma_kernel(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int transposed) {
+    const int vec = mfma_vec(Ci);
+    const int chunks = Ci / (4 * vec), mtiles = (Co + 15) / 16;
+    long long n = 27LL * chunks * mtiles * 64 * vec;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int j = (int)(t % vec);
+    long long r = t / vec;
+    int lane = (int)(r % 64); r /= 64;
+    int mt = (int)(r % mtiles); r /= mtiles;
+    int chunk = (int)(r % chunks);
+    int tap = (int)(r / chunks);
+    int m = lane & 15, kq = lane >> 4;
+    int co = mt * 16 + m, ci = chunk * 4 * vec + kq * vec + j;
+    float v = 0.0f;
+    if (co < Co) v = transposed ? w[((long long)ci * Co + co) * 27 + tap] : w[((long long)co * Ci + ci) * 27 + tap];
+    packed[t] = v;
+}
+
+template <int CIN, int COUT, int MODE, int NT>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wm, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, MfmaDims dm, int relu) {
+    constexpr int VEC = (CIN >= 16) ? 4 : 2;
+    constexpr int CHUNKS = CIN / (4 * VEC);
+    constexpr int MTILES = (COUT + 15) / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int mt = blockIdx.y;
+    const int pc = (MODE == MF_T2) ? blockIdx.z : 0;                 // output parity class (transposed only)
+    const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+    const long long tile0 = ((long long)blockIdx.x * 4 + wave) * NT;
+    if (tile0 * 16 >= dm.cells) return;
+
+    // per n-tile cell coordinates of this lane
+    int cb[NT], cd[NT], ch[NT], cw[NT];
+    bool cv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        long long c = (tile0 + t) * 16 + n;
+        cv[t] = c < dm.cells;
+        long long cc = cv[t] ? c : 0;
+        cw[t] = (int)(cc % dm.Wg); cc /= dm.Wg;
+        ch[t] = (int)(cc % dm.Hg); cc /= dm.Hg;
+        cd[t] = (int)(cc % dm.Dg);
+        cb[t] = (int)(cc / dm.Dg);
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* wbase = wm + ((long long)mt * 64 + lane) * VEC;
+    constexpr long long W_TAP_STRIDE = (long long)CHUNKS * MTILES * 64 * VEC;
+    constexpr long long W_CHUNK_STRIDE = (long long)MTILES * 64 * VEC;
+
+    for (int kd = 0; kd < 3; ++kd) {
+        if (MODE == MF_T2 && ((pd + 1 - kd) & 1)) continue;          // wave-uniform: tap does not hit this parity
+        for (int kh = 0; kh < 3; ++kh) {
+            if (MODE == MF_T2 && ((ph + 1 - kh) & 1)) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                if (MODE == MF_T2 && ((pw + 1 - kw) & 1)) continue;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                long long off[NT];
+                bool ok[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    int id, ih, iw;
+                    if (MODE == MF_S1) { id = cd[t] + kd - 1; ih = ch[t] + kh - 1; iw = cw[t] + kw - 1; }
+                    else if (MODE == MF_S2) { id = 2 * cd[t] + kd - 1; ih = 2 * ch[t] + kh - 1; iw = 2 * cw[t] + kw - 1; }
+                    else { id = cd[t] + ((pd + 1 - kd) >> 1); ih = ch[t] + ((ph + 1 - kh) >> 1); iw = cw[t] + ((pw + 1 - kw) >> 1); }
+                    ok[t] = cv[t] && id >= 0 && id < dm.D && ih >= 0 && ih < dm.H && iw >= 0 && iw < dm.W;
+                    off[t] = ((((long long)cb[t] * dm.D + id) * dm.H + ih) * dm.W + iw) * CIN + kq * VEC;
+                }
+                const float* wt = wbase + (long long)tap * W_TAP_STRIDE;
+#pragma unroll
+                for (int c = 0; c < CHUNKS; ++c) {
+                    float a[VEC];
+                    if (VEC == 4) {
+                        float4 a4 = *reinterpret_cast<const float4*>(wt + c * W_CHUNK_STRIDE);
+                        a[0] = a4.x; a[1] = a4.y; a[2 % VEC] = a4.z; a[3 % VEC] = a4.w;
+                    } else {
+                        float2 a2 = *reinterpret_cast<const float2*>(wt + c * W_CHUNK_STRIDE);
+                        a[0] = a2.x; a[1] = a2.y;
+                    }
+                    float bv[NT][VEC];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (VEC == 4) {
+                            float4 b4 = ok[t] ? *reinterpret_cast<const float4*>(x + off[t] + c * 4 * VEC) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            bv[t][0] = b4.x; bv[t][1] = b4.y; bv[t][2 % VEC] = b4.z; bv[t][3 % VEC] = b4.w;
+                        } else {
+                            float2 b2 = ok[t] ? *reinterpret_cast<const float2*>(x + off[t] + c * 4 * VEC) : make_float2(0.f, 0.f);
+                            bv[t][0] = b2.x; bv[t][1] = b2.y;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bv[t][j], acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: this lane owns output channels m0..m0+3 of cell n of every n-tile
+    const int m0 = mt * 16 + kq * 4;
+    if (m0 >= COUT) return;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) { sc = *reinterpret_cast<const float4*>(scale + m0); sh = *reinterpret_cast<const float4*>(shift + m0); }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!cv[t]) continue;
+        long long ov;
+        if (MODE == MF_T2)
+            ov = (((long long)cb[t] * dm.Do + 2 * cd[t] + pd) * dm.Ho + 2 * ch[t] + ph) * dm.Wo + 2 * cw[t] + pw;
+        else
+            ov = (((long long)cb[t] * dm.Do + cd[t]) * dm.Ho + ch[t]) * dm.Wo + cw[t];
+        float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if (scale) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (res) {
+            float4 r4 = *reinterpret_cast<const float4*>(res + ov * COUT + m0);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        *reinterpret_cast<float4*>(y + ov * COUT + m0) = v;
+    }
+}
+
+bool conv3d_mfma_supported(int Ci, int Co, int mode) {
+    (void)mode;
+    if (Co < 16 || (Co % 16)) return false;
+    return Ci == 8 || Ci == 16 || Ci == 32 || Ci == 64;
+}
+
+template <int MODE>
+static int mfma_dispatch(const float* x, const float* wm, const float* scale, const float* shift, const float* res,
+                         float* y, const MfmaDims& dm, int Ci, int Co, int relu, hipStream_t st) {
+    const long long ntiles = cdiv(dm.cells, 16);
+    // few tiles (deep U-Net levels): one n-tile per wave so that every SIMD gets work
+    const bool small = ntiles < 4096;
+    const int nt = small ? 1 : 4;
+    dim3 grid((unsigned)cdiv(ntiles, 4LL * nt), (Co + 15) / 16, MODE == MF_T2 ? 8 : 1), block(256);
+#define RCMVS_MFMA_CASE(CI, CO)                                                                                     \
+    if (Ci == CI && Co == CO) {                                                                                     \
+        if (small) hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
+        else       hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
+        return launch_status("conv3d_mfma");                                                                        \
+    }
+    RCMVS_MFMA_CASE(8, 16) RCMVS_MFMA_CASE(16, 16) RCMVS_MFMA_CASE(16, 32) RCMVS_MFMA_CASE(32, 32)
+    RCMVS_MFMA_CASE(32, 64) RCMVS_MFMA_CASE(64, 64) RCMVS_MFMA_CASE(64, 32) RCMVS_MFMA_CASE(32, 16)
+#undef RCMVS_MFMA_CASE
+    (void)nt;
+    return fail(-1, "conv3d_mfma: unsupported channel pair Ci=%d Co=%d", Ci, Co);
+}
+
+// mode: 0 stride-1 conv, 1 stride-2 conv, 2 transposed stride-2
+int conv3d_mfma_launch(const float* x, const float* wm, const float* scale, const float* shift, const float* res,
+                       float* y, int B, int D, int H, int W, int Ci, int Co, int mode, int relu, hipStream_t st) {
+    MfmaDims dm;
+    dm.B = B; dm.D = D; dm.H = H; dm.W = W;
+    if (mode == MF_T2) { dm.Dg = D; dm.Hg = H; dm.Wg = W; dm.Do = 2 * D; dm.Ho = 2 * H; dm.Wo = 2 * W; }
+    else {
+        int s = mode == MF_S2 ? 2 : 1;
+        dm.Do = (D - 1) / s + 1; dm.Ho = (H - 1) / s + 1; dm.Wo = (W - 1) / s + 1;
+        dm.Dg = dm.Do; dm.Hg = dm.Ho; dm.Wg = dm.Wo;
+    }
+    dm.cells = (long long)B * dm.Dg * dm.Hg * dm.Wg;
+    if (mode == MF_S1) return mfma_dispatch<MF_S1>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
+    if (mode == MF_S2) return mfma_dispatch<MF_S2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
+    return mfma_dispatch<MF_T2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
+}
+
+int pack_weight_mfma_launch(const float* w, float* packed, int Co, int Ci, int transposed, hipStream_t st) {
+    long long n = mfma_weight_floats(Ci, Co);
+    hipLaunchKernelGGL(pack_weight_mfma_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w, packed, Co, Ci, transposed);
+    return launch_status("pack_weight_mfma");
+}
+
+long long mfma_weight_floats_host(int Ci, int Co) { return mfma_weight_floats(Ci, Co); }
 
 }  // namespace rcmvs

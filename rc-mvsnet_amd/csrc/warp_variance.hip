@@ -81,7 +81,46 @@ __device__ __forceinline__ float4 bilerp4(const float* __restrict__ src, const W
     return r;
 }
 
-template <int C>
+// VARIANT: 0 = one tap computation per (lane, plane, view), exact arithmetic (bit-comparable with
+//              the oracle);
+//          4 = taps computed once per (pixel, plane, view) by ONE of the pixel's C/4 lanes and
+//              broadcast to the others with ds_bpermute (cross-lane, no LDS storage), exact;
+//          5 = 4 with FMA contraction in the bilinear blend and Markstein-style division by V
+//              (q = x*r; q += fma(-V,q,x)*r) instead of the IEEE sequence -- <= 1 ulp from 4;
+//          1,2,3 = ablations for profiling only (no gathers / no coordinate math / store only).
+template <bool FAST>
+__device__ __forceinline__ float4 bilerp4v(const float* __restrict__ src, int o0, int o1, int o2, int o3,
+                                           float w0, float w1, float w2, float w3) {
+    float4 a = *reinterpret_cast<const float4*>(src + o0);
+    float4 b = *reinterpret_cast<const float4*>(src + o1);
+    float4 c = *reinterpret_cast<const float4*>(src + o2);
+    float4 d = *reinterpret_cast<const float4*>(src + o3);
+    float4 r;
+    if (FAST) {
+        r.x = fmaf(d.x, w3, fmaf(c.x, w2, fmaf(b.x, w1, a.x * w0)));
+        r.y = fmaf(d.y, w3, fmaf(c.y, w2, fmaf(b.y, w1, a.y * w0)));
+        r.z = fmaf(d.z, w3, fmaf(c.z, w2, fmaf(b.z, w1, a.z * w0)));
+        r.w = fmaf(d.w, w3, fmaf(c.w, w2, fmaf(b.w, w1, a.w * w0)));
+    } else {
+#pragma clang fp contract(off)
+        r.x = ((a.x * w0 + b.x * w1) + c.x * w2) + d.x * w3;
+        r.y = ((a.y * w0 + b.y * w1) + c.y * w2) + d.y * w3;
+        r.z = ((a.z * w0 + b.z * w1) + c.z * w2) + d.z * w3;
+        r.w = ((a.w * w0 + b.w * w1) + c.w * w2) + d.w * w3;
+    }
+    return r;
+}
+
+template <bool FAST>
+__device__ __forceinline__ float div_by(float x, float fV, float rV) {
+    if (FAST) {
+        float q = x * rV;
+        return fmaf(fmaf(-fV, q, x), rV, q);
+    }
+    return x / fV;
+}
+
+template <int C, int VARIANT>
 __global__ __launch_bounds__(256) void warp_variance_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int tiles_y) {
@@ -89,14 +128,20 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(
     constexpr int LPP = C / 4;          // lanes per pixel
     constexpr int TW = 256 / C;         // pixels per wave = tile width  (1 KiB of output per plane)
     constexpr int TH = 4;               // one wave per tile row
+    constexpr bool SHARED = (VARIANT == 4 || VARIANT == 5);
+    constexpr bool FAST = (VARIANT == 5);
+    constexpr int ROUNDS = DK / LPP;    // planes whose taps one lane computes per view (SHARED)
     const int b = blockIdx.z;
     const int k0 = blockIdx.y * DK;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int q4 = (threadIdx.x % LPP) * 4;
-    const int x = tx * TW + (threadIdx.x / LPP) % TW;
-    const int y = ty * TH + threadIdx.x / (LPP * TW);
-    if (x >= w || y >= h) return;
+    const int lq = threadIdx.x % LPP;
+    const int q4 = lq * 4;
+    int x = tx * TW + (threadIdx.x / LPP) % TW;
+    int y = ty * TH + threadIdx.x / (LPP * TW);
+    const bool inside = (x < w) && (y < h);
+    if (!SHARED && !inside) return;
+    if (!inside) { x = w - 1; y = h - 1; }                     // SHARED: keep every lane alive for the shuffles
     const long long hw = (long long)h * w;
     const float fx = (float)x, fy = (float)y;
     const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
@@ -111,6 +156,8 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(
         s[k] = ref;
         sq[k] = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
     }
+    const int lane = threadIdx.x & 63;
+    const int grp = lane - lq;                                  // first lane of this pixel's group
     for (int v = 1; v < V; ++v) {
         const float* r = rot + ((long long)b * (V - 1) + (v - 1)) * 9;
         const float* t = trans + ((long long)b * (V - 1) + (v - 1)) * 3;
@@ -119,27 +166,79 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(
         const float rz = (r[6] * fx + r[7] * fy) + r[8];
         const float t0 = t[0], t1 = t[1], t2 = t[2];
         const float* src = fb + (long long)v * hw * C;
+        if (SHARED) {
+            // lane lq of the group computes planes k0 + lq + LPP*rr
+            int pk[ROUNDS];
+            float w0[ROUNDS], w1[ROUNDS], w2[ROUNDS], w3[ROUNDS];
 #pragma unroll
-        for (int k = 0; k < DK; ++k) {
-            const float d = pl.x + (float)(k0 + k) * pl.y;
-            WarpCoord tc = warp_taps(rx, ry, rz, t0, t1, t2, d, half_w, half_h, wm1, hm1, w, h, C);
-            float4 val = bilerp4(src, tc, q4);
-            s[k].x = s[k].x + val.x; s[k].y = s[k].y + val.y; s[k].z = s[k].z + val.z; s[k].w = s[k].w + val.w;
-            sq[k].x = sq[k].x + val.x * val.x; sq[k].y = sq[k].y + val.y * val.y;
-            sq[k].z = sq[k].z + val.z * val.z; sq[k].w = sq[k].w + val.w * val.w;
+            for (int rr = 0; rr < ROUNDS; ++rr) {
+                const float d = pl.x + (float)(k0 + lq + LPP * rr) * pl.y;
+                WarpCoord tc = warp_taps(rx, ry, rz, t0, t1, t2, d, half_w, half_h, wm1, hm1, w, h, C);
+                // off[1]-off[0] is 0 or C, off[2]-off[0] is 0 or w*C: two flag bits in the low bits of the
+                // base offset (a multiple of C >= 8)
+                pk[rr] = tc.off[0] | (tc.off[1] != tc.off[0] ? 1 : 0) | (tc.off[2] != tc.off[0] ? 2 : 0);
+                w0[rr] = tc.wgt[0]; w1[rr] = tc.wgt[1]; w2[rr] = tc.wgt[2]; w3[rr] = tc.wgt[3];
+            }
+#pragma unroll
+            for (int k = 0; k < DK; ++k) {
+                const int rr = k / LPP, sl = grp + (k % LPP);
+                const int pkk = __shfl(pk[rr], sl);
+                const float a0 = __shfl(w0[rr], sl), a1 = __shfl(w1[rr], sl), a2 = __shfl(w2[rr], sl), a3 = __shfl(w3[rr], sl);
+                const int o0 = (pkk & ~3) + q4;
+                const int dx = (pkk & 1) ? C : 0, dy = (pkk & 2) ? w * C : 0;
+                float4 val = bilerp4v<FAST>(src, o0, o0 + dx, o0 + dy, o0 + dy + dx, a0, a1, a2, a3);
+                if (FAST) {
+                    s[k].x += val.x; s[k].y += val.y; s[k].z += val.z; s[k].w += val.w;
+                    sq[k].x = fmaf(val.x, val.x, sq[k].x); sq[k].y = fmaf(val.y, val.y, sq[k].y);
+                    sq[k].z = fmaf(val.z, val.z, sq[k].z); sq[k].w = fmaf(val.w, val.w, sq[k].w);
+                } else {
+                    s[k].x = s[k].x + val.x; s[k].y = s[k].y + val.y; s[k].z = s[k].z + val.z; s[k].w = s[k].w + val.w;
+                    sq[k].x = sq[k].x + val.x * val.x; sq[k].y = sq[k].y + val.y * val.y;
+                    sq[k].z = sq[k].z + val.z * val.z; sq[k].w = sq[k].w + val.w * val.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DK; ++k) {
+                float4 val;
+                if (VARIANT == 3) {
+                    val = ref;
+                } else {
+                    const float d = pl.x + (float)(k0 + k) * pl.y;
+                    WarpCoord tc;
+                    if (VARIANT == 2) {                         // ablation: no coordinate math
+                        int o = ((y * w + x) * C);
+                        tc.off[0] = o; tc.off[1] = o; tc.off[2] = o; tc.off[3] = o;
+                        tc.wgt[0] = 0.25f + d * 0.0f; tc.wgt[1] = 0.25f; tc.wgt[2] = 0.25f; tc.wgt[3] = 0.25f;
+                    } else {
+                        tc = warp_taps(rx, ry, rz, t0, t1, t2, d, half_w, half_h, wm1, hm1, w, h, C);
+                    }
+                    if (VARIANT == 1) {                         // ablation: no gathers
+                        float sw = ((tc.wgt[0] + tc.wgt[1]) + tc.wgt[2]) + tc.wgt[3] + (float)(tc.off[0] & 1);
+                        val = make_float4(ref.x * sw, ref.y * sw, ref.z * sw, ref.w * sw);
+                    } else {
+                        val = bilerp4(src, tc, q4);
+                    }
+                }
+                s[k].x = s[k].x + val.x; s[k].y = s[k].y + val.y; s[k].z = s[k].z + val.z; s[k].w = s[k].w + val.w;
+                sq[k].x = sq[k].x + val.x * val.x; sq[k].y = sq[k].y + val.y * val.y;
+                sq[k].z = sq[k].z + val.z * val.z; sq[k].w = sq[k].w + val.w * val.w;
+            }
         }
     }
-    const float fV = (float)V;
+    if (!inside) return;
+    const float fV = (float)V, rV = 1.0f / fV;
     float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + q4;
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
         if (k0 + k < D) {
             float4 m, o;
-            m.x = s[k].x / fV; m.y = s[k].y / fV; m.z = s[k].z / fV; m.w = s[k].w / fV;
-            o.x = sq[k].x / fV - m.x * m.x;
-            o.y = sq[k].y / fV - m.y * m.y;
-            o.z = sq[k].z / fV - m.z * m.z;
-            o.w = sq[k].w / fV - m.w * m.w;
+            m.x = div_by<FAST>(s[k].x, fV, rV); m.y = div_by<FAST>(s[k].y, fV, rV);
+            m.z = div_by<FAST>(s[k].z, fV, rV); m.w = div_by<FAST>(s[k].w, fV, rV);
+            o.x = div_by<FAST>(sq[k].x, fV, rV) - m.x * m.x;
+            o.y = div_by<FAST>(sq[k].y, fV, rV) - m.y * m.y;
+            o.z = div_by<FAST>(sq[k].z, fV, rV) - m.z * m.z;
+            o.w = div_by<FAST>(sq[k].w, fV, rV) - m.w * m.w;
             *reinterpret_cast<float4*>(ob + (long long)(k0 + k) * hw * C) = o;
         }
     }
@@ -210,7 +309,11 @@ __global__ __launch_bounds__(256) void warp_noref_kernel(
 
 using namespace rcmvs;
 
+static int g_k1_variant = 0;     // profiling hook (rcmvs_debug_k1_variant)
+
 extern "C" {
+
+void rcmvs_debug_k1_variant(int v) { g_k1_variant = v; }
 
 int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                             const float* planes, float* var,
@@ -223,12 +326,25 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
     const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y, (D + DK - 1) / DK, B);
     hipStream_t st = as_stream(stream);
+#define RCMVS_K1_LAUNCH(CC, VV) hipLaunchKernelGGL((warp_variance_kernel<CC, VV>), grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y)
+#define RCMVS_K1_VARIANTS(CC)                                                               \
+    switch (g_k1_variant) {                                                                 \
+        case 0: RCMVS_K1_LAUNCH(CC, 0); break;                                              \
+        case 1: RCMVS_K1_LAUNCH(CC, 1); break;                                              \
+        case 2: RCMVS_K1_LAUNCH(CC, 2); break;                                              \
+        case 3: RCMVS_K1_LAUNCH(CC, 3); break;                                              \
+        case 4: RCMVS_K1_LAUNCH(CC, 4); break;                                              \
+        case 5: RCMVS_K1_LAUNCH(CC, 5); break;                                              \
+        default: return fail(-1, "warp_variance_fwd: unknown debug variant %d", g_k1_variant); \
+    }
     switch (C) {
-        case 8:  hipLaunchKernelGGL(warp_variance_kernel<8>,  grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y); break;
-        case 16: hipLaunchKernelGGL(warp_variance_kernel<16>, grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y); break;
-        case 32: hipLaunchKernelGGL(warp_variance_kernel<32>, grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y); break;
+        case 8:  RCMVS_K1_VARIANTS(8) break;
+        case 16: RCMVS_K1_VARIANTS(16) break;
+        case 32: RCMVS_K1_VARIANTS(32) break;
         default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
     }
+#undef RCMVS_K1_VARIANTS
+#undef RCMVS_K1_LAUNCH
     return launch_status("warp_variance_fwd");
 }
 

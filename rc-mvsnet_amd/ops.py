@@ -105,27 +105,41 @@ def warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first):
 
 
 # ------------------------------------------------------------------------------- K2/K3
+class PackedWeight:
+    """Device blob produced by rcmvs_pack_conv3d_weight plus its channel counts."""
+    __slots__ = ("blob", "ci", "co")
+
+    def __init__(self, blob, ci, co):
+        self.blob, self.ci, self.co = blob, ci, co
+
+
+def force_direct_conv(on):
+    """test/bench hook: route every 3-D conv through the direct (non-MFMA) kernels."""
+    _lib.load().rcmvs_debug_force_direct_conv(int(bool(on)))
+
+
 def pack_conv3d_weight(w, transposed=False):
-    """conv (Co,Ci,3,3,3) / deconv (Ci,Co,3,3,3) -> packed (27,Ci,Co)."""
+    """conv (Co,Ci,3,3,3) / deconv (Ci,Co,3,3,3) -> PackedWeight (direct [27][Ci][Co] + MFMA image)."""
     w = w.detach().contiguous().float()
     Ci, Co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-    packed = torch.empty((27, Ci, Co), device=w.device, dtype=torch.float32)
-    _lib.check(_lib.load().rcmvs_pack_conv3d_weight(_chk(w, "w"), _chk(packed, "packed"), Co, Ci, int(transposed), _stream()),
+    n = _lib.load().rcmvs_packed_weight_floats(Co, Ci)
+    blob = torch.empty((n,), device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_pack_conv3d_weight(_chk(w, "w"), _chk(blob, "packed"), Co, Ci, int(transposed), _stream()),
                "pack_conv3d_weight")
-    return packed
+    return PackedWeight(blob, Ci, Co)
 
 
 def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False):
     """x (B,D,H,W,Ci) -> (B,Do,Ho,Wo,Co) with fused [relu](v*scale+shift) + residual."""
     B, D, H, W, Ci = x.shape
-    Co = w_packed.shape[2]
-    if w_packed.shape[1] != Ci:
-        raise _lib.RcmvsError(f"conv3d: input has {Ci} channels, weight expects {w_packed.shape[1]}")
+    Co = w_packed.co
+    if w_packed.ci != Ci:
+        raise _lib.RcmvsError(f"conv3d: input has {Ci} channels, weight expects {w_packed.ci}")
     y = torch.empty((B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1, Co), device=x.device,
                     dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"conv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
-    _lib.check(_lib.load().rcmvs_conv3d_fwd(_chk(x, "x"), _chk(w_packed, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+    _lib.check(_lib.load().rcmvs_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                             _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
                                             _stream()), "conv3d_fwd")
     return y
@@ -134,14 +148,14 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
 def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     """x (B,D,H,W,Ci) -> (B,2D,2H,2W,Co)."""
     B, D, H, W, Ci = x.shape
-    Co = w_packed.shape[2]
-    if w_packed.shape[1] != Ci:
-        raise _lib.RcmvsError(f"deconv3d: input has {Ci} channels, weight expects {w_packed.shape[1]}")
+    Co = w_packed.co
+    if w_packed.ci != Ci:
+        raise _lib.RcmvsError(f"deconv3d: input has {Ci} channels, weight expects {w_packed.ci}")
     y = torch.empty((B, 2 * D, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"deconv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)} "
                               "(volume sizes must be divisible by 8, as in the reference)")
-    _lib.check(_lib.load().rcmvs_deconv3d_fwd(_chk(x, "x"), _chk(w_packed, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+    _lib.check(_lib.load().rcmvs_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                               _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
                                               _stream()), "deconv3d_fwd")
     return y
@@ -156,7 +170,7 @@ def depth_head(x8, w_prob_packed, planes, want_prob=False):
     depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32) if want_prob else None
-    _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed, "w_prob"), _chk(planes, "planes"),
+    _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
                                                 _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
                                                 _stream()), "depth_head_fwd")
     return (depth, conf, prob) if want_prob else (depth, conf)

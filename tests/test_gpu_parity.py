@@ -142,7 +142,71 @@ def test_warp_variance_properties_full_size(hip):
         assert float(v0.abs().max()) < 1e-5
 
 
+def test_warp_variance_variants_agree(hip):
+    """K1 code variants: tap sharing by cross-lane broadcast (4) must be bit-identical to the plain
+    kernel (0); the FMA / fast-division build (5) must stay within a few ulp."""
+    from rc_mvsnet_amd import _lib, synthetic
+    lib = _lib.load()
+    try:
+        for (C, D, h, w, V) in ((32, 16, 20, 37, 3), (16, 8, 33, 50, 4), (8, 24, 30, 70, 2)):
+            g = torch.Generator().manual_seed(C + V)
+            feats = gpu(torch.randn(2, V, h, w, C, generator=g))
+            pm = gpu(synthetic.proj_matrices(2, V, h * 4, w * 4)["stage1"])
+            rot, trans = hip.compose_homography(pm)
+            planes = gpu(torch.stack((425.0 + 100.0 * torch.rand(2, h, w, generator=g), 2.0 + 8.0 * torch.rand(2, h, w, generator=g)), dim=-1))
+            lib.rcmvs_debug_k1_variant(0)
+            v0 = hip.warp_variance(feats, rot, trans, planes, D)
+            lib.rcmvs_debug_k1_variant(4)
+            v4 = hip.warp_variance(feats, rot, trans, planes, D)
+            lib.rcmvs_debug_k1_variant(5)
+            v5 = hip.warp_variance(feats, rot, trans, planes, D)
+            assert torch.equal(v0, v4)
+            err = float((v5 - v0).abs().max()) / max(1.0, float(v0.abs().max()))
+            print(f"K1 variant 5 vs 0: max rel {err:.2e}")
+            assert err < 2e-6
+    finally:
+        lib.rcmvs_debug_k1_variant(0)
+
+
 # ------------------------------------------------------------------------------------------ K2/K3
+@pytest.mark.parametrize("Ci,Co,mode", [(8, 16, "s2"), (16, 16, "s1"), (16, 32, "s2"), (32, 32, "s1"), (32, 64, "s2"),
+                                        (64, 64, "s1"), (64, 32, "t2"), (32, 16, "t2")])
+@pytest.mark.parametrize("big", [False, True])
+def test_conv3d_mfma_matches_direct(hip, Ci, Co, mode, big):
+    """The MFMA implicit-GEMM kernels against the direct kernels (themselves checked against the
+    oracle): both tile shapes (one / four n-tiles per wave), ragged last tile, all epilogue parts."""
+    g = torch.Generator().manual_seed(Ci + Co)
+    shape = (1, 18, 61, 64) if big else (2, 5, 7, 9)            # big: >= 4096 n-tiles for the conv modes
+    if big and mode == "t2":
+        shape = (1, 17, 62, 64)
+    x = gpu(torch.randn(*shape, Ci, generator=g))
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+    if mode == "t2":
+        w = w.permute(1, 0, 2, 3, 4).contiguous()
+    wp = hip.pack_conv3d_weight(gpu(w), transposed=(mode == "t2"))
+    scale, shift = gpu(0.5 + torch.rand(Co, generator=g)), gpu(0.1 * torch.randn(Co, generator=g))
+
+    def run():
+        if mode == "t2":
+            y = hip.deconv3d(x, wp)
+            res = torch.ones_like(y) * 0.25
+            return y, hip.deconv3d(x, wp, scale, shift, res, relu=True)
+        st = 2 if mode == "s2" else 1
+        y = hip.conv3d(x, wp, stride=st)
+        res = torch.ones_like(y) * 0.25
+        return y, hip.conv3d(x, wp, scale, shift, res, stride=st, relu=True)
+
+    try:
+        hip.force_direct_conv(True)
+        d_plain, d_full = run()
+    finally:
+        hip.force_direct_conv(False)
+    m_plain, m_full = run()
+    assert m_plain.shape == d_plain.shape
+    assert rel_err(m_plain.cpu(), d_plain.cpu()) < 1e-5
+    assert rel_err(m_full.cpu(), d_full.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("Ci,Co,stride", [(8, 8, 1), (32, 8, 1), (16, 16, 1), (32, 32, 1), (64, 64, 1), (8, 1, 1),
                                           (8, 16, 2), (16, 32, 2), (32, 64, 2), (41, 8, 1)])
 def test_conv3d_vs_oracle(hip, Ci, Co, stride):
