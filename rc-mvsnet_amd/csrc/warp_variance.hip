@@ -245,6 +245,185 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 v6: two-phase, plane-major.
+//   Phase A  every (pixel, plane, view) of the block's tile is handled by exactly one thread: the
+//            full coordinate chain runs once (not once per channel lane) and leaves
+//            {packed base offset, 4 masked weights} in LDS (structure-of-arrays, conflict-free).
+//   Phase B  thread = (pixel, channel quad); for each plane: start from the reference value, add
+//            every source view's bilinear sample (tap data broadcast-read from LDS, four 16-byte
+//            gathers), form the variance and STORE THE PLANE IMMEDIATELY -- stores are spread over
+//            the whole kernel and only 8 accumulator registers are live, so many waves fit and the
+//            HBM write stream overlaps the arithmetic of other waves.
+// Division: IEEE-correct quotients without the compiler's div_scale/div_fmas/div_fixup sequence
+//   (and its denormal-mode switches): v_rcp_f32 refined by one Newton step, then two
+//   fma-residual corrections of the quotient (Markstein).  The operands here are far from the
+//   exponent limits, which is all the omitted scaling protects against; b == 0 yields NaN and
+//   the tap is dropped exactly like the reference's inf coordinate.
+// Source views are processed in chunks of VC (LDS budget); with more than one chunk the per-plane
+//   sums persist in registers across chunks (T&T, 6 source views at C = 8).
+// ------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float rcp_nr(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    float e = fmaf(-b, r, 1.0f);
+    return fmaf(e, r, r);
+}
+// correctly rounded a / b given r ~ 1/b (rcp_nr)
+__device__ __forceinline__ float div_cr(float a, float b, float r) {
+    float q = a * r;
+    float rem = fmaf(-b, q, a);
+    q = fmaf(rem, r, q);
+    rem = fmaf(-b, q, a);
+    return fmaf(rem, r, q);
+}
+
+struct TapPack { int pk; float w0, w1, w2, w3; };
+
+__device__ __forceinline__ TapPack warp_taps_fastdiv(float rx, float ry, float rz, float tx, float ty, float tz, float d,
+                                                    float half_w, float half_h, float r_half_w, float r_half_h,
+                                                    float wm1, float hm1, int w, int C) {
+#pragma clang fp contract(off)
+    float px = rx * d + tx;
+    float py = ry * d + ty;
+    float pz = rz * d + tz;
+    float rpz = rcp_nr(pz);
+    float u = div_cr(px, pz, rpz);
+    float v = div_cr(py, pz, rpz);
+    float gx = div_cr(u, half_w, r_half_w) - 1.0f;
+    float gy = div_cr(v, half_h, r_half_h) - 1.0f;
+    float ix = ((gx + 1.0f) * 0.5f) * wm1;
+    float iy = ((gy + 1.0f) * 0.5f) * hm1;
+    float x0 = floorf(ix), y0 = floorf(iy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    float wx1 = ix - x0, wx0 = x1 - ix;
+    float wy1 = iy - y0, wy0 = y1 - iy;
+    bool vx0 = (x0 >= 0.0f) && (x0 <= wm1);
+    bool vx1 = (x1 >= 0.0f) && (x1 <= wm1);
+    bool vy0 = (y0 >= 0.0f) && (y0 <= hm1);
+    bool vy1 = (y1 >= 0.0f) && (y1 <= hm1);
+    int xi0 = (int)fminf(fmaxf(x0, 0.0f), wm1);
+    int xi1 = (int)fminf(fmaxf(x1, 0.0f), wm1);
+    int yi0 = (int)fminf(fmaxf(y0, 0.0f), hm1);
+    int yi1 = (int)fminf(fmaxf(y1, 0.0f), hm1);
+    TapPack t;
+    // base offset is a multiple of C >= 8: two flag bits ride in its low bits (x step, y step)
+    t.pk = ((yi0 * w + xi0) * C) | (xi1 != xi0 ? 1 : 0) | (yi1 != yi0 ? 2 : 0);
+    t.w0 = (vx0 && vy0) ? wx0 * wy0 : 0.0f;
+    t.w1 = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
+    t.w2 = (vx0 && vy1) ? wx0 * wy1 : 0.0f;
+    t.w3 = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
+    return t;
+}
+
+template <int C, int TH, bool NT, bool FAST, bool MULTI>
+__global__ __launch_bounds__(256) void warp_variance_v6_kernel(
+    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
+#pragma clang fp contract(off)
+    constexpr int LPP = C / 4;
+    constexpr int PIX = 256 / LPP;      // pixels per block
+    constexpr int TW = PIX / TH;
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];   // [VC][5][DK][PIX]
+    float* lds_f = reinterpret_cast<float*>(lds_i);
+    const int b = blockIdx.z;
+    const int k0 = blockIdx.y * DK;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const long long hw = (long long)h * w;
+    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
+    const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
+    const float r_half_w = rcp_nr(half_w), r_half_h = rcp_nr(half_h);
+    const float* fb = feats + (long long)b * V * hw * C;
+    const float2* plb = reinterpret_cast<const float2*>(planes) + (long long)b * hw;
+
+    // phase-B identity of this thread
+    const int p = threadIdx.x / LPP;
+    const int q4 = (threadIdx.x % LPP) * 4;
+    const int x = tx0 + p % TW, y = ty0 + p / TW;
+    const bool inside = (x < w) && (y < h);
+    float4 ref = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) ref = *reinterpret_cast<const float4*>(fb + ((long long)y * w + x) * C + q4);
+    const float fV = (float)V, rV = rcp_nr(fV);
+    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + q4;
+
+    float4 s[MULTI ? DK : 1], sq[MULTI ? DK : 1];
+    if (MULTI) {
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+            s[k] = ref;
+            sq[k] = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
+        }
+    }
+
+    for (int v0 = 1; v0 < V; v0 += VC) {
+        const int nv = min(VC, V - v0);
+        if (MULTI && v0 > 1) __syncthreads();                   // LDS reuse across chunks
+        // ---------------- phase A: one (pixel, plane, view) per thread-iteration
+        for (int i = threadIdx.x; i < PIX * DK * nv; i += 256) {
+            const int pa = i % PIX, ka = (i / PIX) % DK, va = i / (PIX * DK);
+            int xa = tx0 + pa % TW, ya = ty0 + pa / TW;
+            xa = min(xa, w - 1); ya = min(ya, h - 1);
+            const float fx = (float)xa, fy = (float)ya;
+            const float* r = rot + ((long long)b * (V - 1) + (v0 + va - 1)) * 9;
+            const float* t = trans + ((long long)b * (V - 1) + (v0 + va - 1)) * 3;
+            const float rx = (r[0] * fx + r[1] * fy) + r[2];
+            const float ry = (r[3] * fx + r[4] * fy) + r[5];
+            const float rz = (r[6] * fx + r[7] * fy) + r[8];
+            const float2 pl = plb[(long long)ya * w + xa];
+            const float d = pl.x + (float)(k0 + ka) * pl.y;
+            TapPack tp = warp_taps_fastdiv(rx, ry, rz, t[0], t[1], t[2], d, half_w, half_h, r_half_w, r_half_h, wm1, hm1, w, C);
+            const int base = ((va * 5) * DK + ka) * PIX + pa;
+            lds_i[base] = tp.pk;
+            lds_f[base + 1 * DK * PIX] = tp.w0;
+            lds_f[base + 2 * DK * PIX] = tp.w1;
+            lds_f[base + 3 * DK * PIX] = tp.w2;
+            lds_f[base + 4 * DK * PIX] = tp.w3;
+        }
+        __syncthreads();
+        // ---------------- phase B: plane-major accumulation
+        if (inside) {
+#pragma unroll
+            for (int k = 0; k < DK; ++k) {
+                float4 a, a2;
+                if (MULTI) { a = s[k]; a2 = sq[k]; }
+                else { a = ref; a2 = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w); }
+                for (int va = 0; va < nv; ++va) {
+                    const int base = ((va * 5) * DK + k) * PIX + p;
+                    const int pk = lds_i[base];
+                    const float w0 = lds_f[base + 1 * DK * PIX], w1 = lds_f[base + 2 * DK * PIX];
+                    const float w2 = lds_f[base + 3 * DK * PIX], w3 = lds_f[base + 4 * DK * PIX];
+                    const float* src = fb + (long long)(v0 + va) * hw * C;
+                    const int o0 = (pk & ~3) + q4;
+                    const int dx = (pk & 1) ? C : 0, dy = (pk & 2) ? w * C : 0;
+                    float4 val = bilerp4v<FAST>(src, o0, o0 + dx, o0 + dy, o0 + dy + dx, w0, w1, w2, w3);
+                    if (FAST) {
+                        a.x += val.x; a.y += val.y; a.z += val.z; a.w += val.w;
+                        a2.x = fmaf(val.x, val.x, a2.x); a2.y = fmaf(val.y, val.y, a2.y);
+                        a2.z = fmaf(val.z, val.z, a2.z); a2.w = fmaf(val.w, val.w, a2.w);
+                    } else {
+                        a.x = a.x + val.x; a.y = a.y + val.y; a.z = a.z + val.z; a.w = a.w + val.w;
+                        a2.x = a2.x + val.x * val.x; a2.y = a2.y + val.y * val.y;
+                        a2.z = a2.z + val.z * val.z; a2.w = a2.w + val.w * val.w;
+                    }
+                }
+                if (MULTI && v0 + nv < V) { s[k] = a; sq[k] = a2; continue; }
+                if (k0 + k < D) {
+                    float mx = div_cr(a.x, fV, rV), my = div_cr(a.y, fV, rV), mz = div_cr(a.z, fV, rV), mw = div_cr(a.w, fV, rV);
+                    v4f o;
+                    o.x = div_cr(a2.x, fV, rV) - mx * mx;
+                    o.y = div_cr(a2.y, fV, rV) - my * my;
+                    o.z = div_cr(a2.z, fV, rV) - mz * mz;
+                    o.w = div_cr(a2.w, fV, rV) - mw * mw;
+                    v4f* dst = reinterpret_cast<v4f*>(ob + (long long)(k0 + k) * hw * C);
+                    if (NT) __builtin_nontemporal_store(o, dst); else *dst = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // train-variant extra: warped RGB of every source view ++ source-only variance / V, written in
 // the reference's NCDHW layout because the tensor crosses the module boundary
 // (CascadeMVSNet.forward returns it, models/casmvsnet.py:231).  One thread per (pixel, plane).
@@ -326,6 +505,32 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
     const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y, (D + DK - 1) / DK, B);
     hipStream_t st = as_stream(stream);
+    if (g_k1_variant >= 6 && g_k1_variant <= 13) {
+        const int opt = g_k1_variant - 6;
+        const int th = (opt & 1) ? 1 : 4;
+        const bool nt = opt & 2, fastm = opt & 4;
+        const int LPP = C / 4, PIX = 256 / LPP;
+        const size_t per_view = (size_t)5 * DK * PIX * sizeof(float);
+        int VC = (int)((64 * 1024) / per_view);
+        if (VC > V - 1) VC = V - 1;
+        const bool multi = VC < V - 1;
+        const size_t lds = per_view * VC;
+        const int TW6 = PIX / th;
+        const int tx6 = (w + TW6 - 1) / TW6, ty6 = (h + th - 1) / th;
+        dim3 grid6(tx6 * ty6, (D + DK - 1) / DK, B);
+#define RCMVS_K1V6(CC, TT, NN, FF, MM) hipLaunchKernelGGL((warp_variance_v6_kernel<CC, TT, NN, FF, MM>), grid6, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, tx6, VC)
+#define RCMVS_K1V6_M(CC, TT, NN, FF) do { if (multi) RCMVS_K1V6(CC, TT, NN, FF, true); else RCMVS_K1V6(CC, TT, NN, FF, false); } while (0)
+#define RCMVS_K1V6_F(CC, TT, NN) do { if (fastm) RCMVS_K1V6_M(CC, TT, NN, true); else RCMVS_K1V6_M(CC, TT, NN, false); } while (0)
+#define RCMVS_K1V6_N(CC, TT) do { if (nt) RCMVS_K1V6_F(CC, TT, true); else RCMVS_K1V6_F(CC, TT, false); } while (0)
+#define RCMVS_K1V6_T(CC) do { if (th == 1) RCMVS_K1V6_N(CC, 1); else RCMVS_K1V6_N(CC, 4); } while (0)
+        switch (C) {
+            case 8:  RCMVS_K1V6_T(8); break;
+            case 16: RCMVS_K1V6_T(16); break;
+            case 32: RCMVS_K1V6_T(32); break;
+            default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+        }
+        return launch_status("warp_variance_fwd(v6)");
+    }
 #define RCMVS_K1_LAUNCH(CC, VV) hipLaunchKernelGGL((warp_variance_kernel<CC, VV>), grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y)
 #define RCMVS_K1_VARIANTS(CC)                                                               \
     switch (g_k1_variant) {                                                                 \

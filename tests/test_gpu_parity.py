@@ -164,6 +164,15 @@ def test_warp_variance_variants_agree(hip):
             err = float((v5 - v0).abs().max()) / max(1.0, float(v0.abs().max()))
             print(f"K1 variant 5 vs 0: max rel {err:.2e}")
             assert err < 2e-6
+            for var in range(6, 14):          # v6 family: LDS tap table, plane-major, custom exact division
+                lib.rcmvs_debug_k1_variant(var)
+                vv = hip.warp_variance(feats, rot, trans, planes, D)
+                err = float((vv - v0).abs().max()) / max(1.0, float(v0.abs().max()))
+                exact = float((vv == v0).float().mean())
+                print(f"K1 variant {var} vs 0: max rel {err:.2e} bit-identical fraction {exact:.6f}")
+                assert err < 2e-6
+                if not (var - 6) & 4:          # the non-FMA builds are expected to be bit-identical
+                    assert exact > 0.9999
     finally:
         lib.rcmvs_debug_k1_variant(0)
 

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Diagnostic: error of the delegated FeatureNet (PyTorch-ROCm / MIOpen) against the CPU oracle at
+small and BASELINE config-2 sizes, and per-stage depth error of the cascade vs the reference golden."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from conftest import load_golden
+from rc_mvsnet_amd import synthetic
+from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+from oracle.feature_net import feature_net
+dev = "cuda:0"
+sd = synthetic.cascade_state_dict(0)
+m = CascadeMVSNet_eval(); m.load_state_dict(sd, strict=True); m = m.to(dev).eval()
+for (H, W) in ((64, 96), (512, 640)):
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, H, W, 0)
+    with torch.no_grad():
+        ref = feature_net(imgs[:, 1], sd)
+        out = m.feature(imgs[:, 1].to(dev))
+        outb = m.feature(imgs.reshape(3, 3, H, W).to(dev))
+    for k in ref:
+        e = (out[k].cpu() - ref[k]).abs(); eb = (outb[k][1:2].cpu() - ref[k]).abs()
+        print(f"{H}x{W} {k}: max|ref| {float(ref[k].abs().max()):.3f}  single max err {float(e.max()):.3e} mean {float(e.mean()):.3e} | batched max err {float(eb.max()):.3e}")
+g = load_golden("cascade_c2")
+imgs, pm, dv = synthetic.cascade_inputs(1, 3, 512, 640, 0)
+with torch.no_grad():
+    out = m(imgs.to(dev), {k: v.to(dev) for k, v in pm.items()}, dv.to(dev))
+for name, key in (("stage1", "depth1"), ("stage2", "depth2")):
+    d = (out[name]["depth"].cpu() - g[key]).abs()
+    print(name, "max %.3e mean %.3e unstable>0.05 %.4f" % (float(d.max()), float(d.mean()), float((d > 0.05).float().mean())))
+d = (out["depth"].cpu() - g["depth"]).abs()
+print("stage3 max %.3e mean %.3e unstable>0.05 %.4f" % (float(d.max()), float(d.mean()), float((d > 0.05).float().mean())))

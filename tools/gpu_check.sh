@@ -13,7 +13,9 @@ PY
 echo "== pytest -m gpu"
 timeout 900 python -m pytest tests -q -m gpu -s -p no:cacheprovider 2>&1 | tail -60 | tee gpurun_out/pytest_gpu.log
 echo "== k1 ablation"
-timeout 300 python tools/k1_ablate.py 2>&1 | tail -30 | tee gpurun_out/k1_ablate.log
+timeout 300 python tools/k1_ablate.py 2>&1 | tail -50 | tee gpurun_out/k1_ablate.log
+echo "== featnet diag"
+timeout 300 python tools/featnet_diag.py 2>&1 | grep -v "^\*\*\*" | tail -12 | tee gpurun_out/featnet_diag.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 echo "== bench"

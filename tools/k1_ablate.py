@@ -10,8 +10,9 @@ lib = _lib.load()
 dev = "cuda:0"
 V, H, W = 3, 512, 640
 names = {0: "v0 exact/per-lane", 1: "abl: no gather", 2: "abl: no coord math", 3: "abl: store only",
-         4: "v4 shared taps", 5: "v5 shared+fma+fastdiv"}
-variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 5]
+         4: "v4 shared taps", 5: "v5 shared+fma+fastdiv", 6: "v6 th4", 7: "v6 th1", 8: "v6 th4 nt", 9: "v6 th1 nt",
+         10: "v6 th4 fma", 11: "v6 th1 fma", 12: "v6 th4 nt fma", 13: "v6 th1 nt fma", 100: "torch zero_ (memset)"}
+variants = [int(a) for a in sys.argv[1:]] or [0, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 100]
 dv = synthetic.depth_values(1).to(dev)
 tot = {v: 0.0 for v in variants}
 for (C, D, sc, key) in ((32, 48, 4, "stage1"), (16, 32, 2, "stage2"), (8, 8, 1, "stage3")):
@@ -25,16 +26,21 @@ for (C, D, sc, key) in ((32, 48, 4, "stage1"), (16, 32, 2, "stage2"), (8, 8, 1, 
         prev = (600.0 + 100.0 * torch.rand(1, h // 2, w // 2, generator=g)).to(dev)
         planes = ops.hypothesis_planes(prev, dv, (H, W), sc, D, float(sc))
     nbytes = 4 * ((V - 1) * C * h * w + C * h * w + D * h * w + C * D * h * w)
+    outbuf = torch.empty((1, D, h, w, C), device=dev)
     for v in variants:
-        lib.rcmvs_debug_k1_variant(v)
+        if v == 100:
+            run = lambda: outbuf.zero_()
+        else:
+            lib.rcmvs_debug_k1_variant(v)
+            run = lambda: ops.warp_variance(feats, rot, trans, planes, D)
         for _ in range(3):
-            ops.warp_variance(feats, rot, trans, planes, D)
+            run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         R = 20
         for _ in range(R):
-            ops.warp_variance(feats, rot, trans, planes, D)
+            run()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / R
