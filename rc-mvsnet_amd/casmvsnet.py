@@ -371,11 +371,14 @@ class _CascadeBase(nn.Module):
         return self.cost_regularization if self.share_cr else self.cost_regularization[s]
 
     # ---------------------------------------------------------------- native inference path
-    def _forward_hip(self, imgs, proj_matrices, depth_values):
+    def _forward_hip(self, imgs, proj_matrices, depth_values, features=None, homographies=None):
+        """Test hooks: `features` {'stageK': (B*V, C, h, w)} bypasses the feature pyramid;
+        `homographies` {'stageK': (rot (B,V-1,9), trans (B,V-1,3))} bypasses the fp64 composer (to
+        feed the hot path the reference's own fp32 values)."""
         B, V, _, H, W = imgs.shape
         imgs = imgs.float()
         depth_values = depth_values.contiguous().float()
-        feats = self.feature(imgs.reshape(B * V, 3, H, W))          # eval-mode BN: batching over views is exact
+        feats = features if features is not None else self.feature(imgs.reshape(B * V, 3, H, W))   # eval BN: batching over views is exact
         outputs = {}
         depth = None
         for s in range(self.num_stage):
@@ -385,7 +388,10 @@ class _CascadeBase(nn.Module):
             f = feats[key]
             C, h, w = f.shape[1:]
             f_cl = ops.to_channels_last(f.contiguous()).view(B, V, h, w, C)
-            rot, trans = ops.compose_homography(proj_matrices[key].contiguous().float())
+            if homographies is not None:
+                rot, trans = homographies[key]
+            else:
+                rot, trans = ops.compose_homography(proj_matrices[key].contiguous().float())
             planes = ops.hypothesis_planes(depth, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
             var = ops.warp_variance(f_cl, rot, trans, planes, D)
             cr = self._cr(s)
