@@ -7,15 +7,14 @@
 //
 // Mapping (wave = 64 lanes): channels-last everywhere.  A pixel's C channels are handled by
 // C/4 adjacent lanes (one float4 each), a wave covers 1024 B of contiguous output per plane
-// (256/C pixels of one image row), a 256-thread block covers a 4-row tile, and each thread keeps
-// DK = 8 planes x 4 channels of {sum, square-sum} in registers while it loops over the source
-// views -- so every bilinear tap is a 16-byte load of 4 channels and the output store of a wave
-// is one fully coalesced 1 KiB line.
+// (256/C pixels of one image row) and a 256-thread block covers a 4-row tile x 8 (4 for C=8)
+// planes, so every bilinear tap is a 16-byte load of 4 channels and the output store of a wave
+// is one fully coalesced 1 KiB line.  See warp_variance_tp_kernel for the two-phase structure.
 //
-// Numerics: the coordinate chain and the accumulation are compiled with fp contraction OFF and
-// IEEE division, in the operation order of oracle/warp.py (itself the reference's op order), so
-// the kernel is bit-comparable with the oracle; taps outside the source image, and non-finite
-// coordinates (z == 0), contribute zero (grid_sample zeros padding, CUDA/HIP semantics).
+// Numerics: the coordinate chain and the accumulation follow the operation order of
+// oracle/warp.py (itself the reference's op order) with fp contraction OFF and correctly rounded
+// divisions, so the kernel is bit-comparable with the oracle; taps outside the source image, and
+// non-finite coordinates (z == 0), contribute zero (grid_sample zeros padding, CUDA/HIP semantics).
 #include "common.h"
 
 namespace rcmvs {
@@ -81,73 +80,31 @@ __device__ __forceinline__ float4 bilerp4(const float* __restrict__ src, const W
     return r;
 }
 
-// VARIANT: 0 = one tap computation per (lane, plane, view), exact arithmetic (bit-comparable with
-//              the oracle);
-//          4 = taps computed once per (pixel, plane, view) by ONE of the pixel's C/4 lanes and
-//              broadcast to the others with ds_bpermute (cross-lane, no LDS storage), exact;
-//          5 = 4 with FMA contraction in the bilinear blend and Markstein-style division by V
-//              (q = x*r; q += fma(-V,q,x)*r) instead of the IEEE sequence -- <= 1 ulp from 4;
-//          1,2,3 = ablations for profiling only (no gathers / no coordinate math / store only).
-template <bool FAST>
-__device__ __forceinline__ float4 bilerp4v(const float* __restrict__ src, int o0, int o1, int o2, int o3,
-                                           float w0, float w1, float w2, float w3) {
-    float4 a = *reinterpret_cast<const float4*>(src + o0);
-    float4 b = *reinterpret_cast<const float4*>(src + o1);
-    float4 c = *reinterpret_cast<const float4*>(src + o2);
-    float4 d = *reinterpret_cast<const float4*>(src + o3);
-    float4 r;
-    if (FAST) {
-        r.x = fmaf(d.x, w3, fmaf(c.x, w2, fmaf(b.x, w1, a.x * w0)));
-        r.y = fmaf(d.y, w3, fmaf(c.y, w2, fmaf(b.y, w1, a.y * w0)));
-        r.z = fmaf(d.z, w3, fmaf(c.z, w2, fmaf(b.z, w1, a.z * w0)));
-        r.w = fmaf(d.w, w3, fmaf(c.w, w2, fmaf(b.w, w1, a.w * w0)));
-    } else {
-#pragma clang fp contract(off)
-        r.x = ((a.x * w0 + b.x * w1) + c.x * w2) + d.x * w3;
-        r.y = ((a.y * w0 + b.y * w1) + c.y * w2) + d.y * w3;
-        r.z = ((a.z * w0 + b.z * w1) + c.z * w2) + d.z * w3;
-        r.w = ((a.w * w0 + b.w * w1) + c.w * w2) + d.w * w3;
-    }
-    return r;
-}
-
-template <bool FAST>
-__device__ __forceinline__ float div_by(float x, float fV, float rV) {
-    if (FAST) {
-        float q = x * rV;
-        return fmaf(fmaf(-fV, q, x), rV, q);
-    }
-    return x / fV;
-}
-
-template <int C, int VARIANT>
-__global__ __launch_bounds__(256) void warp_variance_kernel(
+// Reference-order kernel (debug variant 2): every lane runs the full coordinate chain for its own
+// (plane, view) with the compiler's IEEE division -- the straightforward transcription of
+// oracle/warp.py that the production kernel below is checked against bit for bit.
+// STORE_ONLY (debug variant 3) is a profiling ablation: no warp, just the output stream.
+template <int C, bool STORE_ONLY>
+__global__ __launch_bounds__(256) void warp_variance_ref_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int tiles_y) {
 #pragma clang fp contract(off)
     constexpr int LPP = C / 4;          // lanes per pixel
     constexpr int TW = 256 / C;         // pixels per wave = tile width  (1 KiB of output per plane)
     constexpr int TH = 4;               // one wave per tile row
-    constexpr bool SHARED = (VARIANT == 4 || VARIANT == 5);
-    constexpr bool FAST = (VARIANT == 5);
-    constexpr int ROUNDS = DK / LPP;    // planes whose taps one lane computes per view (SHARED)
     const int b = blockIdx.z;
     const int k0 = blockIdx.y * DK;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int lq = threadIdx.x % LPP;
-    const int q4 = lq * 4;
-    int x = tx * TW + (threadIdx.x / LPP) % TW;
-    int y = ty * TH + threadIdx.x / (LPP * TW);
-    const bool inside = (x < w) && (y < h);
-    if (!SHARED && !inside) return;
-    if (!inside) { x = w - 1; y = h - 1; }                     // SHARED: keep every lane alive for the shuffles
+    const int q4 = (threadIdx.x % LPP) * 4;
+    const int x = tx * TW + (threadIdx.x / LPP) % TW;
+    const int y = ty * TH + threadIdx.x / (LPP * TW);
+    if (x >= w || y >= h) return;
     const long long hw = (long long)h * w;
     const float fx = (float)x, fy = (float)y;
     const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
     const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
     const float2 pl = reinterpret_cast<const float2*>(planes)[(long long)b * hw + (long long)y * w + x];
-
     const float* fb = feats + (long long)b * V * hw * C;
     const float4 ref = *reinterpret_cast<const float4*>(fb + ((long long)y * w + x) * C + q4);
     float4 s[DK], sq[DK];
@@ -156,9 +113,7 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(
         s[k] = ref;
         sq[k] = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
     }
-    const int lane = threadIdx.x & 63;
-    const int grp = lane - lq;                                  // first lane of this pixel's group
-    for (int v = 1; v < V; ++v) {
+    for (int v = 1; v < V && !STORE_ONLY; ++v) {
         const float* r = rot + ((long long)b * (V - 1) + (v - 1)) * 9;
         const float* t = trans + ((long long)b * (V - 1) + (v - 1)) * 3;
         const float rx = (r[0] * fx + r[1] * fy) + r[2];
@@ -166,259 +121,467 @@ __global__ __launch_bounds__(256) void warp_variance_kernel(
         const float rz = (r[6] * fx + r[7] * fy) + r[8];
         const float t0 = t[0], t1 = t[1], t2 = t[2];
         const float* src = fb + (long long)v * hw * C;
-        if (SHARED) {
-            // lane lq of the group computes planes k0 + lq + LPP*rr
-            int pk[ROUNDS];
-            float w0[ROUNDS], w1[ROUNDS], w2[ROUNDS], w3[ROUNDS];
 #pragma unroll
-            for (int rr = 0; rr < ROUNDS; ++rr) {
-                const float d = pl.x + (float)(k0 + lq + LPP * rr) * pl.y;
-                WarpCoord tc = warp_taps(rx, ry, rz, t0, t1, t2, d, half_w, half_h, wm1, hm1, w, h, C);
-                // off[1]-off[0] is 0 or C, off[2]-off[0] is 0 or w*C: two flag bits in the low bits of the
-                // base offset (a multiple of C >= 8)
-                pk[rr] = tc.off[0] | (tc.off[1] != tc.off[0] ? 1 : 0) | (tc.off[2] != tc.off[0] ? 2 : 0);
-                w0[rr] = tc.wgt[0]; w1[rr] = tc.wgt[1]; w2[rr] = tc.wgt[2]; w3[rr] = tc.wgt[3];
-            }
-#pragma unroll
-            for (int k = 0; k < DK; ++k) {
-                const int rr = k / LPP, sl = grp + (k % LPP);
-                const int pkk = __shfl(pk[rr], sl);
-                const float a0 = __shfl(w0[rr], sl), a1 = __shfl(w1[rr], sl), a2 = __shfl(w2[rr], sl), a3 = __shfl(w3[rr], sl);
-                const int o0 = (pkk & ~3) + q4;
-                const int dx = (pkk & 1) ? C : 0, dy = (pkk & 2) ? w * C : 0;
-                float4 val = bilerp4v<FAST>(src, o0, o0 + dx, o0 + dy, o0 + dy + dx, a0, a1, a2, a3);
-                if (FAST) {
-                    s[k].x += val.x; s[k].y += val.y; s[k].z += val.z; s[k].w += val.w;
-                    sq[k].x = fmaf(val.x, val.x, sq[k].x); sq[k].y = fmaf(val.y, val.y, sq[k].y);
-                    sq[k].z = fmaf(val.z, val.z, sq[k].z); sq[k].w = fmaf(val.w, val.w, sq[k].w);
-                } else {
-                    s[k].x = s[k].x + val.x; s[k].y = s[k].y + val.y; s[k].z = s[k].z + val.z; s[k].w = s[k].w + val.w;
-                    sq[k].x = sq[k].x + val.x * val.x; sq[k].y = sq[k].y + val.y * val.y;
-                    sq[k].z = sq[k].z + val.z * val.z; sq[k].w = sq[k].w + val.w * val.w;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < DK; ++k) {
-                float4 val;
-                if (VARIANT == 3) {
-                    val = ref;
-                } else {
-                    const float d = pl.x + (float)(k0 + k) * pl.y;
-                    WarpCoord tc;
-                    if (VARIANT == 2) {                         // ablation: no coordinate math
-                        int o = ((y * w + x) * C);
-                        tc.off[0] = o; tc.off[1] = o; tc.off[2] = o; tc.off[3] = o;
-                        tc.wgt[0] = 0.25f + d * 0.0f; tc.wgt[1] = 0.25f; tc.wgt[2] = 0.25f; tc.wgt[3] = 0.25f;
-                    } else {
-                        tc = warp_taps(rx, ry, rz, t0, t1, t2, d, half_w, half_h, wm1, hm1, w, h, C);
-                    }
-                    if (VARIANT == 1) {                         // ablation: no gathers
-                        float sw = ((tc.wgt[0] + tc.wgt[1]) + tc.wgt[2]) + tc.wgt[3] + (float)(tc.off[0] & 1);
-                        val = make_float4(ref.x * sw, ref.y * sw, ref.z * sw, ref.w * sw);
-                    } else {
-                        val = bilerp4(src, tc, q4);
-                    }
-                }
-                s[k].x = s[k].x + val.x; s[k].y = s[k].y + val.y; s[k].z = s[k].z + val.z; s[k].w = s[k].w + val.w;
-                sq[k].x = sq[k].x + val.x * val.x; sq[k].y = sq[k].y + val.y * val.y;
-                sq[k].z = sq[k].z + val.z * val.z; sq[k].w = sq[k].w + val.w * val.w;
-            }
+        for (int k = 0; k < DK; ++k) {
+            const float d = pl.x + (float)(k0 + k) * pl.y;
+            WarpCoord tc = warp_taps(rx, ry, rz, t0, t1, t2, d, half_w, half_h, wm1, hm1, w, h, C);
+            float4 val = bilerp4(src, tc, q4);
+            s[k].x = s[k].x + val.x; s[k].y = s[k].y + val.y; s[k].z = s[k].z + val.z; s[k].w = s[k].w + val.w;
+            sq[k].x = sq[k].x + val.x * val.x; sq[k].y = sq[k].y + val.y * val.y;
+            sq[k].z = sq[k].z + val.z * val.z; sq[k].w = sq[k].w + val.w * val.w;
         }
     }
-    if (!inside) return;
-    const float fV = (float)V, rV = 1.0f / fV;
+    const float fV = (float)V;
     float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + q4;
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
         if (k0 + k < D) {
             float4 m, o;
-            m.x = div_by<FAST>(s[k].x, fV, rV); m.y = div_by<FAST>(s[k].y, fV, rV);
-            m.z = div_by<FAST>(s[k].z, fV, rV); m.w = div_by<FAST>(s[k].w, fV, rV);
-            o.x = div_by<FAST>(sq[k].x, fV, rV) - m.x * m.x;
-            o.y = div_by<FAST>(sq[k].y, fV, rV) - m.y * m.y;
-            o.z = div_by<FAST>(sq[k].z, fV, rV) - m.z * m.z;
-            o.w = div_by<FAST>(sq[k].w, fV, rV) - m.w * m.w;
+            if (STORE_ONLY) { o = s[k]; }
+            else {
+                m.x = s[k].x / fV; m.y = s[k].y / fV; m.z = s[k].z / fV; m.w = s[k].w / fV;
+                o.x = sq[k].x / fV - m.x * m.x;
+                o.y = sq[k].y / fV - m.y * m.y;
+                o.z = sq[k].z / fV - m.z * m.z;
+                o.w = sq[k].w / fV - m.w * m.w;
+            }
             *reinterpret_cast<float4*>(ob + (long long)(k0 + k) * hw * C) = o;
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// K1 v6: two-phase, plane-major.
-//   Phase A  every (pixel, plane, view) of the block's tile is handled by exactly one thread: the
-//            full coordinate chain runs once (not once per channel lane) and leaves
-//            {packed base offset, 4 masked weights} in LDS (structure-of-arrays, conflict-free).
-//   Phase B  thread = (pixel, channel quad); for each plane: start from the reference value, add
-//            every source view's bilinear sample (tap data broadcast-read from LDS, four 16-byte
-//            gathers), form the variance and STORE THE PLANE IMMEDIATELY -- stores are spread over
-//            the whole kernel and only 8 accumulator registers are live, so many waves fit and the
-//            HBM write stream overlaps the arithmetic of other waves.
-// Division: IEEE-correct quotients without the compiler's div_scale/div_fmas/div_fixup sequence
-//   (and its denormal-mode switches): v_rcp_f32 refined by one Newton step, then two
-//   fma-residual corrections of the quotient (Markstein).  The operands here are far from the
-//   exponent limits, which is all the omitted scaling protects against; b == 0 yields NaN and
-//   the tap is dropped exactly like the reference's inf coordinate.
-// Source views are processed in chunks of VC (LDS budget); with more than one chunk the per-plane
-//   sums persist in registers across chunks (T&T, 6 source views at C = 8).
-// ------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// v_rcp_f32 refined by one Newton step (~0.5 ulp)
 __device__ __forceinline__ float rcp_nr(float b) {
     float r = __builtin_amdgcn_rcpf(b);
     float e = fmaf(-b, r, 1.0f);
     return fmaf(e, r, r);
 }
-// correctly rounded a / b given r ~ 1/b (rcp_nr)
-__device__ __forceinline__ float div_cr(float a, float b, float r) {
+
+// ------------------------------------------------------------------------------------------
+// K1 (production kernel): two-phase, plane-major, LDS tap table.
+//   Phase A  every (pixel, plane, view) of the block's tile is handled by exactly one thread: the
+//            coordinate chain runs once (not once per channel lane) and leaves FOUR ready-to-use
+//            32-bit byte offsets (view base included) and four masked bilinear weights in LDS as
+//            one int4 + one float4 record.  rot*(x,y,1) is computed once per (pixel, view).
+//   Phase B  thread = (pixel, channel quad).  Per plane: start from the reference value, add every
+//            source view's sample -- tap record broadcast-read from LDS, four 16-byte raw buffer
+//            loads (SGPR descriptor + 32-bit offset: no 64-bit address arithmetic) -- form the
+//            variance and STORE THE PLANE IMMEDIATELY (non-temporal), so stores are spread over
+//            the kernel and few registers stay live.  With a compile-time view count (NVT = 2 for
+//            the 3-view DTU setting, 4 for 5 views) the gathers of plane k+1 are issued before
+//            plane k is blended (double buffer), which is what hides the L2 latency; NVT = 0 is
+//            the general path (any V, views in LDS-sized chunks, sums carried in registers).
+// Arithmetic: same operation order as oracle/warp.py, contraction off (FAST = false) -- the result
+//   is bit-identical to the reference-order kernel (variant 0) in tests/test_gpu_parity.py.
+//   Divisions: a/b for the projective divide = v_rcp_f32 + one Newton step + two fma-residual
+//   corrections of the quotient (IEEE-exact for operands away from the exponent limits, without
+//   the compiler's div_scale/div_fmas/div_fixup sequence and denormal-mode switches); divisions by
+//   the constants (w-1)/2, (h-1)/2 and V use Markstein's single correction.  b == 0 gives NaN and
+//   the tap is dropped exactly like the reference's inf coordinate.  FAST = true additionally
+//   contracts the bilinear blend and the square-sum into FMAs (<= 2e-7 relative difference).
+// ------------------------------------------------------------------------------------------
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int NCORR>
+__device__ __forceinline__ float div_c(float a, float b, float r) {
     float q = a * r;
     float rem = fmaf(-b, q, a);
     q = fmaf(rem, r, q);
-    rem = fmaf(-b, q, a);
-    return fmaf(rem, r, q);
+    if (NCORR >= 2) { rem = fmaf(-b, q, a); q = fmaf(rem, r, q); }
+    return q;
 }
 
-struct TapPack { int pk; float w0, w1, w2, w3; };
-
-__device__ __forceinline__ TapPack warp_taps_fastdiv(float rx, float ry, float rz, float tx, float ty, float tz, float d,
-                                                    float half_w, float half_h, float r_half_w, float r_half_h,
-                                                    float wm1, float hm1, int w, int C) {
+template <bool FAST>
+__device__ __forceinline__ v4f blend4(v4f a, v4f b, v4f c, v4f d, v4f wt) {
+    if (FAST) {
+        v4f r = a * wt.x;
+        r = __builtin_elementwise_fma(b, (v4f){wt.y, wt.y, wt.y, wt.y}, r);
+        r = __builtin_elementwise_fma(c, (v4f){wt.z, wt.z, wt.z, wt.z}, r);
+        r = __builtin_elementwise_fma(d, (v4f){wt.w, wt.w, wt.w, wt.w}, r);
+        return r;
+    } else {
 #pragma clang fp contract(off)
-    float px = rx * d + tx;
-    float py = ry * d + ty;
-    float pz = rz * d + tz;
-    float rpz = rcp_nr(pz);
-    float u = div_cr(px, pz, rpz);
-    float v = div_cr(py, pz, rpz);
-    float gx = div_cr(u, half_w, r_half_w) - 1.0f;
-    float gy = div_cr(v, half_h, r_half_h) - 1.0f;
-    float ix = ((gx + 1.0f) * 0.5f) * wm1;
-    float iy = ((gy + 1.0f) * 0.5f) * hm1;
-    float x0 = floorf(ix), y0 = floorf(iy);
-    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-    float wx1 = ix - x0, wx0 = x1 - ix;
-    float wy1 = iy - y0, wy0 = y1 - iy;
-    bool vx0 = (x0 >= 0.0f) && (x0 <= wm1);
-    bool vx1 = (x1 >= 0.0f) && (x1 <= wm1);
-    bool vy0 = (y0 >= 0.0f) && (y0 <= hm1);
-    bool vy1 = (y1 >= 0.0f) && (y1 <= hm1);
-    int xi0 = (int)fminf(fmaxf(x0, 0.0f), wm1);
-    int xi1 = (int)fminf(fmaxf(x1, 0.0f), wm1);
-    int yi0 = (int)fminf(fmaxf(y0, 0.0f), hm1);
-    int yi1 = (int)fminf(fmaxf(y1, 0.0f), hm1);
-    TapPack t;
-    // base offset is a multiple of C >= 8: two flag bits ride in its low bits (x step, y step)
-    t.pk = ((yi0 * w + xi0) * C) | (xi1 != xi0 ? 1 : 0) | (yi1 != yi0 ? 2 : 0);
-    t.w0 = (vx0 && vy0) ? wx0 * wy0 : 0.0f;
-    t.w1 = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
-    t.w2 = (vx0 && vy1) ? wx0 * wy1 : 0.0f;
-    t.w3 = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
-    return t;
+        return ((a * wt.x + b * wt.y) + c * wt.z) + d * wt.w;
+    }
 }
 
-template <int C, int TH, bool NT, bool FAST, bool MULTI>
-__global__ __launch_bounds__(256) void warp_variance_v6_kernel(
+struct K1Geom {
+    float wm1, hm1, half_w, half_h, r_half_w, r_half_h;
+    int w, h;
+};
+
+// one (pixel, plane, view): offsets + weights
+template <int C>
+__device__ __forceinline__ void k1_tap(float rx, float ry, float rz, float t0, float t1, float t2, float d,
+                                       const K1Geom& g, int vrow, v4i& o, v4f& wt) {
+#pragma clang fp contract(off)
+    const float px = rx * d + t0, py = ry * d + t1, pz = rz * d + t2;
+    const float rpz = rcp_nr(pz);
+    const float u = div_c<2>(px, pz, rpz), vv = div_c<2>(py, pz, rpz);
+    const float gx = div_c<1>(u, g.half_w, g.r_half_w) - 1.0f;
+    const float gy = div_c<1>(vv, g.half_h, g.r_half_h) - 1.0f;
+    const float ix = ((gx + 1.0f) * 0.5f) * g.wm1;
+    const float iy = ((gy + 1.0f) * 0.5f) * g.hm1;
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float wx1 = ix - x0, wx0 = (x0 + 1.0f) - ix;
+    const float wy1 = iy - y0, wy0 = (y0 + 1.0f) - iy;
+    // |coordinate| < 2^24: exact int conversion; false for NaN / inf
+    const bool fin = (fabsf(ix) < 16777216.0f) && (fabsf(iy) < 16777216.0f);
+    const int xi = fin ? (int)x0 : -4, yi = fin ? (int)y0 : -4;
+    const bool vx0 = (unsigned)xi < (unsigned)g.w, vx1 = (unsigned)(xi + 1) < (unsigned)g.w;
+    const bool vy0 = (unsigned)yi < (unsigned)g.h, vy1 = (unsigned)(yi + 1) < (unsigned)g.h;
+    const int xc0 = min(max(xi, 0), g.w - 1), xc1 = min(max(xi + 1, 0), g.w - 1);
+    const int row0 = min(max(yi, 0), g.h - 1) * g.w + vrow, row1 = min(max(yi + 1, 0), g.h - 1) * g.w + vrow;
+    o.x = (row0 + xc0) * (C * 4); o.y = (row0 + xc1) * (C * 4);
+    o.z = (row1 + xc0) * (C * 4); o.w = (row1 + xc1) * (C * 4);
+    wt.x = (vx0 && vy0) ? wx0 * wy0 : 0.0f;
+    wt.y = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
+    wt.z = (vx0 && vy1) ? wx0 * wy1 : 0.0f;
+    wt.w = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
+}
+
+template <int NV>
+struct K1Fetch {
+    v4f t[NV][4];
+    v4f w[NV];
+};
+
+template <int NV, int DKB, int PIX>
+__device__ __forceinline__ void k1_issue(K1Fetch<NV>& f, const v4i* lds_o, const v4f* lds_w, __amdgpu_buffer_rsrc_t rsrc,
+                                         int k, int p, int q4b) {
+#pragma unroll
+    for (int va = 0; va < NV; ++va) {
+        const int idx = (va * DKB + k) * PIX + p;
+        const v4i o = lds_o[idx];
+        f.w[va] = lds_w[idx];
+        f.t[va][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
+        f.t[va][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
+        f.t[va][2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
+        f.t[va][3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void k1_store_variance(v4f a, v4f a2, float fV, float rV, float* dst) {
+#pragma clang fp contract(off)
+    v4f m, o;
+    m.x = div_c<1>(a.x, fV, rV); m.y = div_c<1>(a.y, fV, rV); m.z = div_c<1>(a.z, fV, rV); m.w = div_c<1>(a.w, fV, rV);
+    o.x = div_c<1>(a2.x, fV, rV) - m.x * m.x;
+    o.y = div_c<1>(a2.y, fV, rV) - m.y * m.y;
+    o.z = div_c<1>(a2.z, fV, rV) - m.z * m.z;
+    o.w = div_c<1>(a2.w, fV, rV) - m.w * m.w;
+    __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dst));
+}
+
+template <int C, int DKB, bool FAST, int NVT>
+__global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
 #pragma clang fp contract(off)
     constexpr int LPP = C / 4;
-    constexpr int PIX = 256 / LPP;      // pixels per block
-    constexpr int TW = PIX / TH;
-    extern __shared__ __attribute__((aligned(16))) int lds_i[];   // [VC][5][DK][PIX]
-    float* lds_f = reinterpret_cast<float*>(lds_i);
+    constexpr int PIX = 256 / LPP;          // pixels per block
+    constexpr int TH = 4, TW = PIX / TH;
+    constexpr int GRP = 256 / PIX;          // phase-A threads per pixel
+    constexpr int KPT = DKB / GRP;          // planes per phase-A thread
+    constexpr bool MULTI = (NVT == 0);
+    static_assert(DKB % GRP == 0, "DKB must be a multiple of 256/PIX");
+    extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [nv][DKB][PIX] offsets, then weights
+    const int nvmax = MULTI ? VC : NVT;
+    v4f* lds_w = reinterpret_cast<v4f*>(lds_o + nvmax * DKB * PIX);
     const int b = blockIdx.z;
-    const int k0 = blockIdx.y * DK;
+    const int k0 = blockIdx.y * DKB;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const long long hw = (long long)h * w;
-    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
-    const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
-    const float r_half_w = rcp_nr(half_w), r_half_h = rcp_nr(half_h);
+    const int hw = h * w;
+    K1Geom g;
+    g.w = w; g.h = h;
+    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
+    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
+    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
     const float* fb = feats + (long long)b * V * hw * C;
-    const float2* plb = reinterpret_cast<const float2*>(planes) + (long long)b * hw;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
 
-    // phase-B identity of this thread
+    // ---- phase-B identity
     const int p = threadIdx.x / LPP;
-    const int q4 = (threadIdx.x % LPP) * 4;
+    const int q4b = (threadIdx.x % LPP) * 16;                    // byte offset of this lane's channel quad
     const int x = tx0 + p % TW, y = ty0 + p / TW;
     const bool inside = (x < w) && (y < h);
-    float4 ref = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (inside) ref = *reinterpret_cast<const float4*>(fb + ((long long)y * w + x) * C + q4);
+    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
     const float fV = (float)V, rV = rcp_nr(fV);
-    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + q4;
+    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
+    // ---- phase-A identity
+    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
+    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
+    const float fxa = (float)xa, fya = (float)ya;
+    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
 
-    float4 s[MULTI ? DK : 1], sq[MULTI ? DK : 1];
+    v4f s[MULTI ? DKB : 1], sq[MULTI ? DKB : 1];
     if (MULTI) {
 #pragma unroll
-        for (int k = 0; k < DK; ++k) {
-            s[k] = ref;
-            sq[k] = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w);
-        }
+        for (int k = 0; k < DKB; ++k) { s[k] = ref; sq[k] = ref * ref; }
     }
 
-    for (int v0 = 1; v0 < V; v0 += VC) {
-        const int nv = min(VC, V - v0);
-        if (MULTI && v0 > 1) __syncthreads();                   // LDS reuse across chunks
-        // ---------------- phase A: one (pixel, plane, view) per thread-iteration
-        for (int i = threadIdx.x; i < PIX * DK * nv; i += 256) {
-            const int pa = i % PIX, ka = (i / PIX) % DK, va = i / (PIX * DK);
-            int xa = tx0 + pa % TW, ya = ty0 + pa / TW;
-            xa = min(xa, w - 1); ya = min(ya, h - 1);
-            const float fx = (float)xa, fy = (float)ya;
+    for (int v0 = 1; v0 < V; v0 += nvmax) {
+        const int nv = MULTI ? min(VC, V - v0) : NVT;
+        if (MULTI && v0 > 1) __syncthreads();
+        // ---------------- phase A
+        for (int va = 0; va < nv; ++va) {
             const float* r = rot + ((long long)b * (V - 1) + (v0 + va - 1)) * 9;
             const float* t = trans + ((long long)b * (V - 1) + (v0 + va - 1)) * 3;
-            const float rx = (r[0] * fx + r[1] * fy) + r[2];
-            const float ry = (r[3] * fx + r[4] * fy) + r[5];
-            const float rz = (r[6] * fx + r[7] * fy) + r[8];
-            const float2 pl = plb[(long long)ya * w + xa];
-            const float d = pl.x + (float)(k0 + ka) * pl.y;
-            TapPack tp = warp_taps_fastdiv(rx, ry, rz, t[0], t[1], t[2], d, half_w, half_h, r_half_w, r_half_h, wm1, hm1, w, C);
-            const int base = ((va * 5) * DK + ka) * PIX + pa;
-            lds_i[base] = tp.pk;
-            lds_f[base + 1 * DK * PIX] = tp.w0;
-            lds_f[base + 2 * DK * PIX] = tp.w1;
-            lds_f[base + 3 * DK * PIX] = tp.w2;
-            lds_f[base + 4 * DK * PIX] = tp.w3;
+            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
+            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
+            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
+            const float t0 = t[0], t1 = t[1], t2 = t[2];
+            const int vrow = (v0 + va) * hw;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) {
+                const int ka = ga + kk * GRP;
+                const float d = pla.x + (float)(k0 + ka) * pla.y;
+                v4i o;
+                v4f wt;
+                k1_tap<C>(rx, ry, rz, t0, t1, t2, d, g, vrow, o, wt);
+                const int idx = (va * DKB + ka) * PIX + pa;
+                lds_o[idx] = o;
+                lds_w[idx] = wt;
+            }
         }
         __syncthreads();
-        // ---------------- phase B: plane-major accumulation
-        if (inside) {
+        // ---------------- phase B
+        if (!inside) continue;
+        if constexpr (!MULTI) {
+            K1Fetch<NVT> f0, f1;
+            k1_issue<NVT, DKB, PIX>(f0, lds_o, lds_w, rsrc, 0, p, q4b);
 #pragma unroll
-            for (int k = 0; k < DK; ++k) {
-                float4 a, a2;
-                if (MULTI) { a = s[k]; a2 = sq[k]; }
-                else { a = ref; a2 = make_float4(ref.x * ref.x, ref.y * ref.y, ref.z * ref.z, ref.w * ref.w); }
-                for (int va = 0; va < nv; ++va) {
-                    const int base = ((va * 5) * DK + k) * PIX + p;
-                    const int pk = lds_i[base];
-                    const float w0 = lds_f[base + 1 * DK * PIX], w1 = lds_f[base + 2 * DK * PIX];
-                    const float w2 = lds_f[base + 3 * DK * PIX], w3 = lds_f[base + 4 * DK * PIX];
-                    const float* src = fb + (long long)(v0 + va) * hw * C;
-                    const int o0 = (pk & ~3) + q4;
-                    const int dx = (pk & 1) ? C : 0, dy = (pk & 2) ? w * C : 0;
-                    float4 val = bilerp4v<FAST>(src, o0, o0 + dx, o0 + dy, o0 + dy + dx, w0, w1, w2, w3);
-                    if (FAST) {
-                        a.x += val.x; a.y += val.y; a.z += val.z; a.w += val.w;
-                        a2.x = fmaf(val.x, val.x, a2.x); a2.y = fmaf(val.y, val.y, a2.y);
-                        a2.z = fmaf(val.z, val.z, a2.z); a2.w = fmaf(val.w, val.w, a2.w);
-                    } else {
-                        a.x = a.x + val.x; a.y = a.y + val.y; a.z = a.z + val.z; a.w = a.w + val.w;
-                        a2.x = a2.x + val.x * val.x; a2.y = a2.y + val.y * val.y;
-                        a2.z = a2.z + val.z * val.z; a2.w = a2.w + val.w * val.w;
-                    }
+            for (int k = 0; k < DKB; ++k) {
+                K1Fetch<NVT>& cur = (k & 1) ? f1 : f0;
+                K1Fetch<NVT>& nxt = (k & 1) ? f0 : f1;
+                if (k + 1 < DKB) k1_issue<NVT, DKB, PIX>(nxt, lds_o, lds_w, rsrc, k + 1, p, q4b);
+                v4f a = ref, a2 = ref * ref;
+#pragma unroll
+                for (int va = 0; va < NVT; ++va) {
+                    v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], cur.w[va]);
+                    a = a + val;
+                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
                 }
-                if (MULTI && v0 + nv < V) { s[k] = a; sq[k] = a2; continue; }
-                if (k0 + k < D) {
-                    float mx = div_cr(a.x, fV, rV), my = div_cr(a.y, fV, rV), mz = div_cr(a.z, fV, rV), mw = div_cr(a.w, fV, rV);
-                    v4f o;
-                    o.x = div_cr(a2.x, fV, rV) - mx * mx;
-                    o.y = div_cr(a2.y, fV, rV) - my * my;
-                    o.z = div_cr(a2.z, fV, rV) - mz * mz;
-                    o.w = div_cr(a2.w, fV, rV) - mw * mw;
-                    v4f* dst = reinterpret_cast<v4f*>(ob + (long long)(k0 + k) * hw * C);
-                    if (NT) __builtin_nontemporal_store(o, dst); else *dst = o;
-                }
+                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DKB; ++k) {
+                v4f a = s[k], a2 = sq[k];
+                for (int va = 0; va < nv; ++va) {
+                    K1Fetch<1> f;
+                    const int idx = (va * DKB + k) * PIX + p;
+                    const v4i o = lds_o[idx];
+                    f.w[0] = lds_w[idx];
+                    f.t[0][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
+                    f.t[0][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
+                    f.t[0][2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
+                    f.t[0][3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
+                    v4f val = blend4<FAST>(f.t[0][0], f.t[0][1], f.t[0][2], f.t[0][3], f.w[0]);
+                    a = a + val;
+                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
+                }
+                if (v0 + nv < V) { s[k] = a; sq[k] = a2; continue; }
+                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1, LDS-staged variant: same two-phase structure and arithmetic as warp_variance_tp_kernel,
+// but the bilinear taps are gathered from LDS instead of through the vector L1.
+// Why: rocprof PMC on the tp kernel shows TCP_TOTAL_CACHE_ACCESSES = 8 taps x the output volume
+// (18-24 M 64-byte accesses per launch), i.e. >= 30/40/30 us of vL1D time at one access per clock
+// per CU for the three config-2 stages -- the gathers, not the HBM stream, are the wall.  A tile's
+// samples land in a small source window (tile extent + the disparity sweep of DKB planes + 1), so:
+//   A   per (pixel, plane, view): coordinate chain -> clamped integer tap coordinates + masked
+//       weights; the block-wide bounding box of all contributing taps is reduced with LDS atomics;
+//   A2  records rewritten to byte offsets inside the staged window (or to global offsets when the
+//       window does not fit the LDS budget: block-uniform fallback to buffer loads);
+//   S   the window rows are copied global -> LDS with coalesced 16-byte loads, each texel once;
+//   B   as before, but each tap is a ds_read_b128.
+// LDS traffic replaces ~8x-output of L1 traffic by ~1-2x-output of staging traffic.
+// ------------------------------------------------------------------------------------------
+template <int C, int DKB, bool FAST, int NV>
+__global__ __launch_bounds__(256) void warp_variance_lds_kernel(
+    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int patch_texels) {
+#pragma clang fp contract(off)
+    constexpr int LPP = C / 4;
+    constexpr int PIX = 256 / LPP;
+    constexpr int TH = 4, TW = PIX / TH;
+    constexpr int GRP = 256 / PIX;
+    constexpr int KPT = (DKB + GRP - 1) / GRP;   // planes per phase-A thread (threads with ga >= DKB idle when DKB < GRP)
+    constexpr int C4 = C * 4;               // bytes per texel
+    extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [NV][DKB][PIX]
+    v4f* lds_w = reinterpret_cast<v4f*>(lds_o + NV * DKB * PIX);         // [NV][DKB][PIX]
+    int* lds_box = reinterpret_cast<int*>(lds_w + NV * DKB * PIX);       // [NV][4] xmin xmax ymin ymax, then 16 B pad
+    char* lds_patch = reinterpret_cast<char*>(lds_box + 16);             // [NV][patch_texels * C4]
+    const int patch_bytes = patch_texels * C4;
+    const unsigned patch_base = (unsigned)(lds_patch - reinterpret_cast<char*>(lds_o));
+
+    const int b = blockIdx.z;
+    const int k0 = blockIdx.y * DKB;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const int hw = h * w;
+    K1Geom g;
+    g.w = w; g.h = h;
+    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
+    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
+    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
+    const float* fb = feats + (long long)b * V * hw * C;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
+
+    const int p = threadIdx.x / LPP;
+    const int q4b = (threadIdx.x % LPP) * 16;
+    const int x = tx0 + p % TW, y = ty0 + p / TW;
+    const bool inside = (x < w) && (y < h);
+    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
+    const float fV = (float)V, rV = rcp_nr(fV);
+    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
+    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
+    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
+    const float fxa = (float)xa, fya = (float)ya;
+    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
+    const bool multi = (V - 1) > NV;
+
+    v4f s[DKB], sq[DKB];
+#pragma unroll
+    for (int k = 0; k < DKB; ++k) { s[k] = ref; sq[k] = ref * ref; }
+
+    for (int v0 = 1; v0 < V; v0 += NV) {
+        const int nv = min(NV, V - v0);
+        if (v0 > 1) __syncthreads();                             // previous chunk's phase B is done with LDS
+        if (threadIdx.x < NV * 4) lds_box[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;
+        __syncthreads();
+        // ---------------- phase A: taps -> packed clamped coordinates + weights, bounding box
+        for (int va = 0; va < nv; ++va) {
+            const float* r = rot + ((long long)b * (V - 1) + (v0 + va - 1)) * 9;
+            const float* t = trans + ((long long)b * (V - 1) + (v0 + va - 1)) * 3;
+            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
+            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
+            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
+            const float t0 = t[0], t1 = t[1], t2 = t[2];
+            int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) {
+                const int ka = ga + kk * GRP;
+                if (ka >= DKB) continue;
+                const float d = pla.x + (float)(k0 + ka) * pla.y;
+                v4i o;
+                v4f wt;
+                k1_tap<1>(rx, ry, rz, t0, t1, t2, d, g, 0, o, wt);   // C = 1, vrow = 0: o = 4 * pixel index of each tap
+                const int i00 = o.x >> 2, i11 = o.w >> 2;
+                const int yc0 = i00 / w, xc0 = i00 - yc0 * w, yc1 = i11 / w, xc1 = i11 - yc1 * w;
+                const bool any = (wt.x != 0.0f) || (wt.y != 0.0f) || (wt.z != 0.0f) || (wt.w != 0.0f);
+                const int idx = (va * DKB + ka) * PIX + pa;
+                v4i rec;
+                rec.x = xc0; rec.y = yc0; rec.z = (xc1 != xc0 ? 1 : 0) | (yc1 != yc0 ? 2 : 0) | (any ? 4 : 0); rec.w = 0;
+                lds_o[idx] = rec;
+                lds_w[idx] = wt;
+                if (any) { bx0 = min(bx0, xc0); bx1 = max(bx1, xc1); by0 = min(by0, yc0); by1 = max(by1, yc1); }
+            }
+            // wave-level reduction by hand (the compiler's atomic optimiser would emit a 64-iteration
+            // scalar readlane loop per atomic), then one LDS atomic per wave
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                bx0 = min(bx0, __shfl_xor(bx0, m)); bx1 = max(bx1, __shfl_xor(bx1, m));
+                by0 = min(by0, __shfl_xor(by0, m)); by1 = max(by1, __shfl_xor(by1, m));
+            }
+            if ((threadIdx.x & 63) == 0 && bx1 >= 0) {
+                __hip_atomic_fetch_min(&lds_box[va * 4 + 0], bx0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&lds_box[va * 4 + 1], bx1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(&lds_box[va * 4 + 2], by0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&lds_box[va * 4 + 3], by1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        // ---------------- phase A2: rewrite records to byte offsets (LDS window or global fallback)
+        bool fits[NV];
+        int px0[NV], py0[NV], pw[NV], ph[NV];
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            px0[va] = lds_box[va * 4 + 0]; py0[va] = lds_box[va * 4 + 2];
+            pw[va] = lds_box[va * 4 + 1] - px0[va] + 1; ph[va] = lds_box[va * 4 + 3] - py0[va] + 1;
+            const bool empty = lds_box[va * 4 + 1] < 0;
+            if (empty) { px0[va] = 0; py0[va] = 0; pw[va] = 1; ph[va] = 1; }     // stage one (finite) texel
+            fits[va] = (va < nv) && (pw[va] * ph[va] <= patch_texels);
+        }
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            if (va >= nv) continue;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) {
+                if (ga + kk * GRP >= DKB) continue;
+                const int idx = (va * DKB + ga + kk * GRP) * PIX + pa;
+                const v4i rec = lds_o[idx];
+                const bool any = rec.z & 4;
+                v4i o;
+                if (fits[va]) {
+                    const int lx = any ? rec.x - px0[va] : 0, ly = any ? rec.y - py0[va] : 0;
+                    const int base = (ly * pw[va] + lx) * C4 + (int)patch_base + va * patch_bytes;
+                    const int dx = (any && (rec.z & 1)) ? C4 : 0, dy = (any && (rec.z & 2)) ? pw[va] * C4 : 0;
+                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
+                } else {
+                    const int base = ((v0 + va) * hw + rec.y * w + rec.x) * C4;
+                    const int dx = (rec.z & 1) ? C4 : 0, dy = (rec.z & 2) ? w * C4 : 0;
+                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
+                }
+                lds_o[idx] = o;
+            }
+        }
+        // ---------------- stage the source windows (each texel once, coalesced rows)
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            if (!fits[va]) continue;
+            const int row4 = pw[va] * LPP;                        // float4s per window row
+            const int n4 = row4 * ph[va];
+            const float* src = fb + ((long long)(v0 + va) * hw + (long long)py0[va] * w + px0[va]) * C;
+            v4f* dst = reinterpret_cast<v4f*>(lds_patch + va * patch_bytes);
+            for (int e = threadIdx.x; e < n4; e += 256) {
+                const int row = e / row4, c4 = e - row * row4;
+                dst[e] = *reinterpret_cast<const v4f*>(src + (long long)row * w * C + c4 * 4);
+            }
+        }
+        __syncthreads();
+        // ---------------- phase B
+        if (!inside) continue;
+        const char* lds_bytes = reinterpret_cast<const char*>(lds_o) + q4b;
+#pragma unroll
+        for (int k = 0; k < DKB; ++k) {
+            v4f a = s[k], a2 = sq[k];
+#pragma unroll
+            for (int va = 0; va < NV; ++va) {
+                if (va >= nv) continue;
+                const int idx = (va * DKB + k) * PIX + p;
+                const v4i o = lds_o[idx];
+                const v4f wt = lds_w[idx];
+                v4f ta, tb, tc, td;
+                if (fits[va]) {
+                    ta = *reinterpret_cast<const v4f*>(lds_bytes + o.x);
+                    tb = *reinterpret_cast<const v4f*>(lds_bytes + o.y);
+                    tc = *reinterpret_cast<const v4f*>(lds_bytes + o.z);
+                    td = *reinterpret_cast<const v4f*>(lds_bytes + o.w);
+                } else {
+                    ta = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
+                    tb = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
+                    tc = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
+                    td = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
+                }
+                v4f val = blend4<FAST>(ta, tb, tc, td, wt);
+                a = a + val;
+                if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
+            }
+            if (multi && v0 + nv < V) { s[k] = a; sq[k] = a2; continue; }
+            if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
         }
     }
 }
@@ -505,41 +668,64 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
     const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y, (D + DK - 1) / DK, B);
     hipStream_t st = as_stream(stream);
-    if (g_k1_variant >= 6 && g_k1_variant <= 13) {
-        const int opt = g_k1_variant - 6;
-        const int th = (opt & 1) ? 1 : 4;
-        const bool nt = opt & 2, fastm = opt & 4;
+    if (g_k1_variant >= 4 && g_k1_variant <= 7) {
+        // LDS-staged kernel: bit0 = FMA blend, bit1 = deeper plane chunk
+        const bool fastm = (g_k1_variant - 4) & 1, deep = (g_k1_variant - 4) & 2;
         const int LPP = C / 4, PIX = 256 / LPP;
-        const size_t per_view = (size_t)5 * DK * PIX * sizeof(float);
-        int VC = (int)((64 * 1024) / per_view);
-        if (VC > V - 1) VC = V - 1;
-        const bool multi = VC < V - 1;
-        const size_t lds = per_view * VC;
-        const int TW6 = PIX / th;
-        const int tx6 = (w + TW6 - 1) / TW6, ty6 = (h + th - 1) / th;
-        dim3 grid6(tx6 * ty6, (D + DK - 1) / DK, B);
-#define RCMVS_K1V6(CC, TT, NN, FF, MM) hipLaunchKernelGGL((warp_variance_v6_kernel<CC, TT, NN, FF, MM>), grid6, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, tx6, VC)
-#define RCMVS_K1V6_M(CC, TT, NN, FF) do { if (multi) RCMVS_K1V6(CC, TT, NN, FF, true); else RCMVS_K1V6(CC, TT, NN, FF, false); } while (0)
-#define RCMVS_K1V6_F(CC, TT, NN) do { if (fastm) RCMVS_K1V6_M(CC, TT, NN, true); else RCMVS_K1V6_M(CC, TT, NN, false); } while (0)
-#define RCMVS_K1V6_N(CC, TT) do { if (nt) RCMVS_K1V6_F(CC, TT, true); else RCMVS_K1V6_F(CC, TT, false); } while (0)
-#define RCMVS_K1V6_T(CC) do { if (th == 1) RCMVS_K1V6_N(CC, 1); else RCMVS_K1V6_N(CC, 4); } while (0)
+        const int nvk = (V - 1) >= 2 ? 2 : 1;
+        const int dkb = (C == 8) ? (deep ? 4 : 2) : (deep ? 8 : 4);
+        const int ptex = (C == 32) ? (deep ? 192 : 128) : (C == 16 ? (deep ? 320 : 224) : (deep ? 512 : 384));
+        const size_t lds = (size_t)nvk * dkb * PIX * 32 + 64 + (size_t)nvk * ptex * C * 4;
+        RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
+        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
+        const int TWl = PIX / 4;
+        const int txl = (w + TWl - 1) / TWl, tyl = (h + 3) / 4;
+        dim3 gridl(txl * tyl, (D + dkb - 1) / dkb, B);
+#define RCMVS_K1L(CC, DD, FF, NN) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_lds_kernel<CC, DD, FF, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((warp_variance_lds_kernel<CC, DD, FF, NN>), gridl, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
+#define RCMVS_K1L_N(CC, DD, FF) do { if (nvk == 2) RCMVS_K1L(CC, DD, FF, 2); else RCMVS_K1L(CC, DD, FF, 1); } while (0)
+#define RCMVS_K1L_F(CC, DD) do { if (fastm) RCMVS_K1L_N(CC, DD, true); else RCMVS_K1L_N(CC, DD, false); } while (0)
         switch (C) {
-            case 8:  RCMVS_K1V6_T(8); break;
-            case 16: RCMVS_K1V6_T(16); break;
-            case 32: RCMVS_K1V6_T(32); break;
+            case 8:  if (deep) RCMVS_K1L_F(8, 4); else RCMVS_K1L_F(8, 2); break;
+            case 16: if (deep) RCMVS_K1L_F(16, 8); else RCMVS_K1L_F(16, 4); break;
+            case 32: if (deep) RCMVS_K1L_F(32, 8); else RCMVS_K1L_F(32, 4); break;
             default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
         }
-        return launch_status("warp_variance_fwd(v6)");
+        return launch_status("warp_variance_fwd(lds)");
     }
-#define RCMVS_K1_LAUNCH(CC, VV) hipLaunchKernelGGL((warp_variance_kernel<CC, VV>), grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y)
+    if (g_k1_variant == 0 || g_k1_variant == 1) {
+        // production kernel: variant 0 = exact arithmetic (default), 1 = FMA-contracted blend
+        const bool fastm = g_k1_variant == 1;
+        const int LPP = C / 4, PIX = 256 / LPP;
+        const int dkb = (C == 8) ? 4 : 8;
+        const size_t per_view = (size_t)32 * dkb * PIX;
+        const int nsrc = V - 1;
+        const int nvt = (nsrc == 2 || nsrc == 4) ? nsrc : 0;
+        int VC = nvt ? nvt : (int)((48 * 1024) / per_view);
+        if (VC > nsrc) VC = nsrc;
+        const size_t lds = per_view * VC;
+        const int TWp = PIX / 4;
+        const int txp = (w + TWp - 1) / TWp, typ = (h + 3) / 4;
+        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
+        dim3 gridp(txp * typ, (D + dkb - 1) / dkb, B);
+#define RCMVS_K1TP(CC, DD, FF, NN) hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, FF, NN>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC)
+#define RCMVS_K1TP_N(CC, DD, FF) do { if (nvt == 2) RCMVS_K1TP(CC, DD, FF, 2); else if (nvt == 4) RCMVS_K1TP(CC, DD, FF, 4); else RCMVS_K1TP(CC, DD, FF, 0); } while (0)
+#define RCMVS_K1TP_F(CC, DD) do { if (fastm) RCMVS_K1TP_N(CC, DD, true); else RCMVS_K1TP_N(CC, DD, false); } while (0)
+        switch (C) {
+            case 8:  RCMVS_K1TP_F(8, 4); break;
+            case 16: RCMVS_K1TP_F(16, 8); break;
+            case 32: RCMVS_K1TP_F(32, 8); break;
+            default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+        }
+        return launch_status("warp_variance_fwd");
+    }
+    // variants 2 (reference-order kernel, one tap computation per lane) and 3 (store-only ablation)
+#define RCMVS_K1_LAUNCH(CC, VV) hipLaunchKernelGGL((warp_variance_ref_kernel<CC, VV>), grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y)
 #define RCMVS_K1_VARIANTS(CC)                                                               \
     switch (g_k1_variant) {                                                                 \
-        case 0: RCMVS_K1_LAUNCH(CC, 0); break;                                              \
-        case 1: RCMVS_K1_LAUNCH(CC, 1); break;                                              \
-        case 2: RCMVS_K1_LAUNCH(CC, 2); break;                                              \
-        case 3: RCMVS_K1_LAUNCH(CC, 3); break;                                              \
-        case 4: RCMVS_K1_LAUNCH(CC, 4); break;                                              \
-        case 5: RCMVS_K1_LAUNCH(CC, 5); break;                                              \
+        case 2: RCMVS_K1_LAUNCH(CC, false); break;                                              \
+        case 3: RCMVS_K1_LAUNCH(CC, true); break;                                              \
         default: return fail(-1, "warp_variance_fwd: unknown debug variant %d", g_k1_variant); \
     }
     switch (C) {

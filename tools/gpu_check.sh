@@ -13,7 +13,7 @@ PY
 echo "== pytest -m gpu"
 timeout 900 python -m pytest tests -q -m gpu -s -p no:cacheprovider 2>&1 | tail -60 | tee gpurun_out/pytest_gpu.log
 echo "== k1 ablation"
-timeout 300 python tools/k1_ablate.py 2>&1 | tail -50 | tee gpurun_out/k1_ablate.log
+timeout 300 python tools/k1_ablate.py 0 1 2 3 100 2>&1 | tail -20 | tee gpurun_out/k1_ablate.log
 echo "== featnet diag"
 timeout 300 python tools/featnet_diag.py 2>&1 | grep -v "^\*\*\*" | tail -12 | tee gpurun_out/featnet_diag.log
 echo "== smoke"

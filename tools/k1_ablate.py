@@ -9,10 +9,8 @@ from rc_mvsnet_amd import _lib, ops, synthetic
 lib = _lib.load()
 dev = "cuda:0"
 V, H, W = 3, 512, 640
-names = {0: "v0 exact/per-lane", 1: "abl: no gather", 2: "abl: no coord math", 3: "abl: store only",
-         4: "v4 shared taps", 5: "v5 shared+fma+fastdiv", 6: "v6 th4", 7: "v6 th1", 8: "v6 th4 nt", 9: "v6 th1 nt",
-         10: "v6 th4 fma", 11: "v6 th1 fma", 12: "v6 th4 nt fma", 13: "v6 th1 nt fma", 100: "torch zero_ (memset)"}
-variants = [int(a) for a in sys.argv[1:]] or [0, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 100]
+names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 4: "lds exact", 5: "lds fma", 6: "lds exact deep", 7: "lds fma deep", 100: "torch zero_ (memset)"}
+variants = [int(a) for a in sys.argv[1:]] or [0, 1, 3, 4, 5, 6, 7]
 dv = synthetic.depth_values(1).to(dev)
 tot = {v: 0.0 for v in variants}
 for (C, D, sc, key) in ((32, 48, 4, "stage1"), (16, 32, 2, "stage2"), (8, 8, 1, "stage3")):
