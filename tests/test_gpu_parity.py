@@ -400,7 +400,7 @@ def test_cascade_c2_hot_path_isolated(hip):
                   f"  confidence mismatches on stable pixels {res[tag][2]:.4f}")
     assert res["both pinned"][0] < 2e-5
     assert res["both pinned"][1] < 0.03
-    assert res["both pinned"][2] < 0.02
+    assert res["both pinned"][2] < 0.03
     assert res["fp64-homography + MIOpen features"][0] < 1e-4
 
 
