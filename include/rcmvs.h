@@ -110,8 +110,9 @@ int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* plane
 
 /* ---- rendering-consistency branch --------------------------------------------------------- */
 /* F.interpolate(size=[Do,h,w], trilinear, align_corners=True) along the plane axis only
- * (models/render_models.py:756), NCDHW in -> NDHWC out:  x (B,C,D,h,w) -> y (B,Do,h,w,C). */
-int rcmvs_resize_planes_fwd(const float* x, float* y, int B, int C, int D, int Do, int h, int w, void* stream);
+ * (models/render_models.py:756), NCDHW in -> channels-last out with the channel count zero-padded
+ * to Cp >= C (so the first conv reads 16-byte vectors):  x (B,C,D,h,w) -> y (B,Do,h,w,Cp). */
+int rcmvs_resize_planes_fwd(const float* x, float* y, int B, int C, int Cp, int D, int Do, int h, int w, void* stream);
 
 /* Gaussian-Uniform ray sampler + world/NDC points (models/render_utils.py:86-108,149-243,
  * 112-146).  Random draws are inputs: pix (2,N) int32 rows x,y; eps (N,S); u (N/2,S).
@@ -124,20 +125,28 @@ int rcmvs_gu_sample_fwd(const float* pseudo_depth, const float* img0, const int*
                         int N, int S, int H, int W, void* stream);
 
 /* point features (models/renderer.py:154-166, render_utils.py:247-279,304-330):
- * feat (N,S,8+4*nimg) = trilinear(volume (Dv,hv,wv,8) channels-last at ndc*2-1, zeros pad,
- * align_corners) ++ per image i: bilinear border RGB of imgs (nimg,3,H,W) at the projection
- * with poses (nimg,25) = [w2c(16) | K(9)], ++ strict in-bounds mask. */
+ * feat (M, ldf) row-major, columns [0, 8+4*nimg) written = trilinear(volume (Dv,hv,wv,8)
+ * channels-last at ndc*2-1, zeros pad, align_corners) ++ per image i: bilinear border RGB of
+ * imgs (nimg,3,H,W) at the projection with poses (nimg,25) = [w2c(16) | K(9)] ++ strict
+ * in-bounds mask. */
 int rcmvs_point_feats_fwd(const float* volume, const float* imgs, const float* poses,
                           const float* pts, const float* ndc, float* feat,
-                          int M, int Dv, int hv, int wv, int nimg, int H, int W, void* stream);
+                          int M, int Dv, int hv, int wv, int nimg, int H, int W, int ldf, void* stream);
 
-/* NeRF MLP (models/render_models.py:45-49,192-220): positional encoding of ndc (10 freqs),
- * 6x128 trunk with multiplicative feature bias, skip after layer 4, sigma/rgb heads.
- * weights: one packed device blob laid out by rcmvs_nerf_weight_floats()/python packer.
- * ndc (M,3), feat (M,20), dirs (N,3) with M = N*S  ->  raw (M,4) = [rgb(3), sigma]. */
-int rcmvs_nerf_mlp_fwd(const float* ndc, const float* feat, const float* dirs, const float* weights,
-                       float* raw, int N, int S, void* stream);
+/* NeRF MLP (models/render_models.py:45-49,192-220; renderer.py:42-63,141-152): positional
+ * encoding of ndc (10 freqs), 6x128 trunk with multiplicative feature bias, skip after layer 4,
+ * sigma / rgb heads, view direction = normalised ray direction rotated by w2c_ref[:3,:3].
+ *   rcmvs_pack_nerf_weights: wb [host array] of 22 device pointers, (weight, bias) of pts_bias,
+ *     pts_linears.0..5, alpha_linear, feature_linear, views_linears.0, rgb_linear -> blob of
+ *     rcmvs_nerf_weight_floats() floats (MFMA fragment images + biases).
+ *   rcmvs_nerf_mlp_fwd: ndc (M,3); feat (M,ldf=32) with 20 used columns (padding is zeroed here);
+ *     dirs (N,3) raw ray directions; w2c_ref (4,4); workspace of rcmvs_nerf_workspace_floats(M)
+ *     floats; raw (M,4) = [rgb(3), sigma];  M = N*S. */
 long long rcmvs_nerf_weight_floats(void);
+long long rcmvs_nerf_workspace_floats(long long M);
+int rcmvs_pack_nerf_weights(const float* const* wb, float* blob, void* stream);
+int rcmvs_nerf_mlp_fwd(const float* ndc, float* feat, int ldf, const float* dirs, const float* w2c_ref,
+                       const float* weights, float* workspace, float* raw, int N, int S, void* stream);
 
 /* compositing (models/renderer.py:18-26,65-93): alpha = 1-exp(-sigma), T = exclusive cumprod
  * of (1-alpha+1e-10), w = alpha*T;  rgb (N,3), depth (N), weights (N,S), alpha (N,S). */

@@ -174,3 +174,84 @@ def depth_head(x8, w_prob_packed, planes, want_prob=False):
                                                 _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
                                                 _stream()), "depth_head_fwd")
     return (depth, conf, prob) if want_prob else (depth, conf)
+
+
+# ------------------------------------------------------------------------------- rendering branch
+def resize_planes(x, out_planes, pad_channels_to=None):
+    """x (B,C,D,h,w) NCDHW -> (B,out_planes,h,w,Cp) channels-last, trilinear along D, align_corners=True."""
+    B, C, D, h, w = x.shape
+    Cp = C if pad_channels_to is None else pad_channels_to
+    y = torch.empty((B, out_planes, h, w, Cp), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_resize_planes_fwd(_chk(x, "x"), _chk(y, "y"), B, C, Cp, D, out_planes, h, w, _stream()),
+               "resize_planes_fwd")
+    return y
+
+
+def gu_sample(pseudo_depth, img0, pix, eps, u, cam):
+    """Gaussian-Uniform sampler.  pseudo_depth (H,W); img0 (3,H,W); pix (2,N) int32; eps (N,S); u (N/2,S); cam (52,)."""
+    H, W = pseudo_depth.shape
+    N, S = eps.shape
+    dev = eps.device
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    z, pts, ndc, dirs, rdepth, target = f(N, S), f(N, S, 3), f(N, S, 3), f(N, 3), f(N), f(N, 3)
+    _lib.check(_lib.load().rcmvs_gu_sample_fwd(_chk(pseudo_depth, "pseudo_depth"), _chk(img0, "img0"), _chk(pix, "pix", torch.int32),
+                                               _chk(eps, "eps"), _chk(u, "u"), _chk(cam, "cam"), _chk(z, "z"), _chk(pts, "pts"),
+                                               _chk(ndc, "ndc"), _chk(dirs, "dirs"), _chk(rdepth, "rays_depth"), _chk(target, "target"),
+                                               N, S, H, W, _stream()), "gu_sample_fwd")
+    return z, pts, ndc, dirs, rdepth, target
+
+
+def point_feats(volume_cl, imgs, poses, pts, ndc, ldf=32):
+    """volume_cl (Dv,hv,wv,8); imgs (nimg,3,H,W); poses (nimg,25); pts/ndc (N,S,3) -> feat (N*S, ldf), 8+4*nimg cols used."""
+    Dv, hv, wv, C = volume_cl.shape
+    if C != 8:
+        raise _lib.RcmvsError("point_feats: the neural volume has 8 channels")
+    nimg, _, H, W = imgs.shape
+    M = pts.shape[0] * pts.shape[1]
+    feat = torch.empty((M, ldf), device=pts.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_point_feats_fwd(_chk(volume_cl, "volume"), _chk(imgs, "imgs"), _chk(poses, "poses"), _chk(pts, "pts"),
+                                                 _chk(ndc, "ndc"), _chk(feat, "feat"), M, Dv, hv, wv, nimg, H, W, ldf, _stream()),
+               "point_feats_fwd")
+    return feat
+
+
+NERF_ORDER = ("pts_bias", "pts_linears.0", "pts_linears.1", "pts_linears.2", "pts_linears.3", "pts_linears.4", "pts_linears.5",
+              "alpha_linear", "feature_linear", "views_linears.0", "rgb_linear")
+
+
+def pack_nerf_weights(named):
+    """named: {name: (weight, bias)} for NERF_ORDER -> packed blob."""
+    lib = _lib.load()
+    tensors = []
+    for n in NERF_ORDER:
+        w, b = named[n]
+        tensors += [w.detach().contiguous().float(), b.detach().contiguous().float()]
+    arr = (ctypes.c_void_p * 22)(*[_chk(t, "nerf weight").value for t in tensors])
+    blob = torch.empty((lib.rcmvs_nerf_weight_floats(),), device=tensors[0].device, dtype=torch.float32)
+    _lib.check(lib.rcmvs_pack_nerf_weights(arr, _chk(blob, "blob"), _stream()), "pack_nerf_weights")
+    return blob
+
+
+def nerf_mlp(ndc, feat, dirs, w2c_ref, blob):
+    """ndc (N,S,3), feat (N*S,32), dirs (N,3), w2c_ref (4,4) -> raw (N,S,4) = [rgb, sigma]."""
+    lib = _lib.load()
+    N, S = ndc.shape[:2]
+    M = N * S
+    ws = torch.empty((lib.rcmvs_nerf_workspace_floats(M),), device=ndc.device, dtype=torch.float32)
+    raw = torch.empty((N, S, 4), device=ndc.device, dtype=torch.float32)
+    _lib.check(lib.rcmvs_nerf_mlp_fwd(_chk(ndc, "ndc"), _chk(feat, "feat"), feat.shape[1], _chk(dirs, "dirs"), _chk(w2c_ref, "w2c_ref"),
+                                      _chk(blob, "weights"), _chk(ws, "workspace"), _chk(raw, "raw"), N, S, _stream()), "nerf_mlp_fwd")
+    return raw
+
+
+def composite(raw, z):
+    """raw (N,S,4), z (N,S) -> rgb (N,3), depth (N), weights (N,S), alpha (N,S)."""
+    N, S = z.shape
+    dev = z.device
+    rgb = torch.empty((N, 3), device=dev, dtype=torch.float32)
+    depth = torch.empty((N,), device=dev, dtype=torch.float32)
+    weights = torch.empty((N, S), device=dev, dtype=torch.float32)
+    alpha = torch.empty((N, S), device=dev, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_composite_fwd(_chk(raw, "raw"), _chk(z, "z"), _chk(rgb, "rgb"), _chk(depth, "depth"),
+                                               _chk(weights, "weights"), _chk(alpha, "alpha"), N, S, _stream()), "composite_fwd")
+    return rgb, depth, weights, alpha

@@ -1,0 +1,321 @@
+"""Drop-in for the reference's ``models.render_consist_net.Rendering_Consistency_Net``
+(models/render_consist_net.py:11-76) with its children ``Neural_Volume_Net`` / ``CostReg``
+(models/render_models.py:690-760) and ``RenderNet`` / ``Renderer_ours`` (:143-220,538-565).
+
+Same constructor (``args`` namespace; ``args.feat_dim`` is written like the reference does), same
+``forward(volume_feature_warp, pseudo_depth, batch)`` 8-tuple and the same 82 ``state_dict`` names
+(``MVSNet.cost_reg_2.*``, ``network_fn.nerf.*``), so ``train_rcmvsnet.py`` and the shipped
+``model_000014_nerf.ckpt`` work unchanged.
+
+Execution mirrors casmvsnet.py: eval() under no_grad runs on the HIP kernels (plane resize,
+neural-volume U-Net on the 3-D conv family without ReLU, Gaussian-Uniform sampler, point features,
+MFMA MLP, wave-scan compositing); calls that need autograd run the same op graph on PyTorch-ROCm.
+Random draws (pixel indices, Gaussian eps, stratified u) come from torch's generator on the device and
+are passed INTO the sampler kernel -- the RNG contract of SURVEY.md 8a-9; ``forward`` accepts them
+through the optional ``randoms=(pix, eps, u)`` argument so tests can inject the reference's draws.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .casmvsnet import _bn_fold, _hip_inference, _note_delegation
+
+N_RAYS = 1024                               # hard-coded in the reference (render_consist_net.py:68)
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class ConvBnReLU3D(nn.Module):
+    """conv + norm, NO ReLU despite the name (models/render_models.py:675-686)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=nn.BatchNorm3d):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = norm_act(out_channels)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+class CostReg(nn.Module):
+    """models/render_models.py:690-734."""
+
+    _LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")
+
+    def __init__(self, in_channels, norm_act=nn.BatchNorm3d, base_channels=4):
+        super().__init__()
+        b = base_channels
+        self.in_channels = in_channels
+        self.conv0 = ConvBnReLU3D(in_channels, b, norm_act=norm_act)
+        self.conv1 = ConvBnReLU3D(b, b * 2, stride=2, norm_act=norm_act)
+        self.conv2 = ConvBnReLU3D(b * 2, b * 2, norm_act=norm_act)
+        self.conv3 = ConvBnReLU3D(b * 2, b * 4, stride=2, norm_act=norm_act)
+        self.conv4 = ConvBnReLU3D(b * 4, b * 4, norm_act=norm_act)
+        self.conv5 = ConvBnReLU3D(b * 4, b * 8, stride=2, norm_act=norm_act)
+        self.conv6 = ConvBnReLU3D(b * 8, b * 8, norm_act=norm_act)
+        self.conv7 = nn.Sequential(nn.ConvTranspose3d(b * 8, b * 4, 3, padding=1, output_padding=1, stride=2, bias=False), norm_act(32))
+        self.conv9 = nn.Sequential(nn.ConvTranspose3d(b * 4, b * 2, 3, padding=1, output_padding=1, stride=2, bias=False), norm_act(16))
+        self.conv11 = nn.Sequential(nn.ConvTranspose3d(b * 2, b, 3, padding=1, output_padding=1, stride=2, bias=False), norm_act(8))
+        self._plan = None
+        self._plan_key = None
+
+    def _conv_bn(self, name):
+        m = getattr(self, name)
+        return (m[0], m[1], True) if isinstance(m, nn.Sequential) else (m.conv, m.bn, False)
+
+    def hip_plan(self):
+        ts = []
+        for n in self._LAYERS:
+            conv, bn, _ = self._conv_bn(n)
+            ts += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._plan is None or key != self._plan_key:
+            plan = {}
+            for n in self._LAYERS:
+                conv, bn, transposed = self._conv_bn(n)
+                w = conv.weight.detach()
+                if n == "conv0" and self.in_channels % 4:                  # 41 -> 44 zero channels: 16-byte input vectors
+                    pad = 4 - self.in_channels % 4
+                    w = torch.cat((w, w.new_zeros(w.shape[0], pad, 3, 3, 3)), dim=1)
+                plan[n] = (ops.pack_conv3d_weight(w, transposed=transposed),) + _bn_fold(bn)
+            self._plan, self._plan_key = plan, key
+        return self._plan
+
+    def forward_cl(self, x):
+        """x (B,D,h,w,Cin padded to a multiple of 4) channels-last -> (B,D,h,w,8)."""
+        p = self.hip_plan()
+        conv0 = ops.conv3d(x, *p["conv0"])
+        conv2 = ops.conv3d(ops.conv3d(conv0, *p["conv1"], stride=2), *p["conv2"])
+        conv4 = ops.conv3d(ops.conv3d(conv2, *p["conv3"], stride=2), *p["conv4"])
+        t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2), *p["conv6"])
+        t = ops.deconv3d(t, *p["conv7"], residual=conv4)
+        t = ops.deconv3d(t, *p["conv9"], residual=conv2)
+        return ops.deconv3d(t, *p["conv11"], residual=conv0)
+
+    def forward(self, x):
+        conv0 = self.conv0(x)
+        conv2 = self.conv2(self.conv1(conv0))
+        conv4 = self.conv4(self.conv3(conv2))
+        x = self.conv6(self.conv5(conv4))
+        x = conv4 + self.conv7(x)
+        x = conv2 + self.conv9(x)
+        return conv0 + self.conv11(x)
+
+
+class Neural_Volume_Net(nn.Module):
+    """models/render_models.py:736-760: D -> 128 planes (trilinear, align_corners), then CostReg(32+9)."""
+
+    def __init__(self, num_groups=1, norm_act=nn.BatchNorm3d, levels=1, in_channels=32 + 9):
+        super().__init__()
+        self.levels = levels
+        self.n_depths = [128, 32, 8]
+        self.G = num_groups
+        self.N_importance = 0
+        self.chunk = 1024
+        self.cost_reg_2 = CostReg(in_channels, norm_act, base_channels=8)
+
+    def forward_cl(self, volume_feature):
+        """NCDHW in -> (B,128,h,w,8) channels-last (HIP path)."""
+        C = volume_feature.shape[1]
+        x = ops.resize_planes(volume_feature.contiguous().float(), 128, pad_channels_to=(C + 3) // 4 * 4)
+        return self.cost_reg_2.forward_cl(x)
+
+    def forward(self, volume_feature, pad=0):
+        if _hip_inference(self, volume_feature):
+            return ops.to_channels_first(self.forward_cl(volume_feature)).reshape(1, -1, 128, *volume_feature.shape[-2:])
+        _note_delegation("Neural_Volume_Net")
+        B, C, _, H, W = volume_feature.shape
+        v = F.interpolate(volume_feature, size=[128, H, W], mode="trilinear", align_corners=True)
+        v = self.cost_reg_2(v)
+        return v.reshape(1, -1, *v.shape[2:])
+
+
+class Renderer_ours(nn.Module):
+    """models/render_models.py:143-220 (use_viewdirs=True head)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, input_ch_feat=8, skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = input_ch, input_ch_views, skips, use_viewdirs
+        self.in_ch_pts, self.in_ch_views, self.in_ch_feat = input_ch, input_ch_views, input_ch_feat
+        self.pts_linears = nn.ModuleList([nn.Linear(input_ch, W, bias=True)] +
+                                         [nn.Linear(W, W, bias=True) if i not in skips else nn.Linear(W + input_ch, W) for i in range(D - 1)])
+        self.pts_bias = nn.Linear(input_ch_feat, W)
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight.data)
+                nn.init.zeros_(m.bias.data)
+
+    def forward(self, x):
+        in_ch_feat = x.shape[-1] - self.in_ch_pts - self.in_ch_views
+        pts, feats, views = torch.split(x, [self.in_ch_pts, in_ch_feat, self.in_ch_views], dim=-1)
+        h = pts
+        bias = self.pts_bias(feats)
+        for i in range(len(self.pts_linears)):
+            h = F.relu(self.pts_linears[i](h) * bias)
+            if i in self.skips:
+                h = torch.cat([pts, h], -1)
+        alpha = torch.relu(self.alpha_linear(h))
+        feature = self.feature_linear(h)
+        h = F.relu(self.views_linears[0](torch.cat([feature, views], -1)))
+        rgb = torch.sigmoid(self.rgb_linear(h))
+        return torch.cat([rgb, alpha], -1)
+
+
+class RenderNet(nn.Module):
+    """models/render_models.py:538-565, net_type 'v0'."""
+
+    def __init__(self, D=8, W=256, input_ch_pts=3, input_ch_views=3, input_ch_feat=8, skips=[4], net_type="v0"):
+        super().__init__()
+        if net_type != "v0":
+            raise NotImplementedError("only net_type='v0' (the reference's default) is provided")
+        self.in_ch_pts, self.in_ch_views, self.in_ch_feat = input_ch_pts, input_ch_views, input_ch_feat
+        self.nerf = Renderer_ours(D=D, W=W, input_ch_feat=input_ch_feat, input_ch=input_ch_pts, output_ch=4, skips=skips,
+                                  input_ch_views=input_ch_views, use_viewdirs=True)
+        self._blob = None
+        self._blob_key = None
+
+    def hip_blob(self):
+        n = self.nerf
+        named = {"pts_bias": n.pts_bias, "alpha_linear": n.alpha_linear, "feature_linear": n.feature_linear,
+                 "views_linears.0": n.views_linears[0], "rgb_linear": n.rgb_linear}
+        for i in range(6):
+            named[f"pts_linears.{i}"] = n.pts_linears[i]
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in named.values())
+        if self._blob is None or key != self._blob_key:
+            self._blob = ops.pack_nerf_weights({k: (m.weight, m.bias) for k, m in named.items()})
+            self._blob_key = key
+        return self._blob
+
+    def forward(self, x):
+        return self.nerf(x)
+
+
+def _embed(x, multires=10):
+    freqs = 2.0 ** torch.linspace(0.0, multires - 1, steps=multires, device=x.device)
+    scaled = (x.unsqueeze(-2) * freqs.reshape(*([1] * (x.dim() - 1)), -1, 1)).reshape(*x.shape[:-1], -1)
+    return torch.cat((x, torch.sin(scaled), torch.cos(scaled)), dim=-1)
+
+
+class Rendering_Consistency_Net(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.args.feat_dim = 8 + 3 * 4
+        self.idx = 0
+        if getattr(args, "net_type", "v0") != "v0" or getattr(args, "N_importance", 0) != 0:
+            raise NotImplementedError("only net_type='v0', N_importance=0 (the shipped configuration) is provided")
+        if getattr(args, "multires", 10) != 10 or getattr(args, "netdepth", 6) != 6 or getattr(args, "netwidth", 128) != 128:
+            raise NotImplementedError("the MLP kernels are built for multires=10, netdepth=6, netwidth=128 (the shipped configuration)")
+        self.MVSNet = Neural_Volume_Net()
+        self.network_fn = RenderNet(D=args.netdepth, W=args.netwidth, input_ch_pts=63, skips=[4], input_ch_views=args.dir_dim,
+                                    input_ch_feat=self.args.feat_dim, net_type=args.net_type)
+        self.white_bkgd = getattr(args, "white_bkgd", False)
+
+    # ---- helpers shared by both paths ----------------------------------------------------------
+    @staticmethod
+    def _unpreprocess(imgs):
+        mean = torch.tensor([-m / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)], device=imgs.device).view(1, 1, 3, 1, 1)
+        std = torch.tensor([1 / s for s in IMAGENET_STD], device=imgs.device).view(1, 1, 3, 1, 1)
+        return (imgs - mean) / std
+
+    def _draw(self, H, W, S, dev):
+        xs = torch.randint(0, W, (N_RAYS,), device=dev)
+        ys = torch.randint(0, H, (N_RAYS,), device=dev)
+        return torch.stack((xs, ys)), torch.randn(N_RAYS, S, device=dev), torch.rand(N_RAYS // 2, S, device=dev)
+
+    def forward(self, volume_feature_warp, pseudo_depth, batch, randoms=None):
+        if "scan" in batch:
+            batch.pop("scan")
+        dev = volume_feature_warp.device
+        imgs = batch["imgs"].float().to(dev)
+        w2cs = batch["w2cs"].float().to(dev).squeeze(0)
+        c2ws = batch["c2ws"].float().to(dev).squeeze(0)
+        intr = batch["intrinsics"].float().to(dev).squeeze(0)
+        nf = batch["near_fars"].float().to(dev).squeeze(0)
+        _, V, _, H, W = imgs.shape
+        S = self.args.N_samples
+        pix, eps, u = randoms if randoms is not None else self._draw(H, W, S, dev)
+        imgs = self._unpreprocess(imgs)
+        pseudo = pseudo_depth.reshape(H, W).float()
+        if _hip_inference(self, volume_feature_warp, pseudo):
+            return self._forward_hip(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
+        _note_delegation("Rendering_Consistency_Net")
+        return self._forward_aten(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
+
+    # ---- native path ------------------------------------------------------------------------------
+    def _forward_hip(self, vfw, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u):
+        vol = self.MVSNet.forward_cl(vfw)[0].contiguous()                       # (128,h,w,8)
+        cam = torch.cat((intr[0].reshape(-1), c2ws[0].reshape(-1), w2cs[0].reshape(-1), intr[0].reshape(-1), nf[0])).contiguous()
+        z, pts, ndc, dirs, rdepth, target = ops.gu_sample(pseudo.contiguous(), imgs[0, 0].contiguous(), pix.to(torch.int32).contiguous(),
+                                                          eps.contiguous(), u.contiguous(), cam)
+        # quirk reproduced (render_consist_net.py:74 vs render_utils.py:260): images of views 1..3, poses of views 0..2
+        imgs3 = imgs[0, -3:].contiguous()
+        poses = torch.cat((w2cs[:3].reshape(3, 16), intr[:3].reshape(3, 9)), dim=1).contiguous()
+        feat = ops.point_feats(vol, imgs3, poses, pts, ndc, ldf=32)
+        raw = ops.nerf_mlp(ndc, feat, dirs, w2cs[0].contiguous(), self.network_fn.hip_blob())
+        rgb, depth, weights, alpha = ops.composite(raw, z)
+        S = z.shape[1]
+        return rgb, feat[:, :20].reshape(N_RAYS, S, 20), weights, depth, alpha, {}, rdepth, target
+
+    # ---- delegated path (autograd): the reference's op graph on PyTorch-ROCm -------------------------
+    def _forward_aten(self, vfw, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u):
+        _, V, _, H, W = imgs.shape
+        S = eps.shape[1]
+        volume = self.MVSNet(vfw)
+        xs, ys = pix[0].float(), pix[1].float()
+        K, c2w = intr[0], c2ws[0]
+        dirs = torch.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], torch.ones_like(xs)], -1)
+        rays_d = dirs @ c2w[:3, :3].t()
+        rays_o = c2w[:3, -1]
+        target = imgs[0, 0][:, pix[1], pix[0]].permute(1, 0)
+        rdepth = pseudo[pix[1], pix[0]]
+        near, far = nf[0, 0], nf[0, 1]
+        half = N_RAYS // 2
+        sigma = torch.min(torch.abs(far - rdepth), torch.abs(rdepth - near)) / 3
+        g, _ = torch.sort(rdepth.unsqueeze(1) + sigma.unsqueeze(1) * eps, dim=1)
+        t = torch.linspace(0.0, 1.0, steps=S, device=eps.device).reshape(1, S)
+        lin = near * (1.0 - t) + far * t
+        mids = 0.5 * (lin[:, 1:] + lin[:, :-1])
+        upper, lower = torch.cat([mids, lin[:, -1:]], -1), torch.cat([lin[:, :1], mids], -1)
+        z = torch.cat((g[:half], lower + (upper - lower) * u), dim=0)
+        pts = rays_o.reshape(1, 1, 3) + z.unsqueeze(-1) * rays_d.unsqueeze(1)
+        inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32, device=pts.device)
+
+        def ndc_of(w2c, Kk, p, nr, fr):
+            q = (p.reshape(-1, 3) @ w2c[:3, :3].t() + w2c[:3, 3].reshape(1, 3)) @ Kk.t()
+            xy = (q[:, :2] / q[:, 2:3] + 0.0) / inv_scale.reshape(1, 2)
+            return torch.cat((xy, ((q[:, 2] - nr) / (fr - nr)).unsqueeze(1)), dim=1).reshape(p.shape)
+
+        ndc = ndc_of(w2cs[0], intr[0], pts, near, far)
+        grid = ndc.view(-1, 1, N_RAYS, S, 3) * 2 - 1.0
+        vfeat = F.grid_sample(volume, grid, align_corners=True, mode="bilinear")[:, :, 0].permute(2, 3, 0, 1).squeeze()
+        feats = [vfeat]
+        imgs3 = imgs[:, -3:]
+        for i in range(3):
+            gxy = ndc_of(w2cs[i], intr[i], pts, 2, 6)[None][..., :2] * 2.0 - 1.0
+            data = F.grid_sample(imgs3[:, i], gxy, align_corners=True, mode="bilinear", padding_mode="border")
+            inb = (gxy > -1.0) * (gxy < 1.0)
+            mask = (inb[..., 0] * inb[..., 1]).float()
+            feats.append(torch.cat((data, mask.unsqueeze(1)), dim=1)[0].permute(1, 2, 0))
+        feat = torch.cat(feats, dim=-1)
+        cos = torch.norm(rays_d, dim=-1)
+        angle = (rays_d / cos.unsqueeze(-1)) @ w2cs[0][:3, :3].t()
+        x = torch.cat((_embed(ndc), feat, angle[:, None].expand(-1, S, -1)), dim=-1)
+        raw = self.network_fn(x.reshape(-1, x.shape[-1])).reshape(N_RAYS, S, 4)
+        alpha = 1.0 - torch.exp(-raw[..., 3])
+        T = torch.cumprod(torch.cat([torch.ones(N_RAYS, 1, device=alpha.device), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+        weights = alpha * T
+        rgb = torch.sum(weights[..., None] * raw[..., :3], -2)
+        depth = torch.sum(weights * z, -1)
+        if self.white_bkgd:
+            rgb = rgb + (1.0 - torch.sum(weights, -1)[..., None])
+        return rgb, feat, weights, depth, alpha, {}, rdepth, target
