@@ -135,6 +135,11 @@ bool conv3d_mfma_supported(int Ci, int Co, int mode);
 int pack_weight_mfma_launch(const float* w, float* packed, int Co, int Ci, int transposed, hipStream_t st);
 long long mfma_weight_floats_host(int Ci, int Co);
 
+// conv3d_lds.hip
+bool conv3d_lds_supported(int Ci, int Co, int stride);
+int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
+
 // packed weight blob = [27][Ci][Co] (direct kernels) followed by the MFMA image when the pair has one
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
 
@@ -179,6 +184,8 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
     if (conv3d_mfma_supported(Ci, Co, mode) && !g_force_direct)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
                                   mode, relu, st);
+    if (conv3d_lds_supported(Ci, Co, stride) && !g_force_direct)
+        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
     if (stride == 1) return direct_dispatch<CONV_S1>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
     return direct_dispatch<CONV_S2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
 }

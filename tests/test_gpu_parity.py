@@ -241,6 +241,32 @@ def test_conv3d_vs_oracle(hip, Ci, Co, stride):
     assert rel_err(y2.cpu().permute(0, 4, 1, 2, 3), ref2) < 2e-5
 
 
+@pytest.mark.parametrize("Ci", [8, 16, 32, 44])
+def test_conv3d_lds_halo_kernel(hip, Ci):
+    """Cout = 8 stride-1 layers run on the LDS-staged halo kernel: against the oracle (ragged tiles: sizes
+    that are not multiples of the 2x8x16 tile, batch 2, full epilogue) and against the direct kernel."""
+    from oracle import conv3d as oc
+    g = torch.Generator().manual_seed(Ci)
+    x = torch.randn(2, Ci, 5, 11, 21, generator=g)
+    w = torch.randn(8, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+    scale, shift = 0.5 + torch.rand(8, generator=g), 0.1 * torch.randn(8, generator=g)
+    ref = oc.conv3d(x, w)
+    res = torch.randn_like(ref)
+    ref2 = torch.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)) + res
+    wp = hip.pack_conv3d_weight(gpu(w))
+    xcl = gpu(x.permute(0, 2, 3, 4, 1))
+    y = hip.conv3d(xcl, wp)
+    y2 = hip.conv3d(xcl, wp, gpu(scale), gpu(shift), gpu(res.permute(0, 2, 3, 4, 1)), relu=True)
+    assert rel_err(y.cpu().permute(0, 4, 1, 2, 3), ref) < 2e-5
+    assert rel_err(y2.cpu().permute(0, 4, 1, 2, 3), ref2) < 2e-5
+    try:
+        hip.force_direct_conv(True)
+        yd = hip.conv3d(xcl, wp)
+    finally:
+        hip.force_direct_conv(False)
+    assert rel_err(y.cpu(), yd.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("Ci,Co", [(64, 32), (32, 16), (16, 8)])
 def test_deconv3d_vs_oracle(hip, Ci, Co):
     from oracle import conv3d as oc
