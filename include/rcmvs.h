@@ -82,7 +82,7 @@ int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot
  * fragment-ordered image [27][Ci/(4*VEC)][Co/16][64 lanes][VEC] those kernels read. */
 long long rcmvs_packed_weight_floats(int Co, int Ci);   /* size of `packed` in floats ([27][Ci][Co] + MFMA image) */
 int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream);
-/* test/bench hook: 1 = route every layer through the direct (non-MFMA) kernels */
+/* test/bench hook: bit0 = route every layer through the direct kernels; bits 1.. = LDS-conv tuning config */
 void rcmvs_debug_force_direct_conv(int on);
 
 /* y = epilogue(conv3d(x, w, k=3, pad=1, stride)),  x (B,D,H,W,Ci) -> y (B,Do,Ho,Wo,Co),

@@ -140,6 +140,8 @@ bool conv3d_lds_supported(int Ci, int Co, int stride);
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                       int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
 
+void conv3d_lds_set_config(int c);
+
 // packed weight blob = [27][Ci][Co] (direct kernels) followed by the MFMA image when the pair has one
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
 
@@ -151,7 +153,7 @@ static int g_force_direct = 0;   // test/bench hook: route everything through th
 
 extern "C" {
 
-void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on; }
+void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; conv3d_lds_set_config(on >> 1); }
 
 long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;

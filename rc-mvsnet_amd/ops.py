@@ -115,7 +115,7 @@ class PackedWeight:
 
 def force_direct_conv(on):
     """test/bench hook: route every 3-D conv through the direct (non-MFMA) kernels."""
-    _lib.load().rcmvs_debug_force_direct_conv(int(bool(on)))
+    _lib.load().rcmvs_debug_force_direct_conv(int(on))    # bit0 force direct; bits 1.. = LDS-kernel tuning config
 
 
 def pack_conv3d_weight(w, transposed=False):
