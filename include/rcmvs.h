@@ -99,6 +99,18 @@ int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale
                        const float* residual, float* y,
                        int B, int D, int H, int W, int Ci, int Co, int relu, void* stream);
 
+/* ---- 2-D feature pyramid (FeatureNet fpn, models/modules.py:363-464), channels-last, inference -------- */
+/* imgs (N,3,H,W) NCHW -> (N,H,W,4) with a zero 4th channel (16-byte input vectors). */
+int rcmvs_rgb_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream);
+/* w (Co,Ci,K,K) -> packed [K*K][Cip][Co], input channels zero-padded to Cip. */
+int rcmvs_pack_conv2d_weight(const float* w, float* packed, int Co, int Ci, int Cip, int K, void* stream);
+/* y = [relu]( up2(up_add) + conv2d(x, w, K, pad K/2, stride) * scale + shift ),  x (N,H,W,Ci) -> y (N,Ho,Wo,Co);
+ * scale / shift / up_add may be NULL (shift alone = plain bias; up_add (N,Ho/2,Wo/2,Co) is added after
+ * nearest x2 up-sampling: the FPN merge `F.interpolate(intra) + inner(conv)`, modules.py:448-455).
+ * Replaces Conv2d.forward = conv + BN(eval) + ReLU (modules.py:53-59) and the bare 1x1 / 3x3 output convs. */
+int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
+                     float* y, int N, int H, int W, int Ci, int Co, int K, int stride, int relu, void* stream);
+
 /* ---- K4: prob conv + softmax + soft-argmin + photometric confidence ---------------------- */
 /* replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression and the
  * confidence gather of DepthNet_eval.forward (models/casmvsnet.py:293-309).

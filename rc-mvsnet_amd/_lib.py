@@ -33,6 +33,9 @@ SIGNATURES = {
     "rcmvs_debug_force_direct_conv": [_i],
     "rcmvs_conv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_deconv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_rgb_to_nhwc4": [_p, _p, _i, _i, _i, _p],
+    "rcmvs_pack_conv2d_weight": [_p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_depth_head_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_resize_planes_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_gu_sample_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -82,6 +82,55 @@ class FeatureNet(nn.Module):
             self.out2 = nn.Conv2d(final_chs, b, 3, padding=1, bias=False)
             self.out_channels.append(b)
 
+    # -- native inference path: channels-last HIP kernels (conv + folded BN + ReLU, FPN merge fused) --------
+    def hip_plan(self):
+        mods = [m for seq in (self.conv0, self.conv1, self.conv2) for m in seq]
+        tens = []
+        for m in mods:
+            tens += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+        extra = [self.out1.weight]
+        if self.num_stage >= 2:
+            extra += [self.inner1.weight, self.inner1.bias, self.out2.weight]
+        if self.num_stage == 3:
+            extra += [self.inner2.weight, self.inner2.bias, self.out3.weight]
+        key = tuple((t.data_ptr(), t._version) for t in tens + extra)
+        if getattr(self, "_plan", None) is None or key != self._plan_key:
+            plan = {}
+            names = ["conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv1.2", "conv2.0", "conv2.1", "conv2.2"]
+            for n, m in zip(names, mods):
+                pad_to = 4 if m.conv.in_channels == 3 else None
+                plan[n] = (ops.pack_conv2d_weight(m.conv.weight, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
+            plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
+            if self.num_stage >= 2:
+                plan["inner1"] = (ops.pack_conv2d_weight(self.inner1.weight), self.inner1.bias.detach().float().contiguous())
+                plan["out2"] = ops.pack_conv2d_weight(self.out2.weight)
+            if self.num_stage == 3:
+                plan["inner2"] = (ops.pack_conv2d_weight(self.inner2.weight), self.inner2.bias.detach().float().contiguous())
+                plan["out3"] = ops.pack_conv2d_weight(self.out3.weight)
+            self._plan, self._plan_key = plan, key
+        return self._plan
+
+    def forward_cl(self, x):
+        """x (N,3,H,W) NCHW -> {'stageK': (N,h,w,C)} channels-last feature maps (HIP path, eval-mode BN)."""
+        p = self.hip_plan()
+
+        def cbr(t, n):
+            w, sc, sh, stride = p[n]
+            return ops.conv2d(t, w, sc, sh, stride=stride, relu=True)
+
+        t = ops.rgb_to_nhwc4(x.contiguous().float())
+        c0 = cbr(cbr(t, "conv0.0"), "conv0.1")
+        c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
+        c2 = cbr(cbr(cbr(c1, "conv2.0"), "conv2.1"), "conv2.2")
+        out = {"stage1": ops.conv2d(c2, p["out1"])}
+        if self.num_stage >= 2:
+            intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
+            out["stage2"] = ops.conv2d(intra, p["out2"])
+        if self.num_stage == 3:
+            intra = ops.conv2d(c0, p["inner2"][0], None, p["inner2"][1], up_add=intra)
+            out["stage3"] = ops.conv2d(intra, p["out3"])
+        return out
+
     def forward(self, x):
         conv0 = self.conv0(x)
         conv1 = self.conv1(conv0)
@@ -378,16 +427,23 @@ class _CascadeBase(nn.Module):
         B, V, _, H, W = imgs.shape
         imgs = imgs.float()
         depth_values = depth_values.contiguous().float()
-        feats = features if features is not None else self.feature(imgs.reshape(B * V, 3, H, W))   # eval BN: batching over views is exact
+        # eval-mode BN: batching the V views is exact.  `features` (test hook) are NCHW maps; the native pyramid
+        # already produces the channels-last maps K1 reads.
+        feats_cl = None
+        if features is None:
+            feats_cl = self.feature.forward_cl(imgs.reshape(B * V, 3, H, W))
         outputs = {}
         depth = None
         for s in range(self.num_stage):
             key = "stage{}".format(s + 1)
             scale = int(self.stage_infos[key]["scale"])
             D = self.ndepths[s]
-            f = feats[key]
-            C, h, w = f.shape[1:]
-            f_cl = ops.to_channels_last(f.contiguous()).view(B, V, h, w, C)
+            if feats_cl is not None:
+                h, w, C = feats_cl[key].shape[1:]
+                f_cl = feats_cl[key].view(B, V, h, w, C)
+            else:
+                C, h, w = features[key].shape[1:]
+                f_cl = ops.to_channels_last(features[key].contiguous()).view(B, V, h, w, C)
             if homographies is not None:
                 rot, trans = homographies[key]
             else:

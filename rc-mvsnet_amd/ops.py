@@ -107,7 +107,7 @@ def warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first):
 # ------------------------------------------------------------------------------- K2/K3
 class PackedWeight:
     """Device blob produced by rcmvs_pack_conv3d_weight plus its channel counts."""
-    __slots__ = ("blob", "ci", "co")
+    __slots__ = ("blob", "ci", "co", "k")
 
     def __init__(self, blob, ci, co):
         self.blob, self.ci, self.co = blob, ci, co
@@ -158,6 +158,43 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     _lib.check(_lib.load().rcmvs_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                               _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
                                               _stream()), "deconv3d_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------- 2-D feature pyramid
+def rgb_to_nhwc4(x):
+    """(N,3,H,W) -> (N,H,W,4), zero 4th channel."""
+    N, _, H, W = x.shape
+    y = torch.empty((N, H, W, 4), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_rgb_to_nhwc4(_chk(x, "x"), _chk(y, "y"), N, H, W, _stream()), "rgb_to_nhwc4")
+    return y
+
+
+def pack_conv2d_weight(w, pad_in_to=None):
+    """(Co,Ci,K,K) -> PackedWeight ([K*K][Cip][Co])."""
+    w = w.detach().contiguous().float()
+    Co, Ci, K, _ = w.shape
+    Cip = Ci if pad_in_to is None else pad_in_to
+    blob = torch.empty((K * K * Cip * Co,), device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_pack_conv2d_weight(_chk(w, "w"), _chk(blob, "packed"), Co, Ci, Cip, K, _stream()), "pack_conv2d_weight")
+    pw = PackedWeight(blob, Cip, Co)
+    pw.k = K
+    return pw
+
+
+def conv2d(x, w_packed, scale=None, shift=None, up_add=None, stride=1, relu=False):
+    """x (N,H,W,Ci) -> (N,Ho,Wo,Co) = [relu](up2(up_add) + conv*scale + shift)."""
+    N, H, W, Ci = x.shape
+    K, Co = w_packed.k, w_packed.co
+    if w_packed.ci != Ci:
+        raise _lib.RcmvsError(f"conv2d: input has {Ci} channels, weight expects {w_packed.ci}")
+    Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+    y = torch.empty((N, Ho, Wo, Co), device=x.device, dtype=torch.float32)
+    if up_add is not None and tuple(up_add.shape) != (N, Ho // 2, Wo // 2, Co):
+        raise _lib.RcmvsError(f"conv2d: up_add {tuple(up_add.shape)} does not match half of the output {tuple(y.shape)}")
+    _lib.check(_lib.load().rcmvs_conv2d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                            _opt(up_add, "up_add"), _chk(y, "y"), N, H, W, Ci, Co, K, stride, int(relu), _stream()),
+               "conv2d_fwd")
     return y
 
 

@@ -306,6 +306,50 @@ def test_costreg_vs_golden(hip):
     assert rel_err(out.cpu(), g["out"]) < 5e-5
 
 
+# ------------------------------------------------------------------------------------------ 2-D pyramid
+@pytest.mark.parametrize("Ci,Co,K,stride", [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1),
+                                            (32, 32, 1, 1), (16, 32, 1, 1), (32, 16, 3, 1), (8, 32, 1, 1), (32, 8, 3, 1)])
+def test_conv2d_vs_torch_cpu(hip, Ci, Co, K, stride):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(Ci * 10 + Co)
+    x = torch.randn(2, Ci, 38, 52, generator=g)               # ragged tiles, batch 2
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    scale, shift = 0.5 + torch.rand(Co, generator=g), 0.1 * torch.randn(Co, generator=g)
+    ref = F.conv2d(x, w, None, stride, K // 2)
+    Cip = 4 if Ci == 3 else Ci
+    wp = hip.pack_conv2d_weight(gpu(w), pad_in_to=Cip)
+    xcl = gpu(x) if Ci != 3 else None
+    xin = hip.rgb_to_nhwc4(gpu(x)) if Ci == 3 else gpu(x.permute(0, 2, 3, 1))
+    y = hip.conv2d(xin, wp, stride=stride)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 2e-5
+    y2 = hip.conv2d(xin, wp, gpu(scale), gpu(shift), stride=stride, relu=True)
+    assert rel_err(y2.cpu().permute(0, 3, 1, 2), torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))) < 2e-5
+    if stride == 1:                                           # FPN merge: nearest x2 up-sample add + bias
+        up = torch.randn(2, Co, 19, 26, generator=g)
+        y3 = hip.conv2d(xin, wp, None, gpu(shift), up_add=gpu(up.permute(0, 2, 3, 1)), stride=1)
+        ref3 = F.interpolate(up, scale_factor=2, mode="nearest") + (ref + shift.view(1, -1, 1, 1))
+        assert rel_err(y3.cpu().permute(0, 3, 1, 2), ref3) < 2e-5
+
+
+def test_feature_net_vs_oracle(hip):
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    from oracle.feature_net import feature_net
+    sd = synthetic.cascade_state_dict(0)
+    m = CascadeMVSNet_eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    for (H, W) in ((64, 96), (512, 640)):
+        imgs = synthetic.images(1, 3, H, W, 0)[0]
+        with torch.no_grad():
+            ref = feature_net(imgs, sd)
+            out = m.feature.forward_cl(gpu(imgs))
+        for k in ref:
+            e = (out[k].cpu().permute(0, 3, 1, 2) - ref[k]).abs()
+            print(f"FeatureNet {H}x{W} {k}: max err {float(e.max()):.3e} mean {float(e.mean()):.3e} (|ref| max {float(ref[k].abs().max()):.2f})")
+            assert float(e.max()) < 5e-5 * max(1.0, float(ref[k].abs().max()))
+
+
 # ------------------------------------------------------------------------------------------ K4
 @pytest.mark.parametrize("D,h,w", [(8, 12, 16), (48, 16, 24), (32, 9, 130)])
 def test_depth_head_vs_oracle(hip, D, h, w):
