@@ -115,7 +115,7 @@ int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, 
 /* replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression and the
  * confidence gather of DepthNet_eval.forward (models/casmvsnet.py:293-309).
  *   x (B,D,h,w,8) channels-last, w_prob packed [27][8][1];  depth, conf (B,h,w);
- *   prob (B,D,h,w) optional (NULL to skip). */
+ *   prob (B,D,h,w): required -- receives the logits, then the probabilities in place. */
 int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
                          float* depth, float* conf, float* prob,
                          int B, int D, int h, int w, void* stream);

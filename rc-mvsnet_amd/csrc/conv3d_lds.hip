@@ -99,13 +99,18 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
         if (rp) v += rp[co];
         acc[co] = v;
     }
+    if constexpr (COT % 4 == 0) {
 #pragma unroll
-    for (int co = 0; co < COT; co += 4)
-        *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+        for (int co = 0; co < COT; co += 4)
+            *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+    } else {
+#pragma unroll
+        for (int co = 0; co < COT; ++co) yp[co] = acc[co];
+    }
 }
 
 bool conv3d_lds_supported(int Ci, int Co, int stride) {
-    return stride == 1 && Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32 || Ci == 44);
+    return stride == 1 && ((Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32 || Ci == 44)) || (Co == 1 && Ci == 8));
 }
 
 static int g_lds_cfg = 0;   // debug override: 0 = tuned default; else bit0 = 16-channel chunks, bit1 = force split, bit2 = force no split
@@ -127,6 +132,12 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
         if (split == 2) { if (ckt == 8) RCMVS_LDS_LAUNCH(CI, 2, 8); else RCMVS_LDS_LAUNCH(CI, 2, 16); } \
         else            { if (ckt == 8) RCMVS_LDS_LAUNCH(CI, 1, 8); else RCMVS_LDS_LAUNCH(CI, 1, 16); } \
         return launch_status("conv3d_lds");                                                 \
+    }
+    if (Co == 1 && Ci == 8) {                                   // prob conv 8 -> 1 (logits, (B,D,H,W) since Co = 1)
+        dim3 block1(256);
+        hipLaunchKernelGGL((conv3d_lds_kernel<8, 1, 1, 8>), grid, block1, (size_t)LH_VOX * 12 * sizeof(float), st, x, wp, scale, shift,
+                           res, y, D, H, W, tiles_w, tiles_h, relu);
+        return launch_status("conv3d_lds(prob)");
     }
     RCMVS_LDS_CASE(8) RCMVS_LDS_CASE(16) RCMVS_LDS_CASE(32) RCMVS_LDS_CASE(44)
 #undef RCMVS_LDS_CASE

@@ -4,92 +4,47 @@
 // Replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression (x2),
 // F.pad + avg_pool3d and torch.gather in DepthNet_eval.forward (models/casmvsnet.py:293-309).
 //
-// A 256-thread block owns 32 consecutive pixels x all D planes.  Phase 1: every thread computes
-// logits for (pixel = t % 32, plane = t / 32 + 8 i): 27 taps x 8 channels, two 16-byte loads per
-// tap, weights wave-uniform -- B*D*h*w-way parallel, so stage 1 (20 480 pixels) still fills the
-// chip.  The logits go to an LDS column [k][pixel] (conflict-free).  Phase 2: one thread per
-// pixel runs the softmax / regression / confidence over its column in place.
+// Two launches: (1) the prob conv runs on the LDS-staged halo kernel of conv3d_lds.hip (Cout = 1: the
+// logits land in the caller's (B,D,h,w) probability buffer); (2) one thread per pixel turns its logit
+// column into probabilities IN PLACE (max, exp, sum, divide -- coalesced plane-major accesses, the
+// column stays in L2) and accumulates depth = sum p*d, index = sum p*k and the 4-tap confidence window.
+// The logit volume is D*h*w*4 B = 4-10 MB per stage, so the round trip is noise next to the 31-84 MB
+// input volume, which is read exactly once.
 #include "common.h"
 
 namespace rcmvs {
 
-constexpr int HEAD_PX = 32;
-constexpr int HEAD_THREADS = 256;
-constexpr int HEAD_KPAR = HEAD_THREADS / HEAD_PX;   // planes computed concurrently per pixel
+int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);   // conv3d_lds.hip
 
-__global__ __launch_bounds__(HEAD_THREADS) void depth_head_kernel(
-    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ planes,
-    float* __restrict__ depth, float* __restrict__ conf, float* __restrict__ prob, int D, int h, int w) {
-    extern __shared__ __attribute__((aligned(16))) float col[];   // [D][HEAD_PX]
+__global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict__ prob, const float* __restrict__ planes,
+                                                               float* __restrict__ depth, float* __restrict__ conf, int D, long long hw) {
     const int b = blockIdx.y;
-    const long long hw = (long long)h * w;
-    const int px = threadIdx.x % HEAD_PX;
-    const int kpar = threadIdx.x / HEAD_PX;
-    long long p = (long long)blockIdx.x * HEAD_PX + px;
-    const bool active = p < hw;
-    if (!active) p = hw - 1;
-    const int y = (int)(p / w), xx = (int)(p % w);
-    const float* xb = x + (long long)b * D * hw * 8;
-
-    for (int k = kpar; k < D; k += HEAD_KPAR) {
-        float acc = 0.0f;
-        for (int kd = 0; kd < 3; ++kd) {
-            int id = k + kd - 1;
-            if (id < 0 || id >= D) continue;
-            for (int kh = 0; kh < 3; ++kh) {
-                int ih = y + kh - 1;
-                if (ih < 0 || ih >= h) continue;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    int iw = xx + kw - 1;
-                    if (iw < 0 || iw >= w) continue;
-                    const float* xp = xb + (((long long)id * h + ih) * w + iw) * 8;
-                    const float* wt = wp + ((kd * 3 + kh) * 3 + kw) * 8;
-                    float4 a = *reinterpret_cast<const float4*>(xp);
-                    float4 c = *reinterpret_cast<const float4*>(xp + 4);
-                    acc = fmaf(a.x, wt[0], acc); acc = fmaf(a.y, wt[1], acc);
-                    acc = fmaf(a.z, wt[2], acc); acc = fmaf(a.w, wt[3], acc);
-                    acc = fmaf(c.x, wt[4], acc); acc = fmaf(c.y, wt[5], acc);
-                    acc = fmaf(c.z, wt[6], acc); acc = fmaf(c.w, wt[7], acc);
-                }
-            }
-        }
-        col[k * HEAD_PX + px] = acc;
-    }
-    __syncthreads();
-    if (kpar != 0) return;
-
+    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    float* col = prob + (long long)b * D * hw + p;              // element k at col[k*hw]
     float mx = -INFINITY;
-    for (int k = 0; k < D; ++k) mx = fmaxf(mx, col[k * HEAD_PX + px]);
-    // softmax (exp(x - max) / sum), in place
+    for (int k = 0; k < D; ++k) mx = fmaxf(mx, col[(long long)k * hw]);
     float sum = 0.0f;
-    for (int k = 0; k < D; ++k) {
-        float e = expf(col[k * HEAD_PX + px] - mx);
-        col[k * HEAD_PX + px] = e;
-        sum += e;
-    }
+    for (int k = 0; k < D; ++k) sum += expf(col[(long long)k * hw] - mx);
     const float2 pl = reinterpret_cast<const float2*>(planes)[(long long)b * hw + p];
     float dsum = 0.0f, isum = 0.0f;
     for (int k = 0; k < D; ++k) {
-        float pk = col[k * HEAD_PX + px] / sum;
-        col[k * HEAD_PX + px] = pk;
-        float dk = pl.x + (float)k * pl.y;
-        dsum += pk * dk;
+        const float pk = expf(col[(long long)k * hw] - mx) / sum;
+        col[(long long)k * hw] = pk;
+        dsum += pk * (pl.x + (float)k * pl.y);
         isum += pk * (float)k;
-        if (prob && active) prob[((long long)b * D + k) * hw + p] = pk;
     }
     int idx = (int)isum;                       // .long(): truncation
     idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
     float c = 0.0f;                            // ((p[i-1] + p[i]) + p[i+1]) + p[i+2], zero padded
 #pragma unroll
     for (int j = -1; j <= 2; ++j) {
-        int kk = idx + j;
-        c += (kk >= 0 && kk < D) ? col[kk * HEAD_PX + px] : 0.0f;
+        const int kk = idx + j;
+        c += (kk >= 0 && kk < D) ? col[(long long)kk * hw] : 0.0f;
     }
-    if (active) {
-        depth[(long long)b * hw + p] = dsum;
-        conf[(long long)b * hw + p] = c;
-    }
+    depth[(long long)b * hw + p] = dsum;
+    conf[(long long)b * hw + p] = c;
 }
 
 }  // namespace rcmvs
@@ -99,16 +54,12 @@ using namespace rcmvs;
 extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
                                     float* depth, float* conf, float* prob,
                                     int B, int D, int h, int w, void* stream) {
-    RCMVS_REQUIRE(x && w_prob && planes && depth && conf, "depth_head_fwd: null pointer");
+    RCMVS_REQUIRE(x && w_prob && planes && depth && conf && prob, "depth_head_fwd: null pointer (prob is required: it doubles as the logit scratch)");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "depth_head_fwd: bad sizes");
-    size_t lds = (size_t)D * HEAD_PX * sizeof(float);
-    RCMVS_REQUIRE(lds <= 160 * 1024, "depth_head_fwd: D=%d needs %zu B of LDS (max 160 KiB)", D, lds);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)depth_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail((int)e, "depth_head_fwd: cannot raise dynamic LDS to %zu", lds);
-    }
-    dim3 grid((unsigned)cdiv((long long)h * w, HEAD_PX), B);
-    hipLaunchKernelGGL(depth_head_kernel, grid, dim3(HEAD_THREADS), lds, as_stream(stream), x, w_prob, planes, depth, conf,
-                       prob, D, h, w);
+    hipStream_t st = as_stream(stream);
+    int rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st);
+    if (rc) return rc;
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(softmax_regress_kernel, dim3((unsigned)cdiv(hw, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
     return launch_status("depth_head_fwd");
 }

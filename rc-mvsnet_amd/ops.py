@@ -206,7 +206,7 @@ def depth_head(x8, w_prob_packed, planes, want_prob=False):
         raise _lib.RcmvsError("depth_head: the prob conv takes 8 channels")
     depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
-    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32) if want_prob else None
+    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32)     # logit scratch -> probabilities
     _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
                                                 _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
                                                 _stream()), "depth_head_fwd")
