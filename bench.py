@@ -134,9 +134,15 @@ def main():
     bytes_stage = k1_algorithmic_bytes()
     tot_ms = sum(per_stage_ms)
     achieved = sum(bytes_stage) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "rcmvs::warp_variance_kernel (K1, 3 launches per scene)",
+    traffic = None                      # HBM bytes per scene from the committed PMC profile (FETCH_SIZE x2 + WRITE_SIZE)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_k1_traffic.json")))["bytes_per_scene"]
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "rcmvs::warp_variance_tp_kernel (K1, 3 launches per scene)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_note": "bytes per scene (sum of the 3 launches), rocprofv3 PMC passes of profiles/r1_k1_traffic.json",
                 "algorithmic_bytes_per_scene": sum(bytes_stage),
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)]}
