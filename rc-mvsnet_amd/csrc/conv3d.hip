@@ -149,11 +149,12 @@ static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci 
 
 using namespace rcmvs;
 
+static int g_prefer_lds = 1;     // LDS/scalar-weight kernel before the MFMA kernel where both exist (debug bit 16 clears it)
 static int g_force_direct = 0;   // test/bench hook: route everything through the direct kernels
 
 extern "C" {
 
-void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; conv3d_lds_set_config(on >> 1); }
+void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; g_prefer_lds = !(on & 16); conv3d_lds_set_config((on >> 1) & 7); }
 
 long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;
@@ -183,6 +184,8 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
     ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
+    if (g_prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !g_force_direct)
+        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
     if (conv3d_mfma_supported(Ci, Co, mode) && !g_force_direct)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
                                   mode, relu, st);

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
 }
 
 bool conv3d_lds_supported(int Ci, int Co, int stride) {
-    return stride == 1 && ((Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32 || Ci == 44)) || (Co == 1 && Ci == 8));
+    return stride == 1 && ((Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32 || Ci == 44)) || (Co == 1 && Ci == 8) ||
+                           (Co == 16 && Ci == 16));
 }
 
 static int g_lds_cfg = 0;   // debug override: 0 = tuned default; else bit0 = 16-channel chunks, bit1 = force split, bit2 = force no split
@@ -122,7 +123,7 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
     // tuned on MI355X (tools/conv_bench.py): 8-channel chunks keep the per-pass weight set (6.9 KB) in the scalar
     // cache; splitting Cout over two wave groups pays only when there are >= 4 chunk passes (Cin >= 32)
     const int ckt = (g_lds_cfg & 1) ? 16 : 8;
-    const int split = (g_lds_cfg & 2) ? 2 : ((g_lds_cfg & 4) ? 1 : (Ci >= 32 ? 2 : 1));
+    const int split = (g_lds_cfg & 2) ? 2 : ((g_lds_cfg & 4) ? 1 : ((Ci >= 32 || Co >= 16) ? 2 : 1));
     dim3 grid(tiles_w * tiles_h, tiles_d, B), block(256 * split);
     const int ck = Ci < ckt ? Ci : ckt;
     const size_t lds = (size_t)LH_VOX * (ck + 4) * sizeof(float);
@@ -132,6 +133,11 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
         if (split == 2) { if (ckt == 8) RCMVS_LDS_LAUNCH(CI, 2, 8); else RCMVS_LDS_LAUNCH(CI, 2, 16); } \
         else            { if (ckt == 8) RCMVS_LDS_LAUNCH(CI, 1, 8); else RCMVS_LDS_LAUNCH(CI, 1, 16); } \
         return launch_status("conv3d_lds");                                                 \
+    }
+    if (Co == 16 && Ci == 16) {                                 // conv2 of the U-Nets: 16 accumulators, 64 scalar weights per (tap, 4 ch)
+        if (split == 2) hipLaunchKernelGGL((conv3d_lds_kernel<16, 16, 2, 8>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu);
+        else            hipLaunchKernelGGL((conv3d_lds_kernel<16, 16, 1, 8>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu);
+        return launch_status("conv3d_lds(16x16)");
     }
     if (Co == 1 && Ci == 8) {                                   // prob conv 8 -> 1 (logits, (B,D,H,W) since Co = 1)
         dim3 block1(256);

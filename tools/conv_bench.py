@@ -30,3 +30,17 @@ for (C, D, h, w) in ((32, 48, 128, 160), (16, 32, 256, 320), (8, 8, 512, 640)):
     wt = ops.pack_conv3d_weight(torch.randn(16, 8, 3, 3, 3, device=dev) * 0.05, transposed=True)
     us = t(lambda: ops.deconv3d(x16, wt, sc, sh, x8, relu=True))
     print(f"deconv11 16->8 -> {D}x{h}x{w}: {us:8.1f} us  {2 * 27 * 16 * 8 * D * h * w / 8 / us / 1e6:6.1f} TF")
+
+print("-- conv2 16->16 (stage L1 volumes): LDS/scalar-weight kernel vs MFMA kernel")
+for (D, h, w) in ((24, 64, 80), (16, 128, 160), (4, 256, 320)):
+    x = torch.randn(1, D, h, w, 16, device=dev)
+    wp = ops.pack_conv3d_weight(torch.randn(16, 16, 3, 3, 3, device=dev) * 0.05)
+    sc, sh = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
+    fl = 2 * 27 * 16 * 16 * D * h * w
+    res = []
+    for cfg, name in ((0, "lds"), (4, "lds split"), (16, "mfma")):
+        ops.force_direct_conv(cfg)
+        us = t(lambda: ops.conv3d(x, wp, sc, sh, relu=True))
+        res.append(f"{name} {us:7.1f} us {fl / us / 1e6:5.1f} TF")
+    ops.force_direct_conv(0)
+    print(f"conv2 16->16 @ {D}x{h}x{w}: " + " | ".join(res))
