@@ -110,8 +110,12 @@ class FeatureNet(nn.Module):
             self._plan, self._plan_key = plan, key
         return self._plan
 
-    def forward_cl(self, x):
-        """x (N,3,H,W) NCHW -> {'stageK': (N,h,w,C)} channels-last feature maps (HIP path, eval-mode BN)."""
+    def forward_cl(self, x, lazy=False):
+        """x (N,3,H,W) NCHW -> {'stageK': (N,h,w,C)} channels-last feature maps (HIP path, eval-mode BN).
+        lazy=True returns {'stageK': thunk}: the trunk and the FPN merges run now, each stage's output conv
+        runs when its thunk is called -- the cascade calls it right before that stage's warp so the maps are
+        still in L2 / Infinity Cache when K1 gathers from them (they are produced ~1 ms and ~400 MB of volume
+        traffic earlier otherwise)."""
         p = self.hip_plan()
 
         def cbr(t, n):
@@ -122,14 +126,14 @@ class FeatureNet(nn.Module):
         c0 = cbr(cbr(t, "conv0.0"), "conv0.1")
         c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = cbr(cbr(cbr(c1, "conv2.0"), "conv2.1"), "conv2.2")
-        out = {"stage1": ops.conv2d(c2, p["out1"])}
+        out = {"stage1": (lambda t=c2: ops.conv2d(t, p["out1"]))}
         if self.num_stage >= 2:
             intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
-            out["stage2"] = ops.conv2d(intra, p["out2"])
+            out["stage2"] = (lambda t=intra: ops.conv2d(t, p["out2"]))
         if self.num_stage == 3:
             intra = ops.conv2d(c0, p["inner2"][0], None, p["inner2"][1], up_add=intra)
-            out["stage3"] = ops.conv2d(intra, p["out3"])
-        return out
+            out["stage3"] = (lambda t=intra: ops.conv2d(t, p["out3"]))
+        return out if lazy else {k: f() for k, f in out.items()}
 
     def forward(self, x):
         conv0 = self.conv0(x)
@@ -431,7 +435,7 @@ class _CascadeBase(nn.Module):
         # already produces the channels-last maps K1 reads.
         feats_cl = None
         if features is None:
-            feats_cl = self.feature.forward_cl(imgs.reshape(B * V, 3, H, W))
+            feats_cl = self.feature.forward_cl(imgs.reshape(B * V, 3, H, W), lazy=True)
         outputs = {}
         depth = None
         for s in range(self.num_stage):
@@ -439,8 +443,9 @@ class _CascadeBase(nn.Module):
             scale = int(self.stage_infos[key]["scale"])
             D = self.ndepths[s]
             if feats_cl is not None:
-                h, w, C = feats_cl[key].shape[1:]
-                f_cl = feats_cl[key].view(B, V, h, w, C)
+                fk = feats_cl[key]()                                 # this stage's output conv, just in time
+                h, w, C = fk.shape[1:]
+                f_cl = fk.view(B, V, h, w, C)
             else:
                 C, h, w = features[key].shape[1:]
                 f_cl = ops.to_channels_last(features[key].contiguous()).view(B, V, h, w, C)
