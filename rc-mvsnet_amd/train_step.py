@@ -1,0 +1,70 @@
+"""Synthetic-input driver reproducing the call sequence of one reference training iteration
+(train_rcmvsnet.py:145-204,279-312,330-376,397-446): forward #1 of CascadeMVSNet (returns the stage-1
+volume_feature_no_ref), forward #2 on augmented images, Rendering_Consistency_Net.forward on the detached
+pseudo depth, ONE backward over the summed losses, optimizer step.
+
+The reference's self-supervised losses (losses/*.py) are out of scope; simple
+surrogates with the same data flow stand in for them: a smoothness-style term on every stage depth, an
+L1 augmentation-consistency term against the detached pseudo depth, and the renderer's MSE + smooth-L1.
+The renderer is hard-wired to 4 views (1 ref + 3 src; SURVEY.md header note 2).
+"""
+import types
+
+import torch
+import torch.nn.functional as F
+
+from . import synthetic
+from .casmvsnet import CascadeMVSNet
+from .render_consist_net import Rendering_Consistency_Net
+
+
+def render_args(n_samples=128):
+    return types.SimpleNamespace(multires=10, i_embed=0, pts_dim=3, dir_dim=3, netdepth=6, netwidth=128, net_type="v0",
+                                 netchunk=1024, ckpt=None, N_samples=n_samples, N_importance=0, perturb=1.0, use_viewdirs=True,
+                                 white_bkgd=False, raw_noise_std=0.0, pad=0, img_downscale=1.0, use_color_volume=False,
+                                 multires_views=4)
+
+
+def build(device, ndepths=(48, 32, 8), n_samples=128, seed=0):
+    model = CascadeMVSNet(ndepths=list(ndepths), depth_interals_ratio=[4, 2, 1])
+    model.load_state_dict(synthetic.cascade_state_dict(seed), strict=True)
+    model_nerf = Rendering_Consistency_Net(render_args(n_samples))
+    model_nerf.load_state_dict(synthetic.render_state_dict(seed + 1), strict=True)
+    model, model_nerf = model.to(device), model_nerf.to(device)
+    opt = torch.optim.Adam(list(model.parameters()) + list(model_nerf.parameters()), lr=1e-4, betas=(0.9, 0.999))
+    return model, model_nerf, opt
+
+
+def synthetic_sample(device, H=512, W=640, V=4, seed=0):
+    imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, seed)
+    batch = synthetic.render_batch(V, H, W, seed)
+    to = lambda t: t.to(device)
+    return to(imgs), {k: to(v) for k, v in pm.items()}, to(dv), {k: to(v) for k, v in batch.items()}
+
+
+def train_step(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.01):
+    """One iteration; returns a dict of scalar losses (python floats)."""
+    model.train()
+    model_nerf.train()
+    opt.zero_grad(set_to_none=True)
+    # ---- forward #1 (train_rcmvsnet.py:342) + surrogate base loss
+    outputs, volume_feature = model(imgs, proj, depth_values)
+    loss_base = 0.0
+    for k, wgt in (("stage1", 0.5), ("stage2", 1.0), ("stage3", 2.0)):
+        d = outputs[k]["depth"]
+        loss_base = loss_base + wgt * ((d[:, 1:] - d[:, :-1]).abs().mean() + (d[:, :, 1:] - d[:, :, :-1]).abs().mean())
+    pseudo_depth = outputs["depth"].detach()
+    # ---- forward #2 on masked images (train_rcmvsnet.py:412-423)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    mask = (torch.rand(imgs.shape[0], 1, 1, imgs.shape[3] // 8, imgs.shape[4] // 8, generator=g) > 0.1).float().to(imgs.device)
+    mask = F.interpolate(mask[:, 0], size=imgs.shape[-2:], mode="nearest").unsqueeze(1)
+    imgs_aug = torch.cat((imgs[:, :1] * mask, imgs[:, 1:]), dim=1)
+    outputs_aug, _ = model(imgs_aug, proj, depth_values)
+    loss_aug = w_aug * (outputs_aug["depth"] - pseudo_depth).abs().mean()
+    # ---- rendering-consistency branch (train_rcmvsnet.py:285-298)
+    rgb, _, _, depth_pred, _, _, rays_depth, target = model_nerf(volume_feature, pseudo_depth, dict(batch))
+    loss_render = F.mse_loss(rgb, target) + F.smooth_l1_loss(depth_pred, rays_depth)
+    loss = loss_base + loss_aug + loss_render
+    loss.backward()                                           # one backward over both forwards (:311)
+    opt.step()
+    return {"loss": float(loss), "base": float(loss_base), "aug": float(loss_aug), "render": float(loss_render)}
