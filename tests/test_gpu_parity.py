@@ -494,3 +494,35 @@ def test_no_silent_fallback_on_cpu_tensor(hip):
     from rc_mvsnet_amd._lib import RcmvsError
     with pytest.raises(RcmvsError):
         hip.to_channels_last(torch.zeros(1, 4, 2, 2))
+
+
+def test_tanks_and_temples_shape(hip):
+    """BASELINE config 5: 7 views, 1056x1920, D = (64, 32, 8) -- the general-V K1 path (6 source views in
+    LDS-sized chunks), 1 GB variance volumes, D = 64 depth head.  No reference golden at this size (a CPU
+    run takes minutes): size-independent properties only -- finite, depth inside the hypothesis range of
+    each stage, confidence in [0, 1], deterministic."""
+    import time
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    H, W, V = 1056, 1920, 7
+    m = CascadeMVSNet_eval(ndepths=[64, 32, 8], depth_interals_ratio=[4, 2, 1])
+    m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
+    m = m.to(DEV).eval()
+    imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, 0)
+    gi, gp, gd = gpu(imgs), {k: gpu(v) for k, v in pm.items()}, gpu(dv)
+    with torch.no_grad():
+        out = m(gi, gp, gd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out2 = m(gi, gp, gd)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"T&T-shape forward: {dt * 1e3:.1f} ms")
+    assert out["depth"].shape == (1, H, W)
+    for k in ("stage1", "stage2", "stage3"):
+        assert torch.isfinite(out[k]["depth"]).all() and torch.isfinite(out[k]["photometric_confidence"]).all()
+    d1 = out["stage1"]["depth"]
+    assert float(d1.min()) >= 425.0 - 1e-2 and float(d1.max()) <= 425.0 + 2.65 * 191 + 1e-2
+    c = out["photometric_confidence"]
+    assert float(c.min()) >= 0.0 and float(c.max()) <= 1.0 + 1e-5
+    assert torch.equal(out["depth"], out2["depth"])
