@@ -74,6 +74,18 @@ int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot
                          const float* planes, float* out,
                          int B, int V, int C, int D, int h, int w, int square_first, void* stream);
 
+/* K1 backward: gradient w.r.t. the feature maps (the only differentiable inputs: homo_warping
+ * builds its grid under torch.no_grad(), models/modules.py:313).  Replaces the autograd graph of
+ * grid_sample x (V-1) + the variance chain (models/casmvsnet.py:59-101).
+ *   grad_var   (B,D,h,w,C) channels-last: d loss / d var;
+ *   grad_noref (B,D,h,w,C) channels-last or NULL: d loss / d (source-only variance), i.e. the last C
+ *              channels of volume_feature_no_ref (train mode, square_first == 0);
+ *   grad_feats (B,V,h,w,C): MUST be zero-filled by the caller; views 1.. are accumulated with
+ *              hardware fp32 atomics (unordered, like grid_sample's backward), view 0 is stored. */
+int rcmvs_warp_variance_bwd(const float* feats, const float* rot, const float* trans, const float* planes,
+                            const float* grad_var, const float* grad_noref, float* grad_feats,
+                            int B, int V, int C, int D, int h, int w, void* stream);
+
 /* ---- K2/K3: 3-D convolution family, channels-last, fused epilogue ----------------------- */
 /* weight packing (host-visible layout change, done once per weight update):
  *   conv   w (Co,Ci,3,3,3) -> packed [27][Ci][Co]      (nn.Conv3d,          modules.py:145)

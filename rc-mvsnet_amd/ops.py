@@ -104,6 +104,52 @@ def warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first):
     return out
 
 
+def warp_variance_bwd(feats, rot, trans, planes, grad_var, grad_noref=None):
+    """d loss / d feats (B,V,h,w,C) from d loss / d var (and, optionally, d loss / d no-ref variance), both
+    (B,D,h,w,C) channels-last."""
+    B, V, h, w, C = feats.shape
+    D = grad_var.shape[1]
+    if tuple(grad_var.shape) != (B, D, h, w, C) or (grad_noref is not None and grad_noref.shape != grad_var.shape):
+        raise _lib.RcmvsError(f"warp_variance_bwd: gradient shape {tuple(grad_var.shape)} does not match (B,D,h,w,C)")
+    gf = torch.zeros_like(feats)
+    _lib.check(_lib.load().rcmvs_warp_variance_bwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                   _chk(planes, "planes"), _chk(grad_var, "grad_var"),
+                                                   _opt(grad_noref, "grad_noref"), _chk(gf, "grad_feats"),
+                                                   B, V, C, D, h, w, _stream()), "warp_variance_bwd")
+    return gf
+
+
+class WarpVarianceFn(torch.autograd.Function):
+    """Differentiable K1: feats (B,V,h,w,C) -> var (B,D,h,w,C) [, volume_feature_no_ref (B,3(V-1)+C,D,h,w)].
+
+    Forward = rcmvs_warp_variance_fwd (+ rcmvs_warp_noref_fwd when `imgs` is given: the train variant of
+    models/casmvsnet.py:59-101 in train mode); backward = rcmvs_warp_variance_bwd.  Only `feats` is
+    differentiable (the reference's sampling grid is built under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, feats, rot, trans, planes, ndepth, imgs):
+        feats = feats.contiguous()
+        ctx.save_for_backward(feats, rot, trans, planes)
+        ctx.ndepth = ndepth
+        var = warp_variance(feats, rot, trans, planes, ndepth)
+        if imgs is None:
+            return var
+        noref = warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first=False)
+        return var, noref
+
+    @staticmethod
+    def backward(ctx, gvar, gnoref=None):
+        feats, rot, trans, planes = ctx.saved_tensors
+        C = feats.shape[-1]
+        if gvar is None:
+            gvar = torch.zeros((feats.shape[0], ctx.ndepth, *feats.shape[2:]), device=feats.device)
+        gnr = None
+        if gnoref is not None:
+            gnr = gnoref[:, -C:].permute(0, 2, 3, 4, 1).contiguous()
+        gf = warp_variance_bwd(feats, rot, trans, planes, gvar.contiguous(), gnr)
+        return gf, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------- K2/K3
 class PackedWeight:
     """Device blob produced by rcmvs_pack_conv3d_weight plus its channel counts."""

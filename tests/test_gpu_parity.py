@@ -526,3 +526,57 @@ def test_tanks_and_temples_shape(hip):
     c = out["photometric_confidence"]
     assert float(c.min()) >= 0.0 and float(c.max()) <= 1.0 + 1e-5
     assert torch.equal(out["depth"], out2["depth"])
+
+
+@pytest.mark.parametrize("C,V,D,h,w,with_noref", [(8, 3, 4, 16, 20, True), (16, 3, 8, 24, 40, False), (32, 5, 6, 12, 24, True),
+                                                  (8, 2, 3, 7, 9, True)])
+def test_warp_variance_backward_vs_oracle_autograd(hip, C, V, D, h, w, with_noref):
+    """K1 backward (rcmvs_warp_variance_bwd through ops.WarpVarianceFn) against torch autograd through the
+    oracle's op-by-op restatement of homo_warping + variance (oracle/warp.py), float64 on the CPU."""
+    from rc_mvsnet_amd import synthetic
+    from oracle import warp as ow
+    gen = torch.Generator().manual_seed(C + V)
+    H, W = 4 * h, 4 * w
+    proj = synthetic.proj_matrices(1, V, H, W)["stage1"]
+    proj[:, :, 1, :2, :3] *= (w / (W / 4.0))                        # intrinsics of an h x w map
+    feats = [torch.randn(1, C, h, w, generator=gen) for _ in range(V)]
+    imgs = torch.rand(1, V, 3, h, w, generator=gen)
+    depth = (450.0 + 80.0 * torch.rand(1, 1, h, w, generator=gen)) + 12.0 * torch.arange(D).view(1, D, 1, 1)
+    planes = torch.stack((depth[:, 0], depth[:, 1] - depth[:, 0]), dim=-1).contiguous()
+    depth = planes[..., 0].unsqueeze(1) + torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) * planes[..., 1].unsqueeze(1)
+    gvar = torch.randn(1, D, h, w, C, generator=gen)
+    gnr = torch.randn(1, 3 * (V - 1) + C, D, h, w, generator=gen)
+    # ---- oracle: autograd through the restated op graph, in float64 (sampling positions from the fp32 chain)
+    f64 = [f.double().requires_grad_(True) for f in feats]
+    rots = [ow.compose_homography(proj[:, v], proj[:, 0]) for v in range(1, V)]
+    warped = []
+    for v in range(1, V):
+        ix, iy = ow.warp_coords(rots[v - 1][0], rots[v - 1][1], depth, h, w)
+        warped.append(ow.bilinear_gather_zeros(f64[v], ix.double(), iy.double()))
+    ref = f64[0].unsqueeze(2).expand(-1, -1, D, -1, -1)
+    s = ref + sum(warped)
+    q = ref ** 2 + sum(t ** 2 for t in warped)
+    var = q / V - (s / V) ** 2
+    loss = (var.permute(0, 2, 3, 4, 1) * gvar.double()).sum()
+    if with_noref:
+        sn = sum(warped)
+        qn = sum(t ** 2 for t in warped)
+        loss = loss + ((qn / V - (sn / V) ** 2) * gnr[:, -C:].double()).sum()
+    loss.backward()
+    ref_grads = torch.stack([f.grad[0].permute(1, 2, 0) for f in f64]).float()          # (V,h,w,C)
+    # ---- HIP
+    f_cl = torch.stack([f[0].permute(1, 2, 0) for f in feats]).unsqueeze(0).contiguous()
+    f_gpu = gpu(f_cl).requires_grad_(True)
+    rot = gpu(torch.stack([r[0].reshape(1, 9) for r in rots], dim=1))                 # the oracle's fp32 homographies
+    trans = gpu(torch.stack([r[1].reshape(1, 3) for r in rots], dim=1))
+    imgs_cl = gpu(imgs.permute(0, 1, 3, 4, 2).contiguous()) if with_noref else None
+    out = hip.WarpVarianceFn.apply(f_gpu, rot, trans, gpu(planes), D, imgs_cl)
+    if with_noref:
+        var_g, noref_g = out
+        (var_g * gpu(gvar)).sum().add((noref_g * gpu(gnr)).sum()).backward()
+    else:
+        (out * gpu(gvar)).sum().backward()
+    got = f_gpu.grad[0].cpu()
+    err = rel_err(got, ref_grads)
+    print(f"K1 bwd C={C} V={V}: rel err {err:.2e}")
+    assert err < 2e-5
