@@ -111,6 +111,37 @@ int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale
                        const float* residual, float* y,
                        int B, int D, int H, int W, int Ci, int Co, int relu, void* stream);
 
+/* ---- training: the 3-D blocks with BATCH statistics, forward and backward ---------------- */
+/* Conv3d / Deconv3d in train mode = conv -> BatchNorm3d(batch stats) -> ReLU (models/modules.py:149-157,
+ * 196-204).  The convolution is rcmvs_conv3d_fwd / rcmvs_deconv3d_fwd with a NULL epilogue; autograd's
+ * backward of the block is rcmvs_bn_bwd_* + the data gradient (the same forward kernels on re-packed
+ * weights: dgrad(conv s1) = conv with flipped, transposed weights; dgrad(conv s2) = deconv; dgrad(deconv) =
+ * conv s2) + rcmvs_conv3d_wgrad.  All tensors channels-last, rows = B*D*H*W.
+ *   rcmvs_bn_stats:          sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2     (fp64, caller zero-fills;
+ *                            these 2C doubles are what a SyncBatchNorm all-reduce exchanges)
+ *   rcmvs_scale_shift_relu:  y = [relu](x*scale[c] + shift[c]) + residual   (scale/shift/residual may be NULL)
+ *   rcmvs_bn_bwd_reduce:     sums[0..C) += sum g, sums[C..2C) += sum g*xhat,  g = dz*[y*scale+shift > 0] (relu) or dz
+ *   rcmvs_bn_bwd_apply:      dy = scale * (g - coef[c] - xhat*coef[C+c]),  coef = {dbeta/N, dgamma/N},
+ *                            xhat = (y-mean)*invstd, scale = gamma*invstd */
+int rcmvs_bn_stats(const float* x, double* sums, long long rows, int C, void* stream);
+int rcmvs_scale_shift_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                           long long rows, int C, int relu, void* stream);
+int rcmvs_bn_bwd_reduce(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, double* sums, long long rows, int C, int relu, void* stream);
+int rcmvs_bn_bwd_apply(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, const float* coef, float* dy, long long rows, int C, int relu, void* stream);
+/* dw[27][Ci][Co] += sum_o x[stride*o + tap - 1][ci] * dy[o][co]   (dw zero-filled by the caller, fp32 atomics).
+ *   x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) with Do = (D-1)/stride+1 ...  nn.Conv3d weight grad = dw permuted to
+ *   (Co,Ci,27); for nn.ConvTranspose3d(Cin,Cout) call with x := grad of the (large) output, dy := the (small)
+ *   input, stride 2: dw[27][Cout][Cin] -> permute to (Cin,Cout,27). */
+int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D, int H, int W, int Ci, int Co, int stride,
+                       void* stream);
+/* data gradient of the 1-output-channel prob conv (modules.py:489): dy (B,D,H,W), w (1,Ci,3,3,3) as stored, dx (B,D,H,W,Ci) */
+int rcmvs_conv3d_dgrad_c1(const float* dy, const float* w, float* dx, int B, int D, int H, int W, int Ci, void* stream);
+/* softmax + soft-argmin backward (casmvsnet.py:299-300): grad_logits = prob * (d_k - depth) * grad_depth */
+int rcmvs_depth_head_bwd(const float* prob, const float* planes, const float* depth, const float* grad_depth,
+                         float* grad_logits, int B, int D, int h, int w, void* stream);
+
 /* ---- 2-D feature pyramid (FeatureNet fpn, models/modules.py:363-464), channels-last, inference -------- */
 /* imgs (N,3,H,W) NCHW -> (N,H,W,4) with a zero 4th channel (16-byte input vectors). */
 int rcmvs_rgb_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream);

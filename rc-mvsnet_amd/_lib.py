@@ -28,6 +28,13 @@ SIGNATURES = {
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_k1_variant": [_i],
     "rcmvs_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_bn_stats": [_p, _p, _ll, _i, _p],
+    "rcmvs_scale_shift_relu": [_p, _p, _p, _p, _p, _ll, _i, _i, _p],
+    "rcmvs_bn_bwd_reduce": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
+    "rcmvs_bn_bwd_apply": [_p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
+    "rcmvs_conv3d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_conv3d_dgrad_c1": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rcmvs_depth_head_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_warp_noref_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_packed_weight_floats": [_i, _i],
     "rcmvs_pack_conv3d_weight": [_p, _p, _i, _i, _i, _p],

@@ -252,6 +252,21 @@ class CostRegNet(nn.Module):
         t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True)
         return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True)
 
+    def features_cl_train(self, x):
+        """Train-mode twin of ``features_cl`` (batch-statistics BatchNorm, autograd through the HIP kernels:
+        train_ops.ConvBnReluFn); updates the running statistics like nn.BatchNorm3d does."""
+        from .train_ops import conv_bn_relu_train as blk
+        B, D, h, w, _ = x.shape
+        if D % 8 or h % 8 or w % 8:
+            raise RcmvsError(f"CostRegNet: volume {D}x{h}x{w} must be divisible by 8 in every axis")
+        conv0 = blk(self.conv0, x)
+        conv2 = blk(self.conv2, blk(self.conv1, conv0))
+        conv4 = blk(self.conv4, blk(self.conv3, conv2))
+        t = blk(self.conv6, blk(self.conv5, conv4))
+        t = blk(self.conv7, t, residual=conv4)
+        t = blk(self.conv9, t, residual=conv2)
+        return blk(self.conv11, t, residual=conv0)
+
     def forward(self, x):
         if _hip_inference(self, x):
             feat = self.features_cl(ops.to_channels_last(x.contiguous().float()))
@@ -275,6 +290,12 @@ _delegation_noted = set()
 def _hip_inference(module, *tensors):
     """The native path is taken for inference: eval mode, autograd off, tensors on the GPU."""
     return (not module.training) and (not torch.is_grad_enabled()) and all(t.is_cuda for t in tensors)
+
+
+def _hip_training(module, *tensors):
+    """Native training path: train mode on the GPU (RCMVS_TRAIN=aten forces the delegated op graph, e.g. to
+    cross-check gradients)."""
+    return module.training and all(t.is_cuda for t in tensors) and os.environ.get("RCMVS_TRAIN", "hip") != "aten"
 
 
 def _note_delegation(what):
@@ -468,6 +489,51 @@ class _CascadeBase(nn.Module):
             outputs.update(out)
         return outputs
 
+    # ---------------------------------------------------------------- native training path
+    def _forward_train_hip(self, imgs, proj_matrices, depth_values):
+        """Train mode with autograd: every op of the three cascade stages -- warp + variance (and the train variant's
+        volume_feature_no_ref), the cost regularisation with batch-statistics BatchNorm, prob conv + softmax +
+        soft-argmin -- runs forward AND backward on the HIP kernels (ops.WarpVarianceFn, train_ops.*).  The 2-D
+        feature pyramid still runs on PyTorch-ROCm (per view, like models/casmvsnet.py:364-366, so its batch
+        statistics match the reference's)."""
+        from . import train_ops
+        _note_delegation("FeatureNet (training)")
+        B, V, _, H, W = imgs.shape
+        imgs = imgs.float()
+        depth_values = depth_values.contiguous().float()
+        features = [self.feature(imgs[:, v]) for v in range(V)]
+        outputs = {}
+        depth = None
+        for s in range(self.num_stage):
+            key = "stage{}".format(s + 1)
+            scale = int(self.stage_infos[key]["scale"])
+            D = self.ndepths[s]
+            f_cl = torch.stack([f[key].permute(0, 2, 3, 1) for f in features], dim=1).contiguous()    # (B,V,h,w,C), differentiable
+            h, w = f_cl.shape[2:4]
+            with torch.no_grad():
+                rot, trans = ops.compose_homography(proj_matrices[key].contiguous().float())
+                prev = None
+                if depth is not None:
+                    if self.grad_method != "detach":
+                        raise RcmvsError("grad_method='undetach' is not supported by the HIP training path (RCMVS_TRAIN=aten)")
+                    prev = depth.detach()
+                planes = ops.hypothesis_planes(prev, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
+                small_cl = None
+                if self.TRAIN_VARIANT:
+                    small = F.interpolate(imgs.reshape(B * V, 3, H, W), (h, w), mode="bilinear", align_corners=False)
+                    small_cl = ops.to_channels_last(small.contiguous()).view(B, V, h, w, 3)
+            res = ops.WarpVarianceFn.apply(f_cl, rot, trans, planes, D, small_cl)
+            var, noref = res if self.TRAIN_VARIANT else (res, None)
+            cr = self._cr(s)
+            x8 = cr.features_cl_train(var)
+            depth, conf = train_ops.ProbDepthHeadFn.apply(x8, cr.prob.weight, planes)
+            out = {"depth": depth, "photometric_confidence": conf}
+            if self.TRAIN_VARIANT:
+                out["volume_feature_no_ref"] = noref
+            outputs[key] = out
+            outputs.update(out)
+        return outputs
+
     # ---------------------------------------------------------------- delegated (autograd) path
     def _forward_aten(self, imgs, proj_matrices, depth_values):
         depth_min = depth_values[0, 0]
@@ -503,6 +569,8 @@ class _CascadeBase(nn.Module):
     def _run(self, imgs, proj_matrices, depth_values):
         if _hip_inference(self, imgs, depth_values):
             return self._forward_hip(imgs, proj_matrices, depth_values)
+        if _hip_training(self, imgs, depth_values):
+            return self._forward_train_hip(imgs, proj_matrices, depth_values)
         return self._forward_aten(imgs, proj_matrices, depth_values)
 
 

@@ -1,0 +1,164 @@
+// Training-mode BatchNorm (+ReLU, + skip add) around the 3-D convolutions, channels-last.
+//
+// Conv3d.forward / Deconv3d.forward in train mode (models/modules.py:149-157,196-204) are
+// conv -> BatchNorm3d with BATCH statistics -> ReLU, and CostRegNet adds the skip after the block
+// (:497-499).  The convolution runs on the kernels of conv3d*.hip with an identity epilogue; this file
+// holds the rest, forward and backward:
+//   bn_stats          per-channel sum / sum of squares of the conv output        (one read)
+//   scale_shift_relu  z = [relu](y * scale[c] + shift[c]) [+ residual]          (one read, one write)
+//   bn_bwd_reduce     dbeta[c] = sum g, dgamma[c] = sum g * xhat,  g = dz * [z > 0]
+//   bn_bwd_apply      dy = gamma * invstd * (g - dbeta / N - xhat * dgamma / N)
+// Tensors are (rows, C) with C a multiple of 4; a lane owns one float4 of channels and walks rows, so
+// every access is a coalesced 16-byte vector.  Per-lane fp32 partial sums cover a few dozen rows; they
+// are combined in fp64 (LDS tree, then one fp64 atomic per channel and block), which keeps the batch
+// statistics of a million-voxel volume accurate to fp32 round-off.  The fp64 sums are what a
+// SyncBatchNorm all-reduce exchanges (train_rcmvsnet.py:525), so the multi-GPU path needs no extra kernel.
+#include "common.h"
+
+namespace rcmvs {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int BN_BLOCK = 256;
+
+// combine the block's per-lane float4 partials that belong to the same channel quad, in fp64
+template <int NACC>
+__device__ __forceinline__ void block_reduce_to_global(const v4f (&part)[NACC], int q, int nq, double* out, int C) {
+    __shared__ double red[BN_BLOCK * 4];
+    for (int a = 0; a < NACC; ++a) {
+        __syncthreads();
+        red[threadIdx.x * 4 + 0] = part[a].x; red[threadIdx.x * 4 + 1] = part[a].y;
+        red[threadIdx.x * 4 + 2] = part[a].z; red[threadIdx.x * 4 + 3] = part[a].w;
+        __syncthreads();
+        // threads 0 .. nq*4-1 each own one channel: sum over the lanes t = q, q + nq, q + 2 nq, ...
+        if ((int)threadIdx.x < nq * 4) {
+            const int qq = threadIdx.x >> 2, comp = threadIdx.x & 3;
+            double s = 0.0;
+            for (int t = qq; t < BN_BLOCK; t += nq) s += red[t * 4 + comp];
+            unsafeAtomicAdd(out + (long long)a * C + qq * 4 + comp, s);
+        }
+    }
+    (void)q;
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums,
+                                                            long long rows, int C) {
+    const int nq = C / 4;                                  // float4 per row; BN_BLOCK % nq == 0 (checked by the host)
+    const int q = threadIdx.x % nq;
+    const long long rpb = BN_BLOCK / nq;                   // rows per block iteration
+    v4f acc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
+    for (long long r = (long long)blockIdx.x * rpb + threadIdx.x / nq; r < rows; r += (long long)gridDim.x * rpb) {
+        const v4f v = *reinterpret_cast<const v4f*>(x + r * C + q * 4);
+        acc[0] += v;
+        acc[1] += v * v;
+    }
+    block_reduce_to_global<2>(acc, q, nq, sums, C);
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void scale_shift_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ res,
+                                                                   float* __restrict__ y, long long n4, int C, int relu) {
+    const int nq = C / 4;
+    for (long long i = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; i < n4; i += (long long)gridDim.x * BN_BLOCK) {
+        const int q = (int)(i % nq);
+        v4f v = reinterpret_cast<const v4f*>(x)[i];
+        if (scale) v = v * reinterpret_cast<const v4f*>(scale)[q] + reinterpret_cast<const v4f*>(shift)[q];
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (res) v += reinterpret_cast<const v4f*>(res)[i];
+        reinterpret_cast<v4f*>(y)[i] = v;
+    }
+}
+
+__device__ __forceinline__ v4f relu_mask(v4f g, v4f z) {
+    g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
+    g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+    return g;
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dz,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                double* __restrict__ sums, long long rows, int C, int relu) {
+    const int nq = C / 4;
+    const int q = threadIdx.x % nq;
+    const long long rpb = BN_BLOCK / nq;
+    const v4f sc = reinterpret_cast<const v4f*>(scale)[q], sh = reinterpret_cast<const v4f*>(shift)[q];
+    const v4f mu = reinterpret_cast<const v4f*>(mean)[q], is = reinterpret_cast<const v4f*>(invstd)[q];
+    v4f acc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
+    for (long long r = (long long)blockIdx.x * rpb + threadIdx.x / nq; r < rows; r += (long long)gridDim.x * rpb) {
+        const v4f v = *reinterpret_cast<const v4f*>(y + r * C + q * 4);
+        v4f g = *reinterpret_cast<const v4f*>(dz + r * C + q * 4);
+        if (relu) g = relu_mask(g, v * sc + sh);
+        acc[0] += g;
+        acc[1] += g * ((v - mu) * is);
+    }
+    block_reduce_to_global<2>(acc, q, nq, sums, C);
+}
+
+// coef = [dbeta / N (C), dgamma / N (C)]
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dz,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ coef, float* __restrict__ dy,
+                                                               long long n4, int C, int relu) {
+    const int nq = C / 4;
+    for (long long i = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; i < n4; i += (long long)gridDim.x * BN_BLOCK) {
+        const int q = (int)(i % nq);
+        const v4f sc = reinterpret_cast<const v4f*>(scale)[q], sh = reinterpret_cast<const v4f*>(shift)[q];
+        const v4f mu = reinterpret_cast<const v4f*>(mean)[q], is = reinterpret_cast<const v4f*>(invstd)[q];
+        const v4f a = reinterpret_cast<const v4f*>(coef)[q], b = reinterpret_cast<const v4f*>(coef + C)[q];
+        const v4f v = reinterpret_cast<const v4f*>(y)[i];
+        v4f g = reinterpret_cast<const v4f*>(dz)[i];
+        if (relu) g = relu_mask(g, v * sc + sh);
+        reinterpret_cast<v4f*>(dy)[i] = sc * (g - a - ((v - mu) * is) * b);
+    }
+}
+
+static inline unsigned grid_for(long long work_items) {
+    long long g = cdiv(work_items, (long long)BN_BLOCK);
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace rcmvs
+
+using namespace rcmvs;
+
+extern "C" {
+
+int rcmvs_bn_stats(const float* x, double* sums, long long rows, int C, void* stream) {
+    RCMVS_REQUIRE(x && sums && rows > 0, "bn_stats: bad arguments");
+    RCMVS_REQUIRE(C >= 4 && C % 4 == 0 && BN_BLOCK % (C / 4) == 0, "bn_stats: C=%d must be 4, 8, 16, 32, 64 ...", C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows * (C / 4) / 8)), dim3(BN_BLOCK), 0, as_stream(stream), x, sums, rows, C);
+    return launch_status("bn_stats");
+}
+
+int rcmvs_scale_shift_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                           long long rows, int C, int relu, void* stream) {
+    RCMVS_REQUIRE(x && y && rows > 0, "scale_shift_relu: bad arguments");
+    RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "scale_shift_relu: scale and shift go together");
+    RCMVS_REQUIRE(C >= 4 && C % 4 == 0, "scale_shift_relu: C=%d must be a multiple of 4", C);
+    const long long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(scale_shift_relu_kernel, dim3(grid_for(n4 / 4)), dim3(BN_BLOCK), 0, as_stream(stream), x, scale, shift, residual, y, n4, C, relu);
+    return launch_status("scale_shift_relu");
+}
+
+int rcmvs_bn_bwd_reduce(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, double* sums, long long rows, int C, int relu, void* stream) {
+    RCMVS_REQUIRE(y && dz && scale && shift && mean && invstd && sums && rows > 0, "bn_bwd_reduce: bad arguments");
+    RCMVS_REQUIRE(C >= 4 && C % 4 == 0 && BN_BLOCK % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows * (C / 4) / 8)), dim3(BN_BLOCK), 0, as_stream(stream),
+                       y, dz, scale, shift, mean, invstd, sums, rows, C, relu);
+    return launch_status("bn_bwd_reduce");
+}
+
+int rcmvs_bn_bwd_apply(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,
+                       const float* invstd, const float* coef, float* dy, long long rows, int C, int relu, void* stream) {
+    RCMVS_REQUIRE(y && dz && scale && shift && mean && invstd && coef && dy && rows > 0, "bn_bwd_apply: bad arguments");
+    RCMVS_REQUIRE(C >= 4 && C % 4 == 0, "bn_bwd_apply: C=%d unsupported", C);
+    const long long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4 / 4)), dim3(BN_BLOCK), 0, as_stream(stream),
+                       y, dz, scale, shift, mean, invstd, coef, dy, n4, C, relu);
+    return launch_status("bn_bwd_apply");
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+// Weight gradient of the 3x3x3 convolution family on v_mfma_f32_16x16x4_f32 (exact fp32), channels-last.
+//
+//   dW[tap][ci][co] = sum over output cells o of  x[S*o + tap - 1][ci] * dy[o][co]        (S = stride 1 | 2)
+// which is what autograd computes for nn.Conv3d (models/modules.py:145) and, with the roles of the two
+// tensors swapped, for nn.ConvTranspose3d (:189; see rcmvs.h).  GEMM view: K = output cells (4 per MFMA),
+// N = output channels, M = (tap, input channel) -- the taps are multiplexed onto the M side so that a
+// 16-row tile is full for every CI:
+//   A[m][k]: lane l (m = l & 15, k = l >> 4) loads ONE float4 = input channels 4*cig .. 4*cig+3 of tap
+//            `tapsel` at cell w0 + k, with (tapsel, cig) = (m / (CI/4), m % (CI/4)); component ja feeds MFMA ja,
+//            so the four MFMAs of a step cover input channels 4*cig + ja (a row permutation of M, undone at
+//            the flush).  One tile = 64/CI taps x all CI channels.
+//   B[k][n]: lane l (n = l & 15) loads NJ = CO/16 consecutive floats dy[cell][NJ*n + jb]; component jb feeds
+//            the MFMAs of column block jb (CO = 8 and 1 use the first CO lanes of one block).
+// A wave keeps up to 128 accumulator registers = G tap groups; the remaining groups go to grid.y.  A wave
+// walks whole output rows (b, od, oh) in steps of four cells, reading both operands straight through the
+// vector L1 (the 27 taps re-read the same lines, so L1/L2 absorb the 27x reuse), and flushes with hardware
+// fp32 atomics into the zero-filled [27][CI][CO] gradient (summation order is not deterministic).
+#include "common.h"
+
+namespace rcmvs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradDims {
+    int B, D, H, W;       // x
+    int Do, Ho, Wo;       // dy
+};
+
+template <int CI, int CO, int STRIDE>
+struct WgradCfg {
+    static constexpr int CQ = CI / 4;
+    static constexpr int TPM = 16 / CQ;
+    static constexpr int NGRP = (27 + TPM - 1) / TPM;
+    static constexpr int NJ = CO >= 16 ? CO / 16 : 1;
+    static constexpr int G = (8 / NJ) < NGRP ? (8 / NJ) : NGRP;
+    static constexpr int SPLITS = (NGRP + G - 1) / G;
+};
+
+template <int CI, int CO, int STRIDE>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dw, WgradDims dm, int rows) {
+    using Cfg = WgradCfg<CI, CO, STRIDE>;
+    constexpr int CQ = Cfg::CQ, TPM = Cfg::TPM, NGRP = Cfg::NGRP, NJ = Cfg::NJ, G = Cfg::G;
+    static_assert(CI % 4 == 0 && CQ <= 16 && 16 % CQ == 0, "CI must be 4, 8, 16, 32 or 64");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int tapsel = m / CQ, cig = m % CQ;
+    const int g0 = blockIdx.y * G;
+
+    int tdx[G];                              // packed (valid << 6) | (td << 4) | (th << 2) | tw of this lane's tap per group
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        const int tap = (g0 + gi) * TPM + tapsel;
+        const bool valid = (g0 + gi) < NGRP && tap < 27;
+        tdx[gi] = valid ? (64 | ((tap / 9) << 4) | (((tap / 3) % 3) << 2) | (tap % 3)) : 0;
+    }
+    f32x4 acc[G][4][NJ];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < NJ; ++jb) acc[gi][ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool n_ok = NJ * m < CO;           // (m doubles as the B-side column index n = lane & 15)
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int oh = row % dm.Ho;
+        const int od = (row / dm.Ho) % dm.Do;
+        const int b = row / (dm.Ho * dm.Do);
+        const float* dyrow = dy + ((((long long)b * dm.Do + od) * dm.Ho + oh) * dm.Wo) * CO + NJ * m;
+        const float* xb = x + (long long)b * dm.D * dm.H * dm.W * CI + cig * 4;
+        for (int w0 = 0; w0 < dm.Wo; w0 += 4) {
+            const int ow = w0 + kq;
+            float bv[NJ];
+            if constexpr (NJ == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(dyrow + (long long)ow * CO);
+                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+            } else if constexpr (NJ == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(dyrow + (long long)ow * CO);
+                bv[0] = t.x; bv[1] = t.y;
+            } else {
+                bv[0] = n_ok ? dyrow[(long long)ow * CO] : 0.0f;
+            }
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) {
+                const int t = tdx[gi];
+                const int id = od * STRIDE + ((t >> 4) & 3) - 1;
+                const int ih = oh * STRIDE + ((t >> 2) & 3) - 1;
+                const int iw = ow * STRIDE + (t & 3) - 1;
+                const bool ok = (t & 64) && (unsigned)id < (unsigned)dm.D && (unsigned)ih < (unsigned)dm.H && (unsigned)iw < (unsigned)dm.W;
+                f32x4 av = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok) av = *reinterpret_cast<const f32x4*>(xb + (((long long)id * dm.H + ih) * dm.W + iw) * CI);
+#pragma unroll
+                for (int jb = 0; jb < NJ; ++jb) {
+                    acc[gi][0][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[jb], acc[gi][0][jb], 0, 0, 0);
+                    acc[gi][1][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[jb], acc[gi][1][jb], 0, 0, 0);
+                    acc[gi][2][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[jb], acc[gi][2][jb], 0, 0, 0);
+                    acc[gi][3][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[jb], acc[gi][3][jb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // flush: D[mrow][n], lane holds rows 4*kq + r of column n = lane & 15
+    const int co0 = NJ * m;
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        if (g0 + gi >= NGRP) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mrow = 4 * kq + r;
+            const int tap = (g0 + gi) * TPM + mrow / CQ;
+            if (tap >= 27) continue;
+            const int cq = mrow % CQ;
+#pragma unroll
+            for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                for (int jb = 0; jb < NJ; ++jb) {
+                    const int co = co0 + jb;
+                    if (co < CO) unsafeAtomicAdd(dw + ((long long)tap * CI + cq * 4 + ja) * CO + co, acc[gi][ja][jb][r]);
+                }
+        }
+    }
+}
+
+// depth head backward, element-wise part (models/casmvsnet.py:299-300): logits -> softmax p -> depth = sum p_k d_k
+//   d loss / d logit_k = p_k * (d_k - depth) * g,   g = d loss / d depth,   d_k = planes.d0 + k * planes.delta
+__global__ void depth_head_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ planes,
+                                      const float* __restrict__ depth, const float* __restrict__ gdepth,
+                                      float* __restrict__ dlogits, int D, long long hw, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i % hw;
+        const long long bk = i / hw;
+        const int k = (int)(bk % D);
+        const long long b = bk / D;
+        const float2 pl = reinterpret_cast<const float2*>(planes)[b * hw + pix];
+        const float dk = pl.x + (float)k * pl.y;
+        dlogits[i] = prob[i] * (dk - depth[b * hw + pix]) * gdepth[b * hw + pix];
+    }
+}
+
+// data gradient of the single-output-channel `prob` convolution (models/modules.py:489: Conv3d(8, 1, 3, pad 1)):
+//   dx[i][c] = sum_tap dy[i - tap + 1] * w[0][c][tap]        one thread per voxel, CI outputs in registers,
+// the 27 neighbours of the 1-channel gradient come through L1, the weights through scalar loads.
+template <int CI>
+__global__ __launch_bounds__(256) void conv3d_dgrad_c1_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int B, int D, int H, int W) {
+    const long long total = (long long)B * D * H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int iw = (int)(i % W), ih = (int)((i / W) % H), id = (int)((i / ((long long)W * H)) % D);
+    const long long b = i / ((long long)W * H * D);
+    float acc[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int od = id - (tap / 9) + 1, oh = ih - ((tap / 3) % 3) + 1, ow = iw - (tap % 3) + 1;
+        float g = 0.0f;
+        if ((unsigned)od < (unsigned)D && (unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W)
+            g = dy[((b * D + od) * H + oh) * W + ow];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) acc[c] = fmaf(g, w[c * 27 + tap], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CI; c += 4)
+        *reinterpret_cast<f32x4*>(dx + i * CI + c) = (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+}
+
+}  // namespace rcmvs
+
+using namespace rcmvs;
+
+template <int CI, int CO, int STRIDE>
+static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradDims& dm, hipStream_t st) {
+    using Cfg = WgradCfg<CI, CO, STRIDE>;
+    const int rows = dm.B * dm.Do * dm.Ho;
+    int gx = (rows + 3) / 4;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE>), dim3(gx, Cfg::SPLITS), dim3(256), 0, st, x, dy, dw, dm, rows);
+    return launch_status("conv3d_wgrad");
+}
+
+extern "C" {
+
+int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D, int H, int W, int Ci, int Co, int stride,
+                       void* stream) {
+    RCMVS_REQUIRE(x && dy && dw, "conv3d_wgrad: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_wgrad: bad sizes");
+    RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride must be 1 or 2");
+    WgradDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
+    RCMVS_REQUIRE(dm.Wo % 4 == 0, "conv3d_wgrad: output width %d must be a multiple of 4", dm.Wo);
+    hipStream_t st = as_stream(stream);
+#define RCMVS_WG(CI, CO, S) if (Ci == CI && Co == CO && stride == S) return wgrad_launch<CI, CO, S>(x, dy, dw, dm, st);
+    RCMVS_WG(8, 8, 1) RCMVS_WG(16, 8, 1) RCMVS_WG(32, 8, 1)
+    RCMVS_WG(16, 16, 1) RCMVS_WG(32, 32, 1) RCMVS_WG(64, 64, 1) RCMVS_WG(8, 1, 1)
+    RCMVS_WG(8, 16, 2) RCMVS_WG(16, 32, 2) RCMVS_WG(32, 64, 2)
+#undef RCMVS_WG
+    return fail(-1, "conv3d_wgrad: unsupported (Ci=%d, Co=%d, stride=%d)", Ci, Co, stride);
+}
+
+int rcmvs_conv3d_dgrad_c1(const float* dy, const float* w, float* dx, int B, int D, int H, int W, int Ci, void* stream) {
+    RCMVS_REQUIRE(dy && w && dx, "conv3d_dgrad_c1: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_dgrad_c1: bad sizes");
+    RCMVS_REQUIRE(Ci == 8, "conv3d_dgrad_c1: Ci=%d unsupported (the prob layer has 8 input channels)", Ci);
+    const long long total = (long long)B * D * H * W;
+    hipLaunchKernelGGL((conv3d_dgrad_c1_kernel<8>), dim3((unsigned)cdiv(total, 256LL)), dim3(256), 0, as_stream(stream), dy, w, dx, B, D, H, W);
+    return launch_status("conv3d_dgrad_c1");
+}
+
+int rcmvs_depth_head_bwd(const float* prob, const float* planes, const float* depth, const float* grad_depth,
+                         float* grad_logits, int B, int D, int h, int w, void* stream) {
+    RCMVS_REQUIRE(prob && planes && depth && grad_depth && grad_logits, "depth_head_bwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "depth_head_bwd: bad sizes");
+    const long long hw = (long long)h * w, total = hw * D * B;
+    long long g = cdiv(total, 256LL);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(depth_head_bwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), prob, planes, depth, grad_depth,
+                       grad_logits, D, hw, total);
+    return launch_status("depth_head_bwd");
+}
+
+}  // extern "C"

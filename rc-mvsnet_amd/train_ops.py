@@ -1,0 +1,206 @@
+"""Training-mode building blocks on the HIP kernels: autograd Functions whose forward AND backward are
+library calls (include/rcmvs.h, section "training"), so that ``loss.backward()`` through the cost
+regularisation never touches an ATen convolution / batch-norm kernel.
+
+    ConvBnReluFn      Conv3d / Deconv3d block in train mode (models/modules.py:149-157,196-204):
+                      conv -> BatchNorm3d with batch statistics -> ReLU [+ skip], channels-last
+    ProbDepthHeadFn   prob conv + softmax + soft-argmin depth (+ confidence, no grad)
+                      (models/modules.py:489,500, models/casmvsnet.py:103-122)
+    (the differentiable fused warp + variance is ops.WarpVarianceFn)
+
+PyTorch's role: it owns the tensors, runs the tiny per-channel vector arithmetic that turns the fp64 sums
+into mean / invstd / running statistics (a few dozen floats), and all-reduces those sums when the module is
+a SyncBatchNorm replica.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+from .ops import _chk, _opt, _stream
+
+
+# --------------------------------------------------------------------------------------- thin wrappers
+def bn_stats(x, sums):
+    C = x.shape[-1]
+    _lib.check(_lib.load().rcmvs_bn_stats(_chk(x, "x"), _chk(sums, "sums", torch.float64), x.numel() // C, C, _stream()), "bn_stats")
+
+
+def scale_shift_relu(x, scale, shift, residual, relu, out=None):
+    C = x.shape[-1]
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.load().rcmvs_scale_shift_relu(_chk(x, "x"), _opt(scale, "scale"), _opt(shift, "shift"), _opt(residual, "residual"),
+                                                  _chk(y, "y"), x.numel() // C, C, int(bool(relu)), _stream()), "scale_shift_relu")
+    return y
+
+
+def bn_bwd_reduce(y, dz, scale, shift, mean, invstd, sums, relu):
+    C = y.shape[-1]
+    _lib.check(_lib.load().rcmvs_bn_bwd_reduce(_chk(y, "y"), _chk(dz, "dz"), _chk(scale, "scale"), _chk(shift, "shift"),
+                                               _chk(mean, "mean"), _chk(invstd, "invstd"), _chk(sums, "sums", torch.float64),
+                                               y.numel() // C, C, int(bool(relu)), _stream()), "bn_bwd_reduce")
+
+
+def bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, relu):
+    C = y.shape[-1]
+    dy = torch.empty_like(y)
+    _lib.check(_lib.load().rcmvs_bn_bwd_apply(_chk(y, "y"), _chk(dz, "dz"), _chk(scale, "scale"), _chk(shift, "shift"),
+                                              _chk(mean, "mean"), _chk(invstd, "invstd"), _chk(coef, "coef"), _chk(dy, "dy"),
+                                              y.numel() // C, C, int(bool(relu)), _stream()), "bn_bwd_apply")
+    return dy
+
+
+def conv3d_wgrad(x, dy, stride):
+    """x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) -> packed gradient (27,Ci,Co)."""
+    B, D, H, W, Ci = x.shape
+    Co = dy.shape[-1]
+    exp = (B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
+    if tuple(dy.shape[:4]) != exp:
+        raise _lib.RcmvsError(f"conv3d_wgrad: dy {tuple(dy.shape)} does not match x {tuple(x.shape)} at stride {stride}")
+    dw = torch.zeros((27, Ci, Co), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_conv3d_wgrad(_chk(x, "x"), _chk(dy, "dy"), _chk(dw, "dw"), B, D, H, W, Ci, Co, stride, _stream()),
+               "conv3d_wgrad")
+    return dw
+
+
+def conv3d_dgrad_c1(dy, w):
+    """dy (B,D,H,W) gradient of the 1-channel prob conv output, w (1,Ci,3,3,3) -> dx (B,D,H,W,Ci)."""
+    B, D, H, W = dy.shape
+    Ci = w.shape[1]
+    dx = torch.empty((B, D, H, W, Ci), device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_conv3d_dgrad_c1(_chk(dy, "dy"), _chk(w, "w"), _chk(dx, "dx"), B, D, H, W, Ci, _stream()),
+               "conv3d_dgrad_c1")
+    return dx
+
+
+def depth_head_bwd(prob, planes, depth, gdepth):
+    B, D, h, w = prob.shape
+    dl = torch.empty_like(prob)
+    _lib.check(_lib.load().rcmvs_depth_head_bwd(_chk(prob, "prob"), _chk(planes, "planes"), _chk(depth, "depth"), _chk(gdepth, "gdepth"),
+                                                _chk(dl, "dlogits"), B, D, h, w, _stream()), "depth_head_bwd")
+    return dl
+
+
+# --------------------------------------------------------------------------------------- conv + BN + ReLU
+def _conv_raw(x, w, transposed, stride):
+    """The block's convolution with an identity epilogue (weights re-packed: they change every step)."""
+    pk = ops.pack_conv3d_weight(w, transposed=transposed)
+    return ops.deconv3d(x, pk) if transposed else ops.conv3d(x, pk, stride=stride)
+
+
+def _conv_dgrad(dy, w, transposed, stride):
+    """d loss / d x of the block's convolution, on the forward kernels with re-packed weights."""
+    w = w.detach()
+    if transposed:                                   # adjoint of ConvTranspose3d(stride 2) = Conv3d(stride 2), same weight tensor
+        return ops.conv3d(dy, ops.pack_conv3d_weight(w, transposed=False), stride=2)
+    if stride == 2:                                  # adjoint of Conv3d(stride 2) = ConvTranspose3d(stride 2, output_padding 1)
+        return ops.deconv3d(dy, ops.pack_conv3d_weight(w, transposed=True))
+    wd = w.transpose(0, 1).flip(2, 3, 4).contiguous()  # adjoint of Conv3d(stride 1, pad 1) = Conv3d with flipped, transposed taps
+    return ops.conv3d(dy, ops.pack_conv3d_weight(wd, transposed=False), stride=1)
+
+
+def _conv_wgrad(x, dy, w_shape, transposed, stride):
+    if transposed:                                   # roles swap: the large tensor (dy) is strided over
+        dwp = conv3d_wgrad(dy, x, 2)                 # (27, Cout_T, Cin_T)
+    else:
+        dwp = conv3d_wgrad(x, dy, stride)            # (27, Ci, Co)
+    return dwp.permute(2, 1, 0).reshape(w_shape)
+
+
+class ConvBnReluFn(torch.autograd.Function):
+    """z = [relu](batchnorm_train(conv(x, w))) [+ residual], channels-last.  `cfg` = dict(transposed, stride, relu,
+    eps, group): group = a process group for SyncBatchNorm statistics, or None.  Also returns the batch mean and the
+    biased batch variance (non-differentiable) for the caller's running-statistics update."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, residual, cfg):
+        x = x.contiguous()
+        y = _conv_raw(x, w.detach(), cfg["transposed"], cfg["stride"])
+        C = y.shape[-1]
+        sums = torch.zeros(2 * C, device=x.device, dtype=torch.float64)
+        bn_stats(y, sums)
+        n = torch.tensor(float(y.numel() // C), device=x.device, dtype=torch.float64)
+        group = cfg.get("group")
+        if group is not None:
+            pack = torch.cat((sums, n.view(1)))
+            dist.all_reduce(pack, group=group)
+            sums, n = pack[:-1], pack[-1]
+        mean64 = sums[:C] / n
+        var64 = (sums[C:] / n - mean64 * mean64).clamp_(min=0.0)
+        invstd = torch.rsqrt(var64 + cfg["eps"]).float()
+        mean = mean64.float()
+        scale = (gamma.detach().float() * invstd).contiguous()
+        shift = (beta.detach().float() - mean * scale).contiguous()
+        res = None if residual is None else residual.contiguous()
+        z = scale_shift_relu(y, scale, shift, res, cfg["relu"])
+        ctx.save_for_backward(x, w, y, scale, shift, mean, invstd)
+        ctx.cfg = cfg
+        ctx.has_res = residual is not None
+        ctx.n_total = n
+        var = var64.float()
+        ctx.mark_non_differentiable(mean, var, n)
+        return z, mean, var, n
+
+    @staticmethod
+    def backward(ctx, dz, _gm, _gv, _gn):
+        x, w, y, scale, shift, mean, invstd = ctx.saved_tensors
+        cfg = ctx.cfg
+        C = y.shape[-1]
+        dz = dz.contiguous()
+        sums = torch.zeros(2 * C, device=y.device, dtype=torch.float64)
+        bn_bwd_reduce(y, dz, scale, shift, mean, invstd, sums, cfg["relu"])
+        dbeta, dgamma = sums[:C].float(), sums[C:].float()          # this replica's parameter gradients
+        tot = sums
+        if cfg.get("group") is not None:
+            tot = sums.clone()
+            dist.all_reduce(tot, group=cfg["group"])
+        coef = (tot / ctx.n_total).float().contiguous()
+        dy = bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, cfg["relu"])
+        dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad(x, dy, w.shape, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[1] else None
+        return dx, dw, dgamma, dbeta, (dz if ctx.has_res else None), None
+
+
+def conv_bn_relu_train(block, x, residual=None):
+    """Run a Conv3d / Deconv3d module (casmvsnet.py) in train mode on the HIP kernels, including the
+    running-statistics update of its BatchNorm3d / SyncBatchNorm (momentum semantics of torch.nn)."""
+    bn = block.bn
+    transposed = isinstance(block.conv, torch.nn.ConvTranspose3d)
+    group = None
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    cfg = {"transposed": transposed, "stride": block.stride, "relu": bool(block.relu), "eps": bn.eps, "group": group}
+    z, mean, var, n = ConvBnReluFn.apply(x, block.conv.weight, bn.weight, bn.bias, residual, cfg)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            unbiased = var * (n / (n - 1.0)).float()
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(unbiased, alpha=mom)
+    return z
+
+
+# --------------------------------------------------------------------------------------- depth head
+class ProbDepthHeadFn(torch.autograd.Function):
+    """x8 (B,D,h,w,8), prob weight (1,8,3,3,3), planes (B,h,w,2) -> depth (B,h,w) [differentiable],
+    photometric confidence (B,h,w) [the reference computes it under no_grad, casmvsnet.py:115]."""
+
+    @staticmethod
+    def forward(ctx, x8, w, planes):
+        x8 = x8.contiguous()
+        depth, conf, prob = ops.depth_head(x8, ops.pack_conv3d_weight(w.detach()), planes, want_prob=True)
+        ctx.save_for_backward(x8, w, planes, prob, depth)
+        ctx.mark_non_differentiable(conf)
+        return depth, conf
+
+    @staticmethod
+    def backward(ctx, gdepth, _gconf):
+        x8, w, planes, prob, depth = ctx.saved_tensors
+        dl = depth_head_bwd(prob, planes, depth, gdepth.contiguous())
+        dx = conv3d_dgrad_c1(dl, w.detach().contiguous()) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = conv3d_wgrad(x8, dl.unsqueeze(-1), 1).permute(2, 1, 0).reshape(w.shape)
+        return dx, dw, None

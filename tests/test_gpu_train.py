@@ -31,3 +31,132 @@ def test_train_step_then_hip_inference():
         d1 = model(imgs, proj, dv)[0]["depth"]
     assert torch.isfinite(d1).all()
     assert float((d1 - d0).abs().max()) > 0.0            # the HIP plan picked up the updated weights
+
+
+# ------------------------------------------------------------------------------------------------
+# native training kernels (include/rcmvs.h, section "training") against torch autograd in float64 on the CPU
+# ------------------------------------------------------------------------------------------------
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("ci,co,stride,transposed", [
+    (8, 8, 1, False), (16, 8, 1, False), (32, 8, 1, False), (16, 16, 1, False), (32, 32, 1, False), (64, 64, 1, False),
+    (8, 16, 2, False), (16, 32, 2, False), (32, 64, 2, False), (64, 32, 2, True), (32, 16, 2, True), (16, 8, 2, True)])
+@pytest.mark.parametrize("relu,with_res", [(True, True), (False, False)])
+def test_conv_bn_relu_block_forward_backward(ci, co, stride, transposed, relu, with_res):
+    """One Conv3d / Deconv3d block in train mode (models/modules.py:149-157,196-204) + skip add: output, batch
+    statistics and the gradients w.r.t. input, weight, gamma, beta and the skip tensor."""
+    import torch.nn.functional as F
+    from rc_mvsnet_amd import _lib, train_ops
+    _lib.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(ci * 100 + co + stride)
+    B, D, H, W = 2, 8, 8, 16
+    x = torch.randn(B, ci, D, H, W, generator=g)
+    w = torch.randn((ci, co, 3, 3, 3) if transposed else (co, ci, 3, 3, 3), generator=g) * (1.0 / (27 * ci) ** 0.5)
+    gamma = 0.5 + torch.rand(co, generator=g)
+    beta = 0.2 * torch.randn(co, generator=g)
+    # ---- reference (float64)
+    xr, wr, gr, br = (t.double().requires_grad_(True) for t in (x, w, gamma, beta))
+    if transposed:
+        yr = F.conv_transpose3d(xr, wr, stride=2, padding=1, output_padding=1)
+    else:
+        yr = F.conv3d(xr, wr, stride=stride, padding=1)
+    zr = F.batch_norm(yr, None, None, gr, br, training=True, eps=1e-5)
+    if relu:
+        zr = F.relu(zr)
+    res = torch.randn(zr.shape, generator=g) if with_res else None
+    rr = res.double().requires_grad_(True) if with_res else None
+    if with_res:
+        zr = zr + rr
+    G = torch.randn(zr.shape, generator=g)
+    (zr * G.double()).sum().backward()
+    # ---- HIP
+    cl = lambda t: t.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    xg = cl(x).requires_grad_(True)
+    wg, gg, bg = (t.to(dev).requires_grad_(True) for t in (w, gamma, beta))
+    rg = cl(res).requires_grad_(True) if with_res else None
+    cfg = {"transposed": transposed, "stride": stride, "relu": relu, "eps": 1e-5, "group": None}
+    z, mean, var, n = train_ops.ConvBnReluFn.apply(xg, wg, gg, bg, rg, cfg)
+    (z * cl(G)).sum().backward()
+    yr_d = yr.detach()
+    assert _rel(z.detach().cpu().permute(0, 4, 1, 2, 3), zr.detach()) < 2e-5
+    assert _rel(mean.cpu(), yr_d.mean(dim=(0, 2, 3, 4))) < 2e-5 or float(mean.abs().max()) < 1e-3
+    assert _rel(var.cpu(), yr_d.var(dim=(0, 2, 3, 4), unbiased=False)) < 2e-5
+    errs = {"dx": _rel(xg.grad.cpu().permute(0, 4, 1, 2, 3), xr.grad), "dw": _rel(wg.grad.cpu(), wr.grad),
+            "dgamma": _rel(gg.grad.cpu(), gr.grad), "dbeta": _rel(bg.grad.cpu(), br.grad)}
+    if with_res:
+        errs["dres"] = _rel(rg.grad.cpu().permute(0, 4, 1, 2, 3), rr.grad)
+    print(f"block {ci}->{co} s{stride} T={transposed}: " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) < 1e-4
+
+
+def test_prob_depth_head_backward():
+    import torch.nn.functional as F
+    from rc_mvsnet_amd import _lib, train_ops
+    _lib.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    B, D, h, w = 2, 8, 16, 24
+    x8 = torch.randn(B, 8, D, h, w, generator=g)
+    wp = torch.randn(1, 8, 3, 3, 3, generator=g) * 0.3
+    planes = torch.stack((450 + 100 * torch.rand(B, h, w, generator=g), 2.0 + torch.rand(B, h, w, generator=g)), dim=-1)
+    G = torch.randn(B, h, w, generator=g)
+    xr, wr = x8.double().requires_grad_(True), wp.double().requires_grad_(True)
+    logits = F.conv3d(xr, wr, padding=1).squeeze(1)
+    p = F.softmax(logits, dim=1)
+    dvals = planes[..., 0].unsqueeze(1).double() + torch.arange(D).view(1, D, 1, 1).double() * planes[..., 1].unsqueeze(1).double()
+    depth_r = (p * dvals).sum(1)
+    (depth_r * G.double()).sum().backward()
+    xg = x8.permute(0, 2, 3, 4, 1).contiguous().to(dev).requires_grad_(True)
+    wg = wp.to(dev).requires_grad_(True)
+    depth, conf = train_ops.ProbDepthHeadFn.apply(xg, wg, planes.to(dev).contiguous())
+    (depth * G.to(dev)).sum().backward()
+    assert float((depth.detach().cpu() - depth_r.detach()).abs().max()) < 2e-3
+    e_dx, e_dw = _rel(xg.grad.cpu().permute(0, 4, 1, 2, 3), xr.grad), _rel(wg.grad.cpu(), wr.grad)
+    print(f"depth head bwd: dx {e_dx:.1e} dw {e_dw:.1e}")
+    assert e_dx < 1e-4 and e_dw < 1e-4
+
+
+def test_cascade_train_native_vs_delegated_gradients(monkeypatch):
+    """CascadeMVSNet in train mode: the HIP training path (WarpVarianceFn + ConvBnReluFn + ProbDepthHeadFn) and the
+    delegated PyTorch-ROCm op graph produce the same outputs, parameter gradients and running statistics."""
+    import copy
+    from rc_mvsnet_amd import _lib, synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet
+    _lib.load()
+    warnings.simplefilter("ignore")
+    dev = "cuda:0"
+    m1 = CascadeMVSNet(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1])
+    m1.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=2.0), strict=True)
+    m1 = m1.to(dev).train()
+    m2 = copy.deepcopy(m1)
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 64, 96, 0)
+    imgs, dv = imgs.to(dev), dv.to(dev)
+    pm = {k: v.to(dev) for k, v in pm.items()}
+
+    def run(model):
+        out, noref = model(imgs, pm, dv)
+        loss = sum((out[f"stage{s}"]["depth"] - 600.0).abs().mean() for s in (1, 2, 3)) + 1e-2 * noref.pow(2).mean()
+        loss.backward()
+        return out, noref, loss
+
+    out1, nr1, l1 = run(m1)
+    monkeypatch.setenv("RCMVS_TRAIN", "aten")
+    out2, nr2, l2 = run(m2)
+    assert _rel(out1["stage1"]["depth"], out2["stage1"]["depth"]) < 1e-4
+    assert _rel(nr1, nr2) < 1e-4
+    worst = ("", 0.0)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert p1.grad is not None and p2.grad is not None, n1
+        if n1.startswith("cost_regularization.0") or n1.startswith("feature"):      # stage 1: identical hypothesis planes
+            e = _rel(p1.grad, p2.grad)
+            if e > worst[1]:
+                worst = (n1, e)
+    print(f"loss {float(l1):.6f} vs {float(l2):.6f}; worst stage-1/feature grad mismatch {worst[1]:.2e} at {worst[0]}")
+    assert worst[1] < 5e-3
+    b1 = dict(m1.named_buffers())
+    for n2, b in m2.named_buffers():
+        if n2.startswith("cost_regularization.0") and "running" in n2:
+            assert _rel(b1[n2], b) < 1e-4, n2
