@@ -71,15 +71,18 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
         const float* xb = x + (long long)b * dm.D * dm.H * dm.W * CI + cig * 4;
         for (int w0 = 0; w0 < dm.Wo; w0 += 4) {
             const int ow = w0 + kq;
+            const bool w_ok = ow < dm.Wo;                       // ragged last step: the cell contributes zero
             float bv[NJ];
             if constexpr (NJ == 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(dyrow + (long long)ow * CO);
+                f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (w_ok) t = *reinterpret_cast<const f32x4*>(dyrow + (long long)ow * CO);
                 bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
             } else if constexpr (NJ == 2) {
-                const float2 t = *reinterpret_cast<const float2*>(dyrow + (long long)ow * CO);
+                float2 t = make_float2(0.f, 0.f);
+                if (w_ok) t = *reinterpret_cast<const float2*>(dyrow + (long long)ow * CO);
                 bv[0] = t.x; bv[1] = t.y;
             } else {
-                bv[0] = n_ok ? dyrow[(long long)ow * CO] : 0.0f;
+                bv[0] = (n_ok && w_ok) ? dyrow[(long long)ow * CO] : 0.0f;
             }
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) {
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
                 const int id = od * STRIDE + ((t >> 4) & 3) - 1;
                 const int ih = oh * STRIDE + ((t >> 2) & 3) - 1;
                 const int iw = ow * STRIDE + (t & 3) - 1;
-                const bool ok = (t & 64) && (unsigned)id < (unsigned)dm.D && (unsigned)ih < (unsigned)dm.H && (unsigned)iw < (unsigned)dm.W;
+                const bool ok = (t & 64) && w_ok && (unsigned)id < (unsigned)dm.D && (unsigned)ih < (unsigned)dm.H && (unsigned)iw < (unsigned)dm.W;
                 f32x4 av = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (ok) av = *reinterpret_cast<const f32x4*>(xb + (((long long)id * dm.H + ih) * dm.W + iw) * CI);
 #pragma unroll
@@ -188,7 +191,6 @@ int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D,
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_wgrad: bad sizes");
     RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride must be 1 or 2");
     WgradDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
-    RCMVS_REQUIRE(dm.Wo % 4 == 0, "conv3d_wgrad: output width %d must be a multiple of 4", dm.Wo);
     hipStream_t st = as_stream(stream);
 #define RCMVS_WG(CI, CO, S) if (Ci == CI && Co == CO && stride == S) return wgrad_launch<CI, CO, S>(x, dy, dw, dm, st);
     RCMVS_WG(8, 8, 1) RCMVS_WG(16, 8, 1) RCMVS_WG(32, 8, 1)

@@ -52,7 +52,7 @@ def test_conv_bn_relu_block_forward_backward(ci, co, stride, transposed, relu, w
     _lib.load()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(ci * 100 + co + stride)
-    B, D, H, W = 2, 8, 8, 16
+    B, D, H, W = (2, 8, 8, 16) if relu else (1, 4, 6, 10)             # second shape: ragged width (Wo = 10 or 5)
     x = torch.randn(B, ci, D, H, W, generator=g)
     w = torch.randn((ci, co, 3, 3, 3) if transposed else (co, ci, 3, 3, 3), generator=g) * (1.0 / (27 * ci) ** 0.5)
     gamma = 0.5 + torch.rand(co, generator=g)
