@@ -168,6 +168,9 @@ int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* plane
  * (models/render_models.py:756), NCDHW in -> channels-last out with the channel count zero-padded
  * to Cp >= C (so the first conv reads 16-byte vectors):  x (B,C,D,h,w) -> y (B,Do,h,w,Cp). */
 int rcmvs_resize_planes_fwd(const float* x, float* y, int B, int C, int Cp, int D, int Do, int h, int w, void* stream);
+/* adjoint of rcmvs_resize_planes_fwd w.r.t. x (autograd of F.interpolate(trilinear, align_corners=True) along D,
+ * models/render_models.py:756): g (B,Do,h,w,ldg) channels-last (first C channels used) -> gx (B,C,D,h,w). */
+int rcmvs_resize_planes_bwd(const float* g, float* gx, int B, int C, int ldg, int D, int Do, int h, int w, void* stream);
 
 /* Gaussian-Uniform ray sampler + world/NDC points (models/render_utils.py:86-108,149-243,
  * 112-146).  Random draws are inputs: pix (2,N) int32 rows x,y; eps (N,S); u (N/2,S).

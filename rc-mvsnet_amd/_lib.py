@@ -28,6 +28,7 @@ SIGNATURES = {
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_k1_variant": [_i],
     "rcmvs_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_resize_planes_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_bn_stats": [_p, _p, _ll, _i, _p],
     "rcmvs_scale_shift_relu": [_p, _p, _p, _p, _p, _ll, _i, _i, _p],
     "rcmvs_bn_bwd_reduce": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],

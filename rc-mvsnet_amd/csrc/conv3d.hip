@@ -121,7 +121,7 @@ static int direct_dispatch(const float* x, const float* wp, const float* scale, 
     }
     // CostRegNet (base 8) with 8/16/32-channel inputs, and the renderer's CostReg (41 -> 8)
     RCMVS_CONV_CASE(8, 8) RCMVS_CONV_CASE(16, 8) RCMVS_CONV_CASE(32, 8) RCMVS_CONV_CASE(41, 8) RCMVS_CONV_CASE(44, 8)
-    RCMVS_CONV_CASE(8, 16) RCMVS_CONV_CASE(8, 32) RCMVS_CONV_CASE(16, 16) RCMVS_CONV_CASE(16, 32) RCMVS_CONV_CASE(32, 32)
+    RCMVS_CONV_CASE(8, 16) RCMVS_CONV_CASE(8, 32) RCMVS_CONV_CASE(8, 48) RCMVS_CONV_CASE(16, 16) RCMVS_CONV_CASE(16, 32) RCMVS_CONV_CASE(32, 32)
     RCMVS_CONV_CASE(32, 64) RCMVS_CONV_CASE(64, 64) RCMVS_CONV_CASE(64, 32) RCMVS_CONV_CASE(32, 16)
     RCMVS_CONV_CASE(8, 1)
 #undef RCMVS_CONV_CASE

@@ -190,7 +190,7 @@ static int mfma_dispatch(const float* x, const float* wm, const float* scale, co
         else       hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
         return launch_status("conv3d_mfma");                                                                        \
     }
-    RCMVS_MFMA_CASE(8, 16) RCMVS_MFMA_CASE(8, 32) RCMVS_MFMA_CASE(16, 16) RCMVS_MFMA_CASE(16, 32) RCMVS_MFMA_CASE(32, 32)
+    RCMVS_MFMA_CASE(8, 16) RCMVS_MFMA_CASE(8, 32) RCMVS_MFMA_CASE(8, 48) RCMVS_MFMA_CASE(16, 16) RCMVS_MFMA_CASE(16, 32) RCMVS_MFMA_CASE(32, 32)
     RCMVS_MFMA_CASE(32, 64) RCMVS_MFMA_CASE(64, 64) RCMVS_MFMA_CASE(64, 32) RCMVS_MFMA_CASE(32, 16)
 #undef RCMVS_MFMA_CASE
     (void)nt;

@@ -38,10 +38,13 @@ struct WgradCfg {
 
 template <int CI, int CO, int STRIDE>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dw, WgradDims dm, int rows) {
+                                                           float* __restrict__ dw, WgradDims dm, int rows,
+                                                           int ldx, int ci_off, int ci_total) {
     using Cfg = WgradCfg<CI, CO, STRIDE>;
     constexpr int CQ = Cfg::CQ, TPM = Cfg::TPM, NGRP = Cfg::NGRP, NJ = Cfg::NJ, G = Cfg::G;
     static_assert(CI % 4 == 0 && CQ <= 16 && 16 % CQ == 0, "CI must be 4, 8, 16, 32 or 64");
+    // x holds ldx channels per cell; this launch handles channels ci_off .. ci_off + CI - 1 of the ci_total the gradient has
+    // (channel counts outside the power-of-two set, e.g. the renderer's 44, are covered by several launches)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int tapsel = m / CQ, cig = m % CQ;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
         const int od = (row / dm.Ho) % dm.Do;
         const int b = row / (dm.Ho * dm.Do);
         const float* dyrow = dy + ((((long long)b * dm.Do + od) * dm.Ho + oh) * dm.Wo) * CO + NJ * m;
-        const float* xb = x + (long long)b * dm.D * dm.H * dm.W * CI + cig * 4;
+        const float* xb = x + (long long)b * dm.D * dm.H * dm.W * ldx + ci_off + cig * 4;
         for (int w0 = 0; w0 < dm.Wo; w0 += 4) {
             const int ow = w0 + kq;
             const bool w_ok = ow < dm.Wo;                       // ragged last step: the cell contributes zero
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
                 const int iw = ow * STRIDE + (t & 3) - 1;
                 const bool ok = (t & 64) && w_ok && (unsigned)id < (unsigned)dm.D && (unsigned)ih < (unsigned)dm.H && (unsigned)iw < (unsigned)dm.W;
                 f32x4 av = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok) av = *reinterpret_cast<const f32x4*>(xb + (((long long)id * dm.H + ih) * dm.W + iw) * CI);
+                if (ok) av = *reinterpret_cast<const f32x4*>(xb + (((long long)id * dm.H + ih) * dm.W + iw) * ldx);
 #pragma unroll
                 for (int jb = 0; jb < NJ; ++jb) {
                     acc[gi][0][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[jb], acc[gi][0][jb], 0, 0, 0);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 #pragma unroll
                 for (int jb = 0; jb < NJ; ++jb) {
                     const int co = co0 + jb;
-                    if (co < CO) unsafeAtomicAdd(dw + ((long long)tap * CI + cq * 4 + ja) * CO + co, acc[gi][ja][jb][r]);
+                    if (co < CO) unsafeAtomicAdd(dw + ((long long)tap * ci_total + ci_off + cq * 4 + ja) * CO + co, acc[gi][ja][jb][r]);
                 }
         }
     }
@@ -174,12 +177,12 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_c1_kernel(const float* __res
 using namespace rcmvs;
 
 template <int CI, int CO, int STRIDE>
-static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradDims& dm, hipStream_t st) {
+static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradDims& dm, int ldx, int ci_off, int ci_total, hipStream_t st) {
     using Cfg = WgradCfg<CI, CO, STRIDE>;
     const int rows = dm.B * dm.Do * dm.Ho;
     int gx = (rows + 3) / 4;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE>), dim3(gx, Cfg::SPLITS), dim3(256), 0, st, x, dy, dw, dm, rows);
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE>), dim3(gx, Cfg::SPLITS), dim3(256), 0, st, x, dy, dw, dm, rows, ldx, ci_off, ci_total);
     return launch_status("conv3d_wgrad");
 }
 
@@ -192,11 +195,23 @@ int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D,
     RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride must be 1 or 2");
     WgradDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
-#define RCMVS_WG(CI, CO, S) if (Ci == CI && Co == CO && stride == S) return wgrad_launch<CI, CO, S>(x, dy, dw, dm, st);
+#define RCMVS_WG(CI, CO, S) if (Ci == CI && Co == CO && stride == S) return wgrad_launch<CI, CO, S>(x, dy, dw, dm, Ci, 0, Ci, st);
     RCMVS_WG(8, 8, 1) RCMVS_WG(16, 8, 1) RCMVS_WG(32, 8, 1)
     RCMVS_WG(16, 16, 1) RCMVS_WG(32, 32, 1) RCMVS_WG(64, 64, 1) RCMVS_WG(8, 1, 1)
     RCMVS_WG(8, 16, 2) RCMVS_WG(16, 32, 2) RCMVS_WG(32, 64, 2)
 #undef RCMVS_WG
+    if (Co == 8 && stride == 1 && Ci % 4 == 0 && Ci < 64) {
+        // other input widths (the renderer's CostReg reads 41 channels padded to 44): 32 + 8 + 4 channel slices
+        int off = 0, rc = 0;
+        while (off < Ci && rc == 0) {
+            const int left = Ci - off;
+            if (left >= 32)      { rc = wgrad_launch<32, 8, 1>(x, dy, dw, dm, Ci, off, Ci, st); off += 32; }
+            else if (left >= 16) { rc = wgrad_launch<16, 8, 1>(x, dy, dw, dm, Ci, off, Ci, st); off += 16; }
+            else if (left >= 8)  { rc = wgrad_launch<8, 8, 1>(x, dy, dw, dm, Ci, off, Ci, st); off += 8; }
+            else                 { rc = wgrad_launch<4, 8, 1>(x, dy, dw, dm, Ci, off, Ci, st); off += 4; }
+        }
+        return rc;
+    }
     return fail(-1, "conv3d_wgrad: unsupported (Ci=%d, Co=%d, stride=%d)", Ci, Co, stride);
 }
 

@@ -34,6 +34,40 @@ __global__ __launch_bounds__(256) void resize_planes_kernel(const float* __restr
     }
 }
 
+// backward of resize_planes_kernel w.r.t. its input: g (B,Do,hw,ldg) channels-last -> gx (B,C,D,hw) NCDHW.
+// One thread per (b, input plane j, pixel): every output plane whose two source planes include j contributes with
+// the forward's weight (same float arithmetic), so the adjoint is exact and needs no atomics.
+__global__ __launch_bounds__(256) void resize_planes_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx,
+                                                                 int C, int ldg, int D, int Do, int hw) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.z, j = blockIdx.y;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const float scale = (Do > 1) ? (float)(D - 1) / (float)(Do - 1) : 0.0f;
+    int klo = 0, khi = Do - 1;
+    if (scale > 0.0f) {
+        klo = (int)floorf((float)(j - 1) / scale) - 1;
+        khi = (int)ceilf((float)(j + 1) / scale) + 1;
+        klo = klo < 0 ? 0 : klo;
+        khi = khi > Do - 1 ? Do - 1 : khi;
+    }
+    float* go = gx + ((long long)b * C * D + j) * hw + p;
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.0f;
+        for (int k = klo; k <= khi; ++k) {
+            const float srcf = scale * (float)k;
+            int i0 = (int)srcf;
+            i0 = i0 > D - 1 ? D - 1 : i0;
+            const int i1 = i0 + 1 > D - 1 ? D - 1 : i0 + 1;
+            const float l1 = srcf - (float)i0, l0 = 1.0f - l1;
+            const float v = g[(((long long)b * Do + k) * hw + p) * ldg + c];
+            if (i0 == j) acc = acc + l0 * v;
+            if (i1 == j) acc = acc + l1 * v;
+        }
+        go[(long long)c * D * hw] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gaussian-Uniform sampler (models/render_utils.py:86-108,149-243,112-146).  One 128-thread block per
 // ray; samples are sorted with an LDS bitonic network (power-of-two S <= 1024 handled by padding
@@ -272,6 +306,14 @@ int rcmvs_resize_planes_fwd(const float* x, float* y, int B, int C, int Cp, int 
     dim3 grid((h * w + 255) / 256, Do, B);
     hipLaunchKernelGGL(resize_planes_kernel, grid, dim3(256), 0, as_stream(stream), x, y, C, Cp, D, Do, h * w);
     return launch_status("resize_planes_fwd");
+}
+
+int rcmvs_resize_planes_bwd(const float* g, float* gx, int B, int C, int ldg, int D, int Do, int h, int w, void* stream) {
+    RCMVS_REQUIRE(g && gx, "resize_planes_bwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && C > 0 && ldg >= C && D > 0 && Do > 0 && h > 0 && w > 0, "resize_planes_bwd: bad sizes");
+    dim3 grid((h * w + 255) / 256, D, B);
+    hipLaunchKernelGGL(resize_planes_bwd_kernel, grid, dim3(256), 0, as_stream(stream), g, gx, C, ldg, D, Do, h * w);
+    return launch_status("resize_planes_bwd");
 }
 
 int rcmvs_gu_sample_fwd(const float* pseudo_depth, const float* img0, const int* pix,

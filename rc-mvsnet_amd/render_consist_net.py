@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .casmvsnet import _bn_fold, _hip_inference, _note_delegation
+from .casmvsnet import _bn_fold, _hip_inference, _hip_training, _note_delegation
 
 N_RAYS = 1024                               # hard-coded in the reference (render_consist_net.py:68)
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -93,6 +93,22 @@ class CostReg(nn.Module):
         t = ops.deconv3d(t, *p["conv9"], residual=conv2)
         return ops.deconv3d(t, *p["conv11"], residual=conv0)
 
+    def forward_cl_train(self, x):
+        """Train-mode twin of ``forward_cl``: batch-statistics norm layers, autograd through the HIP kernels."""
+        from .train_ops import conv_bn_train
+
+        def blk(name, t, residual=None):
+            conv, bn, _ = self._conv_bn(name)
+            return conv_bn_train(conv, bn, t, relu=False, residual=residual)
+
+        conv0 = blk("conv0", x)
+        conv2 = blk("conv2", blk("conv1", conv0))
+        conv4 = blk("conv4", blk("conv3", conv2))
+        t = blk("conv6", blk("conv5", conv4))
+        t = blk("conv7", t, residual=conv4)
+        t = blk("conv9", t, residual=conv2)
+        return blk("conv11", t, residual=conv0)
+
     def forward(self, x):
         conv0 = self.conv0(x)
         conv2 = self.conv2(self.conv1(conv0))
@@ -124,6 +140,13 @@ class Neural_Volume_Net(nn.Module):
     def forward(self, volume_feature, pad=0):
         if _hip_inference(self, volume_feature):
             return ops.to_channels_first(self.forward_cl(volume_feature)).reshape(1, -1, 128, *volume_feature.shape[-2:])
+        if _hip_training(self, volume_feature) and all(isinstance(m, (nn.BatchNorm3d, nn.SyncBatchNorm))
+                                                       for m in self.modules() if isinstance(m, nn.modules.batchnorm._NormBase)):
+            from .train_ops import ResizePlanesFn
+            C = volume_feature.shape[1]
+            x = ResizePlanesFn.apply(volume_feature, 128, (C + 3) // 4 * 4)
+            v = self.cost_reg_2.forward_cl_train(x).permute(0, 4, 1, 2, 3)        # NCDHW view of the channels-last result
+            return v.reshape(1, -1, *v.shape[2:])
         _note_delegation("Neural_Volume_Net")
         B, C, _, H, W = volume_feature.shape
         v = F.interpolate(volume_feature, size=[128, H, W], mode="trilinear", align_corners=True)

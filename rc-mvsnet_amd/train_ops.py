@@ -83,29 +83,44 @@ def depth_head_bwd(prob, planes, depth, gdepth):
 
 
 # --------------------------------------------------------------------------------------- conv + BN + ReLU
+def _pad_in_channels(w, cx):
+    """Conv weight (Co,Ci,3,3,3) -> (Co,cx,3,3,3): zero taps for the input's padding channels (41 -> 44)."""
+    if w.shape[1] == cx:
+        return w
+    return torch.cat((w, w.new_zeros(w.shape[0], cx - w.shape[1], 3, 3, 3)), dim=1)
+
+
 def _conv_raw(x, w, transposed, stride):
     """The block's convolution with an identity epilogue (weights re-packed: they change every step)."""
-    pk = ops.pack_conv3d_weight(w, transposed=transposed)
-    return ops.deconv3d(x, pk) if transposed else ops.conv3d(x, pk, stride=stride)
+    if transposed:
+        return ops.deconv3d(x, ops.pack_conv3d_weight(w, transposed=True))
+    return ops.conv3d(x, ops.pack_conv3d_weight(_pad_in_channels(w, x.shape[-1]), transposed=False), stride=stride)
 
 
-def _conv_dgrad(dy, w, transposed, stride):
-    """d loss / d x of the block's convolution, on the forward kernels with re-packed weights."""
+def _conv_dgrad(dy, w, transposed, stride, cx):
+    """d loss / d x of the block's convolution, on the forward kernels with re-packed weights (cx = channels of x)."""
     w = w.detach()
     if transposed:                                   # adjoint of ConvTranspose3d(stride 2) = Conv3d(stride 2), same weight tensor
         return ops.conv3d(dy, ops.pack_conv3d_weight(w, transposed=False), stride=2)
     if stride == 2:                                  # adjoint of Conv3d(stride 2) = ConvTranspose3d(stride 2, output_padding 1)
         return ops.deconv3d(dy, ops.pack_conv3d_weight(w, transposed=True))
     wd = w.transpose(0, 1).flip(2, 3, 4).contiguous()  # adjoint of Conv3d(stride 1, pad 1) = Conv3d with flipped, transposed taps
-    return ops.conv3d(dy, ops.pack_conv3d_weight(wd, transposed=False), stride=1)
+    co = wd.shape[0]
+    if co not in (1, 8) and co % 16:                 # e.g. 41 input channels: the MFMA kernels want a multiple of 16 outputs
+        cop = (co + 15) // 16 * 16
+        wd = torch.cat((wd, wd.new_zeros(cop - co, *wd.shape[1:])), dim=0)
+    dx = ops.conv3d(dy, ops.pack_conv3d_weight(wd, transposed=False), stride=1)
+    if dx.shape[-1] != cx:                           # back to the (padded) channel count of x; padding channels get zero
+        dx = dx[..., :cx].contiguous() if dx.shape[-1] > cx else torch.nn.functional.pad(dx, (0, cx - dx.shape[-1]))
+    return dx
 
 
 def _conv_wgrad(x, dy, w_shape, transposed, stride):
     if transposed:                                   # roles swap: the large tensor (dy) is strided over
         dwp = conv3d_wgrad(dy, x, 2)                 # (27, Cout_T, Cin_T)
-    else:
-        dwp = conv3d_wgrad(x, dy, stride)            # (27, Ci, Co)
-    return dwp.permute(2, 1, 0).reshape(w_shape)
+        return dwp.permute(2, 1, 0).reshape(w_shape)
+    dwp = conv3d_wgrad(x, dy, stride)                # (27, Cx, Co), Cx >= Ci when the input carries padding channels
+    return dwp[:, :w_shape[1]].permute(2, 1, 0).reshape(w_shape)
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -157,7 +172,7 @@ class ConvBnReluFn(torch.autograd.Function):
             dist.all_reduce(tot, group=cfg["group"])
         coef = (tot / ctx.n_total).float().contiguous()
         dy = bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, cfg["relu"])
-        dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[0] else None
+        dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"], x.shape[-1]) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad(x, dy, w.shape, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[1] else None
         return dx, dw, dgamma, dbeta, (dz if ctx.has_res else None), None
 
@@ -165,13 +180,18 @@ class ConvBnReluFn(torch.autograd.Function):
 def conv_bn_relu_train(block, x, residual=None):
     """Run a Conv3d / Deconv3d module (casmvsnet.py) in train mode on the HIP kernels, including the
     running-statistics update of its BatchNorm3d / SyncBatchNorm (momentum semantics of torch.nn)."""
-    bn = block.bn
-    transposed = isinstance(block.conv, torch.nn.ConvTranspose3d)
+    return conv_bn_train(block.conv, block.bn, x, relu=bool(block.relu), residual=residual)
+
+
+def conv_bn_train(conv, bn, x, relu, residual=None):
+    """conv (nn.Conv3d | nn.ConvTranspose3d, k=3, pad 1, no bias) -> bn (batch statistics) -> [ReLU] [+ residual]."""
+    transposed = isinstance(conv, torch.nn.ConvTranspose3d)
+    stride = conv.stride[0]
     group = None
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    cfg = {"transposed": transposed, "stride": block.stride, "relu": bool(block.relu), "eps": bn.eps, "group": group}
-    z, mean, var, n = ConvBnReluFn.apply(x, block.conv.weight, bn.weight, bn.bias, residual, cfg)
+    cfg = {"transposed": transposed, "stride": stride, "relu": bool(relu), "eps": bn.eps, "group": group}
+    z, mean, var, n = ConvBnReluFn.apply(x, conv.weight, bn.weight, bn.bias, residual, cfg)
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -180,6 +200,26 @@ def conv_bn_relu_train(block, x, residual=None):
             bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1.0 - mom).add_(unbiased, alpha=mom)
     return z
+
+
+# --------------------------------------------------------------------------------------- plane resize (renderer)
+class ResizePlanesFn(torch.autograd.Function):
+    """F.interpolate(trilinear, align_corners=True) along the plane axis (models/render_models.py:756): NCDHW in ->
+    (B,Do,h,w,Cp) channels-last out (channels zero-padded to Cp), with the exact adjoint as backward."""
+
+    @staticmethod
+    def forward(ctx, x, out_planes, cp):
+        ctx.shape = tuple(x.shape)
+        return ops.resize_planes(x.contiguous().float(), out_planes, pad_channels_to=cp)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, D, h, w = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        _lib.check(_lib.load().rcmvs_resize_planes_bwd(_chk(g, "g"), _chk(gx, "gx"), B, C, g.shape[-1], D, g.shape[1], h, w, _stream()),
+                   "resize_planes_bwd")
+        return gx, None, None
 
 
 # --------------------------------------------------------------------------------------- depth head

@@ -160,3 +160,38 @@ def test_cascade_train_native_vs_delegated_gradients(monkeypatch):
     for n2, b in m2.named_buffers():
         if n2.startswith("cost_regularization.0") and "running" in n2:
             assert _rel(b1[n2], b) < 1e-4, n2
+
+
+def test_neural_volume_net_train_native_vs_delegated(monkeypatch):
+    """Rendering branch, a8 in train mode: plane resize + CostReg (conv + batch-stat norm, no ReLU, 41 -> 44 padded
+    input channels) on the HIP kernels vs the delegated op graph: volume, input gradient, parameter gradients."""
+    import copy
+    from rc_mvsnet_amd import _lib
+    from rc_mvsnet_amd.render_consist_net import Neural_Volume_Net
+    _lib.load()
+    warnings.simplefilter("ignore")
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    m1 = Neural_Volume_Net().to(dev).train()
+    for mod in m1.modules():
+        if isinstance(mod, torch.nn.BatchNorm3d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0.0, 0.1)
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 41, 12, 16, 24, generator=g).to(dev)
+    G = torch.randn(1, 8, 128, 16, 24, generator=g).to(dev)
+
+    def run(model):
+        xi = x.clone().requires_grad_(True)
+        v = model(xi)
+        (v * G).sum().backward()
+        return v.detach(), xi.grad
+
+    v1, gx1 = run(m1)
+    monkeypatch.setenv("RCMVS_TRAIN", "aten")
+    v2, gx2 = run(m2)
+    e_v, e_gx = _rel(v1, v2), _rel(gx1, gx2)
+    worst = max(_rel(p1.grad, p2.grad) for p1, p2 in zip(m1.parameters(), m2.parameters()))
+    print(f"Neural_Volume_Net train: volume {e_v:.1e}  d/d input {e_gx:.1e}  worst param grad {worst:.1e}")
+    assert e_v < 1e-4 and e_gx < 1e-3 and worst < 1e-3
