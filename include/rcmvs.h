@@ -124,6 +124,14 @@ int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale
  *   rcmvs_bn_bwd_apply:      dy = scale * (g - coef[c] - xhat*coef[C+c]),  coef = {dbeta/N, dgamma/N},
  *                            xhat = (y-mean)*invstd, scale = gamma*invstd */
 int rcmvs_bn_stats(const float* x, double* sums, long long rows, int C, void* stream);
+/* sums (2C, fp64) + *count -> batch mean / biased var / invstd, scale = gamma*invstd, shift = beta - mean*scale, and
+ * (when given) the momentum update of running_mean / running_var (unbiased), exactly nn.BatchNorm's bookkeeping. */
+int rcmvs_bn_finalize(const double* sums, const double* count, const float* gamma, const float* beta, float eps, float momentum,
+                      float* mean, float* var, float* invstd, float* scale, float* shift,
+                      float* running_mean, float* running_var, int C, void* stream);
+/* local sums -> dgamma, dbeta of this replica; total (all-reduced) sums / *count -> coef for rcmvs_bn_bwd_apply */
+int rcmvs_bn_bwd_finalize(const double* local_sums, const double* total_sums, const double* count, float* dgamma, float* dbeta,
+                          float* coef, int C, void* stream);
 int rcmvs_scale_shift_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                            long long rows, int C, int relu, void* stream);
 int rcmvs_bn_bwd_reduce(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,

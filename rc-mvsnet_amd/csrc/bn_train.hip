@@ -114,6 +114,45 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const float* __r
     }
 }
 
+// fp64 sums -> everything the block needs, in one launch (replaces a dozen 32-element tensor ops):
+// batch mean / biased variance / invstd, the folded scale = gamma*invstd and shift = beta - mean*scale, and the
+// running-statistics update of nn.BatchNorm (running_var takes the unbiased variance).
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = *count;
+    const double m = sums[c] / n;
+    double v = sums[C + c] / n - m * m;
+    v = v < 0.0 ? 0.0 : v;
+    const float is = (float)(1.0 / sqrt(v + (double)eps));
+    const float mf = (float)m;
+    mean[c] = mf; var[c] = (float)v; invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mf * sc;
+    if (running_mean) {
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(v * (n / (n - 1.0)));
+    }
+}
+
+// backward: this replica's parameter gradients from its own sums, the normalisation coefficients from the totals
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ local, const double* __restrict__ total,
+                                       const double* __restrict__ count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = *count;
+    dbeta[c] = (float)local[c];
+    dgamma[c] = (float)local[C + c];
+    coef[c] = (float)(total[c] / n);
+    coef[C + c] = (float)(total[C + c] / n);
+}
+
 static inline unsigned grid_for(long long work_items) {
     long long g = cdiv(work_items, (long long)BN_BLOCK);
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -130,6 +169,24 @@ int rcmvs_bn_stats(const float* x, double* sums, long long rows, int C, void* st
     RCMVS_REQUIRE(C >= 4 && C % 4 == 0 && BN_BLOCK % (C / 4) == 0, "bn_stats: C=%d must be 4, 8, 16, 32, 64 ...", C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows * (C / 4) / 8)), dim3(BN_BLOCK), 0, as_stream(stream), x, sums, rows, C);
     return launch_status("bn_stats");
+}
+
+int rcmvs_bn_finalize(const double* sums, const double* count, const float* gamma, const float* beta, float eps, float momentum,
+                      float* mean, float* var, float* invstd, float* scale, float* shift,
+                      float* running_mean, float* running_var, int C, void* stream) {
+    RCMVS_REQUIRE(sums && count && gamma && beta && mean && var && invstd && scale && shift && C > 0, "bn_finalize: bad arguments");
+    RCMVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), sums, count, gamma, beta, eps, momentum,
+                       mean, var, invstd, scale, shift, running_mean, running_var, C);
+    return launch_status("bn_finalize");
+}
+
+int rcmvs_bn_bwd_finalize(const double* local_sums, const double* total_sums, const double* count, float* dgamma, float* dbeta,
+                          float* coef, int C, void* stream) {
+    RCMVS_REQUIRE(local_sums && total_sums && count && dgamma && dbeta && coef && C > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), local_sums, total_sums, count,
+                       dgamma, dbeta, coef, C);
+    return launch_status("bn_bwd_finalize");
 }
 
 int rcmvs_scale_shift_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,

@@ -128,6 +128,53 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     }
 }
 
+// Weight gradient of the prob conv (8 -> 1).  With one output channel the general kernel would fill 1/16 of a tile, so
+// the GEMM is turned around: M = input channel (8 of 16 rows), N = TAP (27 of 32 columns, two tiles), K = cells:
+//   D[ci][tap] = sum_q x[q][ci] * dy[q - (tap - 1)]
+// A is the unshifted activation (one float per lane), B the 1-channel gradient at the tap's offset.
+__global__ __launch_bounds__(256) void conv3d_wgrad_c1_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, WgradDims dm, int rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    int tdx[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tap = t * 16 + m;
+        tdx[t] = tap < 27 ? (64 | ((tap / 9) << 4) | (((tap / 3) % 3) << 2) | (tap % 3)) : 0;
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int ih = row % dm.H;
+        const int id = (row / dm.H) % dm.D;
+        const int b = row / (dm.H * dm.D);
+        const float* xrow = x + ((((long long)b * dm.D + id) * dm.H + ih) * dm.W) * 8 + m;
+        const float* dyb = dy + (long long)b * dm.D * dm.H * dm.W;
+        for (int w0 = 0; w0 < dm.W; w0 += 4) {
+            const int iw = w0 + kq;
+            const bool w_ok = iw < dm.W;
+            const float av = (w_ok && m < 8) ? xrow[(long long)iw * 8] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int tt = tdx[t];
+                const int od = id - ((tt >> 4) & 3) + 1, oh = ih - ((tt >> 2) & 3) + 1, ow = iw - (tt & 3) + 1;
+                const bool ok = (tt & 64) && w_ok && (unsigned)od < (unsigned)dm.D && (unsigned)oh < (unsigned)dm.H && (unsigned)ow < (unsigned)dm.W;
+                const float bv = ok ? dyb[((long long)od * dm.H + oh) * dm.W + ow] : 0.0f;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tap = t * 16 + m;                  // column n = lane & 15
+        if (tap >= 27) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = 4 * kq + r;               // row
+            if (ci < 8) unsafeAtomicAdd(dw + tap * 8 + ci, acc[t][r]);
+        }
+    }
+}
+
 // depth head backward, element-wise part (models/casmvsnet.py:299-300): logits -> softmax p -> depth = sum p_k d_k
 //   d loss / d logit_k = p_k * (d_k - depth) * g,   g = d loss / d depth,   d_k = planes.d0 + k * planes.delta
 __global__ void depth_head_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ planes,
@@ -195,9 +242,16 @@ int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D,
     RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride must be 1 or 2");
     WgradDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
+    if (Ci == 8 && Co == 1 && stride == 1) {
+        const int rows = B * D * H;
+        int gx = (rows + 3) / 4;
+        if (gx > 2048) gx = 2048;
+        hipLaunchKernelGGL(conv3d_wgrad_c1_kernel, dim3(gx), dim3(256), 0, st, x, dy, dw, dm, rows);
+        return launch_status("conv3d_wgrad_c1");
+    }
 #define RCMVS_WG(CI, CO, S) if (Ci == CI && Co == CO && stride == S) return wgrad_launch<CI, CO, S>(x, dy, dw, dm, Ci, 0, Ci, st);
     RCMVS_WG(8, 8, 1) RCMVS_WG(16, 8, 1) RCMVS_WG(32, 8, 1)
-    RCMVS_WG(16, 16, 1) RCMVS_WG(32, 32, 1) RCMVS_WG(64, 64, 1) RCMVS_WG(8, 1, 1)
+    RCMVS_WG(16, 16, 1) RCMVS_WG(32, 32, 1) RCMVS_WG(64, 64, 1)
     RCMVS_WG(8, 16, 2) RCMVS_WG(16, 32, 2) RCMVS_WG(32, 64, 2)
 #undef RCMVS_WG
     if (Co == 8 && stride == 1 && Ci % 4 == 0 && Ci < 64) {

@@ -35,14 +35,19 @@ __global__ __launch_bounds__(256) void resize_planes_kernel(const float* __restr
 }
 
 // backward of resize_planes_kernel w.r.t. its input: g (B,Do,hw,ldg) channels-last -> gx (B,C,D,hw) NCDHW.
-// One thread per (b, input plane j, pixel): every output plane whose two source planes include j contributes with
-// the forward's weight (same float arithmetic), so the adjoint is exact and needs no atomics.
+// One block per (b, input plane j, 256 pixels), one thread per pixel: every output plane whose two source planes
+// include j contributes with the forward's weight (same float arithmetic), so the adjoint is exact and needs no
+// atomics.  Each contributing plane's (256 x ldg) slab is staged through LDS with coalesced reads (the channels-last
+// rows are ldg floats apart) and the NCDHW writes are coalesced per channel.
+constexpr int RSZ_MAXC = 64;
 __global__ __launch_bounds__(256) void resize_planes_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx,
                                                                  int C, int ldg, int D, int Do, int hw) {
 #pragma clang fp contract(off)
+    extern __shared__ float slab[];                                // [256][ldg + 1]
     const int b = blockIdx.z, j = blockIdx.y;
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= hw) return;
+    const int p0 = blockIdx.x * 256;
+    const int npix = min(256, hw - p0);
+    const int lds_ld = ldg + 1;
     const float scale = (Do > 1) ? (float)(D - 1) / (float)(Do - 1) : 0.0f;
     int klo = 0, khi = Do - 1;
     if (scale > 0.0f) {
@@ -51,20 +56,35 @@ __global__ __launch_bounds__(256) void resize_planes_bwd_kernel(const float* __r
         klo = klo < 0 ? 0 : klo;
         khi = khi > Do - 1 ? Do - 1 : khi;
     }
-    float* go = gx + ((long long)b * C * D + j) * hw + p;
-    for (int c = 0; c < C; ++c) {
-        float acc = 0.0f;
-        for (int k = klo; k <= khi; ++k) {
-            const float srcf = scale * (float)k;
-            int i0 = (int)srcf;
-            i0 = i0 > D - 1 ? D - 1 : i0;
-            const int i1 = i0 + 1 > D - 1 ? D - 1 : i0 + 1;
-            const float l1 = srcf - (float)i0, l0 = 1.0f - l1;
-            const float v = g[(((long long)b * Do + k) * hw + p) * ldg + c];
-            if (i0 == j) acc = acc + l0 * v;
-            if (i1 == j) acc = acc + l1 * v;
+    float acc[RSZ_MAXC];
+#pragma unroll
+    for (int c = 0; c < RSZ_MAXC; ++c) acc[c] = 0.0f;
+    for (int k = klo; k <= khi; ++k) {
+        const float srcf = scale * (float)k;
+        int i0 = (int)srcf;
+        i0 = i0 > D - 1 ? D - 1 : i0;
+        const int i1 = i0 + 1 > D - 1 ? D - 1 : i0 + 1;
+        if (i0 != j && i1 != j) continue;                           // block-uniform
+        const float l1 = srcf - (float)i0, l0 = 1.0f - l1;
+        __syncthreads();
+        const float* gs = g + (((long long)b * Do + k) * hw + p0) * ldg;
+        for (int e = threadIdx.x; e < npix * ldg; e += 256) slab[(e / ldg) * lds_ld + (e % ldg)] = gs[e];
+        __syncthreads();
+        const float* row = slab + threadIdx.x * lds_ld;
+#pragma unroll
+        for (int c = 0; c < RSZ_MAXC; ++c) {
+            if (c < C) {
+                const float v = row[c];
+                if (i0 == j) acc[c] = acc[c] + l0 * v;
+                if (i1 == j) acc[c] = acc[c] + l1 * v;
+            }
         }
-        go[(long long)c * D * hw] = acc;
+    }
+    if ((int)threadIdx.x < npix) {
+        float* go = gx + ((long long)b * C * D + j) * hw + p0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < RSZ_MAXC; ++c)
+            if (c < C) go[(long long)c * D * hw] = acc[c];
     }
 }
 
@@ -311,8 +331,10 @@ int rcmvs_resize_planes_fwd(const float* x, float* y, int B, int C, int Cp, int 
 int rcmvs_resize_planes_bwd(const float* g, float* gx, int B, int C, int ldg, int D, int Do, int h, int w, void* stream) {
     RCMVS_REQUIRE(g && gx, "resize_planes_bwd: null pointer");
     RCMVS_REQUIRE(B > 0 && C > 0 && ldg >= C && D > 0 && Do > 0 && h > 0 && w > 0, "resize_planes_bwd: bad sizes");
+    RCMVS_REQUIRE(C <= RSZ_MAXC && ldg <= 63, "resize_planes_bwd: at most %d channels (row stride <= 63)", RSZ_MAXC);
     dim3 grid((h * w + 255) / 256, D, B);
-    hipLaunchKernelGGL(resize_planes_bwd_kernel, grid, dim3(256), 0, as_stream(stream), g, gx, C, ldg, D, Do, h * w);
+    hipLaunchKernelGGL(resize_planes_bwd_kernel, grid, dim3(256), (size_t)256 * (ldg + 1) * sizeof(float), as_stream(stream), g, gx, C,
+                       ldg, D, Do, h * w);
     return launch_status("resize_planes_bwd");
 }
 

@@ -536,10 +536,11 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
 // the reference's NCDHW layout because the tensor crosses the module boundary
 // (CascadeMVSNet.forward returns it, models/casmvsnet.py:231).  One thread per (pixel, plane).
 // ------------------------------------------------------------------------------------------
+template <int C>
 __global__ __launch_bounds__(256) void warp_noref_kernel(
     const float* __restrict__ feats, const float* __restrict__ imgs, const float* __restrict__ rot,
     const float* __restrict__ trans, const float* __restrict__ planes, float* __restrict__ out,
-    int V, int C, int D, int h, int w, int square_first) {
+    int V, int D, int h, int w, int square_first) {
 #pragma clang fp contract(off)
     const int b = blockIdx.z, k = blockIdx.y;
     const long long hw = (long long)h * w;
@@ -555,40 +556,50 @@ __global__ __launch_bounds__(256) void warp_noref_kernel(
     float* ob = out + (((long long)b * CT) * D + k) * hw + p;      // channel stride = D*hw
     const long long cs = (long long)D * hw;
     const float fV = (float)V;
-    // channel loop outermost over 4-channel groups keeps registers small; taps are recomputed
-    // per view only once (they do not depend on the channel)
+    // one coordinate chain per source view; the C channel sums live in registers (view order = the oracle's)
+    float s[C], sq[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { s[c] = 0.0f; sq[c] = 0.0f; }
     for (int v = 1; v < V; ++v) {
         const float* r = rot + ((long long)b * (V - 1) + (v - 1)) * 9;
         const float* t = trans + ((long long)b * (V - 1) + (v - 1)) * 3;
         const float rx = (r[0] * fx + r[1] * fy) + r[2];
         const float ry = (r[3] * fx + r[4] * fy) + r[5];
         const float rz = (r[6] * fx + r[7] * fy) + r[8];
-        WarpCoord tc = warp_taps(rx, ry, rz, t[0], t[1], t[2], d, half_w, half_h, wm1, hm1, w, h, 1);
+        const WarpCoord tc = warp_taps(rx, ry, rz, t[0], t[1], t[2], d, half_w, half_h, wm1, hm1, w, h, 1);
         const float* im = imgs + ((long long)b * V + v) * hw * 3;
         for (int c = 0; c < 3; ++c) {
             float val = ((im[tc.off[0] * 3 + c] * tc.wgt[0] + im[tc.off[1] * 3 + c] * tc.wgt[1]) +
                          im[tc.off[2] * 3 + c] * tc.wgt[2]) + im[tc.off[3] * 3 + c] * tc.wgt[3];
             ob[(long long)((v - 1) * 3 + c) * cs] = val;
         }
-    }
-    for (int c = 0; c < C; ++c) {
-        float s = 0.0f, sq = 0.0f;
-        for (int v = 1; v < V; ++v) {
-            const float* r = rot + ((long long)b * (V - 1) + (v - 1)) * 9;
-            const float* t = trans + ((long long)b * (V - 1) + (v - 1)) * 3;
-            const float rx = (r[0] * fx + r[1] * fy) + r[2];
-            const float ry = (r[3] * fx + r[4] * fy) + r[5];
-            const float rz = (r[6] * fx + r[7] * fy) + r[8];
-            WarpCoord tc = warp_taps(rx, ry, rz, t[0], t[1], t[2], d, half_w, half_h, wm1, hm1, w, h, 1);
-            const float* src = feats + ((long long)b * V + v) * hw * C + c;
-            float val = ((src[(long long)tc.off[0] * C] * tc.wgt[0] + src[(long long)tc.off[1] * C] * tc.wgt[1]) +
-                         src[(long long)tc.off[2] * C] * tc.wgt[2]) + src[(long long)tc.off[3] * C] * tc.wgt[3];
-            if (square_first) val = val * val;
-            s = s + val;
-            sq = sq + val * val;
+        const float* src = feats + ((long long)b * V + v) * hw * C;
+        const float* s0 = src + (long long)tc.off[0] * C;
+        const float* s1 = src + (long long)tc.off[1] * C;
+        const float* s2 = src + (long long)tc.off[2] * C;
+        const float* s3 = src + (long long)tc.off[3] * C;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(s0 + c), bb = *reinterpret_cast<const float4*>(s1 + c);
+            const float4 cc = *reinterpret_cast<const float4*>(s2 + c), dd = *reinterpret_cast<const float4*>(s3 + c);
+            float val[4];
+            val[0] = ((a.x * tc.wgt[0] + bb.x * tc.wgt[1]) + cc.x * tc.wgt[2]) + dd.x * tc.wgt[3];
+            val[1] = ((a.y * tc.wgt[0] + bb.y * tc.wgt[1]) + cc.y * tc.wgt[2]) + dd.y * tc.wgt[3];
+            val[2] = ((a.z * tc.wgt[0] + bb.z * tc.wgt[1]) + cc.z * tc.wgt[2]) + dd.z * tc.wgt[3];
+            val[3] = ((a.w * tc.wgt[0] + bb.w * tc.wgt[1]) + cc.w * tc.wgt[2]) + dd.w * tc.wgt[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float vv = val[j];
+                if (square_first) vv = vv * vv;
+                s[c + j] = s[c + j] + vv;
+                sq[c + j] = sq[c + j] + vv * vv;
+            }
         }
-        float m = s / fV;
-        ob[(long long)(3 * (V - 1) + c) * cs] = sq / fV - m * m;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float m = s[c] / fV;
+        ob[(long long)(3 * (V - 1) + c) * cs] = sq[c] / fV - m * m;
     }
 }
 
@@ -688,11 +699,13 @@ int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot
                          const float* planes, float* out,
                          int B, int V, int C, int D, int h, int w, int square_first, void* stream) {
     RCMVS_REQUIRE(feats && imgs && rot && trans && planes && out, "warp_noref_fwd: null pointer");
-    RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1 && C > 0, "warp_noref_fwd: bad sizes");
+    RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_noref_fwd: bad sizes");
+    RCMVS_REQUIRE(C == 8 || C == 16 || C == 32, "warp_noref_fwd: C must be 8, 16 or 32 (got %d)", C);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_noref_fwd: V=%d unsupported", V);
     dim3 grid((unsigned)cdiv((long long)h * w, 256), D, B);
-    hipLaunchKernelGGL(warp_noref_kernel, grid, dim3(256), 0, as_stream(stream), feats, imgs, rot, trans, planes, out,
-                       V, C, D, h, w, square_first);
+#define RCMVS_NOREF(CC) hipLaunchKernelGGL((warp_noref_kernel<CC>), grid, dim3(256), 0, as_stream(stream), feats, imgs, rot, trans, planes, out, V, D, h, w, square_first)
+    if (C == 8) RCMVS_NOREF(8); else if (C == 16) RCMVS_NOREF(16); else RCMVS_NOREF(32);
+#undef RCMVS_NOREF
     return launch_status("warp_noref_fwd");
 }
 

@@ -125,56 +125,56 @@ def _conv_wgrad(x, dy, w_shape, transposed, stride):
 
 class ConvBnReluFn(torch.autograd.Function):
     """z = [relu](batchnorm_train(conv(x, w))) [+ residual], channels-last.  `cfg` = dict(transposed, stride, relu,
-    eps, group): group = a process group for SyncBatchNorm statistics, or None.  Also returns the batch mean and the
-    biased batch variance (non-differentiable) for the caller's running-statistics update."""
+    eps, momentum, group): group = a process group for SyncBatchNorm statistics, or None.  `running_mean` /
+    `running_var` (may be None) receive nn.BatchNorm's momentum update inside the same kernel that folds the statistics."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, residual, cfg):
+    def forward(ctx, x, w, gamma, beta, residual, running_mean, running_var, cfg):
         x = x.contiguous()
+        lib = _lib.load()
         y = _conv_raw(x, w.detach(), cfg["transposed"], cfg["stride"])
         C = y.shape[-1]
-        sums = torch.zeros(2 * C, device=x.device, dtype=torch.float64)
-        bn_stats(y, sums)
-        n = torch.tensor(float(y.numel() // C), device=x.device, dtype=torch.float64)
-        group = cfg.get("group")
-        if group is not None:
-            pack = torch.cat((sums, n.view(1)))
-            dist.all_reduce(pack, group=group)
-            sums, n = pack[:-1], pack[-1]
-        mean64 = sums[:C] / n
-        var64 = (sums[C:] / n - mean64 * mean64).clamp_(min=0.0)
-        invstd = torch.rsqrt(var64 + cfg["eps"]).float()
-        mean = mean64.float()
-        scale = (gamma.detach().float() * invstd).contiguous()
-        shift = (beta.detach().float() - mean * scale).contiguous()
+        pack = torch.zeros(2 * C + 1, device=x.device, dtype=torch.float64)      # [sum (C) | sum of squares (C) | count]
+        pack[-1] = float(y.numel() // C)
+        bn_stats(y, pack)
+        if cfg.get("group") is not None:
+            dist.all_reduce(pack, group=cfg["group"])
+        stats = torch.empty((5, C), device=x.device, dtype=torch.float32)        # mean, var, invstd, scale, shift
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(lib.rcmvs_bn_finalize(ptr(pack), ptr(pack[2 * C:]), _chk(g32, "gamma"), _chk(b32, "beta"), float(cfg["eps"]),
+                                         float(cfg.get("momentum", 0.0)), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+                                         ptr(stats[4]), _opt(running_mean, "running_mean"), _opt(running_var, "running_var"), C,
+                                         _stream()), "bn_finalize")
+        mean, invstd, scale, shift = stats[0], stats[2], stats[3], stats[4]
         res = None if residual is None else residual.contiguous()
         z = scale_shift_relu(y, scale, shift, res, cfg["relu"])
-        ctx.save_for_backward(x, w, y, scale, shift, mean, invstd)
+        ctx.save_for_backward(x, w, y, stats, pack)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
-        ctx.n_total = n
-        var = var64.float()
-        ctx.mark_non_differentiable(mean, var, n)
-        return z, mean, var, n
+        return z
 
     @staticmethod
-    def backward(ctx, dz, _gm, _gv, _gn):
-        x, w, y, scale, shift, mean, invstd = ctx.saved_tensors
+    def backward(ctx, dz):
+        x, w, y, stats, pack = ctx.saved_tensors
+        mean, invstd, scale, shift = stats[0], stats[2], stats[3], stats[4]
         cfg = ctx.cfg
         C = y.shape[-1]
         dz = dz.contiguous()
         sums = torch.zeros(2 * C, device=y.device, dtype=torch.float64)
         bn_bwd_reduce(y, dz, scale, shift, mean, invstd, sums, cfg["relu"])
-        dbeta, dgamma = sums[:C].float(), sums[C:].float()          # this replica's parameter gradients
         tot = sums
         if cfg.get("group") is not None:
             tot = sums.clone()
             dist.all_reduce(tot, group=cfg["group"])
-        coef = (tot / ctx.n_total).float().contiguous()
-        dy = bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, cfg["relu"])
+        out = torch.empty((4, C), device=y.device, dtype=torch.float32)           # dgamma, dbeta, coef (2C)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(_lib.load().rcmvs_bn_bwd_finalize(ptr(sums), ptr(tot), ptr(pack[2 * C:]), ptr(out[0]), ptr(out[1]), ptr(out[2]), C,
+                                                     _stream()), "bn_bwd_finalize")
+        dy = bn_bwd_apply(y, dz, scale, shift, mean, invstd, out[2:].reshape(-1), cfg["relu"])
         dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"], x.shape[-1]) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad(x, dy, w.shape, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[1] else None
-        return dx, dw, dgamma, dbeta, (dz if ctx.has_res else None), None
+        return dx, dw, out[0], out[1], (dz if ctx.has_res else None), None, None, None
 
 
 def conv_bn_relu_train(block, x, residual=None):
@@ -190,16 +190,17 @@ def conv_bn_train(conv, bn, x, relu, residual=None):
     group = None
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    cfg = {"transposed": transposed, "stride": stride, "relu": bool(relu), "eps": bn.eps, "group": group}
-    z, mean, var, n = ConvBnReluFn.apply(x, conv.weight, bn.weight, bn.bias, residual, cfg)
-    if bn.track_running_stats and bn.running_mean is not None:
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.0
+    if track:
         with torch.no_grad():
             bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            unbiased = var * (n / (n - 1.0)).float()
-            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1.0 - mom).add_(unbiased, alpha=mom)
-    return z
+        # momentum=None means a cumulative average; that needs the step count on the host (one sync) -- the reference
+        # always sets a momentum (modules.py:146, bn_momentum=0.1), so this branch is cold
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    cfg = {"transposed": transposed, "stride": stride, "relu": bool(relu), "eps": bn.eps, "momentum": mom, "group": group}
+    return ConvBnReluFn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn.running_mean if track else None,
+                              bn.running_var if track else None, cfg)
 
 
 # --------------------------------------------------------------------------------------- plane resize (renderer)

@@ -77,13 +77,15 @@ def test_conv_bn_relu_block_forward_backward(ci, co, stride, transposed, relu, w
     xg = cl(x).requires_grad_(True)
     wg, gg, bg = (t.to(dev).requires_grad_(True) for t in (w, gamma, beta))
     rg = cl(res).requires_grad_(True) if with_res else None
-    cfg = {"transposed": transposed, "stride": stride, "relu": relu, "eps": 1e-5, "group": None}
-    z, mean, var, n = train_ops.ConvBnReluFn.apply(xg, wg, gg, bg, rg, cfg)
+    cfg = {"transposed": transposed, "stride": stride, "relu": relu, "eps": 1e-5, "momentum": 0.1, "group": None}
+    rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+    z = train_ops.ConvBnReluFn.apply(xg, wg, gg, bg, rg, rm, rv, cfg)
     (z * cl(G)).sum().backward()
     yr_d = yr.detach()
     assert _rel(z.detach().cpu().permute(0, 4, 1, 2, 3), zr.detach()) < 2e-5
-    assert _rel(mean.cpu(), yr_d.mean(dim=(0, 2, 3, 4))) < 2e-5 or float(mean.abs().max()) < 1e-3
-    assert _rel(var.cpu(), yr_d.var(dim=(0, 2, 3, 4), unbiased=False)) < 2e-5
+    # running statistics: nn.BatchNorm's momentum update (unbiased variance)
+    assert float((rm.cpu() - 0.1 * yr_d.mean(dim=(0, 2, 3, 4))).abs().max()) < 1e-5
+    assert _rel(rv.cpu(), 0.9 + 0.1 * yr_d.var(dim=(0, 2, 3, 4), unbiased=True)) < 2e-5
     errs = {"dx": _rel(xg.grad.cpu().permute(0, 4, 1, 2, 3), xr.grad), "dw": _rel(wg.grad.cpu(), wr.grad),
             "dgamma": _rel(gg.grad.cpu(), gr.grad), "dbeta": _rel(bg.grad.cpu(), br.grad)}
     if with_res:
