@@ -218,6 +218,14 @@ int rcmvs_nerf_mlp_fwd(const float* ndc, float* feat, int ldf, const float* dirs
  * of (1-alpha+1e-10), w = alpha*T;  rgb (N,3), depth (N), weights (N,S), alpha (N,S). */
 int rcmvs_composite_fwd(const float* raw, const float* z, float* rgb, float* depth,
                         float* weights, float* alpha, int N, int S, void* stream);
+/* backward of rcmvs_composite_fwd: gradients of rgb (N,3), depth (N), weights (N,S), alpha (N,S) (any may be NULL)
+ * -> grad_raw (N,S,4) = d/d [rgb, sigma]  (autograd of renderer.py:18-26,65-93; division-free reverse recurrence). */
+int rcmvs_composite_bwd(const float* raw, const float* z, const float* grad_rgb, const float* grad_depth,
+                        const float* grad_weights, const float* grad_alpha, float* grad_raw, int N, int S, void* stream);
+/* backward of rcmvs_point_feats_fwd w.r.t. the neural volume: grad_feat (M, ldg) (first 8 columns used) scattered to
+ * grad_volume (Dv,hv,wv,8), which the caller zero-fills (fp32 atomics).  Images / coordinates carry no gradient. */
+int rcmvs_point_feats_bwd(const float* ndc, const float* grad_feat, float* grad_volume,
+                          int M, int Dv, int hv, int wv, int ldg, void* stream);
 
 #ifdef __cplusplus
 }

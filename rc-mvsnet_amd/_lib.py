@@ -29,6 +29,8 @@ SIGNATURES = {
     "rcmvs_debug_k1_variant": [_i],
     "rcmvs_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_resize_planes_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_composite_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "rcmvs_point_feats_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rcmvs_bn_stats": [_p, _p, _ll, _i, _p],
     "rcmvs_bn_finalize": [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "rcmvs_bn_bwd_finalize": [_p, _p, _p, _p, _p, _p, _i, _p],

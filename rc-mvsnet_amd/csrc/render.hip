@@ -314,6 +314,77 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the rendering tail (what autograd records for renderer.py:18-26,65-93 and for the trilinear
+// grid_sample of render_utils.py:304-330).
+// composite_bwd: one thread per ray, two serial passes over its S samples.  With t_j = 1 - alpha_j + 1e-10,
+//   T_i = prod_{j<i} t_j, w_i = alpha_i T_i and G_i = g_w_i + g_rgb . c_i + g_depth z_i:
+//   d/d c_i = w_i g_rgb,   d/d alpha_i = g_alpha_i + T_i (G_i - Q_i),   Q_i = G_{i+1} alpha_{i+1} + t_{i+1} Q_{i+1}
+//   (division-free reverse recurrence: no 1/t blow-up where alpha -> 1),   d/d sigma_i = (1 - alpha_i) d/d alpha_i.
+// T_i of the forward pass is parked in graw[...,3] between the passes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                           const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                                           const float* __restrict__ g_w, const float* __restrict__ g_alpha,
+                                                           float* __restrict__ graw, int N, int S) {
+    const int ray = blockIdx.x * 64 + threadIdx.x;
+    if (ray >= N) return;
+    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[ray] : 0.f;
+    const long long base = (long long)ray * S;
+    float T = 1.0f;
+    for (int i = 0; i < S; ++i) {
+        const float a = 1.0f - expf(-raw[(base + i) * 4 + 3]);
+        graw[(base + i) * 4 + 3] = T;
+        T *= (1.0f - a + 1e-10f);
+    }
+    float Q = 0.0f;
+    for (int i = S - 1; i >= 0; --i) {
+        const long long o = base + i;
+        const float4 c = *reinterpret_cast<const float4*>(raw + o * 4);
+        const float a = 1.0f - expf(-c.w);
+        const float Ti = graw[o * 4 + 3];
+        const float wgt = a * Ti;
+        const float G = (g_w ? g_w[o] : 0.f) + (gr * c.x + gg * c.y + gb * c.z) + gd * z[o];
+        const float da = (g_alpha ? g_alpha[o] : 0.f) + Ti * (G - Q);
+        *reinterpret_cast<float4*>(graw + o * 4) = make_float4(wgt * gr, wgt * gg, wgt * gb, (1.0f - a) * da);
+        Q = G * a + (1.0f - a + 1e-10f) * Q;
+    }
+}
+
+// point_feats_bwd: gradient of the 8 volume channels of every point, scattered to the 8 trilinear corners with the
+// forward's weights (hardware fp32 atomics into the zero-filled volume gradient).  The image taps, the mask and the
+// point coordinates carry no gradient (inputs / no_grad in the reference).
+__global__ __launch_bounds__(256) void point_feats_bwd_kernel(const float* __restrict__ ndc, const float* __restrict__ gfeat,
+                                                              float* __restrict__ gvol, int M, int Dv, int hv, int wv, int ldg) {
+#pragma clang fp contract(off)
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float gx = ndc[m * 3 + 0] * 2.0f - 1.0f, gy = ndc[m * 3 + 1] * 2.0f - 1.0f, gz = ndc[m * 3 + 2] * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(wv - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(hv - 1);
+    const float iz = ((gz + 1.0f) / 2.0f) * (float)(Dv - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+    float g[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g[c] = gfeat[(long long)m * ldg + c];
+    for (int dz = 0; dz < 2; ++dz)
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const float xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+                const float wx = dx ? (ix - x0) : ((x0 + 1.0f) - ix);
+                const float wy = dy ? (iy - y0) : ((y0 + 1.0f) - iy);
+                const float wz = dz ? (iz - z0) : ((z0 + 1.0f) - iz);
+                const bool ok = (xx >= 0.0f) && (xx <= (float)(wv - 1)) && (yy >= 0.0f) && (yy <= (float)(hv - 1)) &&
+                                (zz >= 0.0f) && (zz <= (float)(Dv - 1));
+                if (!ok) continue;
+                const float wgt = (wx * wy) * wz;
+                float* vp = gvol + (((long long)(int)zz * hv + (int)yy) * wv + (int)xx) * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) unsafeAtomicAdd(vp + c, g[c] * wgt);
+            }
+}
+
 }  // namespace rcmvs
 
 using namespace rcmvs;
@@ -361,6 +432,24 @@ int rcmvs_point_feats_fwd(const float* volume, const float* imgs, const float* p
     hipLaunchKernelGGL(point_feats_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), volume, imgs, poses, pts,
                        ndc, feat, M, Dv, hv, wv, nimg, H, W, ldf);
     return launch_status("point_feats_fwd");
+}
+
+int rcmvs_point_feats_bwd(const float* ndc, const float* grad_feat, float* grad_volume,
+                          int M, int Dv, int hv, int wv, int ldg, void* stream) {
+    RCMVS_REQUIRE(ndc && grad_feat && grad_volume, "point_feats_bwd: null pointer");
+    RCMVS_REQUIRE(M > 0 && Dv > 0 && hv > 0 && wv > 0 && ldg >= 8, "point_feats_bwd: bad sizes");
+    hipLaunchKernelGGL(point_feats_bwd_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), ndc, grad_feat, grad_volume,
+                       M, Dv, hv, wv, ldg);
+    return launch_status("point_feats_bwd");
+}
+
+int rcmvs_composite_bwd(const float* raw, const float* z, const float* grad_rgb, const float* grad_depth,
+                        const float* grad_weights, const float* grad_alpha, float* grad_raw, int N, int S, void* stream) {
+    RCMVS_REQUIRE(raw && z && grad_raw, "composite_bwd: null pointer");
+    RCMVS_REQUIRE(N > 0 && S > 0, "composite_bwd: bad sizes");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), raw, z, grad_rgb, grad_depth,
+                       grad_weights, grad_alpha, grad_raw, N, S);
+    return launch_status("composite_bwd");
 }
 
 int rcmvs_composite_fwd(const float* raw, const float* z, float* rgb, float* depth,

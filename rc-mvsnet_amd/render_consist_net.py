@@ -137,15 +137,24 @@ class Neural_Volume_Net(nn.Module):
         x = ops.resize_planes(volume_feature.contiguous().float(), 128, pad_channels_to=(C + 3) // 4 * 4)
         return self.cost_reg_2.forward_cl(x)
 
+    def hip_trainable(self, volume_feature):
+        """Train mode on the GPU with 5-D-capable norm layers (the reference's BatchNorm2d default only works after
+        SyncBatchNorm conversion, train_rcmvsnet.py:525)."""
+        return _hip_training(self, volume_feature) and all(isinstance(m, (nn.BatchNorm3d, nn.SyncBatchNorm)) for m in self.modules()
+                                                           if isinstance(m, nn.modules.batchnorm._NormBase))
+
+    def forward_cl_train(self, volume_feature):
+        """Train-mode twin of ``forward_cl``: autograd through the HIP kernels (train_ops)."""
+        from .train_ops import ResizePlanesFn
+        C = volume_feature.shape[1]
+        x = ResizePlanesFn.apply(volume_feature, 128, (C + 3) // 4 * 4)
+        return self.cost_reg_2.forward_cl_train(x)
+
     def forward(self, volume_feature, pad=0):
         if _hip_inference(self, volume_feature):
             return ops.to_channels_first(self.forward_cl(volume_feature)).reshape(1, -1, 128, *volume_feature.shape[-2:])
-        if _hip_training(self, volume_feature) and all(isinstance(m, (nn.BatchNorm3d, nn.SyncBatchNorm))
-                                                       for m in self.modules() if isinstance(m, nn.modules.batchnorm._NormBase)):
-            from .train_ops import ResizePlanesFn
-            C = volume_feature.shape[1]
-            x = ResizePlanesFn.apply(volume_feature, 128, (C + 3) // 4 * 4)
-            v = self.cost_reg_2.forward_cl_train(x).permute(0, 4, 1, 2, 3)        # NCDHW view of the channels-last result
+        if self.hip_trainable(volume_feature):
+            v = self.forward_cl_train(volume_feature).permute(0, 4, 1, 2, 3)      # NCDHW view of the channels-last result
             return v.reshape(1, -1, *v.shape[2:])
         _note_delegation("Neural_Volume_Net")
         B, C, _, H, W = volume_feature.shape
@@ -271,8 +280,35 @@ class Rendering_Consistency_Net(nn.Module):
         pseudo = pseudo_depth.reshape(H, W).float()
         if _hip_inference(self, volume_feature_warp, pseudo):
             return self._forward_hip(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
+        if self.MVSNet.hip_trainable(volume_feature_warp) and pseudo.is_cuda:
+            return self._forward_train_hip(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
         _note_delegation("Rendering_Consistency_Net")
         return self._forward_aten(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
+
+    # ---- training path: HIP kernels with autograd, MLP GEMMs through hipBLASLt ----------------------------
+    def _forward_train_hip(self, vfw, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u):
+        """Same data flow as ``_forward_hip``.  Differentiable w.r.t. the warped volume feature and every parameter:
+        volume network (train_ops.ConvBnReluFn ...), point features (PointFeatsFn: trilinear scatter), compositing
+        (CompositeFn: reverse recurrence) run forward and backward on the library; the 11 plain GEMMs of the NeRF MLP
+        and their gradients go through PyTorch-ROCm (hipBLASLt).  Rays, samples and image taps carry no gradient."""
+        from .train_ops import CompositeFn, PointFeatsFn
+        _note_delegation("RenderNet MLP (training)")
+        vol = self.MVSNet.forward_cl_train(vfw)[0]                                 # (128,h,w,8)
+        with torch.no_grad():
+            cam = torch.cat((intr[0].reshape(-1), c2ws[0].reshape(-1), w2cs[0].reshape(-1), intr[0].reshape(-1), nf[0])).contiguous()
+            z, pts, ndc, dirs, rdepth, target = ops.gu_sample(pseudo.contiguous(), imgs[0, 0].contiguous(),
+                                                              pix.to(torch.int32).contiguous(), eps.contiguous(), u.contiguous(), cam)
+            imgs3 = imgs[0, -3:].contiguous()
+            poses = torch.cat((w2cs[:3].reshape(3, 16), intr[:3].reshape(3, 9)), dim=1).contiguous()
+            angle = (dirs / torch.norm(dirs, dim=-1, keepdim=True)) @ w2cs[0][:3, :3].t()
+        S = z.shape[1]
+        feat = PointFeatsFn.apply(vol, imgs3, poses, pts, ndc, 32)[:, :20].reshape(N_RAYS, S, 20)
+        x = torch.cat((_embed(ndc), feat, angle[:, None].expand(-1, S, -1)), dim=-1)
+        raw = self.network_fn(x.reshape(-1, x.shape[-1])).reshape(N_RAYS, S, 4)
+        rgb, depth, weights, alpha = CompositeFn.apply(raw, z)
+        if self.white_bkgd:
+            rgb = rgb + (1.0 - torch.sum(weights, -1)[..., None])
+        return rgb, feat, weights, depth, alpha, {}, rdepth, target
 
     # ---- native path ------------------------------------------------------------------------------
     def _forward_hip(self, vfw, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u):

@@ -223,6 +223,52 @@ class ResizePlanesFn(torch.autograd.Function):
         return gx, None, None
 
 
+# --------------------------------------------------------------------------------------- rendering tail
+class PointFeatsFn(torch.autograd.Function):
+    """ops.point_feats with the gradient w.r.t. the neural volume (trilinear scatter); images, poses and point
+    coordinates are data (render_utils.py:304-330 samples under the graph only through the volume)."""
+
+    @staticmethod
+    def forward(ctx, volume_cl, imgs, poses, pts, ndc, ldf):
+        volume_cl = volume_cl.contiguous()
+        ndc = ndc.contiguous()
+        ctx.save_for_backward(ndc)
+        ctx.vshape = tuple(volume_cl.shape)
+        return ops.point_feats(volume_cl, imgs, poses, pts, ndc, ldf=ldf)
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        (ndc,) = ctx.saved_tensors
+        Dv, hv, wv, _ = ctx.vshape
+        gfeat = gfeat.contiguous()
+        gvol = torch.zeros(ctx.vshape, device=gfeat.device, dtype=torch.float32)
+        _lib.check(_lib.load().rcmvs_point_feats_bwd(_chk(ndc, "ndc"), _chk(gfeat, "grad_feat"), _chk(gvol, "grad_volume"),
+                                                     gfeat.shape[0], Dv, hv, wv, gfeat.shape[1], _stream()), "point_feats_bwd")
+        return gvol, None, None, None, None, None
+
+
+class CompositeFn(torch.autograd.Function):
+    """ops.composite (renderer.py:18-26,65-93) with its backward w.r.t. raw = [rgb, sigma]; z is data."""
+
+    @staticmethod
+    def forward(ctx, raw, z):
+        raw, z = raw.contiguous(), z.contiguous()
+        ctx.save_for_backward(raw, z)
+        return ops.composite(raw, z)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_w, g_alpha):
+        raw, z = ctx.saved_tensors
+        N, S = z.shape
+        c = lambda t: None if t is None else t.contiguous()
+        g_rgb, g_depth, g_w, g_alpha = c(g_rgb), c(g_depth), c(g_w), c(g_alpha)
+        graw = torch.empty_like(raw)
+        _lib.check(_lib.load().rcmvs_composite_bwd(_chk(raw, "raw"), _chk(z, "z"), _opt(g_rgb, "g_rgb"), _opt(g_depth, "g_depth"),
+                                                   _opt(g_w, "g_w"), _opt(g_alpha, "g_alpha"), _chk(graw, "grad_raw"), N, S, _stream()),
+                   "composite_bwd")
+        return graw, None
+
+
 # --------------------------------------------------------------------------------------- depth head
 class ProbDepthHeadFn(torch.autograd.Function):
     """x8 (B,D,h,w,8), prob weight (1,8,3,3,3), planes (B,h,w,2) -> depth (B,h,w) [differentiable],
