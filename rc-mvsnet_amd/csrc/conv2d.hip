@@ -10,32 +10,41 @@
 
 namespace rcmvs {
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 constexpr int C2_CK = 8;                 // channels staged per pass
 constexpr int C2_STRIDE = C2_CK + 4;     // floats per staged pixel
 
-// TH x TW output tile (TH*TW == 256)
-template <int CI, int CO, int K, int S, int TH, int TW>
+// TH x TW threads (TH*TW == 256), PPT vertically stacked output pixels per thread (rows ly and ly + TH): with two
+// pixels every scalar weight feeds two FMAs, which halves the scalar-cache traffic that bounds the Cout = 32 layers.
+// The tap loops stay rolled (UKY / UKX = 1) where a fully unrolled body would need more weights than there are SGPRs:
+// the compiler otherwise hoists all K*K*CK*CO scalar loads and spills them through v_writelane/v_readlane (2560 spill
+// instructions against 288 packed FMAs in the 8 -> 8 layer: 95 -> 24 us once rolled).
+template <int CI, int CO, int K, int S, int TH, int TW, int PPT, int UKY, int UKX>
 __global__ __launch_bounds__(256) void conv2d_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ up, float* __restrict__ y,
     int H, int W, int Ho, int Wo, int tiles_w, int relu) {
-    static_assert(TH * TW == 256, "tile must have 256 pixels");
+    static_assert(TH * TW == 256, "tile must have 256 threads");
     constexpr int PAD = K / 2;
-    constexpr int HH = (TH - 1) * S + K, HW = (TW - 1) * S + K;     // halo tile
-    extern __shared__ __attribute__((aligned(16))) float tile[];    // [HH*HW][C2_STRIDE]
+    constexpr int HH = (TH * PPT - 1) * S + K, HW = (TW - 1) * S + K;     // halo tile
+    constexpr int CKW = (CI < C2_CK ? CI : C2_CK) * CO;                   // scalar weights per tap and channel chunk
+    // UKY / UKX: unroll counts of the two tap loops, chosen per layer from measurements (rcmvs_conv2d_fwd's table)
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [HH*HW][C2_STRIDE]
     const int n = blockIdx.y;
     const unsigned t2 = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = t2 % tiles_w, th = t2 / tiles_w;
-    const int oy0 = th * TH, ox0 = tw * TW;
+    const int oy0 = th * TH * PPT, ox0 = tw * TW;
     const int lx = threadIdx.x % TW, ly = threadIdx.x / TW;
-    const int oy = oy0 + ly, ox = ox0 + lx;
-    const bool inside = oy < Ho && ox < Wo;
+    const int ox = ox0 + lx;
     const float* xb = x + (long long)n * H * W * CI;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
 
-    float acc[CO];
+    float acc[PPT][CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+    for (int p = 0; p < PPT; ++p)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[p][c] = 0.0f;
 
     for (int c0 = 0; c0 < CI; c0 += C2_CK) {
         const int ck = (CI - c0 < C2_CK) ? (CI - c0) : C2_CK;       // multiple of 4
@@ -51,42 +60,77 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
             *reinterpret_cast<float4*>(tile + v * C2_STRIDE + c4 * 4) = val;
         }
         __syncthreads();
-        for (int ky = 0; ky < K; ++ky)
-#pragma unroll
+#pragma unroll UKY
+        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll UKX
             for (int kx = 0; kx < K; ++kx) {
-                const float* tp = tile + ((ly * S + ky) * HW + (lx * S + kx)) * C2_STRIDE;
                 const float* wt = wp + ((long long)(ky * K + kx) * CI + c0) * CO;
 #pragma unroll
                 for (int c4 = 0; c4 < C2_CK / 4; ++c4) {
                     if (c4 * 4 < ck) {
-                        const float4 xv = *reinterpret_cast<const float4*>(tp + c4 * 4);
+                        f4v xv[PPT];
 #pragma unroll
-                        for (int co = 0; co < CO; ++co) {
-                            acc[co] = fmaf(xv.x, wt[(c4 * 4 + 0) * CO + co], acc[co]);
-                            acc[co] = fmaf(xv.y, wt[(c4 * 4 + 1) * CO + co], acc[co]);
-                            acc[co] = fmaf(xv.z, wt[(c4 * 4 + 2) * CO + co], acc[co]);
-                            acc[co] = fmaf(xv.w, wt[(c4 * 4 + 3) * CO + co], acc[co]);
+                        for (int p = 0; p < PPT; ++p)
+                            xv[p] = *reinterpret_cast<const f4v*>(tile + (((ly + p * TH) * S + ky) * HW + (lx * S + kx)) * C2_STRIDE + c4 * 4);
+                        if constexpr (PPT > 1 || CO <= 8) {
+                            // weights consumed in memory order ([ci][co], co fastest): one s_load_dwordx16 = 16 output
+                            // channels of one input channel, used up before the next block is needed
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                for (int co = 0; co < CO; ++co) {
+                                    const float wv = wt[(c4 * 4 + j) * CO + co];
+#pragma unroll
+                                    for (int p = 0; p < PPT; ++p) acc[p][co] = fmaf(xv[p][j], wv, acc[p][co]);
+                                }
+                            }
+                        } else {
+                            // one pixel, wide Cout: four input channels per accumulator back to back (measured faster
+                            // for the 32 -> 32 / 32 -> 16 3x3 layers: 69 vs 118 us)
+#pragma unroll
+                            for (int co = 0; co < CO; ++co) {
+                                acc[0][co] = fmaf(xv[0].x, wt[(c4 * 4 + 0) * CO + co], acc[0][co]);
+                                acc[0][co] = fmaf(xv[0].y, wt[(c4 * 4 + 1) * CO + co], acc[0][co]);
+                                acc[0][co] = fmaf(xv[0].z, wt[(c4 * 4 + 2) * CO + co], acc[0][co]);
+                                acc[0][co] = fmaf(xv[0].w, wt[(c4 * 4 + 3) * CO + co], acc[0][co]);
+                            }
                         }
                     }
                 }
             }
-    }
-    if (!inside) return;
-    const long long op = ((long long)n * Ho + oy) * Wo + ox;
-    float* yp = y + op * CO;
-    const float* upp = up ? up + (((long long)n * (Ho / 2) + oy / 2) * (Wo / 2) + ox / 2) * CO : nullptr;
-#pragma unroll
-    for (int co = 0; co < CO; ++co) {
-        float v = acc[co];
-        if (scale) v = v * scale[co];
-        if (shift) v = v + shift[co];
-        if (upp) v = upp[co] + v;                                   // F.interpolate(intra) + inner(conv)
-        if (relu) v = fmaxf(v, 0.0f);
-        acc[co] = v;
+        }
     }
 #pragma unroll
-    for (int co = 0; co < CO; co += 4)
-        *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+    for (int p = 0; p < PPT; ++p) {
+        const int oy = oy0 + ly + p * TH;
+        if (!(oy < Ho && ox < Wo)) continue;
+        const long long op = ((long long)n * Ho + oy) * Wo + ox;
+        float* yp = y + op * CO;
+        const float* upp = up ? up + (((long long)n * (Ho / 2) + oy / 2) * (Wo / 2) + ox / 2) * CO : nullptr;
+        if (scale) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[p][co] = acc[p][co] * scale[co];
+        }
+        if (shift) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[p][co] = acc[p][co] + shift[co];
+        }
+        if (upp) {                                                      // F.interpolate(intra) + inner(conv)
+#pragma unroll
+            for (int co = 0; co < CO; co += 4) {
+                const f4v u4 = *reinterpret_cast<const f4v*>(upp + co);
+                acc[p][co] = u4.x + acc[p][co]; acc[p][co + 1] = u4.y + acc[p][co + 1];
+                acc[p][co + 2] = u4.z + acc[p][co + 2]; acc[p][co + 3] = u4.w + acc[p][co + 3];
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[p][co] = fmaxf(acc[p][co], 0.0f);
+        }
+#pragma unroll
+        for (int co = 0; co < CO; co += 4)
+            *reinterpret_cast<float4*>(yp + co) = make_float4(acc[p][co], acc[p][co + 1], acc[p][co + 2], acc[p][co + 3]);
+    }
 }
 
 // (Co,Ci,K,K) -> [K*K][Cip][Co], input channels zero-padded to Cip
@@ -106,15 +150,15 @@ __global__ __launch_bounds__(256) void rgb_to_nhwc4_kernel(const float* __restri
     *reinterpret_cast<float4*>(y + ((long long)n * HW + p) * 4) = make_float4(xb[p], xb[HW + p], xb[2 * HW + p], 0.0f);
 }
 
-template <int CI, int CO, int K, int S, int TH, int TW>
+template <int CI, int CO, int K, int S, int TH, int TW, int PPT, int UKY, int UKX>
 static int conv2d_launch_t(const float* x, const float* wp, const float* scale, const float* shift, const float* up, float* y,
                            int N, int H, int W, int relu, hipStream_t st) {
     constexpr int PAD = K / 2;
     const int Ho = (H + 2 * PAD - K) / S + 1, Wo = (W + 2 * PAD - K) / S + 1;
-    const int tiles_w = (Wo + TW - 1) / TW, tiles_h = (Ho + TH - 1) / TH;
-    constexpr int HH = (TH - 1) * S + K, HW = (TW - 1) * S + K;
+    const int tiles_w = (Wo + TW - 1) / TW, tiles_h = (Ho + TH * PPT - 1) / (TH * PPT);
+    constexpr int HH = (TH * PPT - 1) * S + K, HW = (TW - 1) * S + K;
     const size_t lds = (size_t)HH * HW * C2_STRIDE * sizeof(float);
-    hipLaunchKernelGGL((conv2d_lds_kernel<CI, CO, K, S, TH, TW>), dim3(tiles_w * tiles_h, N), dim3(256), lds, st, x, wp, scale,
+    hipLaunchKernelGGL((conv2d_lds_kernel<CI, CO, K, S, TH, TW, PPT, UKY, UKX>), dim3(tiles_w * tiles_h, N), dim3(256), lds, st, x, wp, scale,
                        shift, up, y, H, W, Ho, Wo, tiles_w, relu);
     return launch_status("conv2d");
 }
@@ -144,13 +188,17 @@ int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, 
     RCMVS_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
     RCMVS_REQUIRE(N > 0 && H > 0 && W > 0, "conv2d_fwd: bad sizes");
     hipStream_t st = as_stream(stream);
-#define RCMVS_C2(CI, CO, KK, SS, TH, TW)                                                                          \
+#define RCMVS_C2(CI, CO, KK, SS, TH, TW, PPT, UY, UX)                                                             \
     if (Ci == CI && Co == CO && K == KK && stride == SS)                                                          \
-        return conv2d_launch_t<CI, CO, KK, SS, TH, TW>(x, w_packed, scale, shift, up_add, y, N, H, W, relu, st);
-    // the 13 layers of FeatureNet(base_channels=8, fpn, 3 stages)
-    RCMVS_C2(4, 8, 3, 1, 16, 16) RCMVS_C2(8, 8, 3, 1, 16, 16) RCMVS_C2(8, 16, 5, 2, 8, 32) RCMVS_C2(16, 16, 3, 1, 16, 16)
-    RCMVS_C2(16, 32, 5, 2, 8, 32) RCMVS_C2(32, 32, 3, 1, 16, 16) RCMVS_C2(32, 32, 1, 1, 16, 16) RCMVS_C2(16, 32, 1, 1, 16, 16)
-    RCMVS_C2(32, 16, 3, 1, 16, 16) RCMVS_C2(8, 32, 1, 1, 16, 16) RCMVS_C2(32, 8, 3, 1, 16, 16)
+        return conv2d_launch_t<CI, CO, KK, SS, TH, TW, PPT, UY, UX>(x, w_packed, scale, shift, up_add, y, N, H, W, relu, st);
+    // the 13 layers of FeatureNet(base_channels=8, fpn, 3 stages): tile, pixels per thread and tap-loop unrolling per layer
+    // (us per 3-view scene at 512x640 in the comments, profiles/r1_run7_kernel_stats.csv)
+    RCMVS_C2(4, 8, 3, 1, 16, 16, 1, 1, 3)     /* conv0.0  18 */  RCMVS_C2(8, 8, 3, 1, 16, 16, 1, 1, 1)    /* conv0.1  24 */
+    RCMVS_C2(8, 16, 5, 2, 8, 32, 1, 1, 1)     /* conv1.0  45 */  RCMVS_C2(16, 16, 3, 1, 16, 16, 2, 1, 1)  /* conv1.1/2  2 x 30 */
+    RCMVS_C2(16, 32, 5, 2, 8, 32, 1, 5, 5)    /* conv2.0  98 */  RCMVS_C2(32, 32, 3, 1, 16, 16, 1, 3, 3)  /* conv2.1/2  2 x 76 */
+    RCMVS_C2(32, 32, 1, 1, 16, 16, 1, 1, 1)   /* out1     14 */  RCMVS_C2(16, 32, 1, 1, 16, 16, 2, 1, 1)  /* inner1   23 */
+    RCMVS_C2(32, 16, 3, 1, 16, 16, 1, 3, 3)   /* out2     47 */  RCMVS_C2(8, 32, 1, 1, 16, 16, 2, 1, 1)   /* inner2   59 */
+    RCMVS_C2(32, 8, 3, 1, 16, 16, 1, 1, 1)    /* out3     91 */
 #undef RCMVS_C2
     return fail(-1, "conv2d_fwd: unsupported layer Ci=%d Co=%d K=%d stride=%d", Ci, Co, K, stride);
 }
