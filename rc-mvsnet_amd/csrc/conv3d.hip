@@ -142,6 +142,11 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
 
 void conv3d_lds_set_config(int c);
 
+// deconv3d_lds.hip
+bool deconv3d_lds_supported(int Ci, int Co);
+int deconv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                        int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
+
 // packed weight blob = [27][Ci][Co] (direct kernels) followed by the MFMA image when the pair has one
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
 
@@ -202,6 +207,8 @@ int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
     RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
     ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
+    if (deconv3d_lds_supported(Ci, Co) && !g_force_direct)
+        return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
     if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !g_force_direct)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
                                   CONV_T2, relu, as_stream(stream));
