@@ -227,5 +227,45 @@ def main():
     save("nerf_mlp", x=x86, out=rn.network_fn(x86.reshape(-1, 86)).reshape(64, 16, 4))
 
 
+TRAIN_GRAD_KEYS = ("cost_regularization.0.conv0.conv.weight", "cost_regularization.0.conv0.bn.weight",
+                   "cost_regularization.0.conv0.bn.bias", "cost_regularization.0.conv3.conv.weight",
+                   "cost_regularization.0.conv6.conv.weight", "cost_regularization.0.conv7.conv.weight",
+                   "cost_regularization.0.conv11.bn.weight", "cost_regularization.0.prob.weight",
+                   "feature.conv0.0.conv.weight", "feature.conv2.2.conv.weight", "feature.out1.weight")
+
+
+def train_loss(outputs, noref):
+    """Stage-1-only smooth loss: independent of the (detached) depth hand-over to stages 2 and 3, so the gradients of
+    two implementations can be compared tightly."""
+    return ((outputs["stage1"]["depth"] - 600.0) ** 2).mean() / 1e4 + 1e-2 * (noref ** 2).mean()
+
+
+def train_grads():
+    """Gradients of the REFERENCE's CascadeMVSNet (train mode: batch-statistics BatchNorm everywhere, train-variant
+    DepthNet) through its own autograd: pins the backward kernels (K1 scatter, conv data/weight gradients, BatchNorm
+    backward, softmax/soft-argmin backward) to the reference rather than to a restatement."""
+    models = import_reference()
+    sd = synthetic.cascade_state_dict(0, prob_gain=2.0)
+    m = models.CascadeMVSNet(ndepths=[8, 8, 8], depth_interals_ratio=[4, 2, 1])
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 64, 96, 0)
+    outputs, noref = m(imgs, pm, dv)
+    loss = train_loss(outputs, noref)
+    loss.backward()
+    params = dict(m.named_parameters())
+    bufs = dict(m.named_buffers())
+    arrays = {"loss": loss.detach(), "depth1": outputs["stage1"]["depth"].detach(), "noref_mean_sq": (noref ** 2).mean().detach(),
+              "running_mean_conv0": bufs["cost_regularization.0.conv0.bn.running_mean"],
+              "running_var_conv0": bufs["cost_regularization.0.conv0.bn.running_var"]}
+    for k in TRAIN_GRAD_KEYS:
+        arrays["grad:" + k] = params[k].grad
+    save("train_grads", H=64, W=96, V=3, ndepths=(8, 8, 8), ratios=(4, 2, 1), prob_gain=2.0, **arrays)
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-train-grads" in sys.argv:
+        train_grads()
+    else:
+        main()
+        train_grads()
