@@ -297,7 +297,23 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
         __syncthreads();
         // ---------------- phase B
         if (!inside) continue;
-        if constexpr (!MULTI) {
+        if constexpr (!MULTI && NVT > 4) {
+            // many views (7-view Tanks&Temples setting): one tap set, all 4*NVT gathers of a plane in flight together
+            // (a second set would not fit the register file); the memory-level parallelism comes from the view count
+#pragma unroll
+            for (int k = 0; k < DKB; ++k) {
+                K1Fetch<NVT> f;
+                k1_issue<NVT, DKB, PIX>(f, lds_o, lds_w, rsrc, k, p, q4b);
+                v4f a = ref, a2 = ref * ref;
+#pragma unroll
+                for (int va = 0; va < NVT; ++va) {
+                    v4f val = blend4<FAST>(f.t[va][0], f.t[va][1], f.t[va][2], f.t[va][3], f.w[va]);
+                    a = a + val;
+                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
+                }
+                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
+            }
+        } else if constexpr (!MULTI) {
             K1Fetch<NVT> f0, f1;
             k1_issue<NVT, DKB, PIX>(f0, lds_o, lds_w, rsrc, 0, p, q4b);
 #pragma unroll
@@ -654,10 +670,11 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         // production kernel: variant 0 = exact arithmetic (default), 1 = FMA-contracted blend
         const bool fastm = g_k1_variant == 1;
         const int LPP = C / 4, PIX = 256 / LPP;
-        const int dkb = (C == 8) ? 4 : 8;
-        const size_t per_view = (size_t)32 * dkb * PIX;
         const int nsrc = V - 1;
-        const int nvt = (nsrc == 2 || nsrc == 4) ? nsrc : 0;
+        const int nvt = (nsrc == 2 || nsrc == 4 || nsrc == 6) ? nsrc : 0;
+        // 6 source views: half the plane chunk so that the tap table of all views still fits 48 KB of LDS
+        const int dkb = (nvt == 6) ? ((C == 8) ? 2 : (C == 16 ? 4 : 8)) : ((C == 8) ? 4 : 8);
+        const size_t per_view = (size_t)32 * dkb * PIX;
         int VC = nvt ? nvt : (int)((48 * 1024) / per_view);
         if (VC > nsrc) VC = nsrc;
         const size_t lds = per_view * VC;
@@ -668,6 +685,16 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
 #define RCMVS_K1TP(CC, DD, FF, NN) hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, FF, NN>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC)
 #define RCMVS_K1TP_N(CC, DD, FF) do { if (nvt == 2) RCMVS_K1TP(CC, DD, FF, 2); else if (nvt == 4) RCMVS_K1TP(CC, DD, FF, 4); else RCMVS_K1TP(CC, DD, FF, 0); } while (0)
 #define RCMVS_K1TP_F(CC, DD) do { if (fastm) RCMVS_K1TP_N(CC, DD, true); else RCMVS_K1TP_N(CC, DD, false); } while (0)
+#define RCMVS_K1TP_6(CC, DD) do { if (fastm) RCMVS_K1TP(CC, DD, true, 6); else RCMVS_K1TP(CC, DD, false, 6); } while (0)
+        if (nvt == 6) {
+            switch (C) {
+                case 8:  RCMVS_K1TP_6(8, 2); break;
+                case 16: RCMVS_K1TP_6(16, 4); break;
+                case 32: RCMVS_K1TP_6(32, 8); break;
+                default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+            }
+            return launch_status("warp_variance_fwd");
+        }
         switch (C) {
             case 8:  RCMVS_K1TP_F(8, 4); break;
             case 16: RCMVS_K1TP_F(16, 8); break;
