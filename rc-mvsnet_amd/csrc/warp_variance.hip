@@ -196,10 +196,10 @@ struct K1Fetch {
 
 template <int NV, int DKB, int PIX>
 __device__ __forceinline__ void k1_issue(K1Fetch<NV>& f, const v4i* lds_o, const v4f* lds_w, __amdgpu_buffer_rsrc_t rsrc,
-                                         int k, int p, int q4b) {
+                                         int k, int p, int q4b, int v0 = 0) {
 #pragma unroll
     for (int va = 0; va < NV; ++va) {
-        const int idx = (va * DKB + k) * PIX + p;
+        const int idx = ((v0 + va) * DKB + k) * PIX + p;
         const v4i o = lds_o[idx];
         f.w[va] = lds_w[idx];
         f.t[va][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
@@ -221,7 +221,7 @@ __device__ __forceinline__ void k1_store_variance(v4f a, v4f a2, float fV, float
     __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dst));
 }
 
-template <int C, int DKB, bool FAST, int NVT>
+template <int C, int DKB, bool FAST, int NVT, int NG = (NVT == 0 ? 1 : (NVT > 4 ? 3 : NVT))>
 __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
@@ -297,38 +297,30 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
         __syncthreads();
         // ---------------- phase B
         if (!inside) continue;
-        if constexpr (!MULTI && NVT > 4) {
-            // many views (7-view Tanks&Temples setting): one tap set, all 4*NVT gathers of a plane in flight together
-            // (a second set would not fit the register file); the memory-level parallelism comes from the view count
+        if constexpr (!MULTI) {
+            // double-buffered gathers over the flattened (plane, view group) sequence: the group after the current one
+            // (same plane or the next) is in flight while the current one is blended.  NG = views per group: all of them
+            // for 2 / 4 source views, 3 for the 7-view setting (two full tap sets of 6 views exceed the register file).
+            // Views are accumulated in ascending order whatever the grouping, so the result is bit-identical.
+            constexpr int NGRP = NVT / NG, NS = DKB * NGRP;
+            static_assert(NVT % NG == 0, "view groups must divide the view count");
+            K1Fetch<NG> f0, f1;
+            k1_issue<NG, DKB, PIX>(f0, lds_o, lds_w, rsrc, 0, p, q4b, 0);
+            v4f a = ref, a2 = ref * ref;
 #pragma unroll
-            for (int k = 0; k < DKB; ++k) {
-                K1Fetch<NVT> f;
-                k1_issue<NVT, DKB, PIX>(f, lds_o, lds_w, rsrc, k, p, q4b);
-                v4f a = ref, a2 = ref * ref;
+            for (int st = 0; st < NS; ++st) {
+                const int k = st / NGRP, gi = st % NGRP;
+                K1Fetch<NG>& cur = (st & 1) ? f1 : f0;
+                K1Fetch<NG>& nxt = (st & 1) ? f0 : f1;
+                if (st + 1 < NS) k1_issue<NG, DKB, PIX>(nxt, lds_o, lds_w, rsrc, (st + 1) / NGRP, p, q4b, ((st + 1) % NGRP) * NG);
+                if (gi == 0) { a = ref; a2 = ref * ref; }
 #pragma unroll
-                for (int va = 0; va < NVT; ++va) {
-                    v4f val = blend4<FAST>(f.t[va][0], f.t[va][1], f.t[va][2], f.t[va][3], f.w[va]);
-                    a = a + val;
-                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
-                }
-                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
-            }
-        } else if constexpr (!MULTI) {
-            K1Fetch<NVT> f0, f1;
-            k1_issue<NVT, DKB, PIX>(f0, lds_o, lds_w, rsrc, 0, p, q4b);
-#pragma unroll
-            for (int k = 0; k < DKB; ++k) {
-                K1Fetch<NVT>& cur = (k & 1) ? f1 : f0;
-                K1Fetch<NVT>& nxt = (k & 1) ? f0 : f1;
-                if (k + 1 < DKB) k1_issue<NVT, DKB, PIX>(nxt, lds_o, lds_w, rsrc, k + 1, p, q4b);
-                v4f a = ref, a2 = ref * ref;
-#pragma unroll
-                for (int va = 0; va < NVT; ++va) {
+                for (int va = 0; va < NG; ++va) {
                     v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], cur.w[va]);
                     a = a + val;
                     if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
                 }
-                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
+                if (gi == NGRP - 1 && k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
             }
         } else {
 #pragma unroll
