@@ -59,7 +59,11 @@ __global__ void pack_weight_mfma_kernel(const float* __restrict__ w, float* __re
     packed[t] = v;
 }
 
-template <int CIN, int COUT, int MODE, int NT>
+// KS = K-split: with KS = 4 the block's four waves share ONE (n-tile, m-tile) and take every fourth tap each, then add
+// their accumulators through LDS.  The deep U-Net levels have only a few hundred tiles (6x16x20 cells = 120 n-tiles): one
+// wave per tile leaves most SIMDs empty and every wave walks a 27-tap dependent chain of load -> MFMA; splitting the taps
+// gives 4x the waves and a 4x shorter chain (measured: the 64->64 level 49 -> 19 us, the stride-2 32->64 level 27 -> 13 us).
+template <int CIN, int COUT, int MODE, int NT, int KS = 1>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wm, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, MfmaDims dm, int relu) {
@@ -72,8 +76,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const int mt = blockIdx.y;
     const int pc = (MODE == MF_T2) ? blockIdx.z : 0;                 // output parity class (transposed only)
     const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
-    const long long tile0 = ((long long)blockIdx.x * 4 + wave) * NT;
-    if (tile0 * 16 >= dm.cells) return;
+    static_assert(KS == 1 || NT == 1, "K-split works on single-tile waves");
+    const long long tile0 = (KS == 1) ? ((long long)blockIdx.x * 4 + wave) * NT : (long long)blockIdx.x;
+    if (KS == 1 && tile0 * 16 >= dm.cells) return;
+    int tap_turn = 0;                                                  // K-split: taps are dealt round-robin to the waves
 
     // per n-tile cell coordinates of this lane
     int cb[NT], cd[NT], ch[NT], cw[NT];
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
             if (MODE == MF_T2 && ((ph + 1 - kh) & 1)) continue;
             for (int kw = 0; kw < 3; ++kw) {
                 if (MODE == MF_T2 && ((pw + 1 - kw) & 1)) continue;
+                if (KS > 1 && (tap_turn++ % KS) != wave) continue;      // wave-uniform
                 const int tap = (kd * 3 + kh) * 3 + kw;
                 long long off[NT];
                 bool ok[NT];
@@ -146,6 +153,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
         }
     }
 
+    if constexpr (KS > 1) {
+        __shared__ f32x4 red[KS][64];
+        red[wave][lane] = acc[0];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) acc[0] += red[k][lane];
+    }
     // epilogue: this lane owns output channels m0..m0+3 of cell n of every n-tile
     const int m0 = mt * 16 + kq * 4;
     if (m0 >= COUT) return;
@@ -183,11 +198,15 @@ static int mfma_dispatch(const float* x, const float* wm, const float* scale, co
     // few tiles (deep U-Net levels): one n-tile per wave so that every SIMD gets work
     const bool small = ntiles < 4096;
     const int nt = small ? 1 : 4;
-    dim3 grid((unsigned)cdiv(ntiles, 4LL * nt), (Co + 15) / 16, MODE == MF_T2 ? 8 : 1), block(256);
+    // small launches: one (n-tile, m-tile) per BLOCK, taps split over its four waves (transposed convs keep one wave per
+    // tile: a parity class has 1-8 taps, too few to split)
+    const bool ksplit = small && MODE != MF_T2;
+    dim3 grid((unsigned)(ksplit ? ntiles : cdiv(ntiles, 4LL * nt)), (Co + 15) / 16, MODE == MF_T2 ? 8 : 1), block(256);
 #define RCMVS_MFMA_CASE(CI, CO)                                                                                     \
     if (Ci == CI && Co == CO) {                                                                                     \
-        if (small) hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
-        else       hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
+        if (ksplit)     hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
+        else if (small) hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
+        else            hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
         return launch_status("conv3d_mfma");                                                                        \
     }
     RCMVS_MFMA_CASE(8, 16) RCMVS_MFMA_CASE(8, 32) RCMVS_MFMA_CASE(8, 48) RCMVS_MFMA_CASE(16, 16) RCMVS_MFMA_CASE(16, 32) RCMVS_MFMA_CASE(32, 32)
