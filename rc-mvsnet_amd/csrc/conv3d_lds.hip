@@ -49,6 +49,10 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
     float acc[COT];
 #pragma unroll
     for (int c = 0; c < COT; ++c) acc[c] = 0.0f;
+    // single output channel (prob conv): two partial sums over even / odd input channels, so that channel pairs go
+    // through v_pk_fma_f32 (x pair from the float4, weight pair from consecutive SGPRs) instead of 216 scalar FMAs
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v acc2 = (f2v){0.f, 0.f};
 
     for (int c0 = 0; c0 < CI; c0 += CK) {
         const int ck = (CI - c0 < CK) ? (CI - c0) : CK;            // channels in this chunk (multiple of 4)
@@ -76,6 +80,12 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
                     for (int c4 = 0; c4 < CK / 4; ++c4) {
                         if (c4 * 4 < ck) {
                             const float4 xv = *reinterpret_cast<const float4*>(tp + c4 * 4);
+                            if constexpr (CO == 1) {
+                                const f2v w01 = (f2v){wt[c4 * 4 + 0], wt[c4 * 4 + 1]}, w23 = (f2v){wt[c4 * 4 + 2], wt[c4 * 4 + 3]};
+                                acc2 = __builtin_elementwise_fma((f2v){xv.x, xv.y}, w01, acc2);
+                                acc2 = __builtin_elementwise_fma((f2v){xv.z, xv.w}, w23, acc2);
+                                continue;
+                            }
 #pragma unroll
                             for (int co = 0; co < COT; ++co) {
                                 acc[co] = fmaf(xv.x, wt[(c4 * 4 + 0) * CO + co], acc[co]);
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
                     }
                 }
     }
+    if constexpr (CO == 1) acc[0] = acc2.x + acc2.y;
     if (!inside) return;
     const long long ov = (((long long)b * D + od) * H + oh) * W + ow;
     float* yp = y + ov * CO + cob;
