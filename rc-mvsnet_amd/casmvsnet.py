@@ -99,7 +99,15 @@ class FeatureNet(nn.Module):
             names = ["conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv1.2", "conv2.0", "conv2.1", "conv2.2"]
             for n, m in zip(names, mods):
                 pad_to = 4 if m.conv.in_channels == 3 else None
-                plan[n] = (ops.pack_conv2d_weight(m.conv.weight, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
+                w = m.conv.weight
+                if w.shape[0] == 32 and w.shape[1] == 32 and w.shape[2] == 3 and m.stride == 1:
+                    # 32 -> 32 3x3: the scalar-weight VALU kernel runs at ~15 TF here; as a one-plane 3-D conv the layer goes
+                    # to the MFMA implicit-GEMM kernel (which skips the two out-of-range tap planes)
+                    w3 = w.detach().new_zeros(32, 32, 3, 3, 3)
+                    w3[:, :, 1] = w.detach()
+                    plan[n] = ("mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
+                    continue
+                plan[n] = (ops.pack_conv2d_weight(w, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
             if self.num_stage >= 2:
                 plan["inner1"] = (ops.pack_conv2d_weight(self.inner1.weight), self.inner1.bias.detach().float().contiguous())
@@ -119,6 +127,9 @@ class FeatureNet(nn.Module):
         p = self.hip_plan()
 
         def cbr(t, n):
+            if p[n][0] == "mfma3d":
+                _, w3, sc, sh = p[n]
+                return ops.conv3d(t.unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)
             w, sc, sh, stride = p[n]
             return ops.conv2d(t, w, sc, sh, stride=stride, relu=True)
 

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 
     for (int kd = 0; kd < 3; ++kd) {
         if (MODE == MF_T2 && ((pd + 1 - kd) & 1)) continue;          // wave-uniform: tap does not hit this parity
+        if (MODE == MF_S1 && dm.D == 1 && kd != 1) continue;         // single-plane volume = a 2-D 3x3 conv (FeatureNet 32->32)
         for (int kh = 0; kh < 3; ++kh) {
             if (MODE == MF_T2 && ((ph + 1 - kh) & 1)) continue;
             for (int kw = 0; kw < 3; ++kw) {
