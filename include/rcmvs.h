@@ -94,7 +94,8 @@ int rcmvs_warp_variance_bwd(const float* feats, const float* rot, const float* t
  * fragment-ordered image [27][Ci/(4*VEC)][Co/16][64 lanes][VEC] those kernels read. */
 long long rcmvs_packed_weight_floats(int Co, int Ci);   /* size of `packed` in floats ([27][Ci][Co] + MFMA image) */
 int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream);
-/* test/bench hook: bit0 = route every layer through the direct kernels; bits 1.. = LDS-conv tuning config */
+/* test/bench hook: bit0 = route every layer through the direct kernels; bits 1-3 = LDS-conv tuning config;
+ * bit4 (16) = prefer the MFMA kernel where both exist; bit5 (32) = one voxel per thread in the LDS kernel */
 void rcmvs_debug_force_direct_conv(int on);
 
 /* y = epilogue(conv3d(x, w, k=3, pad=1, stride)),  x (B,D,H,W,Ci) -> y (B,Do,Ho,Wo,Co),

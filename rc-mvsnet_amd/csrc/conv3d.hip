@@ -159,7 +159,7 @@ static int g_force_direct = 0;   // test/bench hook: route everything through th
 
 extern "C" {
 
-void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; g_prefer_lds = !(on & 16); conv3d_lds_set_config((on >> 1) & 7); }
+void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; g_prefer_lds = !(on & 16); conv3d_lds_set_config(((on >> 1) & 7) | (((on >> 5) & 1) << 3)); }
 
 long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;

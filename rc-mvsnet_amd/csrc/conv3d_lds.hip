@@ -22,19 +22,25 @@ constexpr int LH_VOX = LH_D * LH_H * LH_W;                         // 720
 // (threads [256*g, 256*g+256) own channels [g*CO/SPLIT, (g+1)*CO/SPLIT)), which multiplies the waves per
 // LDS byte -- the tile costs 34-58 KB, so at SPLIT = 1 only two 4-wave blocks fit a CU and every
 // s_waitcnt on the shared LDS/scalar-load counter is exposed.
-template <int CI, int CO, int SPLIT, int CKT>
+// PPT = output voxels per thread, stacked in depth (d and d + LT_D): every scalar weight then feeds PPT FMAs, which halves
+// the scalar-load traffic and the s_waitcnt stalls behind it (the Cin = 32 / 16 conv0 layers sit at 44-70 % VALU busy).
+template <int CI, int CO, int SPLIT, int CKT, int PPT = 1>
 __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     int D, int H, int W, int tiles_w, int tiles_h, int relu) {
     constexpr int CK = (CI < CKT) ? CI : CKT;                       // channel chunk staged at a time
     constexpr int STRIDE = CK + 4;                                  // floats per staged voxel (padding kills bank conflicts)
-    extern __shared__ __attribute__((aligned(16))) float tile[];    // [LH_VOX][STRIDE]
+    constexpr int TD = LT_D * PPT;                                  // output tile depth
+    constexpr int HD = TD + 2;                                      // halo depth
+    constexpr int HVOX = HD * LH_H * LH_W;
+    static_assert(PPT == 1 || CO > 1, "the single-channel path keeps one voxel per thread");
+    extern __shared__ __attribute__((aligned(16))) float tile[];    // [HVOX][STRIDE]
     const int b = blockIdx.z;
     const int td = blockIdx.y;
     const unsigned t2 = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = t2 % tiles_w, th = t2 / tiles_w;
-    const int d0 = td * LT_D, h0 = th * LT_H, w0 = tw * LT_W;
+    const int d0 = td * TD, h0 = th * LT_H, w0 = tw * LT_W;
     constexpr int NT = 256 * SPLIT;                                // threads per block
     constexpr int COT = CO / SPLIT;                                 // output channels per thread
     const int vox = threadIdx.x % 256;
@@ -43,12 +49,13 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
     const int cob = grp * COT;
     const int lw = vox % LT_W, lh = (vox / LT_W) % LT_H, ld = vox / (LT_W * LT_H);
     const int od = d0 + ld, oh = h0 + lh, ow = w0 + lw;
-    const bool inside = od < D && oh < H && ow < W;
     const float* xb = x + (long long)b * D * H * W * CI;
 
-    float acc[COT];
+    float acc[PPT][COT];
 #pragma unroll
-    for (int c = 0; c < COT; ++c) acc[c] = 0.0f;
+    for (int p = 0; p < PPT; ++p)
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[p][c] = 0.0f;
     // single output channel (prob conv): two partial sums over even / odd input channels, so that channel pairs go
     // through v_pk_fma_f32 (x pair from the float4, weight pair from consecutive SGPRs) instead of 216 scalar FMAs
     typedef float f2v __attribute__((ext_vector_type(2)));
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
         const int q = ck >> 2;                                      // float4 per voxel
         if (c0 > 0) __syncthreads();
         // ---- stage the halo tile of this channel chunk (zero outside the volume)
-        for (int e = threadIdx.x; e < LH_VOX * q; e += NT) {
+        for (int e = threadIdx.x; e < HVOX * q; e += NT) {
             const int v = e / q, c4 = e - v * q;
             const int hw_ = v % LH_W, hh = (v / LH_W) % LH_H, hd = v / (LH_W * LH_H);
             const int id = d0 + hd - 1, ih = h0 + hh - 1, iw = w0 + hw_ - 1;
@@ -79,44 +86,56 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
 #pragma unroll
                     for (int c4 = 0; c4 < CK / 4; ++c4) {
                         if (c4 * 4 < ck) {
-                            const float4 xv = *reinterpret_cast<const float4*>(tp + c4 * 4);
+                            float4 xv[PPT];
+#pragma unroll
+                            for (int p = 0; p < PPT; ++p)
+                                xv[p] = *reinterpret_cast<const float4*>(tp + p * (LT_D * LH_H * LH_W * STRIDE) + c4 * 4);
                             if constexpr (CO == 1) {
                                 const f2v w01 = (f2v){wt[c4 * 4 + 0], wt[c4 * 4 + 1]}, w23 = (f2v){wt[c4 * 4 + 2], wt[c4 * 4 + 3]};
-                                acc2 = __builtin_elementwise_fma((f2v){xv.x, xv.y}, w01, acc2);
-                                acc2 = __builtin_elementwise_fma((f2v){xv.z, xv.w}, w23, acc2);
+                                acc2 = __builtin_elementwise_fma((f2v){xv[0].x, xv[0].y}, w01, acc2);
+                                acc2 = __builtin_elementwise_fma((f2v){xv[0].z, xv[0].w}, w23, acc2);
                                 continue;
                             }
 #pragma unroll
                             for (int co = 0; co < COT; ++co) {
-                                acc[co] = fmaf(xv.x, wt[(c4 * 4 + 0) * CO + co], acc[co]);
-                                acc[co] = fmaf(xv.y, wt[(c4 * 4 + 1) * CO + co], acc[co]);
-                                acc[co] = fmaf(xv.z, wt[(c4 * 4 + 2) * CO + co], acc[co]);
-                                acc[co] = fmaf(xv.w, wt[(c4 * 4 + 3) * CO + co], acc[co]);
+                                const float w0 = wt[(c4 * 4 + 0) * CO + co], w1 = wt[(c4 * 4 + 1) * CO + co];
+                                const float w2 = wt[(c4 * 4 + 2) * CO + co], w3 = wt[(c4 * 4 + 3) * CO + co];
+#pragma unroll
+                                for (int p = 0; p < PPT; ++p) {
+                                    acc[p][co] = fmaf(xv[p].x, w0, acc[p][co]);
+                                    acc[p][co] = fmaf(xv[p].y, w1, acc[p][co]);
+                                    acc[p][co] = fmaf(xv[p].z, w2, acc[p][co]);
+                                    acc[p][co] = fmaf(xv[p].w, w3, acc[p][co]);
+                                }
                             }
                         }
                     }
                 }
     }
-    if constexpr (CO == 1) acc[0] = acc2.x + acc2.y;
-    if (!inside) return;
-    const long long ov = (((long long)b * D + od) * H + oh) * W + ow;
-    float* yp = y + ov * CO + cob;
-    const float* rp = res ? res + ov * CO + cob : nullptr;
+    if constexpr (CO == 1) acc[0][0] = acc2.x + acc2.y;
 #pragma unroll
-    for (int co = 0; co < COT; ++co) {
-        float v = acc[co];
-        if (scale) v = v * scale[cob + co] + shift[cob + co];
-        if (relu) v = fmaxf(v, 0.0f);
-        if (rp) v += rp[co];
-        acc[co] = v;
-    }
-    if constexpr (COT % 4 == 0) {
+    for (int p = 0; p < PPT; ++p) {
+        const int odp = od + p * LT_D;
+        if (!(odp < D && oh < H && ow < W)) continue;
+        const long long ov = (((long long)b * D + odp) * H + oh) * W + ow;
+        float* yp = y + ov * CO + cob;
+        const float* rp = res ? res + ov * CO + cob : nullptr;
 #pragma unroll
-        for (int co = 0; co < COT; co += 4)
-            *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
-    } else {
+        for (int co = 0; co < COT; ++co) {
+            float v = acc[p][co];
+            if (scale) v = v * scale[cob + co] + shift[cob + co];
+            if (relu) v = fmaxf(v, 0.0f);
+            if (rp) v += rp[co];
+            acc[p][co] = v;
+        }
+        if constexpr (COT % 4 == 0) {
 #pragma unroll
-        for (int co = 0; co < COT; ++co) yp[co] = acc[co];
+            for (int co = 0; co < COT; co += 4)
+                *reinterpret_cast<float4*>(yp + co) = make_float4(acc[p][co], acc[p][co + 1], acc[p][co + 2], acc[p][co + 3]);
+        } else {
+#pragma unroll
+            for (int co = 0; co < COT; ++co) yp[co] = acc[p][co];
+        }
     }
 }
 
@@ -130,15 +149,19 @@ void conv3d_lds_set_config(int c) { g_lds_cfg = c; }
 
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                       int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st) {
-    const int tiles_w = (W + LT_W - 1) / LT_W, tiles_h = (H + LT_H - 1) / LT_H, tiles_d = (D + LT_D - 1) / LT_D;
+    const int ppt = (Co == 8 && Ci >= 32 && !(g_lds_cfg & 8)) ? 2 : 1;   // two voxels per thread pay at Cin >= 32 (298 -> 250 us; 16 -> 8: 235 vs 243)
+    const int tiles_w = (W + LT_W - 1) / LT_W, tiles_h = (H + LT_H - 1) / LT_H, tiles_d = (D + LT_D * ppt - 1) / (LT_D * ppt);
     // tuned on MI355X (tools/conv_bench.py): 8-channel chunks keep the per-pass weight set (6.9 KB) in the scalar
     // cache; splitting Cout over two wave groups pays only when there are >= 4 chunk passes (Cin >= 32)
     const int ckt = (g_lds_cfg & 1) ? 16 : 8;
     const int split = (g_lds_cfg & 2) ? 2 : ((g_lds_cfg & 4) ? 1 : ((Ci >= 32 || Co >= 16) ? 2 : 1));
     dim3 grid(tiles_w * tiles_h, tiles_d, B), block(256 * split);
     const int ck = Ci < ckt ? Ci : ckt;
-    const size_t lds = (size_t)LH_VOX * (ck + 4) * sizeof(float);
-#define RCMVS_LDS_LAUNCH(CI, SP, CK) hipLaunchKernelGGL((conv3d_lds_kernel<CI, 8, SP, CK>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu)
+    const size_t lds = (size_t)(LT_D * ppt + 2) * LH_H * LH_W * (ck + 4) * sizeof(float);
+#define RCMVS_LDS_LAUNCH(CI, SP, CK) do { \
+        if (ppt == 2) { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv3d_lds_kernel<CI, 8, SP, CK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                        hipLaunchKernelGGL((conv3d_lds_kernel<CI, 8, SP, CK, 2>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu); } \
+        else hipLaunchKernelGGL((conv3d_lds_kernel<CI, 8, SP, CK>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu); } while (0)
 #define RCMVS_LDS_CASE(CI)                                                                  \
     if (Ci == CI) {                                                                         \
         if (split == 2) { if (ckt == 8) RCMVS_LDS_LAUNCH(CI, 2, 8); else RCMVS_LDS_LAUNCH(CI, 2, 16); } \
