@@ -580,3 +580,26 @@ def test_warp_variance_backward_vs_oracle_autograd(hip, C, V, D, h, w, with_nore
     err = rel_err(got, ref_grads)
     print(f"K1 bwd C={C} V={V}: rel err {err:.2e}")
     assert err < 2e-5
+
+
+def test_cascade_batch_two_equals_two_singles(hip):
+    """Batch handling end to end (eval-mode BN makes samples independent): a B = 2 forward must reproduce the two B = 1
+    forwards -- FeatureNet over B*V images, per-sample homographies / plane tables, batched volumes."""
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    m = CascadeMVSNet_eval(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1])
+    m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
+    m = m.to(DEV).eval()
+    a = synthetic.cascade_inputs(1, 3, 64, 96, 0)
+    b = synthetic.cascade_inputs(1, 3, 64, 96, 1)
+    imgs = gpu(torch.cat((a[0], b[0])))
+    pm = {k: gpu(torch.cat((a[1][k], b[1][k]))) for k in a[1]}
+    dv = gpu(torch.cat((a[2], b[2])))
+    with torch.no_grad():
+        o2 = m(imgs, pm, dv)
+        oa = m(gpu(a[0]), {k: gpu(v) for k, v in a[1].items()}, gpu(a[2]))
+        ob = m(gpu(b[0]), {k: gpu(v) for k, v in b[1].items()}, gpu(b[2]))
+    for key in ("depth", "photometric_confidence"):
+        assert o2[key].shape[0] == 2
+        assert float((o2[key][0] - oa[key][0]).abs().max()) < 1e-3, key
+        assert float((o2[key][1] - ob[key][0]).abs().max()) < 1e-3, key
