@@ -66,12 +66,31 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
             for (int jb = 0; jb < NJ; ++jb) acc[gi][ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const bool n_ok = NJ * m < CO;           // (m doubles as the B-side column index n = lane & 15)
+    // x is read through a buffer descriptor with 32-bit byte offsets: out-of-range taps get an offset beyond num_records and
+    // the hardware returns 0 -- no branches, no 64-bit address arithmetic in the inner loop (the first version spent ~10x
+    // more VALU cycles on addresses than the MFMAs took)
+    const long long xbytes = (long long)dm.B * dm.D * dm.H * dm.W * ldx * 4;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)xbytes, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    const int lane_off = (ci_off + cig * 4) * 4;
+    const int cell_bytes = ldx * 4;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const int oh = row % dm.Ho;
         const int od = (row / dm.Ho) % dm.Do;
         const int b = row / (dm.Ho * dm.Do);
         const float* dyrow = dy + ((((long long)b * dm.Do + od) * dm.Ho + oh) * dm.Wo) * CO + NJ * m;
-        const float* xb = x + (long long)b * dm.D * dm.H * dm.W * ldx + ci_off + cig * 4;
+        // per group: byte offset of (b, id, ih, iw = 0) for this lane's tap, or "row invalid"
+        int rbase[G];
+        unsigned rok = 0;                                       // bit gi: the tap's (d, h) row exists
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int t = tdx[gi];
+            const int id = od * STRIDE + ((t >> 4) & 3) - 1;
+            const int ih = oh * STRIDE + ((t >> 2) & 3) - 1;
+            const bool ok = (t & 64) && (unsigned)id < (unsigned)dm.D && (unsigned)ih < (unsigned)dm.H;
+            rbase[gi] = (((b * dm.D + id) * dm.H + ih) * dm.W + ((t & 3) - 1)) * cell_bytes + lane_off;
+            rok |= ok ? (1u << gi) : 0u;
+        }
         for (int w0 = 0; w0 < dm.Wo; w0 += 4) {
             const int ow = w0 + kq;
             const bool w_ok = ow < dm.Wo;                       // ragged last step: the cell contributes zero
@@ -87,21 +106,22 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
             } else {
                 bv[0] = (n_ok && w_ok) ? dyrow[(long long)ow * CO] : 0.0f;
             }
+            const int iw0 = ow * STRIDE;                         // input column of tap tw = 1 (the -1 is folded into rbase)
+            f32x4 av[G];
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) {
-                const int t = tdx[gi];
-                const int id = od * STRIDE + ((t >> 4) & 3) - 1;
-                const int ih = oh * STRIDE + ((t >> 2) & 3) - 1;
-                const int iw = ow * STRIDE + (t & 3) - 1;
-                const bool ok = (t & 64) && w_ok && (unsigned)id < (unsigned)dm.D && (unsigned)ih < (unsigned)dm.H && (unsigned)iw < (unsigned)dm.W;
-                f32x4 av = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok) av = *reinterpret_cast<const f32x4*>(xb + (((long long)id * dm.H + ih) * dm.W + iw) * ldx);
+                const int iw = iw0 + (tdx[gi] & 3) - 1;
+                const bool ok = w_ok && ((rok >> gi) & 1u) && (unsigned)iw < (unsigned)dm.W;
+                av[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? rbase[gi] + iw0 * cell_bytes : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
                 for (int jb = 0; jb < NJ; ++jb) {
-                    acc[gi][0][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[jb], acc[gi][0][jb], 0, 0, 0);
-                    acc[gi][1][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[jb], acc[gi][1][jb], 0, 0, 0);
-                    acc[gi][2][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[jb], acc[gi][2][jb], 0, 0, 0);
-                    acc[gi][3][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[jb], acc[gi][3][jb], 0, 0, 0);
+                    acc[gi][0][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi].x, bv[jb], acc[gi][0][jb], 0, 0, 0);
+                    acc[gi][1][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi].y, bv[jb], acc[gi][1][jb], 0, 0, 0);
+                    acc[gi][2][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi].z, bv[jb], acc[gi][2][jb], 0, 0, 0);
+                    acc[gi][3][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi].w, bv[jb], acc[gi][3][jb], 0, 0, 0);
                 }
             }
         }
@@ -240,6 +260,7 @@ int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D,
     RCMVS_REQUIRE(x && dy && dw, "conv3d_wgrad: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_wgrad: bad sizes");
     RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride must be 1 or 2");
+    RCMVS_REQUIRE((long long)B * D * H * W * Ci * 4 < 0x7ffffff0LL, "conv3d_wgrad: activation tensor too large for 32-bit offsets");
     WgradDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
     if (Ci == 8 && Co == 1 && stride == 1) {
