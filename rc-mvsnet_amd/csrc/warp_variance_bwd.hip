@@ -19,6 +19,12 @@
 // reference-view gradient is a register accumulation and a plain store; source-view gradients are
 // hardware fp32 atomic adds (global_atomic_add_f32) into a zero-initialised buffer -- unordered,
 // like PyTorch's grid_sample backward.
+//
+// Run-length merging (NM = compile-time source-view count, up to 4): the kernel is bound by atomic throughput (251 M
+// atomics for the 512x640x8 stage at 3 source views), and consecutive planes of one reference pixel hit overlapping 2x2
+// footprints (same footprint 35-40 %, one-column shift 50-70 %, profiles/r1_k1_tuning_notes.txt).  Each lane therefore
+// keeps the footprint of the previous plane pending in registers -- four byte offsets + four gradient quads per view --
+// adds into it while the footprint repeats, slides it on a column shift and only flushes the texels that drop out.
 #include "common.h"
 #include "k1_taps.h"
 
@@ -34,7 +40,11 @@ __device__ __forceinline__ void atomic_add4(float* p, v4f v) {
     unsafeAtomicAdd(p + 3, v.w);
 }
 
-template <int C>
+__device__ __forceinline__ void flush4(float* gb, int off, v4f g) {
+    if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) atomic_add4(gb + (off >> 2), g);
+}
+
+template <int C, int NM>
 __global__ __launch_bounds__(256) void warp_variance_bwd_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, const float* __restrict__ gvar, const float* __restrict__ gnr,
@@ -74,6 +84,16 @@ __global__ __launch_bounds__(256) void warp_variance_bwd_kernel(
     const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
 
     v4f gref = (v4f){0.f, 0.f, 0.f, 0.f};
+    // pending footprints (run-length merging), one per source view
+    constexpr int NMS = NM > 0 ? NM : 1;
+    v4i pend_o[NMS];
+    v4f pend_g[NMS][4];
+#pragma unroll
+    for (int va = 0; va < NMS; ++va) {
+        pend_o[va] = (v4i){-1, -1, -1, -1};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pend_g[va][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
     for (int k0 = 0; k0 < D; k0 += DKB) {
         if (k0 > 0) __syncthreads();
         // ---- phase A: tap table of every (pixel, plane, source view) of this chunk
@@ -133,16 +153,46 @@ __global__ __launch_bounds__(256) void warp_variance_bwd_kernel(
                 if (va >= nsrc) continue;
                 const v4f gw = (gv * (wv[va] - mean) + gn * (wv[va] - mnr)) * c2;
                 const int idx = (va * DKB + k) * PIX + p;
-                const v4i o = lds_o[idx];
+                v4i o = lds_o[idx];
                 const v4f wt = lds_w[idx];
-                if (wt.x != 0.0f) atomic_add4(gb + ((o.x + q4b) >> 2), gw * wt.x);
-                if (wt.y != 0.0f) atomic_add4(gb + ((o.y + q4b) >> 2), gw * wt.y);
-                if (wt.z != 0.0f) atomic_add4(gb + ((o.z + q4b) >> 2), gw * wt.z);
-                if (wt.w != 0.0f) atomic_add4(gb + ((o.w + q4b) >> 2), gw * wt.w);
+                o += q4b;                                        // this lane's channel quad
+                if constexpr (NM > 0) {
+                    if (va < NM) {
+                        const v4f c0 = gw * wt.x, c1 = gw * wt.y, c2_ = gw * wt.z, c3 = gw * wt.w;
+                        v4i& P = pend_o[va < NM ? va : 0];
+                        v4f (&G)[4] = pend_g[va < NM ? va : 0];
+                        if (o.x == P.x && o.y == P.y && o.z == P.z && o.w == P.w) {
+                            G[0] += c0; G[1] += c1; G[2] += c2_; G[3] += c3;
+                        } else if (o.x == P.y && o.z == P.w) {       // one column to the right: west slots drop out
+                            flush4(gb, P.x, G[0]); flush4(gb, P.z, G[2]);
+                            G[0] = G[1] + c0; G[2] = G[3] + c2_; G[1] = c1; G[3] = c3; P = o;
+                        } else if (o.y == P.x && o.w == P.z) {       // one column to the left: east slots drop out
+                            flush4(gb, P.y, G[1]); flush4(gb, P.w, G[3]);
+                            G[1] = G[0] + c1; G[3] = G[2] + c3; G[0] = c0; G[2] = c2_; P = o;
+                        } else {
+                            flush4(gb, P.x, G[0]); flush4(gb, P.y, G[1]); flush4(gb, P.z, G[2]); flush4(gb, P.w, G[3]);
+                            G[0] = c0; G[1] = c1; G[2] = c2_; G[3] = c3; P = o;
+                        }
+                    }
+                } else {
+                    if (wt.x != 0.0f) atomic_add4(gb + (o.x >> 2), gw * wt.x);
+                    if (wt.y != 0.0f) atomic_add4(gb + (o.y >> 2), gw * wt.y);
+                    if (wt.z != 0.0f) atomic_add4(gb + (o.z >> 2), gw * wt.z);
+                    if (wt.w != 0.0f) atomic_add4(gb + (o.w >> 2), gw * wt.w);
+                }
             }
         }
     }
-    if (inside) *reinterpret_cast<v4f*>(gb + ((long long)y * w + x) * C + (q4b >> 2)) = gref;
+    if (inside) {
+        if constexpr (NM > 0) {
+#pragma unroll
+            for (int va = 0; va < NM; ++va) {
+                flush4(gb, pend_o[va].x, pend_g[va][0]); flush4(gb, pend_o[va].y, pend_g[va][1]);
+                flush4(gb, pend_o[va].z, pend_g[va][2]); flush4(gb, pend_o[va].w, pend_g[va][3]);
+            }
+        }
+        *reinterpret_cast<v4f*>(gb + ((long long)y * w + x) * C + (q4b >> 2)) = gref;
+    }
 }
 
 }  // namespace rcmvs
@@ -162,14 +212,17 @@ extern "C" int rcmvs_warp_variance_bwd(const float* feats, const float* rot, con
     const size_t lds = (size_t)(V - 1) * BWD_DKB * PIX * 32;
     dim3 grid(tiles_x * tiles_y, B);
     hipStream_t st = as_stream(stream);
-#define RCMVS_K1B(CC) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_bwd_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((warp_variance_bwd_kernel<CC>), grid, dim3(256), lds, st, feats, rot, trans, planes, grad_var, grad_noref, grad_feats, V, D, h, w, tiles_x); } while (0)
+#define RCMVS_K1B(CC, NN) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_bwd_kernel<CC, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((warp_variance_bwd_kernel<CC, NN>), grid, dim3(256), lds, st, feats, rot, trans, planes, grad_var, grad_noref, grad_feats, V, D, h, w, tiles_x); } while (0)
+#define RCMVS_K1B_N(CC) do { switch (V - 1) { case 1: RCMVS_K1B(CC, 1); break; case 2: RCMVS_K1B(CC, 2); break; case 3: RCMVS_K1B(CC, 3); break; \
+                                          case 4: RCMVS_K1B(CC, 4); break; default: RCMVS_K1B(CC, 0); } } while (0)
     switch (C) {
-        case 8:  RCMVS_K1B(8); break;
-        case 16: RCMVS_K1B(16); break;
-        default: RCMVS_K1B(32); break;
+        case 8:  RCMVS_K1B_N(8); break;
+        case 16: RCMVS_K1B_N(16); break;
+        default: RCMVS_K1B_N(32); break;
     }
+#undef RCMVS_K1B_N
 #undef RCMVS_K1B
     return launch_status("warp_variance_bwd");
 }
