@@ -6,15 +6,18 @@ models/casmvsnet.py:126-231,313-417 and models/modules.py:28-210,363-501, so the
 ``train_rcmvsnet.py`` / ``eval_rcmvsnet_*.py`` run unchanged and its checkpoints load strict.
 
 Execution:
-  * inference (module in eval mode under ``torch.no_grad()``) runs the plane-sweep hot path on
-    the hand-written HIP kernels of librcmvs_hip.so: fused warp+variance (K1), 3-D conv family
-    with folded BatchNorm (K2/K3), fused prob-conv/softmax/regression/confidence (K4), all in
-    channels-last layout, no host synchronisation anywhere in forward();
-  * the 2-D feature pyramid is delegated to PyTorch-ROCm (MIOpen), as SURVEY.md section 2 row 6
-    scopes it;
-  * anything that needs autograd or batch statistics (training) currently goes through the
-    modules' own nn.Conv3d / BatchNorm3d children on PyTorch-ROCm -- an explicit, logged
-    delegation (set RCMVS_STRICT=1 to make it an error), never a CPU path.
+  * inference (module in eval mode under ``torch.no_grad()``, tensors on the GPU) runs entirely on the
+    hand-written HIP kernels of librcmvs_hip.so: 2-D feature pyramid (conv2d.hip), fused warp+variance
+    (K1), 3-D conv family with folded BatchNorm (K2/K3), prob-conv/softmax/regression/confidence (K4),
+    all in channels-last layout, no host synchronisation anywhere in forward();
+  * training (module in train mode on the GPU) runs the three cascade stages forward AND backward on
+    the library through autograd Functions (ops.WarpVarianceFn, train_ops.ConvBnReluFn /
+    ProbDepthHeadFn: batch-statistics BatchNorm, data / weight gradients, K1 scatter); the 2-D feature
+    pyramid is the part still delegated to PyTorch-ROCm there;
+  * everything else -- CPU tensors, eval mode with autograd on, RCMVS_TRAIN=aten -- runs the
+    reference's op graph through the modules' own nn.Conv / BatchNorm children on PyTorch: an
+    explicit, logged delegation (RCMVS_STRICT=1 makes it an error), never a silent fallback of the
+    GPU paths above.
 """
 import os
 import warnings
@@ -30,7 +33,7 @@ Align_Corners_Range = False
 
 
 # ----------------------------------------------------------------------------------------------
-# 2-D blocks (models/modules.py:28-116) -- delegated to PyTorch-ROCm
+# 2-D blocks (models/modules.py:28-116): parameter holders; HIP inference path in FeatureNet.forward_cl
 # ----------------------------------------------------------------------------------------------
 class Conv2d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
@@ -315,8 +318,8 @@ def _note_delegation(what):
                          "not provide yet (RCMVS_STRICT=1 forbids delegating it to PyTorch ops)")
     if what not in _delegation_noted:
         _delegation_noted.add(what)
-        warnings.warn(f"rc_mvsnet_amd: {what} is running through PyTorch-ROCm ops (autograd / training path); "
-                      "the hand-written HIP kernels cover inference (eval() under torch.no_grad()).")
+        warnings.warn(f"rc_mvsnet_amd: {what} is running through PyTorch ops (delegated path: CPU tensors, autograd in "
+                      "eval mode, RCMVS_TRAIN=aten, or a block the HIP training path does not cover yet).")
 
 
 def depth_regression(p, depth_values):

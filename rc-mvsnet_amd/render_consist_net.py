@@ -9,7 +9,10 @@ Same constructor (``args`` namespace; ``args.feat_dim`` is written like the refe
 
 Execution mirrors casmvsnet.py: eval() under no_grad runs on the HIP kernels (plane resize,
 neural-volume U-Net on the 3-D conv family without ReLU, Gaussian-Uniform sampler, point features,
-MFMA MLP, wave-scan compositing); calls that need autograd run the same op graph on PyTorch-ROCm.
+MFMA MLP, wave-scan compositing).  In train mode on the GPU the volume network, the point-feature
+gather / scatter and the compositing run forward and backward on the library through autograd
+Functions (train_ops.py); the plain GEMMs of the NeRF MLP go through PyTorch-ROCm (hipBLASLt).
+CPU tensors / RCMVS_TRAIN=aten run the reference's op graph on PyTorch (logged delegation).
 Random draws (pixel indices, Gaussian eps, stratified u) come from torch's generator on the device and
 are passed INTO the sampler kernel -- the RNG contract of SURVEY.md 8a-9; ``forward`` accepts them
 through the optional ``randoms=(pix, eps, u)`` argument so tests can inject the reference's draws.
