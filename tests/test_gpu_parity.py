@@ -603,3 +603,29 @@ def test_cascade_batch_two_equals_two_singles(hip):
         assert o2[key].shape[0] == 2
         assert float((o2[key][0] - oa[key][0]).abs().max()) < 1e-3, key
         assert float((o2[key][1] - ob[key][0]).abs().max()) < 1e-3, key
+
+
+def test_dtu_eval_shape(hip):
+    """The reference's DTU evaluation setting (eval_rcmvsnet_dtu.py:49-51: 5 views, 1600 x 1184, D = 48/32/8): compile-time
+    4-source-view K1 path, 0.7 GB stage-1 volume.  Properties only (no golden at this size)."""
+    import time
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    H, W, V = 1184, 1600, 5
+    m = CascadeMVSNet_eval()
+    m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
+    m = m.to(DEV).eval()
+    imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, 0)
+    gi, gp, gd = gpu(imgs), {k: gpu(v) for k, v in pm.items()}, gpu(dv)
+    with torch.no_grad():
+        out = m(gi, gp, gd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = m(gi, gp, gd)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"DTU-eval-shape forward: {dt * 1e3:.1f} ms")
+    assert out["depth"].shape == (1, H, W)
+    assert torch.isfinite(out["depth"]).all() and torch.isfinite(out["photometric_confidence"]).all()
+    c = out["photometric_confidence"]
+    assert float(c.min()) >= 0.0 and float(c.max()) <= 1.0 + 1e-5
