@@ -61,3 +61,20 @@ def test_state_dict_contract():
         m.load_state_dict(sd, strict=True)
         assert len(m.state_dict()) == 238
         assert set(m.state_dict().keys()) == set(sd.keys())
+
+
+def test_training_entry_points_validate_arguments(lib):
+    """The backward / training entry points reject bad arguments on the host with a message (no GPU needed)."""
+    one = ctypes.c_void_p(16)                      # any non-null pointer: validation happens before any launch
+    assert lib.rcmvs_warp_variance_bwd(None, None, None, None, None, None, None, 1, 3, 8, 4, 8, 8, None) < 0
+    assert b"null pointer" in lib.rcmvs_last_error_string()
+    assert lib.rcmvs_warp_variance_bwd(one, one, one, one, one, None, one, 1, 3, 12, 4, 8, 8, None) < 0
+    assert b"C must be" in lib.rcmvs_last_error_string()
+    assert lib.rcmvs_bn_stats(one, one, 10, 6, None) < 0
+    assert b"C=6" in lib.rcmvs_last_error_string()
+    assert lib.rcmvs_conv3d_wgrad(one, one, one, 1, 4, 8, 8, 12, 24, 1, None) < 0
+    assert b"unsupported" in lib.rcmvs_last_error_string()
+    assert lib.rcmvs_conv3d_wgrad(one, one, one, 1, 4, 8, 8, 8, 8, 3, None) < 0
+    assert b"stride" in lib.rcmvs_last_error_string()
+    assert lib.rcmvs_composite_bwd(None, None, None, None, None, None, None, 4, 4, None) < 0
+    assert lib.rcmvs_resize_planes_bwd(one, one, 1, 80, 80, 4, 8, 4, 4, None) < 0       # more channels than the kernel holds
