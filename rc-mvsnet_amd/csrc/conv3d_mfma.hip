@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    constexpr int MF_OOB = 0x7ffffff0;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0,
+                                                                    (int)((long long)dm.B * dm.D * dm.H * dm.W * CIN * 4), 0x00020000);
     const float* wbase = wm + ((long long)mt * 64 + lane) * VEC;
     constexpr long long W_TAP_STRIDE = (long long)CHUNKS * MTILES * 64 * VEC;
     constexpr long long W_CHUNK_STRIDE = (long long)MTILES * 64 * VEC;
@@ -111,16 +114,18 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
                 if (MODE == MF_T2 && ((pw + 1 - kw) & 1)) continue;
                 if (KS > 1 && (tap_turn++ % KS) != wave) continue;      // wave-uniform
                 const int tap = (kd * 3 + kh) * 3 + kw;
-                long long off[NT];
-                bool ok[NT];
+                // activation operand through the buffer descriptor: a 32-bit byte offset per n-tile, pushed past num_records
+                // for taps outside the volume so the bounds check returns 0 -- unconditional loads the scheduler can hoist
+                // across taps (the exec-masked global loads of the first version were scheduling barriers)
+                int off[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     int id, ih, iw;
                     if (MODE == MF_S1) { id = cd[t] + kd - 1; ih = ch[t] + kh - 1; iw = cw[t] + kw - 1; }
                     else if (MODE == MF_S2) { id = 2 * cd[t] + kd - 1; ih = 2 * ch[t] + kh - 1; iw = 2 * cw[t] + kw - 1; }
                     else { id = cd[t] + ((pd + 1 - kd) >> 1); ih = ch[t] + ((ph + 1 - kh) >> 1); iw = cw[t] + ((pw + 1 - kw) >> 1); }
-                    ok[t] = cv[t] && id >= 0 && id < dm.D && ih >= 0 && ih < dm.H && iw >= 0 && iw < dm.W;
-                    off[t] = ((((long long)cb[t] * dm.D + id) * dm.H + ih) * dm.W + iw) * CIN + kq * VEC;
+                    const bool ok = cv[t] && id >= 0 && id < dm.D && ih >= 0 && ih < dm.H && iw >= 0 && iw < dm.W;
+                    off[t] = ok ? ((((cb[t] * dm.D + id) * dm.H + ih) * dm.W + iw) * CIN + kq * VEC) * 4 : MF_OOB;
                 }
                 const float* wt = wbase + (long long)tap * W_TAP_STRIDE;
 #pragma unroll
@@ -137,10 +142,11 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         if (VEC == 4) {
-                            float4 b4 = ok[t] ? *reinterpret_cast<const float4*>(x + off[t] + c * 4 * VEC) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[t] + c * 4 * VEC * 4, 0, 0));
                             bv[t][0] = b4.x; bv[t][1] = b4.y; bv[t][2 % VEC] = b4.z; bv[t][3 % VEC] = b4.w;
                         } else {
-                            float2 b2 = ok[t] ? *reinterpret_cast<const float2*>(x + off[t] + c * 4 * VEC) : make_float2(0.f, 0.f);
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 b2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off[t] + c * 4 * VEC * 4, 0, 0));
                             bv[t][0] = b2.x; bv[t][1] = b2.y;
                         }
                     }
@@ -229,6 +235,7 @@ int conv3d_mfma_launch(const float* x, const float* wm, const float* scale, cons
         dm.Dg = dm.Do; dm.Hg = dm.Ho; dm.Wg = dm.Wo;
     }
     dm.cells = (long long)B * dm.Dg * dm.Hg * dm.Wg;
+    if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_mfma: input volume too large for 32-bit offsets");
     if (mode == MF_S1) return mfma_dispatch<MF_S1>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
     if (mode == MF_S2) return mfma_dispatch<MF_S2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
     return mfma_dispatch<MF_T2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
