@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
     constexpr int C4 = C * 4;               // bytes per texel
     extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [NV][DKB][PIX]
     v4f* lds_w = reinterpret_cast<v4f*>(lds_o + NV * DKB * PIX);         // [NV][DKB][PIX]
-    int* lds_box = reinterpret_cast<int*>(lds_w + NV * DKB * PIX);       // [NV][4] xmin xmax ymin ymax, then 16 B pad
-    char* lds_patch = reinterpret_cast<char*>(lds_box + 16);             // [NV][patch_texels * C4]
+    int* lds_box = reinterpret_cast<int*>(lds_w + NV * DKB * PIX);       // [4 waves][NV][4] xmin xmax ymin ymax
+    char* lds_patch = reinterpret_cast<char*>(lds_box + 16 * NV);        // [NV][patch_texels * C4]
     const int patch_bytes = patch_texels * C4;
     const unsigned patch_base = (unsigned)(lds_patch - reinterpret_cast<char*>(lds_o));
 
@@ -413,8 +413,6 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
     for (int v0 = 1; v0 < V; v0 += NV) {
         const int nv = min(NV, V - v0);
         if (v0 > 1) __syncthreads();                             // previous chunk's phase B is done with LDS
-        if (threadIdx.x < NV * 4) lds_box[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;
-        __syncthreads();
         // ---------------- phase A: taps -> packed clamped coordinates + weights, bounding box
         for (int va = 0; va < nv; ++va) {
             const float* r = rot + ((long long)b * (V - 1) + (v0 + va - 1)) * 9;
@@ -431,9 +429,10 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
                 const float d = pla.x + (float)(k0 + ka) * pla.y;
                 v4i o;
                 v4f wt;
-                k1_tap<1>(rx, ry, rz, t0, t1, t2, d, g, 0, o, wt);   // C = 1, vrow = 0: o = 4 * pixel index of each tap
-                const int i00 = o.x >> 2, i11 = o.w >> 2;
-                const int yc0 = i00 / w, xc0 = i00 - yc0 * w, yc1 = i11 / w, xc1 = i11 - yc1 * w;
+                int xi, yi;
+                k1_chain(rx, ry, rz, t0, t1, t2, d, g, xi, yi, wt);
+                const int xc0 = min(max(xi, 0), w - 1), xc1 = min(max(xi + 1, 0), w - 1);
+                const int yc0 = min(max(yi, 0), h - 1), yc1 = min(max(yi + 1, 0), h - 1);
                 const bool any = (wt.x != 0.0f) || (wt.y != 0.0f) || (wt.z != 0.0f) || (wt.w != 0.0f);
                 const int idx = (va * DKB + ka) * PIX + pa;
                 v4i rec;
@@ -441,20 +440,14 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
                 lds_o[idx] = rec;
                 lds_w[idx] = wt;
                 if (any) { bx0 = min(bx0, xc0); bx1 = max(bx1, xc1); by0 = min(by0, yc0); by1 = max(by1, yc1); }
+                (void)o;
             }
-            // wave-level reduction by hand (the compiler's atomic optimiser would emit a 64-iteration
-            // scalar readlane loop per atomic), then one LDS atomic per wave
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                bx0 = min(bx0, __shfl_xor(bx0, m)); bx1 = max(bx1, __shfl_xor(bx1, m));
-                by0 = min(by0, __shfl_xor(by0, m)); by1 = max(by1, __shfl_xor(by1, m));
-            }
-            if ((threadIdx.x & 63) == 0 && bx1 >= 0) {
-                __hip_atomic_fetch_min(&lds_box[va * 4 + 0], bx0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_max(&lds_box[va * 4 + 1], bx1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_min(&lds_box[va * 4 + 2], by0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_max(&lds_box[va * 4 + 3], by1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            // wave-level reduction in registers (DPP + readlane), one plain LDS store per wave: LDS atomics -- even from a
+            // single lane -- are expanded by the compiler into a 64-iteration scalar loop each (2.7 k SALU per wave, PMC)
+            bx0 = wave_reduce_i32<true>(bx0); bx1 = wave_reduce_i32<false>(bx1);
+            by0 = wave_reduce_i32<true>(by0); by1 = wave_reduce_i32<false>(by1);
+            if ((threadIdx.x & 63) == 0)
+                *reinterpret_cast<v4i*>(lds_box + ((threadIdx.x >> 6) * NV + va) * 4) = (v4i){bx0, bx1, by0, by1};
         }
         __syncthreads();
         // ---------------- phase A2: rewrite records to byte offsets (LDS window or global fallback)
@@ -462,9 +455,15 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
         int px0[NV], py0[NV], pw[NV], ph[NV];
 #pragma unroll
         for (int va = 0; va < NV; ++va) {
-            px0[va] = lds_box[va * 4 + 0]; py0[va] = lds_box[va * 4 + 2];
-            pw[va] = lds_box[va * 4 + 1] - px0[va] + 1; ph[va] = lds_box[va * 4 + 3] - py0[va] + 1;
-            const bool empty = lds_box[va * 4 + 1] < 0;
+            v4i bb = *reinterpret_cast<const v4i*>(lds_box + va * 4);
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) {
+                const v4i t = *reinterpret_cast<const v4i*>(lds_box + (wv * NV + va) * 4);
+                bb.x = min(bb.x, t.x); bb.y = max(bb.y, t.y); bb.z = min(bb.z, t.z); bb.w = max(bb.w, t.w);
+            }
+            px0[va] = bb.x; py0[va] = bb.z;
+            pw[va] = bb.y - bb.x + 1; ph[va] = bb.w - bb.z + 1;
+            const bool empty = bb.y < 0;
             if (empty) { px0[va] = 0; py0[va] = 0; pw[va] = 1; ph[va] = 1; }     // stage one (finite) texel
             fits[va] = (va < nv) && (pw[va] * ph[va] <= patch_texels);
         }
@@ -499,9 +498,12 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
             const int n4 = row4 * ph[va];
             const float* src = fb + ((long long)(v0 + va) * hw + (long long)py0[va] * w + px0[va]) * C;
             v4f* dst = reinterpret_cast<v4f*>(lds_patch + va * patch_bytes);
+            int row = threadIdx.x / row4, c4 = threadIdx.x - row * row4;   // one division per view, then incremental
+            const int drow = 256 / row4, dc4 = 256 - drow * row4;
             for (int e = threadIdx.x; e < n4; e += 256) {
-                const int row = e / row4, c4 = e - row * row4;
                 dst[e] = *reinterpret_cast<const v4f*>(src + (long long)row * w * C + c4 * 4);
+                c4 += dc4; row += drow;
+                if (c4 >= row4) { c4 -= row4; ++row; }
             }
         }
         __syncthreads();
@@ -639,7 +641,7 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         const int nvk = (V - 1) >= 2 ? 2 : 1;
         const int dkb = (C == 8) ? (deep ? 4 : 2) : (deep ? 8 : 4);
         const int ptex = (C == 32) ? (deep ? 192 : 128) : (C == 16 ? (deep ? 320 : 224) : (deep ? 512 : 384));
-        const size_t lds = (size_t)nvk * dkb * PIX * 32 + 64 + (size_t)nvk * ptex * C * 4;
+        const size_t lds = (size_t)nvk * dkb * PIX * 32 + 64 * nvk + (size_t)nvk * ptex * C * 4;
         RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
         const int TWl = PIX / 4;
