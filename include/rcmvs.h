@@ -89,7 +89,8 @@ int rcmvs_warp_variance_bwd(const float* feats, const float* rot, const float* t
 /* ---- K2/K3: 3-D convolution family, channels-last, fused epilogue ----------------------- */
 /* weight packing (host-visible layout change, done once per weight update):
  *   conv   w (Co,Ci,3,3,3) -> packed [27][Ci][Co]      (nn.Conv3d,          modules.py:145)
- *   deconv w (Ci,Co,3,3,3) -> packed [27][Ci][Co]      (nn.ConvTranspose3d, modules.py:189)
+ *   deconv w (Ci,Co,3,3,3) -> packed [27][Ci][Co]      (nn.ConvTranspose3d, modules.py:189); transposed == 2 also
+ *          flips the taps: the adjoint of a stride-1 nn.Conv3d with weight (Ci,Co,3,3,3) (data gradient)
  * followed, for channel pairs served by the MFMA kernels (Co a multiple of 16), by the
  * fragment-ordered image [27][Ci/(4*VEC)][Co/16][64 lanes][VEC] those kernels read. */
 long long rcmvs_packed_weight_floats(int Co, int Ci);   /* size of `packed` in floats ([27][Ci][Co] + MFMA image) */
@@ -139,10 +140,10 @@ int rcmvs_bn_bwd_reduce(const float* y, const float* dz, const float* scale, con
                         const float* invstd, double* sums, long long rows, int C, int relu, void* stream);
 int rcmvs_bn_bwd_apply(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,
                        const float* invstd, const float* coef, float* dy, long long rows, int C, int relu, void* stream);
-/* dw[27][Ci][Co] += sum_o x[stride*o + tap - 1][ci] * dy[o][co]   (dw zero-filled by the caller, fp32 atomics).
- *   x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) with Do = (D-1)/stride+1 ...  nn.Conv3d weight grad = dw permuted to
- *   (Co,Ci,27); for nn.ConvTranspose3d(Cin,Cout) call with x := grad of the (large) output, dy := the (small)
- *   input, stride 2: dw[27][Cout][Cin] -> permute to (Cin,Cout,27). */
+/* dw[co][ci][tap] += sum_o x[stride*o + tap - 1][ci] * dy[o][co]   (dw (Co,Ci,27) zero-filled by the caller, fp32 atomics).
+ *   x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) with Do = (D-1)/stride+1 ...  dw is nn.Conv3d's weight-gradient layout as is; for
+ *   nn.ConvTranspose3d(Cin,Cout) call with x := grad of the (large) output, dy := the (small) input, stride 2: the
+ *   result (Cin, Cout, 27) is that module's weight-gradient layout. */
 int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D, int H, int W, int Ci, int Co, int stride,
                        void* stream);
 /* data gradient of the 1-output-channel prob conv (modules.py:489): dy (B,D,H,W), w (1,Ci,3,3,3) as stored, dx (B,D,H,W,Ci) */

@@ -98,13 +98,14 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     }
 }
 
-// weight repack: conv (Co,Ci,27) / deconv (Ci,Co,27) -> [27][Ci][Co]
+// weight repack: conv (Co,Ci,27) / deconv (Ci,Co,27) -> [27][Ci][Co]; transposed == 2 additionally flips the taps
+// (the adjoint of a stride-1 conv: data gradient on the forward kernels)
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int transposed) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int n = 27 * Ci * Co;
     if (t >= n) return;
     int co = t % Co, ci = (t / Co) % Ci, tap = t / (Co * Ci);
-    long long src = transposed ? ((long long)ci * Co + co) * 27 + tap : ((long long)co * Ci + ci) * 27 + tap;
+    long long src = transposed ? ((long long)ci * Co + co) * 27 + (transposed == 2 ? 26 - tap : tap) : ((long long)co * Ci + ci) * 27 + tap;
     packed[t] = w[src];
 }
 

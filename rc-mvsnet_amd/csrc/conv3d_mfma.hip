@@ -55,7 +55,7 @@ __global__ void pack_weight_mfma_kernel(const float* __restrict__ w, float* __re
     int m = lane & 15, kq = lane >> 4;
     int co = mt * 16 + m, ci = chunk * 4 * vec + kq * vec + j;
     float v = 0.0f;
-    if (co < Co) v = transposed ? w[((long long)ci * Co + co) * 27 + tap] : w[((long long)co * Ci + ci) * 27 + tap];
+    if (co < Co) v = transposed ? w[((long long)ci * Co + co) * 27 + (transposed == 2 ? 26 - tap : tap)] : w[((long long)co * Ci + ci) * 27 + tap];
     packed[t] = v;
 }
 

@@ -14,7 +14,8 @@
 // A wave keeps up to 128 accumulator registers = G tap groups; the remaining groups go to grid.y.  A wave
 // walks whole output rows (b, od, oh) in steps of four cells, reading both operands straight through the
 // vector L1 (the 27 taps re-read the same lines, so L1/L2 absorb the 27x reuse), and flushes with hardware
-// fp32 atomics into the zero-filled [27][CI][CO] gradient (summation order is not deterministic).
+// fp32 atomics into the zero-filled gradient, laid out (CO, CI, 27) = nn.Conv3d's weight layout so that no permute pass
+// follows (summation order is not deterministic).
 #include "common.h"
 
 namespace rcmvs {
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 #pragma unroll
                 for (int jb = 0; jb < NJ; ++jb) {
                     const int co = co0 + jb;
-                    if (co < CO) unsafeAtomicAdd(dw + ((long long)tap * ci_total + ci_off + cq * 4 + ja) * CO + co, acc[gi][ja][jb][r]);
+                    if (co < CO) unsafeAtomicAdd(dw + ((long long)co * ci_total + ci_off + cq * 4 + ja) * 27 + tap, acc[gi][ja][jb][r]);
                 }
         }
     }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_c1_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = 4 * kq + r;               // row
-            if (ci < 8) unsafeAtomicAdd(dw + tap * 8 + ci, acc[t][r]);
+            if (ci < 8) unsafeAtomicAdd(dw + ci * 27 + tap, acc[t][r]);
         }
     }
 }

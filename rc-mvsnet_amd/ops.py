@@ -165,7 +165,8 @@ def force_direct_conv(on):
 
 
 def pack_conv3d_weight(w, transposed=False):
-    """conv (Co,Ci,3,3,3) / deconv (Ci,Co,3,3,3) -> PackedWeight (direct [27][Ci][Co] + MFMA image)."""
+    """conv (Co,Ci,3,3,3) / deconv (Ci,Co,3,3,3) -> PackedWeight (direct [27][Ci][Co] + MFMA image).
+    transposed=2: the adjoint of a stride-1 conv whose weight is (Ci,Co,3,3,3) (taps flipped as well)."""
     w = w.detach().contiguous().float()
     Ci, Co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     n = _lib.load().rcmvs_packed_weight_floats(Co, Ci)

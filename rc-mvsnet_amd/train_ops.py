@@ -52,13 +52,13 @@ def bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, relu):
 
 
 def conv3d_wgrad(x, dy, stride):
-    """x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) -> packed gradient (27,Ci,Co)."""
+    """x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) -> weight gradient (Co,Ci,27) (nn.Conv3d layout)."""
     B, D, H, W, Ci = x.shape
     Co = dy.shape[-1]
     exp = (B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
     if tuple(dy.shape[:4]) != exp:
         raise _lib.RcmvsError(f"conv3d_wgrad: dy {tuple(dy.shape)} does not match x {tuple(x.shape)} at stride {stride}")
-    dw = torch.zeros((27, Ci, Co), device=x.device, dtype=torch.float32)
+    dw = torch.zeros((Co, Ci, 27), device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().rcmvs_conv3d_wgrad(_chk(x, "x"), _chk(dy, "dy"), _chk(dw, "dw"), B, D, H, W, Ci, Co, stride, _stream()),
                "conv3d_wgrad")
     return dw
@@ -104,23 +104,23 @@ def _conv_dgrad(dy, w, transposed, stride, cx):
         return ops.conv3d(dy, ops.pack_conv3d_weight(w, transposed=False), stride=2)
     if stride == 2:                                  # adjoint of Conv3d(stride 2) = ConvTranspose3d(stride 2, output_padding 1)
         return ops.deconv3d(dy, ops.pack_conv3d_weight(w, transposed=True))
-    wd = w.transpose(0, 1).flip(2, 3, 4).contiguous()  # adjoint of Conv3d(stride 1, pad 1) = Conv3d with flipped, transposed taps
-    co = wd.shape[0]
+    # adjoint of Conv3d(stride 1, pad 1) = Conv3d with flipped taps and swapped channel roles: pack mode 2 does both
+    co = w.shape[1]                                  # output channels of the adjoint = input channels of the layer
     if co not in (1, 8) and co % 16:                 # e.g. 41 input channels: the MFMA kernels want a multiple of 16 outputs
-        cop = (co + 15) // 16 * 16
-        wd = torch.cat((wd, wd.new_zeros(cop - co, *wd.shape[1:])), dim=0)
-    dx = ops.conv3d(dy, ops.pack_conv3d_weight(wd, transposed=False), stride=1)
+        w = _pad_in_channels(w, (co + 15) // 16 * 16)
+    dx = ops.conv3d(dy, ops.pack_conv3d_weight(w, transposed=2), stride=1)
     if dx.shape[-1] != cx:                           # back to the (padded) channel count of x; padding channels get zero
         dx = dx[..., :cx].contiguous() if dx.shape[-1] > cx else torch.nn.functional.pad(dx, (0, cx - dx.shape[-1]))
     return dx
 
 
 def _conv_wgrad(x, dy, w_shape, transposed, stride):
-    if transposed:                                   # roles swap: the large tensor (dy) is strided over
-        dwp = conv3d_wgrad(dy, x, 2)                 # (27, Cout_T, Cin_T)
-        return dwp.permute(2, 1, 0).reshape(w_shape)
-    dwp = conv3d_wgrad(x, dy, stride)                # (27, Cx, Co), Cx >= Ci when the input carries padding channels
-    return dwp[:, :w_shape[1]].permute(2, 1, 0).reshape(w_shape)
+    if transposed:                                   # roles swap: the large tensor (dy) is strided over -> (Cin_T, Cout_T, 27)
+        return conv3d_wgrad(dy, x, 2).reshape(w_shape)
+    dw = conv3d_wgrad(x, dy, stride)                 # (Co, Cx, 27), Cx >= Ci when the input carries padding channels
+    if dw.shape[1] != w_shape[1]:
+        dw = dw[:, :w_shape[1]].contiguous()
+    return dw.reshape(w_shape)
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -289,5 +289,5 @@ class ProbDepthHeadFn(torch.autograd.Function):
         dx = conv3d_dgrad_c1(dl, w.detach().contiguous()) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = conv3d_wgrad(x8, dl.unsqueeze(-1), 1).permute(2, 1, 0).reshape(w.shape)
+            dw = conv3d_wgrad(x8, dl.unsqueeze(-1), 1).reshape(w.shape)
         return dx, dw, None
