@@ -140,10 +140,10 @@ int rcmvs_bn_bwd_reduce(const float* y, const float* dz, const float* scale, con
                         const float* invstd, double* sums, long long rows, int C, int relu, void* stream);
 int rcmvs_bn_bwd_apply(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,
                        const float* invstd, const float* coef, float* dy, long long rows, int C, int relu, void* stream);
-/* dw[co][ci][tap] += sum_o x[stride*o + tap - 1][ci] * dy[o][co]   (dw (Co,Ci,27) zero-filled by the caller, fp32 atomics).
- *   x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) with Do = (D-1)/stride+1 ...  dw is nn.Conv3d's weight-gradient layout as is; for
- *   nn.ConvTranspose3d(Cin,Cout) call with x := grad of the (large) output, dy := the (small) input, stride 2: the
- *   result (Cin, Cout, 27) is that module's weight-gradient layout. */
+/* dw[27][Ci][Co] += sum_o x[stride*o + tap - 1][ci] * dy[o][co]   (dw zero-filled by the caller, fp32 atomics).
+ *   x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) with Do = (D-1)/stride+1 ...  nn.Conv3d weight grad = dw permuted to
+ *   (Co,Ci,27); for nn.ConvTranspose3d(Cin,Cout) call with x := grad of the (large) output, dy := the (small)
+ *   input, stride 2: dw[27][Cout][Cin] -> permute to (Cin,Cout,27). */
 int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D, int H, int W, int Ci, int Co, int stride,
                        void* stream);
 /* data gradient of the 1-output-channel prob conv (modules.py:489): dy (B,D,H,W), w (1,Ci,3,3,3) as stored, dx (B,D,H,W,Ci) */

@@ -149,6 +149,67 @@ class FeatureNet(nn.Module):
             out["stage3"] = (lambda t=intra: ops.conv2d(t, p["out3"]))
         return out if lazy else {k: f() for k, f in out.items()}
 
+    # ---- training on the library: every layer as a one-plane volume on the 3-D conv family -----------------------
+    @staticmethod
+    def _w3(w):
+        """(Co,Ci,k,k) with k = 1 or 3 -> (Co,Ci,3,3,3) whose only non-zero depth slice is the middle one (differentiable)."""
+        p = (3 - w.shape[-1]) // 2
+        return F.pad(w.unsqueeze(2), (p, p, p, p, 1, 1))
+
+    @staticmethod
+    def _w5s2(w):
+        """5x5 stride-2 weight (Co,Ci,5,5) -> the equivalent 3x3 stride-1 weight (Co,4Ci,3,3) on the space-to-depth input:
+        tap k = 2t + a per axis (t = 3x3 tap, a = pixel parity), the k = 5 combinations are zero (differentiable)."""
+        Co, Ci = w.shape[:2]
+        w6 = F.pad(w, (0, 1, 0, 1))                                        # (Co,Ci,6,6)
+        return w6.reshape(Co, Ci, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4).reshape(Co, 4 * Ci, 3, 3)
+
+    @staticmethod
+    def _s2d(x):
+        """(N,H,W,C) -> (N,H/2,W/2,4C), channel order (row parity, column parity, c)."""
+        N, H, W, C = x.shape
+        return x.reshape(N, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, 4 * C)
+
+    def forward_train_cl(self, x, segments=1):
+        """Train-mode twin of ``forward_cl``: x (N,3,H,W) holds `segments` consecutive groups of images (the V views) that
+        are normalised independently, exactly as if the module were called once per group (models/casmvsnet.py:364-366),
+        while every convolution and gradient runs once over all N images.  Batch-statistics BatchNorm, autograd through
+        train_ops (conv / norm / gradients on the HIP kernels; the 5x5 stride-2 layers as space-to-depth + 3x3, the 2x
+        nearest up-sampling and the adds of the FPN merge as PyTorch element-wise ops).  Returns channels-last maps."""
+        from .train_ops import ConvPlainFn, conv_bn_train_w
+        N, _, H, W = x.shape
+        if H % 4 or W % 4:
+            raise RcmvsError("FeatureNet (training): image height and width must be multiples of 4")
+        t = F.pad(x.permute(0, 2, 3, 1), (0, 5)).contiguous()              # (N,H,W,8): RGB + zero channels
+
+        def cbr(t, m):
+            w = m.conv.weight
+            if m.stride == 2:
+                t, w = self._s2d(t), self._w5s2(w)
+            return conv_bn_train_w(self._w3(w), m.bn, t.unsqueeze(1), relu=True, segments=segments).squeeze(1)
+
+        def plain(t, conv):
+            return ConvPlainFn.apply(t.unsqueeze(1), self._w3(conv.weight), conv.bias).squeeze(1)
+
+        def up2(t):
+            return t.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+        c0 = t
+        for m in self.conv0: c0 = cbr(c0, m)
+        c1 = c0
+        for m in self.conv1: c1 = cbr(c1, m)
+        c2 = c1
+        for m in self.conv2: c2 = cbr(c2, m)
+        out = {"stage1": plain(c2, self.out1)}
+        intra = c2
+        if self.num_stage >= 2:
+            intra = up2(intra) + plain(c1, self.inner1)
+            out["stage2"] = plain(intra, self.out2)
+        if self.num_stage == 3:
+            intra = up2(intra) + plain(c0, self.inner2)
+            out["stage3"] = plain(intra, self.out3)
+        return out
+
     def forward(self, x):
         conv0 = self.conv0(x)
         conv1 = self.conv1(conv0)
@@ -511,18 +572,24 @@ class _CascadeBase(nn.Module):
         feature pyramid still runs on PyTorch-ROCm (per view, like models/casmvsnet.py:364-366, so its batch
         statistics match the reference's)."""
         from . import train_ops
-        _note_delegation("FeatureNet (training)")
         B, V, _, H, W = imgs.shape
         imgs = imgs.float()
         depth_values = depth_values.contiguous().float()
-        features = [self.feature(imgs[:, v]) for v in range(V)]
+        native_fpn = self.feature.arch_mode == "fpn" and os.environ.get("RCMVS_TRAIN_FPN", "hip") != "aten"
+        if native_fpn:
+            # all V views in one pass, normalised per view (segments) like the reference's per-view calls (casmvsnet.py:364-366)
+            fv = self.feature.forward_train_cl(imgs.transpose(0, 1).reshape(V * B, 3, H, W), segments=V)
+            features = [{k: f[v * B:(v + 1) * B] for k, f in fv.items()} for v in range(V)]
+        else:
+            _note_delegation("FeatureNet (training)")
+            features = [{k: f.permute(0, 2, 3, 1) for k, f in self.feature(imgs[:, v]).items()} for v in range(V)]
         outputs = {}
         depth = None
         for s in range(self.num_stage):
             key = "stage{}".format(s + 1)
             scale = int(self.stage_infos[key]["scale"])
             D = self.ndepths[s]
-            f_cl = torch.stack([f[key].permute(0, 2, 3, 1) for f in features], dim=1).contiguous()    # (B,V,h,w,C), differentiable
+            f_cl = torch.stack([f[key] for f in features], dim=1).contiguous()                       # (B,V,h,w,C), differentiable
             h, w = f_cl.shape[2:4]
             with torch.no_grad():
                 rot, trans = ops.compose_homography(proj_matrices[key].contiguous().float())

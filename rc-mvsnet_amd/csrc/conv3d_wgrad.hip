@@ -14,8 +14,9 @@
 // A wave keeps up to 128 accumulator registers = G tap groups; the remaining groups go to grid.y.  A wave
 // walks whole output rows (b, od, oh) in steps of four cells, reading both operands straight through the
 // vector L1 (the 27 taps re-read the same lines, so L1/L2 absorb the 27x reuse), and flushes with hardware
-// fp32 atomics into the zero-filled gradient, laid out (CO, CI, 27) = nn.Conv3d's weight layout so that no permute pass
-// follows (summation order is not deterministic).
+// fp32 atomics into the zero-filled [27][CI][CO] gradient: consecutive lanes (output channels) hit consecutive addresses,
+// which the atomic units coalesce -- writing nn.Conv3d's (CO, CI, 27) layout directly made the flush 2-3x slower
+// (summation order is not deterministic).
 #include "common.h"
 
 namespace rcmvs {
@@ -37,10 +38,12 @@ struct WgradCfg {
     static constexpr int SPLITS = (NGRP + G - 1) / G;
 };
 
-template <int CI, int CO, int STRIDE>
+// PLANE = the volume has a single plane (2-D layers run as D = 1): dead tap planes are skipped (kept out of the 3-D
+// instantiation, whose schedule the extra branches would disturb: 64->64 1.4 -> 3.8 ms when they were unconditional).
+template <int CI, int CO, int STRIDE, bool PLANE>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dw, WgradDims dm, int rows,
-                                                           int ldx, int ci_off, int ci_total) {
+                                                           int ldx, int ci_off, int ci_total, int wchunk) {
     using Cfg = WgradCfg<CI, CO, STRIDE>;
     constexpr int CQ = Cfg::CQ, TPM = Cfg::TPM, NGRP = Cfg::NGRP, NJ = Cfg::NJ, G = Cfg::G;
     static_assert(CI % 4 == 0 && CQ <= 16 && 16 % CQ == 0, "CI must be 4, 8, 16, 32 or 64");
@@ -66,6 +69,17 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 #pragma unroll
             for (int jb = 0; jb < NJ; ++jb) acc[gi][ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // one-plane volumes (2-D layers run as D = 1): the tap planes td = 0 and td = 2 never see data; groups made only of
+    // such taps are skipped wholesale (wave-uniform), which removes up to two thirds of the MFMAs
+    unsigned gdead = 0;
+    if (PLANE && STRIDE == 1) {
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int t0 = (g0 + gi) * TPM, t1 = t0 + TPM - 1;
+            if (t1 < 9 || t0 >= 18) gdead |= 1u << gi;
+        }
+    }
+    const int w_lo = PLANE ? blockIdx.z * wchunk : 0, w_hi = PLANE ? min(dm.Wo, w_lo + wchunk) : dm.Wo;   // few rows: the row is split across grid.z
     const bool n_ok = NJ * m < CO;           // (m doubles as the B-side column index n = lane & 15)
     // x is read through a buffer descriptor with 32-bit byte offsets: out-of-range taps get an offset beyond num_records and
     // the hardware returns 0 -- no branches, no 64-bit address arithmetic in the inner loop (the first version spent ~10x
@@ -92,9 +106,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
             rbase[gi] = (((b * dm.D + id) * dm.H + ih) * dm.W + ((t & 3) - 1)) * cell_bytes + lane_off;
             rok |= ok ? (1u << gi) : 0u;
         }
-        for (int w0 = 0; w0 < dm.Wo; w0 += 4) {
+        for (int w0 = w_lo; w0 < w_hi; w0 += 4) {
             const int ow = w0 + kq;
-            const bool w_ok = ow < dm.Wo;                       // ragged last step: the cell contributes zero
+            const bool w_ok = ow < w_hi;                        // ragged last step: the cell contributes zero
             float bv[NJ];
             if constexpr (NJ == 4) {
                 f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -111,12 +125,14 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
             f32x4 av[G];
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) {
+                if (PLANE && ((gdead >> gi) & 1u)) { av[gi] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
                 const int iw = iw0 + (tdx[gi] & 3) - 1;
                 const bool ok = w_ok && ((rok >> gi) & 1u) && (unsigned)iw < (unsigned)dm.W;
                 av[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? rbase[gi] + iw0 * cell_bytes : OOB, 0, 0));
             }
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) {
+                if (PLANE && ((gdead >> gi) & 1u)) continue;
 #pragma unroll
                 for (int jb = 0; jb < NJ; ++jb) {
                     acc[gi][0][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi].x, bv[jb], acc[gi][0][jb], 0, 0, 0);
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     const int co0 = NJ * m;
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
-        if (g0 + gi >= NGRP) continue;
+        if (g0 + gi >= NGRP || (PLANE && ((gdead >> gi) & 1u))) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mrow = 4 * kq + r;
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 #pragma unroll
                 for (int jb = 0; jb < NJ; ++jb) {
                     const int co = co0 + jb;
-                    if (co < CO) unsafeAtomicAdd(dw + ((long long)co * ci_total + ci_off + cq * 4 + ja) * 27 + tap, acc[gi][ja][jb][r]);
+                    if (co < CO) unsafeAtomicAdd(dw + ((long long)tap * ci_total + ci_off + cq * 4 + ja) * CO + co, acc[gi][ja][jb][r]);
                 }
         }
     }
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_c1_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = 4 * kq + r;               // row
-            if (ci < 8) unsafeAtomicAdd(dw + ci * 27 + tap, acc[t][r]);
+            if (ci < 8) unsafeAtomicAdd(dw + tap * 8 + ci, acc[t][r]);
         }
     }
 }
@@ -250,7 +266,18 @@ static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradD
     const int rows = dm.B * dm.Do * dm.Ho;
     int gx = (rows + 3) / 4;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE>), dim3(gx, Cfg::SPLITS), dim3(256), 0, st, x, dy, dw, dm, rows, ldx, ci_off, ci_total);
+    if (dm.D == 1 && STRIDE == 1) {
+        // few rows (one-plane volumes): split each row into chunks of >= 64 cells until there are ~512 waves (more waves cost
+        // more than they gain: every wave ends with an atomic flush of its whole accumulator set)
+        int wchunks = 1;
+        while (gx * 4 * wchunks < 512 && dm.Wo / (wchunks * 2) >= 64) wchunks *= 2;
+        const int wchunk = ((dm.Wo + wchunks - 1) / wchunks + 3) / 4 * 4;
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE, true>), dim3(gx, Cfg::SPLITS, (dm.Wo + wchunk - 1) / wchunk), dim3(256), 0, st,
+                           x, dy, dw, dm, rows, ldx, ci_off, ci_total, wchunk);
+    } else {
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE, false>), dim3(gx, Cfg::SPLITS), dim3(256), 0, st, x, dy, dw, dm, rows, ldx,
+                           ci_off, ci_total, dm.Wo);
+    }
     return launch_status("conv3d_wgrad");
 }
 
@@ -274,6 +301,7 @@ int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D,
 #define RCMVS_WG(CI, CO, S) if (Ci == CI && Co == CO && stride == S) return wgrad_launch<CI, CO, S>(x, dy, dw, dm, Ci, 0, Ci, st);
     RCMVS_WG(8, 8, 1) RCMVS_WG(16, 8, 1) RCMVS_WG(32, 8, 1)
     RCMVS_WG(16, 16, 1) RCMVS_WG(32, 32, 1) RCMVS_WG(64, 64, 1)
+    RCMVS_WG(32, 16, 1) RCMVS_WG(64, 32, 1) RCMVS_WG(16, 32, 1) RCMVS_WG(8, 32, 1)      /* FeatureNet layers as one-plane volumes */
     RCMVS_WG(8, 16, 2) RCMVS_WG(16, 32, 2) RCMVS_WG(32, 64, 2)
 #undef RCMVS_WG
     if (Co == 8 && stride == 1 && Ci % 4 == 0 && Ci < 64) {

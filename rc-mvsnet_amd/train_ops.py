@@ -42,9 +42,9 @@ def bn_bwd_reduce(y, dz, scale, shift, mean, invstd, sums, relu):
                                                y.numel() // C, C, int(bool(relu)), _stream()), "bn_bwd_reduce")
 
 
-def bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, relu):
+def bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, relu, out=None):
     C = y.shape[-1]
-    dy = torch.empty_like(y)
+    dy = torch.empty_like(y) if out is None else out
     _lib.check(_lib.load().rcmvs_bn_bwd_apply(_chk(y, "y"), _chk(dz, "dz"), _chk(scale, "scale"), _chk(shift, "shift"),
                                               _chk(mean, "mean"), _chk(invstd, "invstd"), _chk(coef, "coef"), _chk(dy, "dy"),
                                               y.numel() // C, C, int(bool(relu)), _stream()), "bn_bwd_apply")
@@ -52,13 +52,13 @@ def bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, relu):
 
 
 def conv3d_wgrad(x, dy, stride):
-    """x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) -> weight gradient (Co,Ci,27) (nn.Conv3d layout)."""
+    """x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) -> packed weight gradient (27,Ci,Co)."""
     B, D, H, W, Ci = x.shape
     Co = dy.shape[-1]
     exp = (B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
     if tuple(dy.shape[:4]) != exp:
         raise _lib.RcmvsError(f"conv3d_wgrad: dy {tuple(dy.shape)} does not match x {tuple(x.shape)} at stride {stride}")
-    dw = torch.zeros((Co, Ci, 27), device=x.device, dtype=torch.float32)
+    dw = torch.zeros((27, Ci, Co), device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().rcmvs_conv3d_wgrad(_chk(x, "x"), _chk(dy, "dy"), _chk(dw, "dw"), B, D, H, W, Ci, Co, stride, _stream()),
                "conv3d_wgrad")
     return dw
@@ -115,18 +115,19 @@ def _conv_dgrad(dy, w, transposed, stride, cx):
 
 
 def _conv_wgrad(x, dy, w_shape, transposed, stride):
-    if transposed:                                   # roles swap: the large tensor (dy) is strided over -> (Cin_T, Cout_T, 27)
-        return conv3d_wgrad(dy, x, 2).reshape(w_shape)
-    dw = conv3d_wgrad(x, dy, stride)                 # (Co, Cx, 27), Cx >= Ci when the input carries padding channels
-    if dw.shape[1] != w_shape[1]:
-        dw = dw[:, :w_shape[1]].contiguous()
-    return dw.reshape(w_shape)
+    if transposed:                                   # roles swap: the large tensor (dy) is strided over -> (27, Cout_T, Cin_T)
+        return conv3d_wgrad(dy, x, 2).permute(2, 1, 0).reshape(w_shape)
+    dw = conv3d_wgrad(x, dy, stride)                 # (27, Cx, Co), Cx >= Ci when the input carries padding channels
+    return dw[:, :w_shape[1]].permute(2, 1, 0).reshape(w_shape)
 
 
 class ConvBnReluFn(torch.autograd.Function):
     """z = [relu](batchnorm_train(conv(x, w))) [+ residual], channels-last.  `cfg` = dict(transposed, stride, relu,
-    eps, momentum, group): group = a process group for SyncBatchNorm statistics, or None.  `running_mean` /
-    `running_var` (may be None) receive nn.BatchNorm's momentum update inside the same kernel that folds the statistics."""
+    eps, momentum, group, segments): group = a process group for SyncBatchNorm statistics, or None; segments = S splits
+    the batch into S consecutive groups that are normalised independently, in order (the reference runs FeatureNet once
+    per view, so each view has its own batch statistics and the running statistics are updated once per view) while the
+    convolution and both of its gradients run once over the whole batch.  `running_mean` / `running_var` (may be None)
+    receive nn.BatchNorm's momentum update inside the same kernel that folds the statistics."""
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, residual, running_mean, running_var, cfg):
@@ -134,21 +135,27 @@ class ConvBnReluFn(torch.autograd.Function):
         lib = _lib.load()
         y = _conv_raw(x, w.detach(), cfg["transposed"], cfg["stride"])
         C = y.shape[-1]
-        pack = torch.zeros(2 * C + 1, device=x.device, dtype=torch.float64)      # [sum (C) | sum of squares (C) | count]
-        pack[-1] = float(y.numel() // C)
-        bn_stats(y, pack)
-        if cfg.get("group") is not None:
-            dist.all_reduce(pack, group=cfg["group"])
-        stats = torch.empty((5, C), device=x.device, dtype=torch.float32)        # mean, var, invstd, scale, shift
+        S = int(cfg.get("segments", 1))
+        nb = y.shape[0] // S
+        pack = torch.zeros((S, 2 * C + 1), device=x.device, dtype=torch.float64)   # per segment [sum | sum of squares | count]
+        pack[:, -1] = float(nb * (y.numel() // (C * y.shape[0])))
+        stats = torch.empty((S, 5, C), device=x.device, dtype=torch.float32)     # mean, var, invstd, scale, shift
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(lib.rcmvs_bn_finalize(ptr(pack), ptr(pack[2 * C:]), _chk(g32, "gamma"), _chk(b32, "beta"), float(cfg["eps"]),
-                                         float(cfg.get("momentum", 0.0)), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-                                         ptr(stats[4]), _opt(running_mean, "running_mean"), _opt(running_var, "running_var"), C,
-                                         _stream()), "bn_finalize")
-        mean, invstd, scale, shift = stats[0], stats[2], stats[3], stats[4]
         res = None if residual is None else residual.contiguous()
-        z = scale_shift_relu(y, scale, shift, res, cfg["relu"])
+        z = torch.empty_like(y)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        for sgm in range(S):
+            ys = y[sgm * nb:(sgm + 1) * nb]
+            bn_stats(ys, pack[sgm])
+            if cfg.get("group") is not None:
+                dist.all_reduce(pack[sgm], group=cfg["group"])
+            st = stats[sgm]
+            _lib.check(lib.rcmvs_bn_finalize(ptr(pack[sgm]), ptr(pack[sgm, 2 * C:]), _chk(g32, "gamma"), _chk(b32, "beta"),
+                                             float(cfg["eps"]), float(cfg.get("momentum", 0.0)), ptr(st[0]), ptr(st[1]), ptr(st[2]),
+                                             ptr(st[3]), ptr(st[4]), _opt(running_mean, "running_mean"),
+                                             _opt(running_var, "running_var"), C, _stream()), "bn_finalize")
+            scale_shift_relu(ys, st[3], st[4], None if res is None else res[sgm * nb:(sgm + 1) * nb], cfg["relu"],
+                             out=z[sgm * nb:(sgm + 1) * nb])
         ctx.save_for_backward(x, w, y, stats, pack)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
@@ -157,24 +164,30 @@ class ConvBnReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         x, w, y, stats, pack = ctx.saved_tensors
-        mean, invstd, scale, shift = stats[0], stats[2], stats[3], stats[4]
         cfg = ctx.cfg
         C = y.shape[-1]
+        S = int(cfg.get("segments", 1))
+        nb = y.shape[0] // S
         dz = dz.contiguous()
-        sums = torch.zeros(2 * C, device=y.device, dtype=torch.float64)
-        bn_bwd_reduce(y, dz, scale, shift, mean, invstd, sums, cfg["relu"])
-        tot = sums
-        if cfg.get("group") is not None:
-            tot = sums.clone()
-            dist.all_reduce(tot, group=cfg["group"])
-        out = torch.empty((4, C), device=y.device, dtype=torch.float32)           # dgamma, dbeta, coef (2C)
+        sums = torch.zeros((S, 2 * C), device=y.device, dtype=torch.float64)
+        out = torch.empty((S, 4, C), device=y.device, dtype=torch.float32)        # per segment: dgamma, dbeta, coef (2C)
+        dy = torch.empty_like(y)
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(_lib.load().rcmvs_bn_bwd_finalize(ptr(sums), ptr(tot), ptr(pack[2 * C:]), ptr(out[0]), ptr(out[1]), ptr(out[2]), C,
-                                                     _stream()), "bn_bwd_finalize")
-        dy = bn_bwd_apply(y, dz, scale, shift, mean, invstd, out[2:].reshape(-1), cfg["relu"])
+        for sgm in range(S):
+            sl = slice(sgm * nb, (sgm + 1) * nb)
+            mean, invstd, scale, shift = stats[sgm, 0], stats[sgm, 2], stats[sgm, 3], stats[sgm, 4]
+            bn_bwd_reduce(y[sl], dz[sl], scale, shift, mean, invstd, sums[sgm], cfg["relu"])
+            tot = sums[sgm]
+            if cfg.get("group") is not None:
+                tot = sums[sgm].clone()
+                dist.all_reduce(tot, group=cfg["group"])
+            _lib.check(_lib.load().rcmvs_bn_bwd_finalize(ptr(sums[sgm]), ptr(tot), ptr(pack[sgm, 2 * C:]), ptr(out[sgm, 0]),
+                                                         ptr(out[sgm, 1]), ptr(out[sgm, 2]), C, _stream()), "bn_bwd_finalize")
+            bn_bwd_apply(y[sl], dz[sl], scale, shift, mean, invstd, out[sgm, 2:].reshape(-1), cfg["relu"], out=dy[sl])
+        dgamma, dbeta = (out[0, 0], out[0, 1]) if S == 1 else (out[:, 0].sum(0), out[:, 1].sum(0))
         dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"], x.shape[-1]) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad(x, dy, w.shape, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[1] else None
-        return dx, dw, out[0], out[1], (dz if ctx.has_res else None), None, None, None
+        return dx, dw, dgamma, dbeta, (dz if ctx.has_res else None), None, None, None
 
 
 def conv_bn_relu_train(block, x, residual=None):
@@ -185,8 +198,12 @@ def conv_bn_relu_train(block, x, residual=None):
 
 def conv_bn_train(conv, bn, x, relu, residual=None):
     """conv (nn.Conv3d | nn.ConvTranspose3d, k=3, pad 1, no bias) -> bn (batch statistics) -> [ReLU] [+ residual]."""
-    transposed = isinstance(conv, torch.nn.ConvTranspose3d)
-    stride = conv.stride[0]
+    return conv_bn_train_w(conv.weight, bn, x, relu, residual, isinstance(conv, torch.nn.ConvTranspose3d), conv.stride[0])
+
+
+def conv_bn_train_w(weight, bn, x, relu, residual=None, transposed=False, stride=1, segments=1):
+    """Same with an explicit (Co,Ci,3,3,3) weight tensor (it may be a differentiable function of the module's parameter,
+    e.g. FeatureNet's 2-D weights embedded as one-plane 3-D kernels)."""
     group = None
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         group = bn.process_group if bn.process_group is not None else dist.group.WORLD
@@ -194,13 +211,39 @@ def conv_bn_train(conv, bn, x, relu, residual=None):
     mom = 0.0
     if track:
         with torch.no_grad():
-            bn.num_batches_tracked += 1
+            bn.num_batches_tracked += segments
         # momentum=None means a cumulative average; that needs the step count on the host (one sync) -- the reference
         # always sets a momentum (modules.py:146, bn_momentum=0.1), so this branch is cold
         mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    cfg = {"transposed": transposed, "stride": stride, "relu": bool(relu), "eps": bn.eps, "momentum": mom, "group": group}
-    return ConvBnReluFn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn.running_mean if track else None,
+    cfg = {"transposed": transposed, "stride": stride, "relu": bool(relu), "eps": bn.eps, "momentum": mom, "group": group,
+           "segments": segments}
+    return ConvBnReluFn.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean if track else None,
                               bn.running_var if track else None, cfg)
+
+
+class ConvPlainFn(torch.autograd.Function):
+    """y = conv(x, w) [+ bias], no normalisation (FeatureNet's out* / inner* layers as one-plane volumes): forward and
+    both gradients on the 3-D conv family."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        pk = ops.pack_conv3d_weight(_pad_in_channels(w.detach(), x.shape[-1]))
+        if bias is None:
+            return ops.conv3d(x, pk)
+        b32 = bias.detach().float().contiguous()
+        return ops.conv3d(x, pk, torch.ones_like(b32), b32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _conv_dgrad(dy, w, False, 1, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad(x, dy, w.shape, False, 1) if ctx.needs_input_grad[1] else None
+        db = dy.sum(dim=(0, 1, 2, 3)) if ctx.has_bias else None
+        return dx, dw, db
 
 
 # --------------------------------------------------------------------------------------- plane resize (renderer)
@@ -289,5 +332,5 @@ class ProbDepthHeadFn(torch.autograd.Function):
         dx = conv3d_dgrad_c1(dl, w.detach().contiguous()) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = conv3d_wgrad(x8, dl.unsqueeze(-1), 1).reshape(w.shape)
+            dw = conv3d_wgrad(x8, dl.unsqueeze(-1), 1).permute(2, 1, 0).reshape(w.shape)
         return dx, dw, None

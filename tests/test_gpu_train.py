@@ -290,3 +290,45 @@ def test_hip_training_path_vs_reference_gradients():
     bufs = dict(m.named_buffers())
     assert float((bufs["cost_regularization.0.conv0.bn.running_mean"].cpu() - torch.as_tensor(g["running_mean_conv0"])).abs().max()) < 1e-5
     assert _rel(bufs["cost_regularization.0.conv0.bn.running_var"].cpu(), torch.as_tensor(g["running_var_conv0"])) < 1e-4
+
+
+def test_featurenet_train_native_vs_delegated(monkeypatch):
+    """FeatureNet in train mode on the library (every layer as a one-plane volume on the 3-D conv family, 5x5 stride-2
+    layers as space-to-depth + 3x3) vs the module's own nn.Conv2d / BatchNorm2d graph: feature maps, input-independent
+    parameter gradients, running statistics."""
+    import copy
+    from rc_mvsnet_amd import _lib
+    from rc_mvsnet_amd.casmvsnet import FeatureNet
+    _lib.load()
+    warnings.simplefilter("ignore")
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    m1 = FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="fpn").to(dev).train()
+    for mod in m1.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0.0, 0.1)
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 64, 96, generator=g).to(dev)
+    G = {k: torch.randn(s, generator=g).to(dev) for k, s in (("stage1", (2, 16, 24, 32)), ("stage2", (2, 32, 48, 16)), ("stage3", (2, 64, 96, 8)))}
+    # two "views" of one image each, normalised separately: one batched call with segments=2 vs two module calls
+    o1 = m1.forward_train_cl(x, segments=2)
+    sum((o1[k] * G[k]).sum() for k in G).backward()
+    oa, ob = m2(x[:1]), m2(x[1:])
+    o2 = {k: torch.cat((oa[k], ob[k])) for k in oa}
+    sum((o2[k].permute(0, 2, 3, 1) * G[k]).sum() for k in G).backward()
+    for k in G:
+        assert _rel(o1[k].detach(), o2[k].detach().permute(0, 2, 3, 1)) < 1e-4, k
+    worst = ("", 0.0)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert p1.grad is not None and p2.grad is not None, n1
+        e = _rel(p1.grad, p2.grad)
+        if e > worst[1]:
+            worst = (n1, e)
+    print(f"FeatureNet train: worst parameter-gradient mismatch {worst[1]:.2e} at {worst[0]}")
+    assert worst[1] < 2e-3
+    b1 = dict(m1.named_buffers())
+    for n2, b in m2.named_buffers():
+        if "running" in n2:
+            assert _rel(b1[n2], b) < 1e-4, n2
