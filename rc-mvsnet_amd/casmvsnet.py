@@ -10,10 +10,10 @@ Execution:
     hand-written HIP kernels of librcmvs_hip.so: 2-D feature pyramid (conv2d.hip), fused warp+variance
     (K1), 3-D conv family with folded BatchNorm (K2/K3), prob-conv/softmax/regression/confidence (K4),
     all in channels-last layout, no host synchronisation anywhere in forward();
-  * training (module in train mode on the GPU) runs the three cascade stages forward AND backward on
-    the library through autograd Functions (ops.WarpVarianceFn, train_ops.ConvBnReluFn /
-    ProbDepthHeadFn: batch-statistics BatchNorm, data / weight gradients, K1 scatter); the 2-D feature
-    pyramid is the part still delegated to PyTorch-ROCm there;
+  * training (module in train mode on the GPU) runs the feature pyramid and the three cascade stages
+    forward AND backward on the library through autograd Functions (ops.WarpVarianceFn,
+    train_ops.ConvBnReluFn / ConvPlainFn / ProbDepthHeadFn: batch-statistics BatchNorm, data / weight
+    gradients, K1 scatter); PyTorch supplies element-wise glue only;
   * everything else -- CPU tensors, eval mode with autograd on, RCMVS_TRAIN=aten -- runs the
     reference's op graph through the modules' own nn.Conv / BatchNorm children on PyTorch: an
     explicit, logged delegation (RCMVS_STRICT=1 makes it an error), never a silent fallback of the
@@ -566,11 +566,11 @@ class _CascadeBase(nn.Module):
 
     # ---------------------------------------------------------------- native training path
     def _forward_train_hip(self, imgs, proj_matrices, depth_values):
-        """Train mode with autograd: every op of the three cascade stages -- warp + variance (and the train variant's
-        volume_feature_no_ref), the cost regularisation with batch-statistics BatchNorm, prob conv + softmax +
-        soft-argmin -- runs forward AND backward on the HIP kernels (ops.WarpVarianceFn, train_ops.*).  The 2-D
-        feature pyramid still runs on PyTorch-ROCm (per view, like models/casmvsnet.py:364-366, so its batch
-        statistics match the reference's)."""
+        """Train mode with autograd: the feature pyramid and every op of the three cascade stages -- warp + variance (and
+        the train variant's volume_feature_no_ref), the cost regularisation with batch-statistics BatchNorm, prob conv +
+        softmax + soft-argmin -- run forward AND backward on the HIP kernels (ops.WarpVarianceFn, train_ops.*).  The
+        pyramid sees all V views in one pass but normalises them per view, like models/casmvsnet.py:364-366
+        (RCMVS_TRAIN_FPN=aten keeps it on the module's own nn.Conv2d / BatchNorm2d children)."""
         from . import train_ops
         B, V, _, H, W = imgs.shape
         imgs = imgs.float()
