@@ -263,8 +263,29 @@ def train_grads():
     save("train_grads", H=64, W=96, V=3, ndepths=(8, 8, 8), ratios=(4, 2, 1), prob_gain=2.0, **arrays)
 
 
+def pfm_fixture():
+    """Bytes written by the reference's PFM writer (datasets/data_io.py:45-68) for a small grey and a small colour map."""
+    import tempfile
+    import_reference()
+    from datasets.data_io import read_pfm, save_pfm
+    g = np.random.default_rng(0)
+    grey = (400.0 + 500.0 * g.random((5, 7))).astype(np.float32)
+    col = g.standard_normal((4, 6, 3)).astype(np.float32)
+    out = {"grey": grey, "colour": col}
+    with tempfile.TemporaryDirectory() as d:
+        for name, arr in (("grey", grey), ("colour", col)):
+            path = os.path.join(d, name + ".pfm")
+            save_pfm(path, arr)
+            out[name + "_bytes"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+            back, scale = read_pfm(path)
+            out[name + "_read"] = np.ascontiguousarray(back)
+    save("pfm", **out)
+
+
 if __name__ == "__main__":
-    if "--only-train-grads" in sys.argv:
+    if "--only-pfm" in sys.argv:
+        pfm_fixture()
+    elif "--only-train-grads" in sys.argv:
         train_grads()
     else:
         main()
