@@ -332,3 +332,40 @@ def test_featurenet_train_native_vs_delegated(monkeypatch):
     for n2, b in m2.named_buffers():
         if "running" in n2:
             assert _rel(b1[n2], b) < 1e-4, n2
+
+
+def test_sync_batchnorm_branch_with_simulated_replica(monkeypatch):
+    """The SyncBatchNorm branch of ConvBnReluFn (statistics and backward sums all-reduced as fp64) on one GPU: with
+    dist.all_reduce replaced by "add an identical replica" (t *= 2), the normalisation must be unchanged -- same mean /
+    variance / running statistics, same output and input gradient -- while the parameter gradients stay the local ones."""
+    import torch.distributed as dist
+    from rc_mvsnet_amd import _lib, train_ops
+    _lib.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 8, 16, 16, generator=g).to(dev)
+    w = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.05).to(dev)
+    gamma, beta = (0.5 + torch.rand(16, generator=g)).to(dev), (0.1 * torch.randn(16, generator=g)).to(dev)
+    G = torch.randn(2, 8, 8, 16, 16, generator=g).to(dev)
+    calls = {"n": 0}
+
+    def fake_all_reduce(t, group=None, op=None):
+        calls["n"] += 1
+        t.mul_(2.0)
+
+    def run(group):
+        xi, wi, gi, bi = (t.clone().requires_grad_(True) for t in (x, w, gamma, beta))
+        rm, rv = torch.zeros(16, device=dev), torch.ones(16, device=dev)
+        cfg = {"transposed": False, "stride": 1, "relu": True, "eps": 1e-5, "momentum": 0.1, "group": group}
+        z = train_ops.ConvBnReluFn.apply(xi, wi, gi, bi, None, rm, rv, cfg)
+        (z * G).sum().backward()
+        return z.detach(), xi.grad, wi.grad, gi.grad, bi.grad, rm, rv
+
+    ref = run(None)
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    syn = run("fake-group")
+    assert calls["n"] == 2                                            # one exchange forward, one backward
+    names = ("z", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")
+    for n, a, b in zip(names, syn, ref):
+        tol = 2e-4 if n == "running_var" else 1e-5                    # unbiased correction N/(N-1) sees the doubled count
+        assert _rel(a, b) < tol, n
