@@ -34,7 +34,8 @@ struct WgradCfg {
     static constexpr int TPM = 16 / CQ;
     static constexpr int NGRP = (27 + TPM - 1) / TPM;
     static constexpr int NJ = CO >= 16 ? CO / 16 : 1;
-    static constexpr int G = (8 / NJ) < NGRP ? (8 / NJ) : NGRP;
+    static constexpr int GMAX = 4;                                   // accumulator groups per wave (x 16 NJ registers each)
+    static constexpr int G = (GMAX / NJ) < 1 ? 1 : ((GMAX / NJ) < NGRP ? (GMAX / NJ) : NGRP);
     static constexpr int SPLITS = (NGRP + G - 1) / G;
 };
 
