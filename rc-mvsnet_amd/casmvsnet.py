@@ -110,6 +110,12 @@ class FeatureNet(nn.Module):
                     w3[:, :, 1] = w.detach()
                     plan[n] = ("mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
                     continue
+                if w.shape[0] == 32 and w.shape[1] == 16 and w.shape[2] == 5 and m.stride == 2 and os.environ.get("RCMVS_S2D", "1") != "0":
+                    # 16 -> 32 5x5 stride 2 (12 % VALU busy on the scalar-weight kernel): space-to-depth turns it into a 64 -> 32
+                    # 3x3 stride-1 layer (tap k = 2t + parity; the k = 5 taps are zero), which runs on the MFMA kernel
+                    w3 = self._w3(self._w5s2(w.detach())).contiguous()
+                    plan[n] = ("s2d_mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
+                    continue
                 plan[n] = (ops.pack_conv2d_weight(w, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
             if self.num_stage >= 2:
@@ -133,6 +139,9 @@ class FeatureNet(nn.Module):
             if p[n][0] == "mfma3d":
                 _, w3, sc, sh = p[n]
                 return ops.conv3d(t.unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)
+            if p[n][0] == "s2d_mfma3d":
+                _, w3, sc, sh = p[n]
+                return ops.conv3d(self._s2d(t).contiguous().unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)
             w, sc, sh, stride = p[n]
             return ops.conv2d(t, w, sc, sh, stride=stride, relu=True)
 
