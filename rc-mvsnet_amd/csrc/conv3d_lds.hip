@@ -169,6 +169,13 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
         return launch_status("conv3d_lds");                                                 \
     }
     if (Co == 16 && Ci == 16) {                                 // conv2 of the U-Nets: 16 accumulators, 64 scalar weights per (tap, 4 ch)
+        if (!(g_lds_cfg & 8)) {                                 // two voxels per thread (debug bit 5 of rcmvs_debug_force_direct_conv: one)
+            const int td2 = (D + 2 * LT_D - 1) / (2 * LT_D);
+            const size_t lds2 = (size_t)(2 * LT_D + 2) * LH_H * LH_W * 12 * sizeof(float);
+            dim3 grid2(tiles_w * tiles_h, td2, B);
+            hipLaunchKernelGGL((conv3d_lds_kernel<16, 16, 2, 8, 2>), grid2, dim3(512), lds2, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu);
+            return launch_status("conv3d_lds(16x16, 2 voxels)");
+        }
         if (split == 2) hipLaunchKernelGGL((conv3d_lds_kernel<16, 16, 2, 8>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu);
         else            hipLaunchKernelGGL((conv3d_lds_kernel<16, 16, 1, 8>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu);
         return launch_status("conv3d_lds(16x16)");
