@@ -17,34 +17,65 @@ namespace rcmvs {
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                       int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);   // conv3d_lds.hip
 
+// LP adjacent lanes share one pixel and own the planes k = j, j + LP, ... (at most 16 each, held in registers): the logit
+// column is read ONCE with all of a lane's loads in flight, max / sum / soft-argmin / window sums are combined across the
+// LP lanes with shuffles, the probabilities are written once.  LP = 1, 2, 4 for D <= 16, 32, 64 -- the 128x160 stage has
+// only 20 k pixels, so spreading a pixel over four lanes is also what fills the machine there.
+template <int LP>
 __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict__ prob, const float* __restrict__ planes,
                                                                float* __restrict__ depth, float* __restrict__ conf, int D, long long hw) {
+    constexpr int MAXK = 16;
     const int b = blockIdx.y;
-    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= hw) return;
-    float* col = prob + (long long)b * D * hw + p;              // element k at col[k*hw]
+    const int j = threadIdx.x % LP;
+    const long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LP;
+    const bool live = p < hw;
+    float* col = prob + (long long)b * D * hw + (live ? p : 0);  // element k at col[k*hw]
+    float v[MAXK];
     float mx = -INFINITY;
-    for (int k = 0; k < D; ++k) mx = fmaxf(mx, col[(long long)k * hw]);
-    float sum = 0.0f;
-    for (int k = 0; k < D; ++k) sum += expf(col[(long long)k * hw] - mx);
-    const float2 pl = reinterpret_cast<const float2*>(planes)[(long long)b * hw + p];
-    float dsum = 0.0f, isum = 0.0f;
-    for (int k = 0; k < D; ++k) {
-        const float pk = expf(col[(long long)k * hw] - mx) / sum;
-        col[(long long)k * hw] = pk;
-        dsum += pk * (pl.x + (float)k * pl.y);
-        isum += pk * (float)k;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+        const int k = j + i * LP;
+        v[i] = (k < D) ? col[(long long)k * hw] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
     }
+#pragma unroll
+    for (int m = 1; m < LP; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+        v[i] = (j + i * LP < D) ? expf(v[i] - mx) : 0.0f;
+        sum += v[i];
+    }
+#pragma unroll
+    for (int m = 1; m < LP; m <<= 1) sum += __shfl_xor(sum, m);
+    const float2 pl = reinterpret_cast<const float2*>(planes)[(long long)b * hw + (live ? p : 0)];
+    float dsum = 0.0f, isum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+        const int k = j + i * LP;
+        v[i] = v[i] / sum;
+        if (k < D) {
+            if (live) col[(long long)k * hw] = v[i];
+            dsum += v[i] * (pl.x + (float)k * pl.y);
+            isum += v[i] * (float)k;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < LP; m <<= 1) { dsum += __shfl_xor(dsum, m); isum += __shfl_xor(isum, m); }
     int idx = (int)isum;                       // .long(): truncation
     idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
-    float c = 0.0f;                            // ((p[i-1] + p[i]) + p[i+1]) + p[i+2], zero padded
+    float c = 0.0f;                            // p[i-1] + p[i] + p[i+1] + p[i+2], zero padded
 #pragma unroll
-    for (int j = -1; j <= 2; ++j) {
-        const int kk = idx + j;
-        c += (kk >= 0 && kk < D) ? col[(long long)kk * hw] : 0.0f;
+    for (int i = 0; i < MAXK; ++i) {
+        const int k = j + i * LP;
+        if (k < D && k >= idx - 1 && k <= idx + 2) c += v[i];
     }
-    depth[(long long)b * hw + p] = dsum;
-    conf[(long long)b * hw + p] = c;
+#pragma unroll
+    for (int m = 1; m < LP; m <<= 1) c += __shfl_xor(c, m);
+    if (live && j == 0) {
+        depth[(long long)b * hw + p] = dsum;
+        conf[(long long)b * hw + p] = c;
+    }
 }
 
 }  // namespace rcmvs
@@ -60,6 +91,9 @@ extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const f
     int rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st);
     if (rc) return rc;
     const long long hw = (long long)h * w;
-    hipLaunchKernelGGL(softmax_regress_kernel, dim3((unsigned)cdiv(hw, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
+    RCMVS_REQUIRE(D <= 64, "depth_head_fwd: at most 64 depth hypotheses per stage (got %d)", D);
+    if (D <= 16)      hipLaunchKernelGGL(softmax_regress_kernel<1>, dim3((unsigned)cdiv(hw, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
+    else if (D <= 32) hipLaunchKernelGGL(softmax_regress_kernel<2>, dim3((unsigned)cdiv(hw * 2, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
+    else              hipLaunchKernelGGL(softmax_regress_kernel<4>, dim3((unsigned)cdiv(hw * 4, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
     return launch_status("depth_head_fwd");
 }
