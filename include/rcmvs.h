@@ -229,6 +229,37 @@ int rcmvs_composite_bwd(const float* raw, const float* z, const float* grad_rgb,
 int rcmvs_point_feats_bwd(const float* ndc, const float* grad_feat, float* grad_volume,
                           int M, int Dv, int hv, int wv, int ldg, void* stream);
 
+/* ---- self-supervised photometric loss -------------------------------------------------
+ * Replaces losses/homography.py:6-200 (inverse_warping + _bilinear_sample), losses/modules.py:6-82 (SSIM,
+ * depth_smoothness, compute_reconstr_loss) and the per-stage body of UnSupLoss.forward (losses/unsup_loss.py:14-94).
+ * Images are channels-last (B,H,W,3) at the stage resolution; depth / mask (B,H,W); all device pointers.
+ * coef (Vs,B,12) = per source view and batch item {M 3x3 row-major, t 3} with p = M (x,y,1)^T d + t, where
+ * M = K_ref R_rel K_ref^-1, t = K_ref t_rel, R_rel = R_src R_ref^T, t_rel = t_src - R_rel t_ref (homography.py:9-56;
+ * the reference projects with the REFERENCE view's intrinsics and that is kept). */
+#define RCMVS_UNSUP_MAX_VIEWS 8
+/* inverse_warping of one source image: warped (B,H,W,3), mask (B,H,W) in {0,1}; coef (B,12). */
+int rcmvs_inverse_warp(const float* src, const float* depth, const float* coef, float* warped, float* mask,
+                       int B, int H, int W, void* stream);
+/* One stage of UnSupLoss.forward for Vs source views: srcs (Vs,B,H,W,3) -> warped (Vs,B,H,W,3), masks (Vs,B,H,W) (kept
+ * for the backward), out[0..3] = {reconstr_loss, ssim_loss, smooth_loss, 12 r + 6 s + 0.18 m}, out[4+v] = the scalar
+ * reconstruction loss of view v.  sums (4 Vs + 2 doubles) and counts (Vs ints: pixels won by each view) are workspace
+ * the call zero-fills; counts feed the backward.  No host synchronisation. */
+int rcmvs_unsup_loss_fwd(const float* ref, const float* srcs, const float* depth, const float* coef,
+                         float* warped, float* masks, double* sums, int* counts, float* out,
+                         int B, int Vs, int H, int W, void* stream);
+/* Backward of rcmvs_unsup_loss_fwd w.r.t. depth (the images carry no gradient): gout = 3 device floats, the gradients of
+ * {reconstr_loss, ssim_loss, smooth_loss}; grad_depth (B,H,W) is overwritten.  Workspace: ssim_ws (B,H-2,W-2,9) floats,
+ * kbuf (4 Vs + 2) floats. */
+int rcmvs_unsup_loss_bwd(const float* ref, const float* srcs, const float* depth, const float* coef,
+                         const float* warped, const float* masks, const int* counts, const float* gout,
+                         float* ssim_ws, float* kbuf, float* grad_depth, int B, int Vs, int H, int W, void* stream);
+/* Masked smooth-L1 mean (losses/aug_loss.py:58-59 and losses/sl1loss.py:9-13: F.smooth_l1_loss(pred[mask], target[mask])):
+ * sums[0] = sum of smooth_l1(pred - target) over elements with mask > 0.5, sums[1] = their number (fp64, zero-filled by the
+ * call); the loss is sums[0] / sums[1].  Backward: grad_pred = gout[0] / sums[1] * clamp(pred - target, -1, 1) on the mask. */
+int rcmvs_masked_sl1_fwd(const float* pred, const float* target, const float* mask, double* sums, long long n, void* stream);
+int rcmvs_masked_sl1_bwd(const float* pred, const float* target, const float* mask, const double* sums,
+                         const float* gout, float* grad_pred, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

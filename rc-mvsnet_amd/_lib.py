@@ -31,6 +31,11 @@ SIGNATURES = {
     "rcmvs_resize_planes_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_composite_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "rcmvs_point_feats_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rcmvs_inverse_warp": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "rcmvs_unsup_loss_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_unsup_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_masked_sl1_fwd": [_p, _p, _p, _p, _ll, _p],
+    "rcmvs_masked_sl1_bwd": [_p, _p, _p, _p, _p, _p, _ll, _p],
     "rcmvs_bn_stats": [_p, _p, _ll, _i, _p],
     "rcmvs_bn_finalize": [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "rcmvs_bn_bwd_finalize": [_p, _p, _p, _p, _p, _p, _i, _p],

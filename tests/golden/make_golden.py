@@ -282,11 +282,72 @@ def pfm_fixture():
     save("pfm", **out)
 
 
+def loss_depths(B, H, W, seed):
+    """Smooth seeded depth maps (B,h,w) for the three stage resolutions, inside the synthetic rig's depth range."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for i, s in enumerate((4, 2, 1)):
+        h, w = H // s, W // s
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+        d = 640.0 + 90.0 * torch.sin(3.1 * xx + 0.3 * i) * torch.cos(2.3 * yy) + 25.0 * xx
+        d = d.unsqueeze(0).repeat(B, 1, 1) + 2.0 * torch.randn(B, h, w, generator=g)
+        out["stage%d" % (i + 1)] = d.float()
+    return out
+
+
+def unsup_loss_fixture():
+    """The reference's UnsupLossMultiStage / AugLossMultiStage (losses/unsup_loss.py:423-451, losses/aug_loss.py:31-67)
+    and their depth gradients through the reference's own autograd, plus one view's warped image and mask."""
+    import_reference()
+    from losses.unsup_loss import UnsupLossMultiStage
+    from losses.aug_loss import AugLossMultiStage
+    from losses.homography import inverse_warping
+    import torch.nn.functional as F
+    arrays = {}
+    for tag, (B, V, H, W, seed) in {"a": (1, 3, 64, 80, 0), "b": (2, 4, 48, 64, 1)}.items():
+        imgs = synthetic.images(B, V, H, W, seed)
+        cams = synthetic.proj_matrices(B, V, H, W)
+        depths = loss_depths(B, H, W, seed + 10)
+        inputs = {k: {"depth": d.clone().requires_grad_(True)} for k, d in depths.items()}
+        dlossw = [0.5, 1.0, 2.0]
+        total, scalars = UnsupLossMultiStage()(inputs, imgs, cams, dlossw=dlossw)
+        total.backward()
+        arrays[tag + ":dims"] = np.array([B, V, H, W, seed])
+        arrays[tag + ":total"] = total.detach()
+        for k, d in depths.items():
+            arrays[tag + ":depth:" + k] = d
+            arrays[tag + ":grad:" + k] = inputs[k]["depth"].grad
+        for k, v in scalars.items():
+            arrays[tag + ":" + k] = torch.as_tensor(v).detach()
+        src = F.interpolate(imgs[:, 1], scale_factor=0.5, recompute_scale_factor=True).permute(0, 2, 3, 1)
+        warped, mask = inverse_warping(src, cams["stage2"][:, 0], cams["stage2"][:, 1], depths["stage2"])
+        arrays[tag + ":warped2"] = warped
+        arrays[tag + ":mask2"] = mask
+        # augmentation-consistency loss against a pseudo depth, with a blanked rectangle
+        g = torch.Generator().manual_seed(seed + 20)
+        pseudo = depths["stage3"] + 3.0 * torch.randn(depths["stage3"].shape, generator=g)
+        fmask = torch.ones(B, 3, H, W)
+        fmask[:, :, H // 4:H // 2, W // 8:W // 2] = 0.0
+        inputs = {k: {"depth": d.clone().requires_grad_(True)} for k, d in depths.items()}
+        atotal, ascal = AugLossMultiStage()(inputs, pseudo, None, fmask, dlossw=dlossw)
+        atotal.backward()
+        arrays[tag + ":aug:pseudo"] = pseudo
+        arrays[tag + ":aug:total"] = atotal.detach()
+        for k in depths:
+            arrays[tag + ":aug:grad:" + k] = inputs[k]["depth"].grad
+        for k, v in ascal.items():
+            arrays[tag + ":aug:" + k] = torch.as_tensor(v).detach()
+    save("unsup_loss", **arrays)
+
+
 if __name__ == "__main__":
     if "--only-pfm" in sys.argv:
         pfm_fixture()
     elif "--only-train-grads" in sys.argv:
         train_grads()
+    elif "--only-unsup-loss" in sys.argv:
+        unsup_loss_fixture()
     else:
         main()
         train_grads()
+        unsup_loss_fixture()
