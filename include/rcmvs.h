@@ -260,6 +260,29 @@ int rcmvs_masked_sl1_fwd(const float* pred, const float* target, const float* ma
 int rcmvs_masked_sl1_bwd(const float* pred, const float* target, const float* mask, const double* sums,
                          const float* gout, float* grad_pred, long long n, void* stream);
 
+/* ---- depth-map fusion filter -----------------------------------------------------------
+ * Replaces reproject_with_depth / check_geometric_consistency (eval_rcmvsnet_dtu.py:281-338, eval_rcmvsnet_tanks.py:206-262)
+ * and the per-reference-view body of filter_depth (:369-425) for one reference view and its N source views.
+ * depth_all: every depth map of the scan, (n_views,H,W) fp32, resident on the device; ref_idx / src_idx_host (HOST array of
+ * N ints) index it.  conf (H,W) photometric confidence, img (H,W,3) fp32 in [0,1] (may be NULL together with rgb).
+ * mats (device, doubles, row-major; the reference's float32 numpy results promoted):
+ *   [K_ref^-1 (9)][K_ref (9)][(E_ref^-1)[:3,:4] (12)] then per source view
+ *   [(E_src E_ref^-1)[:3,:4] (12)][K_src (9)][K_src^-1 (9)][(E_ref E_src^-1)[:3,:4] (12)].
+ * Outputs: masks (3,H,W) u8 = photo (conf > prob_thresh), geo (consistent views >= num_consistent), final;
+ * depth_avg (H,W) = (sum of masked reprojected depths + depth_ref) / (consistent views + 1); xyz (H,W,3) world point of every
+ * pixel at depth_avg, cast to fp32; rgb (H,W,3) u8 = (img * 255) truncated.  Optional per-source outputs (NULL to skip):
+ * dbg_depth (N,H,W) the masked reprojected depth, dbg_geo (N,H,W) u8 the per-view consistency mask,
+ * dbg_xy (N,H,W,2) the fp32 sampling position in the source view (the x2d_src / y2d_src the reference returns). */
+#define RCMVS_FUSE_MAX_SRC 16
+int rcmvs_fuse_view(const float* depth_all, int ref_idx, const int* src_idx_host, const float* conf, const float* img,
+                    const double* mats, float prob_thresh, int num_consistent, double dist_thresh, float depth_thresh,
+                    unsigned char* masks, float* depth_avg, float* xyz, unsigned char* rgb,
+                    float* dbg_depth, unsigned char* dbg_geo, float* dbg_xy, int N, int H, int W, void* stream);
+/* numpy's xyz[mask], rgb[mask] (row-major order kept): out_xyz (n,3) / out_rgb (n,3) sized for the worst case;
+ * block_offsets = workspace of ceil(n / 256) + 1 ints whose LAST element receives the number of points kept. */
+int rcmvs_compact_points(const unsigned char* mask, const float* xyz, const unsigned char* rgb, float* out_xyz,
+                         unsigned char* out_rgb, int* block_offsets, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

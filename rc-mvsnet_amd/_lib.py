@@ -16,6 +16,7 @@ _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 _ll = ctypes.c_longlong
+_d = ctypes.c_double
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/rcmvs.h
 SIGNATURES = {
@@ -36,6 +37,8 @@ SIGNATURES = {
     "rcmvs_unsup_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_masked_sl1_fwd": [_p, _p, _p, _p, _ll, _p],
     "rcmvs_masked_sl1_bwd": [_p, _p, _p, _p, _p, _p, _ll, _p],
+    "rcmvs_fuse_view": [_p, _i, _p, _p, _p, _p, _f, _i, _d, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "rcmvs_compact_points": [_p, _p, _p, _p, _p, _p, _ll, _p],
     "rcmvs_bn_stats": [_p, _p, _ll, _i, _p],
     "rcmvs_bn_finalize": [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "rcmvs_bn_bwd_finalize": [_p, _p, _p, _p, _p, _p, _i, _p],

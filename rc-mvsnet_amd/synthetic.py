@@ -182,3 +182,67 @@ def render_randoms(H, W, n_rays=1024, n_samples=128, seed=0):
     eps = torch.randn(n_rays, n_samples, generator=g)
     u = torch.rand(n_rays // 2, n_samples, generator=g)
     return torch.stack((xs, ys)), eps, u
+
+
+# ----------------------------------------------------------------------------------------
+# a multi-view-consistent scan for the fusion filter
+# ----------------------------------------------------------------------------------------
+def _surface(X, Y):
+    return 650.0 + 40.0 * np.sin(X / 80.0) * np.cos(Y / 60.0)
+
+
+def fusion_scan(V=5, H=48, W=64, seed=0, n_src=4):
+    """Depth maps of one smooth world surface seen from V cameras (so that they reproject onto each other), with seeded
+    noise, a band of gross outliers per view, random confidences and 8-bit images.
+    Returns dict: K (V,3,3) f32, E (V,4,4) f32, depth (V,H,W) f32, conf (V,H,W) f32, img (V,H,W,3) uint8, pairs."""
+    Kq, Es = cameras(V, H, W)
+    K = Kq.copy()
+    K[:2] *= 4.0
+    rng = np.random.default_rng(seed)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    rays = np.linalg.inv(K) @ np.stack([xs.ravel(), ys.ravel(), np.ones(H * W)])
+    depth = np.zeros((V, H, W), np.float32)
+    for v in range(V):
+        Ei = np.linalg.inv(Es[v])
+        d = np.full(H * W, 650.0)
+        for _ in range(25):                                   # fixed-point ray / surface intersection
+            Pw = Ei[:3, :3] @ (rays * d) + Ei[:3, 3:4]
+            d = d + (_surface(Pw[0], Pw[1]) - Pw[2])
+        d = d + 0.25 * rng.standard_normal(H * W)
+        d = d.reshape(H, W)
+        d[:, (7 * v) % W:(7 * v) % W + 5] *= 1.06             # a band that fails the 1 % depth test
+        depth[v] = d.astype(np.float32)
+    conf = (0.55 + 0.45 * rng.random((V, H, W))).astype(np.float32)
+    img = (255.0 * rng.random((V, H, W, 3))).astype(np.uint8)
+    pairs = [(v, [(v + k) % V for k in range(1, n_src + 1)]) for v in range(V)]
+    return {"K": np.broadcast_to(K.astype(np.float32), (V, 3, 3)).copy(), "E": np.stack(Es).astype(np.float32),
+            "depth": depth, "conf": conf, "img": img, "pairs": pairs}
+
+
+def write_fusion_scan(scan, pair_folder, out_folder, image_ext="png"):
+    """Lay the scan out the way the reference's filter_depth reads it (eval_rcmvsnet_dtu.py:341-368): pair.txt in
+    pair_folder, cams/ + images/ + depth_est/ + confidence/ under out_folder (= its scan_folder)."""
+    import os
+    from PIL import Image
+    from .data_io import save_pfm
+    for sub in ("cams", "images", "depth_est", "confidence"):
+        os.makedirs(os.path.join(out_folder, sub), exist_ok=True)
+    os.makedirs(pair_folder, exist_ok=True)
+    V = len(scan["depth"])
+    with open(os.path.join(pair_folder, "pair.txt"), "w") as f:
+        f.write("%d\n" % V)
+        for ref, srcs in scan["pairs"]:
+            f.write("%d\n%d %s\n" % (ref, len(srcs), " ".join("%d %.3f" % (s, 100.0 - i) for i, s in enumerate(srcs))))
+    for v in range(V):
+        with open(os.path.join(out_folder, "cams", "{:0>8}_cam.txt".format(v)), "w") as f:
+            f.write("extrinsic\n")
+            for row in scan["E"][v]:
+                f.write(" ".join(repr(float(x)) for x in row) + "\n")
+            f.write("\nintrinsic\n")
+            for row in scan["K"][v]:
+                f.write(" ".join(repr(float(x)) for x in row) + "\n")
+            f.write("\n425.0 2.5\n")
+        # the reference opens '<view>.jpg'; PNG bytes under that name keep the fixture lossless (PIL sniffs the content)
+        Image.fromarray(scan["img"][v]).save(os.path.join(out_folder, "images", "{:0>8}.jpg".format(v)), format=image_ext)
+        save_pfm(os.path.join(out_folder, "depth_est", "{:0>8}.pfm".format(v)), scan["depth"][v])
+        save_pfm(os.path.join(out_folder, "confidence", "{:0>8}.pfm".format(v)), scan["conf"][v])

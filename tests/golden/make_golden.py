@@ -340,6 +340,70 @@ def unsup_loss_fixture():
     save("unsup_loss", **arrays)
 
 
+def import_reference_eval():
+    """Import eval_rcmvsnet_dtu.py as a module (its argparse runs at import: give it an empty command line).  Absent
+    third-party packages are stubbed: cv2.remap -> the oracle's restatement of OpenCV's published INTER_LINEAR remap (the one
+    step of the fusion filter that is therefore NOT pinned by the reference, see oracle/fusion.py), plyfile -> a recorder of
+    the vertex array handed to PlyData (the reference's own code builds that array)."""
+    import importlib
+    import_reference()
+    from oracle import fusion as ofu
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_LINEAR = 1
+    cv2.remap = lambda src, mx, my, interpolation=1: ofu.remap_linear(src, mx, my)
+    ply = types.ModuleType("plyfile")
+    captured = {}
+
+    class PlyElement:
+        @staticmethod
+        def describe(arr, name):
+            captured[name] = arr
+            return arr
+
+    class PlyData:
+        def __init__(self, els):
+            self.els = els
+
+        def write(self, fn):
+            captured["filename"] = fn
+
+    ply.PlyElement, ply.PlyData = PlyElement, PlyData
+    sys.modules["plyfile"] = ply
+    sys.modules["torchvision"].transforms.Compose = lambda *a, **k: None
+    argv, sys.argv = sys.argv, ["eval_rcmvsnet_dtu.py"]
+    try:
+        mod = importlib.import_module("eval_rcmvsnet_dtu")
+    finally:
+        sys.argv = argv
+    return mod, captured
+
+
+def fusion_fixture():
+    """The reference's check_geometric_consistency and filter_depth (eval_rcmvsnet_dtu.py:324-446) on a small synthetic scan
+    written to disk in its own layout: per-pair masks / reprojected depths, the three mask images of every reference view
+    and the fused vertex array."""
+    import tempfile
+    from PIL import Image
+    mod, captured = import_reference_eval()
+    scan = synthetic.fusion_scan(V=5, H=48, W=64, seed=0, n_src=4)
+    arrays = {"dims": np.array([5, 48, 64, 0, 4]), "thresholds": np.array([0.8, 3, 0.5, 0.01])}
+    m, back, xs, ys = mod.check_geometric_consistency(scan["depth"][0], scan["K"][0], scan["E"][0], scan["depth"][2], scan["K"][2],
+                                                      scan["E"][2], 0.5, 0.01)
+    arrays.update({"pair02:mask": m, "pair02:depth": back, "pair02:x_src": xs, "pair02:y_src": ys})
+    with tempfile.TemporaryDirectory() as d:
+        pair_folder, out_folder = os.path.join(d, "data", "scan1"), os.path.join(d, "out", "scan1")
+        synthetic.write_fusion_scan(scan, pair_folder, out_folder)
+        mod.filter_depth(pair_folder, out_folder, out_folder, os.path.join(d, "out", "fused.ply"), prob_threshold=0.8, num_consistent=3,
+                         img_dist_thresh=0.5, depth_thresh=0.01)
+        for v in range(5):
+            for kind in ("photo", "geo", "final"):
+                arrays["mask:%d:%s" % (v, kind)] = np.array(Image.open(os.path.join(out_folder, "mask", "{:0>8}_{}.png".format(v, kind)))) > 0
+    vert = captured["vertex"]
+    arrays["xyz"] = np.stack([vert["x"], vert["y"], vert["z"]], 1)
+    arrays["rgb"] = np.stack([vert["red"], vert["green"], vert["blue"]], 1)
+    save("fusion", **arrays)
+
+
 if __name__ == "__main__":
     if "--only-pfm" in sys.argv:
         pfm_fixture()
@@ -347,7 +411,10 @@ if __name__ == "__main__":
         train_grads()
     elif "--only-unsup-loss" in sys.argv:
         unsup_loss_fixture()
+    elif "--only-fusion" in sys.argv:
+        fusion_fixture()
     else:
         main()
         train_grads()
         unsup_loss_fixture()
+        fusion_fixture()

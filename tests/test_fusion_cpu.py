@@ -1,0 +1,158 @@
+"""Depth-map fusion filter and the scan file formats (rank 4) without a GPU: the oracle
+against the reference's golden outputs, the shared per-pixel arithmetic of csrc/fusion_math.h (compiled with g++ into a loop
+harness) against the oracle, and the host-side parsers / writers."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion as O
+from rc_mvsnet_amd import _lib, fusion, scan_io, synthetic
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "fusion.npz"))
+PROB, NCONS, DIST, DEPTH = 0.8, 3, 0.5, 0.01
+
+
+def scan():
+    V, H, W, seed, n_src = [int(x) for x in GOLD["dims"]]
+    return synthetic.fusion_scan(V=V, H=H, W=W, seed=seed, n_src=n_src)
+
+
+def test_oracle_matches_reference_golden():
+    s = scan()
+    m, back, xs, ys = O.check_geometric_consistency(s["depth"][0], s["K"][0], s["E"][0], s["depth"][2], s["K"][2], s["E"][2], DIST, DEPTH)
+    assert np.array_equal(m, GOLD["pair02:mask"])
+    assert np.array_equal(back, GOLD["pair02:depth"])
+    assert np.array_equal(xs, GOLD["pair02:x_src"]) and np.array_equal(ys, GOLD["pair02:y_src"])
+    pts, cols = [], []
+    for ref, srcs in s["pairs"]:
+        r = O.fuse_view(s["depth"][ref], s["conf"][ref], s["img"][ref].astype(np.float32) / 255.0, s["K"][ref], s["E"][ref],
+                        [s["depth"][i] for i in srcs], [s["K"][i] for i in srcs], [s["E"][i] for i in srcs], PROB, NCONS, DIST, DEPTH)
+        for kind in ("photo", "geo", "final"):
+            assert np.array_equal(r[kind], GOLD["mask:%d:%s" % (ref, kind)]), (ref, kind)
+        pts.append(r["xyz"])
+        cols.append(r["rgb"])
+    assert np.array_equal(np.concatenate(pts), GOLD["xyz"])
+    assert np.array_equal(np.concatenate(cols), GOLD["rgb"])
+
+
+def test_remap_linear_properties():
+    """The restated cv2.remap: integer positions return the pixel, positions are quantised to 1/32 pixel, taps outside the
+    image contribute 0, NaN positions give 0."""
+    g = np.random.default_rng(0)
+    img = g.random((6, 7)).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(6, dtype=np.float32), np.arange(7, dtype=np.float32), indexing="ij")
+    assert np.array_equal(O.remap_linear(img, xx, yy), img)
+    half = O.remap_linear(img, xx[:, :-1] + 0.5, yy[:, :-1])
+    assert np.allclose(half, 0.5 * (img[:, :-1] + img[:, 1:]), atol=1e-7)
+    assert np.array_equal(O.remap_linear(img, xx + 0.01, yy), img)                          # 0.01 px rounds to 0/32
+    edge = O.remap_linear(img, np.full((1, 1), -0.5, np.float32), np.zeros((1, 1), np.float32))
+    assert np.allclose(edge, 0.5 * img[0, 0])
+    bad = O.remap_linear(img, np.array([[np.nan, 1e30, -3.0]], np.float32), np.zeros((1, 3), np.float32))
+    assert np.array_equal(bad, np.zeros((1, 3), np.float32))
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("fu") / "fu_harness.so")
+    subprocess.run(["g++", "-O2", "-w", "-ffp-contract=off", "-shared", "-fPIC", "-o", out,
+                    os.path.join(HERE, "harness", "fusion_harness.cpp")], check=True)
+    return ctypes.CDLL(out)
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(0)
+
+
+def test_kernel_arithmetic_matches_oracle(harness):
+    s = scan()
+    V, H, W = s["depth"].shape
+    depth_all = np.ascontiguousarray(s["depth"])
+    total_flips = 0
+    for ref, srcs in s["pairs"]:
+        N = len(srcs)
+        mats = fusion.fusion_matrices(s["K"][ref], s["E"][ref], [s["K"][i] for i in srcs], [s["E"][i] for i in srcs])
+        img = np.ascontiguousarray(s["img"][ref].astype(np.float32) / 255.0)
+        masks, avg = np.empty((3, H, W), np.uint8), np.empty((H, W), np.float32)
+        xyz, rgb = np.empty((H, W, 3), np.float32), np.empty((H, W, 3), np.uint8)
+        dd, dg, dxy = np.empty((N, H, W), np.float32), np.empty((N, H, W), np.uint8), np.empty((N, H, W, 2), np.float32)
+        idx = np.array(srcs, np.int32)
+        harness.h_fuse_view(_p(depth_all), ref, _p(idx), _p(np.ascontiguousarray(s["conf"][ref])), _p(img), _p(mats),
+                            ctypes.c_float(PROB), NCONS, ctypes.c_double(DIST), ctypes.c_float(DEPTH),
+                            _p(masks), _p(avg), _p(xyz), _p(rgb), _p(dd), _p(dg), _p(dxy), N, H, W)
+        r = O.fuse_view(s["depth"][ref], s["conf"][ref], img, s["K"][ref], s["E"][ref], [s["depth"][i] for i in srcs],
+                        [s["K"][i] for i in srcs], [s["E"][i] for i in srcs], PROB, NCONS, DIST, DEPTH)
+        assert np.array_equal(masks[0].astype(bool), r["photo"])
+        flips = int((masks[1].astype(bool) != r["geo"]).sum())
+        total_flips += flips
+        same = masks[2].astype(bool) == r["final"]
+        assert np.allclose(avg[same], r["depth_avg"].astype(np.float32)[same], rtol=1e-6)
+        both = masks[2].astype(bool) & r["final"]
+        want = np.zeros((H, W, 3), np.float32)
+        want[r["final"]] = r["xyz"]
+        assert np.allclose(xyz[both], want[both], rtol=1e-5, atol=1e-3)
+        wrgb = np.zeros((H, W, 3), np.uint8)
+        wrgb[r["final"]] = r["rgb"]
+        assert np.array_equal(rgb[both], wrgb[both])
+        for n, src in enumerate(srcs):
+            m, back, xs, ys = O.check_geometric_consistency(s["depth"][ref], s["K"][ref], s["E"][ref], s["depth"][src], s["K"][src],
+                                                            s["E"][src], DIST, DEPTH)
+            assert np.allclose(dxy[n, ..., 0], xs, rtol=1e-6, atol=1e-4) and np.allclose(dxy[n, ..., 1], ys, rtol=1e-6, atol=1e-4)
+            agree = dg[n].astype(bool) == m
+            assert agree.mean() > 0.995
+            assert np.allclose(dd[n][agree], back[agree], rtol=1e-6, atol=1e-3)
+    assert total_flips <= 3                                             # threshold knife edges only
+
+
+def test_scan_files_round_trip(tmp_path):
+    s = scan()
+    pair_folder, out_folder = str(tmp_path / "data" / "scan1"), str(tmp_path / "out" / "scan1")
+    synthetic.write_fusion_scan(s, pair_folder, out_folder)
+    assert scan_io.read_pair_file(os.path.join(pair_folder, "pair.txt")) == s["pairs"]
+    K, E = scan_io.read_camera_parameters(os.path.join(out_folder, "cams", "{:0>8}_cam.txt".format(3)))
+    assert K.dtype == np.float32 and E.dtype == np.float32
+    assert np.array_equal(K, s["K"][3]) and np.array_equal(E, s["E"][3])
+    Kq, E2, dmin, dint = scan_io.read_cam_file(os.path.join(out_folder, "cams", "{:0>8}_cam.txt".format(3)), interval_scale=1.06)
+    assert np.allclose(Kq[:2] * 4.0, s["K"][3][:2]) and np.array_equal(Kq[2], s["K"][3][2]) and np.array_equal(E2, E)
+    assert dmin == 425.0 and abs(dint - 2.5 * 1.06) < 1e-12
+    img = scan_io.read_img(os.path.join(out_folder, "images", "{:0>8}.jpg".format(1)))
+    assert img.dtype == np.float32 and np.array_equal((img * 255).astype(np.uint8), s["img"][1])
+    # a camera file that carries a plane count rescales the interval to ndepths planes (datasets/dtu_test.py:98-101)
+    cam = np.zeros((2, 4, 4), np.float32)
+    cam[0], cam[1, :3, :3], cam[1, 3] = E, K, [425.0, 2.5, 256, 1065.0]
+    path = str(tmp_path / "cam.txt")
+    scan_io.write_cam(path, cam)
+    K3, E3 = scan_io.read_camera_parameters(path)
+    assert np.array_equal(K3, K) and np.array_equal(E3, E)
+    _, _, dmin, dint = scan_io.read_cam_file(path, interval_scale=1.0, ndepths=192)
+    assert dmin == 425.0 and abs(dint - 256 * 2.5 / 192) < 1e-12
+    m = np.zeros((4, 5), bool)
+    m[1, 2] = True
+    scan_io.save_mask(str(tmp_path / "m.png"), m)
+    assert np.array_equal(scan_io.read_mask(str(tmp_path / "m.png")), m)
+    with pytest.raises(TypeError):
+        scan_io.save_mask(str(tmp_path / "m2.png"), m.astype(np.uint8))
+
+
+def test_ply_bytes():
+    xyz, rgb = GOLD["xyz"][:100], GOLD["rgb"][:100]
+    b = fusion.ply_bytes(xyz, rgb)
+    assert b == O.ply_bytes(xyz, rgb)
+    head, body = b.split(b"end_header\n", 1)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 100\nproperty float x\n") and len(body) == 100 * 15
+    rec = np.frombuffer(body, dtype=[("p", "<f4", 3), ("c", "u1", 3)])
+    assert np.array_equal(rec["p"], xyz) and np.array_equal(rec["c"], rgb)
+
+
+def test_fusion_fails_loudly_without_a_gpu(tmp_path):
+    s = scan()
+    with pytest.raises((_lib.RcmvsError, RuntimeError, AssertionError)):
+        fusion.check_geometric_consistency(s["depth"][0], s["K"][0], s["E"][0], s["depth"][1], s["K"][1], s["E"][1], DIST, DEPTH, device="cpu")
+    mats = fusion.fusion_matrices(s["K"][0], s["E"][0], [s["K"][1]], [s["E"][1]])
+    assert mats.dtype == np.float64 and mats.shape == (72,)
+    with pytest.raises(_lib.RcmvsError):
+        fusion.fuse_view(torch.zeros(2, 4, 4), 0, list(range(17)), torch.zeros(4, 4), None, torch.zeros(72, dtype=torch.float64), 0.8, 3, 0.5, 0.01)

@@ -1,0 +1,52 @@
+"""Fusion filter at the reference's DTU evaluation shape (49 views of 1184 x 1600, 10 source views per reference view): ms per
+reference view on the HIP path (fuse + compaction, maps resident) beside the oracle (the reference's numpy path) on the CPU."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from oracle import fusion as O                           # noqa: E402
+from rc_mvsnet_amd import _lib, fusion, synthetic        # noqa: E402
+
+
+def main():
+    _lib.load()
+    dev = "cuda:0"
+    V, H, W, n_src = 11, 1184, 1600, 10
+    s = synthetic.fusion_scan(V=V, H=H, W=W, seed=0, n_src=n_src)
+    depth_all = torch.from_numpy(s["depth"]).to(dev)
+    jobs = []
+    for ref, srcs in s["pairs"]:
+        mats = torch.from_numpy(fusion.fusion_matrices(s["K"][ref], s["E"][ref], [s["K"][i] for i in srcs], [s["E"][i] for i in srcs])).to(dev)
+        jobs.append((ref, srcs, torch.from_numpy(s["conf"][ref]).to(dev), torch.from_numpy(s["img"][ref].astype(np.float32) / 255.0).to(dev), mats))
+
+    def run():
+        n = 0
+        for ref, srcs, conf, img, mats in jobs:
+            r = fusion.fuse_view(depth_all, ref, srcs, conf, img, mats, 0.8, 3, 0.5, 0.01)
+            xyz, rgb = fusion.compact_points(r["masks"][2], r["xyz"], r["rgb"])
+            n += len(xyz)
+        return n
+
+    run()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        n = run()
+    torch.cuda.synchronize()
+    hip_ms = (time.perf_counter() - t) * 1e3 / (reps * len(jobs))
+    ref, srcs = s["pairs"][0]
+    t = time.perf_counter()
+    O.fuse_view(s["depth"][ref], s["conf"][ref], s["img"][ref].astype(np.float32) / 255.0, s["K"][ref], s["E"][ref],
+                [s["depth"][i] for i in srcs], [s["K"][i] for i in srcs], [s["E"][i] for i in srcs], 0.8, 3, 0.5, 0.01)
+    cpu_ms = (time.perf_counter() - t) * 1e3
+    px = H * W
+    print(f"fusion, {n_src} source views, {H}x{W}: HIP {hip_ms:.3f} ms per reference view ({px * n_src / hip_ms / 1e6:.1f} G pixel-pairs/s, "
+          f"{n // len(jobs)} points kept) | oracle on CPU {cpu_ms:.0f} ms per reference view")
+
+
+if __name__ == "__main__":
+    main()
