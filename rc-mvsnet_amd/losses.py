@@ -27,16 +27,19 @@ MAX_VIEWS = 8     # RCMVS_UNSUP_MAX_VIEWS
 
 # ---------------------------------------------------------------------------------------------------------- geometry
 def inverse_warp_coefs(ref_cam, src_cam):
-    """(B,12) fp32: {M row-major, t} with p = M (x,y,1)^T d + t for the pair of cameras (B,2,4,4)
-    (homography.py:9-56 composed in fp64; the projection keeps the REFERENCE view's intrinsics, as the reference does)."""
-    R_l, R_r = ref_cam[:, 0, :3, :3].double(), src_cam[:, 0, :3, :3].double()
-    t_l, t_r = ref_cam[:, 0, :3, 3:4].double(), src_cam[:, 0, :3, 3:4].double()
-    K = ref_cam[:, 1, :3, :3].double()
-    R_rel = R_r @ R_l.transpose(1, 2)
-    t_rel = t_r - R_rel @ t_l
+    """{M row-major, t} fp32 with p = M (x,y,1)^T d + t (homography.py:9-56 composed in fp64; the projection keeps the
+    REFERENCE view's intrinsics, as the reference does).  ref_cam (B,2,4,4) with src_cam (B,2,4,4) -> (B,12), or with
+    src_cam (B,Vs,2,4,4) -> (Vs,B,12) for all source views in one batch of small matrix products."""
+    many = src_cam.dim() == 5
+    src = (src_cam if many else src_cam.unsqueeze(1)).double()
+    ref = ref_cam.double().unsqueeze(1)
+    R_l, t_l, K = ref[:, :, 0, :3, :3], ref[:, :, 0, :3, 3:4], ref[:, :, 1, :3, :3]
+    R_rel = src[:, :, 0, :3, :3] @ R_l.transpose(-1, -2)
+    t_rel = src[:, :, 0, :3, 3:4] - R_rel @ t_l
     M = K @ R_rel @ torch.linalg.inv(K)
     t = K @ t_rel
-    return torch.cat([M.reshape(-1, 9), t.reshape(-1, 3)], 1).float().contiguous()
+    coef = torch.cat([M.flatten(-2), t.flatten(-2)], -1).float()          # (B,Vs,12)
+    return coef.transpose(0, 1).contiguous() if many else coef[:, 0].contiguous()
 
 
 def _nearest_index(n_in, n_out, device):
@@ -127,8 +130,8 @@ class UnSupLoss(nn.Module):
         V = imgs.shape[1]
         assert cams.shape[1] == V, "Different number of images and projection matrices"
         ref = stage_image(imgs[:, 0], stage_idx)
-        srcs = torch.stack([stage_image(imgs[:, v], stage_idx) for v in range(1, V)])
-        coef = torch.stack([inverse_warp_coefs(cams[:, 0], cams[:, v]) for v in range(1, V)])
+        srcs = nearest_reduce(imgs[:, 1:], (4, 2, 1)[stage_idx]).permute(1, 0, 3, 4, 2).contiguous()      # (Vs,B,h,w,3)
+        coef = inverse_warp_coefs(cams[:, 0], cams[:, 1:])
         terms = UnsupStageLossFn.apply(depth, ref, srcs, coef)
         self.reconstr_loss, self.ssim_loss, self.smooth_loss = terms[0], terms[1], terms[2]
         self.unsup_loss = 12 * self.reconstr_loss + 6 * self.ssim_loss + 0.18 * self.smooth_loss
