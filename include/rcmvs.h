@@ -283,6 +283,14 @@ int rcmvs_fuse_view(const float* depth_all, int ref_idx, const int* src_idx_host
 int rcmvs_compact_points(const unsigned char* mask, const float* xyz, const unsigned char* rgb, float* out_xyz,
                          unsigned char* out_rgb, int* block_offsets, long long n, void* stream);
 
+/* ---- evaluation loader: image preparation ------------------------------------------------
+ * Replaces read_img (/255), scale_mvs_input's cv2.resize and ToTensor + Normalize of datasets/dtu_test.py:78-81,107-112,
+ * 127-145 (same in datasets/tanks.py): src = decoded image (H,W,3) uint8 on the device -> out (3,h,w) fp32 =
+ * (bilinear_resize(src / 255) - mean[c]) / std[c] with cv2.resize's INTER_LINEAR coordinate rule (a copy when the size is
+ * unchanged).  mean_host / std_host: HOST arrays of 3 floats. */
+int rcmvs_prepare_image(const unsigned char* src, float* out, int H, int W, int h, int w, const float* mean_host,
+                        const float* std_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,10 +2,14 @@
 ``CascadeMVSNet_eval`` over (scan, reference view) items and write ``<outdir>/<scan>/depth_est/<view:08d>.pfm`` and
 ``.../confidence/<view:08d>.pfm`` -- sharded one process per GPU with no collective.
 
-The datasets are out of scope, so the items here are seeded synthetic DTU-shaped scenes; a loader
-yielding the same ``(imgs, proj_matrices, depth_values)`` triple drops in through ``make_sample``.
+Two item sources: seeded synthetic DTU-shaped scenes (default), or real MVSNet-style scan folders through
+``rc_mvsnet_amd.mvs_dataset.MVSDataset`` (``--testpath`` + ``--testlist``), in which case the reference view's camera and image
+are written next to the depth maps as the reference does (eval_rcmvsnet_dtu.py:238-253) and ``--filter`` runs the fusion step
+(``rc_mvsnet_amd.fusion.filter_depth``, the reference's step 2) on this rank's scans.  With real data the shard unit is the scan,
+so that a rank owns every depth map its fusion needs.
 
     python -m rc_mvsnet_amd.eval_driver --outdir out --scans 4 --views 3 --height 512 --width 640
+    python -m rc_mvsnet_amd.eval_driver --outdir out --testpath /data/dtu_test --testlist lists/dtu/test.txt --loadckpt model.ckpt --filter
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m rc_mvsnet_amd.eval_driver --outdir out ...
 """
 import argparse
@@ -49,8 +53,76 @@ def run(model, items, make_sample, outdir, device):
     return times
 
 
+def save_reference_view(outdir, filename, cam, img):
+    """cams/<view>_cam.txt and images/<view>.jpg of the reference view (eval_rcmvsnet_dtu.py:203-253): cam (2,4,4) at the last
+    stage's scale, img (3,h,w) normalised -- de-normalised with the reference's constants (its blue std is 0.255, kept)."""
+    import numpy as np
+    from PIL import Image
+    from .scan_io import write_cam
+    cam_path = os.path.join(outdir, filename.format("cams", "_cam.txt"))
+    img_path = os.path.join(outdir, filename.format("images", ".jpg"))
+    for path in (cam_path, img_path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+    write_cam(cam_path, cam)
+    mean = torch.tensor([-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.255], device=img.device).view(3, 1, 1)
+    std = torch.tensor([1 / 0.229, 1 / 0.224, 1 / 0.255], device=img.device).view(3, 1, 1)
+    rgb = ((img - mean) / std).permute(1, 2, 0).mul(255).clamp(0, 255).to(torch.uint8).cpu().numpy()
+    Image.fromarray(np.ascontiguousarray(rgb)).save(img_path, format="JPEG", quality=95)
+
+
+def run_scans(model, args, device, rank, world):
+    """Real data: this rank's scans through the loader, the model, the writers and (``--filter``) the fusion step."""
+    from . import fusion
+    from .mvs_dataset import MVSDataset
+    with open(args.testlist) as f:
+        scans = [line.rstrip() for line in f.readlines() if line.strip()]
+    mine = shard_items(scans, rank, world)
+    nstage = len(args.ndepths.split(","))
+    times = []
+    for scan in mine:
+        ds = MVSDataset(args.testpath, [scan], "test", args.num_view, args.numdepth, args.interval_scale, device=device,
+                        max_h=args.max_h, max_w=args.max_w)
+        with torch.no_grad():
+            for i in range(len(ds)):
+                item = ds[i]
+                imgs = item["imgs"].unsqueeze(0)
+                proj = {k: torch.from_numpy(v).unsqueeze(0).to(device) for k, v in item["proj_matrices"].items()}
+                dv = torch.from_numpy(item["depth_values"]).unsqueeze(0).to(device)
+                t0 = time.perf_counter()
+                out = model(imgs, proj, dv)
+                torch.cuda.synchronize(device)
+                times.append(time.perf_counter() - t0)
+                name = item["filename"]
+                for kind, t in (("depth_est", out["depth"][0]), ("confidence", out["photometric_confidence"][0])):
+                    path = os.path.join(args.outdir, name.format(kind, ".pfm"))
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    save_pfm(path, t.float().cpu().numpy())
+                save_reference_view(args.outdir, name, item["proj_matrices"]["stage{}".format(nstage)][0], item["imgs"][0])
+        if args.filter:
+            folder = os.path.join(args.outdir, scan)
+            fusion.filter_depth(os.path.join(args.testpath, scan), folder, folder, os.path.join(args.outdir, scan + ".ply"),
+                                args.prob_thres, args.num_consistency, args.img_dist_thres, args.depth_thres,
+                                num_stage=nstage, device=str(device))
+    if times:
+        warm = times[1:] or times
+        print(f"rank {rank}/{world}: {len(mine)} of {len(scans)} scans, {len(times)} reference views, "
+              f"{1.0 / (sum(warm) / len(warm)):.1f} ref-views/s (model time), outputs under {args.outdir}")
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--testpath", default=None, help="folder of MVSNet-style scans (real data instead of synthetic scenes)")
+    ap.add_argument("--testlist", default=None, help="text file, one scan name per line")
+    ap.add_argument("--num_view", type=int, default=5)
+    ap.add_argument("--numdepth", type=int, default=192)
+    ap.add_argument("--interval_scale", type=float, default=1.06)
+    ap.add_argument("--max_h", type=int, default=1200)
+    ap.add_argument("--max_w", type=int, default=1600)
+    ap.add_argument("--filter", action="store_true", help="fuse each scan's depth maps into <outdir>/<scan>.ply afterwards")
+    ap.add_argument("--prob_thres", type=float, default=0.8)
+    ap.add_argument("--num_consistency", type=int, default=3)
+    ap.add_argument("--img_dist_thres", type=float, default=0.5)
+    ap.add_argument("--depth_thres", type=float, default=0.01)
     ap.add_argument("--outdir", required=True)
     ap.add_argument("--scans", type=int, default=2)
     ap.add_argument("--ref-views", type=int, default=2, help="reference views per scan")
@@ -73,6 +145,11 @@ def main(argv=None):
     sd = torch.load(args.loadckpt, map_location="cpu")["model"] if args.loadckpt else synthetic.cascade_state_dict(0)
     model.load_state_dict(sd, strict=True)
     model = model.to(device).eval()
+
+    if args.testpath:
+        if device.type != "cuda":
+            raise SystemExit("eval_driver: real data needs a GPU (the loader's image preparation has no CPU fallback)")
+        return run_scans(model, args, device, rank, world)
 
     items = [("scan{}".format(s + 1), v) for s in range(args.scans) for v in range(args.ref_views)]
     mine = shard_items(items, rank, world)

@@ -1,0 +1,111 @@
+"""Evaluation loader for MVSNet-style scan folders: the test-mode ``MVSDataset`` of
+datasets/dtu_test.py:11-229 with the per-image work moved to the GPU.
+
+Same constructor arguments, item order and item dict (``imgs`` (V,3,h,w), ``proj_matrices`` {stage1..3: (V,2,4,4)},
+``depth_values`` (ndepths,), ``filename``) as the reference, so ``eval_rcmvsnet_dtu.py:174-197`` iterates it unchanged.  The
+host parses the text files and decodes the JPEG; ``/255``, the ``cv2.resize`` of ``scale_mvs_input`` / the common-size resize,
+``ToTensor`` and ``Normalize`` are one kernel per image (``rcmvs_prepare_image``) on the uploaded bytes -- that work costs the
+reference's single loader worker ~10x the network's time per item.  ``imgs`` is therefore a CUDA tensor; everything else is
+numpy like the reference's.  No CPU fallback: ``device`` must be a GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import _lib, scan_io
+from .ops import _chk, _stream
+
+MEAN = (0.485, 0.456, 0.406)      # transforms.Normalize of datasets/dtu_test.py:78-81
+STD = (0.229, 0.224, 0.225)
+
+
+def scaled_size(h, w, max_h, max_w, base=32):
+    """Target (new_h, new_w) of scale_mvs_input (datasets/dtu_test.py:127-137): fit inside (max_h, max_w), then round both
+    sides down to a multiple of ``base``.  Floats, as the reference computes them."""
+    if h > max_h or w > max_w:
+        scale = 1.0 * max_h / h
+        if scale * w > max_w:
+            scale = 1.0 * max_w / w
+        return scale * h // base * base, scale * w // base * base
+    return 1.0 * h // base * base, 1.0 * w // base * base
+
+
+def prepare_image(img_u8, out_hw, device):
+    """Decoded image (H,W,3) uint8 numpy -> (3,h,w) fp32 CUDA tensor, resized and normalised on the device."""
+    if img_u8.dtype != np.uint8 or img_u8.ndim != 3 or img_u8.shape[2] != 3:
+        raise _lib.RcmvsError(f"prepare_image: expected an (H,W,3) uint8 image, got {img_u8.dtype} {img_u8.shape}")
+    H, W = img_u8.shape[:2]
+    h, w = int(out_hw[0]), int(out_hw[1])
+    src = torch.from_numpy(np.ascontiguousarray(img_u8)).to(device, non_blocking=True)
+    out = torch.empty((3, h, w), device=device, dtype=torch.float32)
+    mean, std = (ctypes.c_float * 3)(*MEAN), (ctypes.c_float * 3)(*STD)
+    _lib.check(_lib.load().rcmvs_prepare_image(_chk(src, "src", torch.uint8), _chk(out, "out"), H, W, h, w,
+                                               ctypes.cast(mean, ctypes.c_void_p), ctypes.cast(std, ctypes.c_void_p), _stream()),
+               "prepare_image")
+    return out
+
+
+class MVSDataset(torch.utils.data.Dataset):
+    def __init__(self, datapath, listfile, mode, nviews, ndepths=192, interval_scale=1.06, device="cuda:0", **kwargs):
+        super().__init__()
+        assert mode == "test"
+        self.datapath, self.listfile, self.mode, self.nviews, self.ndepths = datapath, listfile, mode, nviews, ndepths
+        self.max_h, self.max_w = kwargs["max_h"], kwargs["max_w"]
+        self.fix_res = kwargs.get("fix_res", False)      # accepted for signature parity; see __getitem__ on mixed sizes
+        self.device = torch.device(device)
+        self.interval_scale = {scan: (interval_scale if isinstance(interval_scale, float) else interval_scale[scan]) for scan in listfile}
+        self.metas = self.build_list()
+
+    def build_list(self):
+        """[(scan, ref_view, src_views, scan)]; short source lists are padded with their first entry (dtu_test.py:28-57)."""
+        metas = []
+        for scan in self.listfile:
+            for ref, srcs in scan_io.read_pair_file(os.path.join(self.datapath, "{}/pair.txt".format(scan))):
+                if len(srcs) < self.nviews:
+                    srcs = srcs + [srcs[0]] * (self.nviews - len(srcs))
+                metas.append((scan, ref, srcs, scan))
+        return metas
+
+    def __len__(self):
+        return len(self.metas)
+
+    def __getitem__(self, idx):
+        scan, ref_view, src_views, scene = self.metas[idx]
+        view_ids = [ref_view] + src_views[:self.nviews - 1]
+        imgs, projs, depth_values = [], [], None
+        for i, vid in enumerate(view_ids):
+            name = os.path.join(self.datapath, "{}/images_post/{:0>8}.jpg".format(scan, vid))
+            if not os.path.exists(name):
+                name = os.path.join(self.datapath, "{}/images/{:0>8}.jpg".format(scan, vid))
+            K, E, depth_min, depth_interval = scan_io.read_cam_file(
+                os.path.join(self.datapath, "{}/cams/{:0>8}_cam.txt".format(scan, vid)), self.interval_scale[scene], self.ndepths)
+            raw = np.array(Image.open(name), dtype=np.uint8)
+            h0, w0 = raw.shape[:2]
+            new_h, new_w = scaled_size(h0, w0, self.max_h, self.max_w)
+            K[0, :] *= 1.0 * new_w / w0
+            K[1, :] *= 1.0 * new_h / h0
+            c_h, c_w = int(new_h), int(new_w)
+            if i == 0:
+                size = (c_h, c_w)
+            elif (c_h, c_w) != size:
+                # dtu_test.py:171-189 has a "resize to the standard size" branch, but it measures the already channels-first
+                # tensor ((3, h) instead of (h, w)) and would hand that tensor to cv2.resize: views of one item must agree
+                raise _lib.RcmvsError(f"view {vid} of {scan}: size {(c_h, c_w)} differs from the reference view's {size}")
+            imgs.append(prepare_image(raw, (c_h, c_w), self.device))
+            p = np.zeros((2, 4, 4), dtype=np.float32)
+            p[0, :4, :4] = E
+            p[1, :3, :3] = K
+            projs.append(p)
+            if i == 0:
+                depth_values = np.arange(depth_min, depth_interval * (self.ndepths - 0.5) + depth_min, depth_interval, dtype=np.float32)
+        proj = np.stack(projs)
+        stages = {"stage1": proj}
+        for key, mul in (("stage2", 2), ("stage3", 4)):
+            q = proj.copy()
+            q[:, 1, :2, :] = proj[:, 1, :2, :] * mul
+            stages[key] = q
+        return {"imgs": torch.stack(imgs), "proj_matrices": stages, "depth_values": depth_values,
+                "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}

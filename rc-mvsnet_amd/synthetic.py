@@ -219,7 +219,7 @@ def fusion_scan(V=5, H=48, W=64, seed=0, n_src=4):
             "depth": depth, "conf": conf, "img": img, "pairs": pairs}
 
 
-def write_fusion_scan(scan, pair_folder, out_folder, image_ext="png"):
+def write_fusion_scan(scan, pair_folder, out_folder, image_ext="png", depth_line="425.0 2.5"):
     """Lay the scan out the way the reference's filter_depth reads it (eval_rcmvsnet_dtu.py:341-368): pair.txt in
     pair_folder, cams/ + images/ + depth_est/ + confidence/ under out_folder (= its scan_folder)."""
     import os
@@ -241,7 +241,7 @@ def write_fusion_scan(scan, pair_folder, out_folder, image_ext="png"):
             f.write("\nintrinsic\n")
             for row in scan["K"][v]:
                 f.write(" ".join(repr(float(x)) for x in row) + "\n")
-            f.write("\n425.0 2.5\n")
+            f.write("\n" + depth_line + "\n")
         # the reference opens '<view>.jpg'; PNG bytes under that name keep the fixture lossless (PIL sniffs the content)
         Image.fromarray(scan["img"][v]).save(os.path.join(out_folder, "images", "{:0>8}.jpg".format(v)), format=image_ext)
         save_pfm(os.path.join(out_folder, "depth_est", "{:0>8}.pfm".format(v)), scan["depth"][v])

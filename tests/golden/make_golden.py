@@ -404,6 +404,60 @@ def fusion_fixture():
     save("fusion", **arrays)
 
 
+def dataset_fixture():
+    """Items of the reference's test-mode MVSDataset (datasets/dtu_test.py) on a small synthetic scan folder.  cv2.resize and
+    torchvision's ToTensor / Normalize are absent from this image: the reference gets the oracle's restatements of them
+    (oracle/dataset.py), so the golden pins the reference's item assembly -- file parsing, target size, intrinsics scaling,
+    depth values, stage matrices, view padding, filename -- around an unpinned resize."""
+    import importlib
+    import tempfile
+    import_reference()
+    from oracle import dataset as ods
+    cv2 = sys.modules["cv2"]
+    cv2.resize = lambda img, dsize: ods.resize_linear(img, dsize)
+    tv = sys.modules["torchvision"].transforms
+
+    class ToTensor:
+        def __call__(self, a):
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(a).transpose(2, 0, 1)))
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.mean) / self.std
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    tv.ToTensor, tv.Normalize, tv.Compose = ToTensor, Normalize, Compose
+    mod = importlib.import_module("datasets.dtu_test")
+    scan = synthetic.fusion_scan(V=5, H=75, W=100, seed=2, n_src=4)
+    arrays = {"dims": np.array([5, 75, 100, 2, 4])}
+    with tempfile.TemporaryDirectory() as d:
+        for name, line in (("scan1", "425.0 2.5"), ("scan2", "425.0 2.5 256 1065.0")):
+            folder = os.path.join(d, name)
+            synthetic.write_fusion_scan(scan, folder, folder, depth_line=line)
+        for tag, (scans, nviews, max_h, max_w) in {"a": (["scan1"], 3, 1200, 1600), "b": (["scan1", "scan2"], 6, 64, 64)}.items():
+            ds = mod.MVSDataset(d, scans, "test", nviews, 192, 1.06, max_h=max_h, max_w=max_w, fix_res=False)
+            arrays[tag + ":len"] = np.array(len(ds))
+            for idx in (0, len(ds) - 1):
+                item = ds[idx]
+                arrays["%s:%d:imgs" % (tag, idx)] = np.stack([np.asarray(t) for t in item["imgs"]])
+                for k, v in item["proj_matrices"].items():
+                    arrays["%s:%d:%s" % (tag, idx, k)] = v
+                arrays["%s:%d:depth_values" % (tag, idx)] = item["depth_values"]
+                arrays["%s:%d:filename" % (tag, idx)] = np.array(item["filename"])
+    save("dataset", **arrays)
+
+
 if __name__ == "__main__":
     if "--only-pfm" in sys.argv:
         pfm_fixture()
@@ -413,8 +467,11 @@ if __name__ == "__main__":
         unsup_loss_fixture()
     elif "--only-fusion" in sys.argv:
         fusion_fixture()
+    elif "--only-dataset" in sys.argv:
+        dataset_fixture()
     else:
         main()
         train_grads()
         unsup_loss_fixture()
         fusion_fixture()
+        dataset_fixture()

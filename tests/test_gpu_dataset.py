@@ -1,0 +1,81 @@
+"""GPU: the evaluation loader with its image preparation on the device (rcmvs_prepare_image) against the reference's golden
+items, and the whole evaluation pipeline -- loader, CascadeMVSNet_eval, PFM / camera / image writers, fusion -- on a scan
+folder."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rc_mvsnet_amd import _lib, mvs_dataset, synthetic
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "dataset.npz"))
+CASES = {"a": (["scan1"], 3, 1200, 1600), "b": (["scan1", "scan2"], 6, 64, 64)}
+
+
+@pytest.fixture(scope="module")
+def folder(tmp_path_factory):
+    V, H, W, seed, n_src = [int(x) for x in GOLD["dims"]]
+    scan = synthetic.fusion_scan(V=V, H=H, W=W, seed=seed, n_src=n_src)
+    d = str(tmp_path_factory.mktemp("scans"))
+    for name, line in (("scan1", "425.0 2.5"), ("scan2", "425.0 2.5 256 1065.0")):
+        synthetic.write_fusion_scan(scan, os.path.join(d, name), os.path.join(d, name), depth_line=line)
+    return d
+
+
+def test_loader_items_match_reference(folder):
+    _lib.load()
+    for tag, (scans, nviews, max_h, max_w) in CASES.items():
+        ds = mvs_dataset.MVSDataset(folder, scans, "test", nviews, 192, 1.06, device="cuda:0", max_h=max_h, max_w=max_w)
+        assert len(ds) == int(GOLD[tag + ":len"])
+        for idx in (0, len(ds) - 1):
+            item = ds[idx]
+            assert item["imgs"].is_cuda
+            assert np.allclose(item["imgs"].cpu().numpy(), GOLD["%s:%d:imgs" % (tag, idx)], rtol=0, atol=1e-6)
+            for k in ("stage1", "stage2", "stage3"):
+                assert np.array_equal(item["proj_matrices"][k], GOLD["%s:%d:%s" % (tag, idx, k)])
+            assert np.array_equal(item["depth_values"], GOLD["%s:%d:depth_values" % (tag, idx)])
+            assert item["filename"] == str(GOLD["%s:%d:filename" % (tag, idx)])
+
+
+def test_prepare_image_full_size_against_oracle():
+    from oracle import dataset as O
+    _lib.load()
+    g = np.random.default_rng(0)
+    img = (255 * g.random((1200, 1600, 3))).astype(np.uint8)
+    want = O.prepare_view(img, np.eye(3, dtype=np.float32), 1200, 1600)
+    got = mvs_dataset.prepare_image(img, want.shape[1:], "cuda:0").cpu().numpy()
+    assert got.shape == (3, 1184, 1600) and np.allclose(got, want, rtol=0, atol=1e-6)
+    same = mvs_dataset.prepare_image(img, (1200, 1600), "cuda:0").cpu().numpy()
+    plain = ((img.astype(np.float32) / 255.0).transpose(2, 0, 1) - O.MEAN[:, None, None]) / O.STD[:, None, None]
+    assert np.allclose(same, plain, rtol=0, atol=1e-6)                          # unchanged size: no resampling at all
+    with pytest.raises(_lib.RcmvsError):
+        mvs_dataset.prepare_image(img[..., :2], (64, 64), "cuda:0")
+
+
+def test_evaluation_pipeline_on_a_scan_folder(tmp_path):
+    """eval_driver on real-layout data: loader -> CascadeMVSNet_eval -> depth_est / confidence PFMs, cams, images -> fusion."""
+    from rc_mvsnet_amd import eval_driver, scan_io
+    from rc_mvsnet_amd.data_io import read_pfm
+    _lib.load()
+    scan = synthetic.fusion_scan(V=4, H=128, W=160, seed=1, n_src=3)
+    data = str(tmp_path / "data")
+    synthetic.write_fusion_scan(scan, os.path.join(data, "scan7"), os.path.join(data, "scan7"))
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("scan7\n")
+    out = str(tmp_path / "out")
+    eval_driver.main(["--outdir", out, "--testpath", data, "--testlist", lst, "--num_view", "3", "--ndepths", "16,8,8", "--filter",
+                      "--prob_thres", "0.0", "--num_consistency", "1", "--img_dist_thres", "4.0", "--depth_thres", "0.5"])
+    for v in range(4):
+        d, _ = read_pfm(os.path.join(out, "scan7", "depth_est", "{:0>8}.pfm".format(v)))
+        c, _ = read_pfm(os.path.join(out, "scan7", "confidence", "{:0>8}.pfm".format(v)))
+        assert d.shape == (128, 160) and c.shape == (128, 160) and np.isfinite(d).all()
+        K, E = scan_io.read_camera_parameters(os.path.join(out, "scan7", "cams", "{:0>8}_cam.txt".format(v)))
+        assert np.allclose(E, scan["E"][v], atol=1e-4) and np.allclose(K, scan["K"][v], rtol=1e-5)
+        assert scan_io.read_img(os.path.join(out, "scan7", "images", "{:0>8}.jpg".format(v))).shape == (128, 160, 3)
+        assert os.path.exists(os.path.join(out, "scan7", "mask", "{:0>8}_final.png".format(v)))
+    head = open(os.path.join(out, "scan7.ply"), "rb").read(200)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex ")

@@ -12,14 +12,12 @@ except Exception as e: print("no cpu.max", e)
 PY
 echo "== pytest -m gpu"
 timeout 900 python -m pytest tests -q -m gpu -s -p no:cacheprovider 2>&1 | tail -60 | tee gpurun_out/pytest_gpu.log
-echo "== k1 ablation"
-timeout 300 python tools/k1_ablate.py 0 1 2 3 100 2>&1 | tail -20 | tee gpurun_out/k1_ablate.log
-echo "== featnet diag"
-timeout 300 python tools/featnet_diag.py 2>&1 | grep -v "^\*\*\*" | tail -12 | tee gpurun_out/featnet_diag.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 echo "== bench"
 timeout 600 python bench.py --steps 30 --warmup 5 2>&1 | tail -3 | tee gpurun_out/bench.log
+echo "== train bench"
+timeout 300 python tools/train_bench.py 2>&1 | tail -4 | tee gpurun_out/train_bench.log
 echo "== rocprof"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1 )
 ls -R gpurun_out/prof | head -20
