@@ -156,3 +156,16 @@ def test_fusion_fails_loudly_without_a_gpu(tmp_path):
     assert mats.dtype == np.float64 and mats.shape == (72,)
     with pytest.raises(_lib.RcmvsError):
         fusion.fuse_view(torch.zeros(2, 4, 4), 0, list(range(17)), torch.zeros(4, 4), None, torch.zeros(72, dtype=torch.float64), 0.8, 3, 0.5, 0.01)
+
+
+def test_filter_scans_shards_scans_round_robin(monkeypatch):
+    """pcd_filter's pool over scans -> every world-th scan per rank, no collective."""
+    seen = []
+    monkeypatch.setattr(fusion, "filter_depth", lambda device, **job: seen.append((device, job["plyfilename"])) or job["plyfilename"])
+    jobs = [{"plyfilename": "scan%d.ply" % i} for i in range(5)]
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert fusion.filter_scans(jobs, rank=1, world=2) == ["scan1.ply", "scan3.ply"]
+    assert seen == [("cuda:1", "scan1.ply"), ("cuda:1", "scan3.ply")]
+    assert fusion.filter_scans(jobs, rank=0, world=2) == ["scan0.ply", "scan2.ply", "scan4.ply"]
+    all_ranks = sorted(fusion.filter_scans(jobs, rank=r, world=3)[i] for r in range(3) for i in range(len(jobs[r::3])))
+    assert all_ranks == sorted(j["plyfilename"] for j in jobs)
