@@ -1,12 +1,13 @@
 """Fusion filter at the reference's DTU evaluation shape (49 views of 1184 x 1600, 10 source views per reference view): ms per
 reference view on the HIP path (fuse + compaction, maps resident) beside the oracle (the reference's numpy path) on the CPU."""
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import fusion as O                           # noqa: E402
 from rc_mvsnet_amd import _lib, fusion, synthetic        # noqa: E402
 

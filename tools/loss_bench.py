@@ -1,11 +1,12 @@
 """Self-supervised loss at BASELINE config 3 shape (4 views, 512x640, batch 1): UnsupLossMultiStage forward + backward on
 the HIP path (ms, HIP events) beside the oracle (the reference's op graph) on the host CPU."""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import unsup_loss as O                      # noqa: E402
 from rc_mvsnet_amd import _lib, losses, synthetic       # noqa: E402
 
