@@ -1,5 +1,6 @@
-"""Evaluation loader for MVSNet-style scan folders: the test-mode ``MVSDataset`` of
-datasets/dtu_test.py:11-229 with the per-image work moved to the GPU.
+"""Evaluation loaders for MVSNet-style scan folders: the test-mode ``MVSDataset`` of
+datasets/dtu_test.py:11-229 and the Tanks-and-Temples one of datasets/tanks.py:11-186 (``TanksDataset`` here), with the
+per-image work moved to the GPU.
 
 Same constructor arguments, item order and item dict (``imgs`` (V,3,h,w), ``proj_matrices`` {stage1..3: (V,2,4,4)},
 ``depth_values`` (ndepths,), ``filename``) as the reference, so ``eval_rcmvsnet_dtu.py:174-197`` iterates it unchanged.  The
@@ -101,6 +102,72 @@ class MVSDataset(torch.utils.data.Dataset):
             projs.append(p)
             if i == 0:
                 depth_values = np.arange(depth_min, depth_interval * (self.ndepths - 0.5) + depth_min, depth_interval, dtype=np.float32)
+        proj = np.stack(projs)
+        stages = {"stage1": proj}
+        for key, mul in (("stage2", 2), ("stage3", 4)):
+            q = proj.copy()
+            q[:, 1, :2, :] = proj[:, 1, :2, :] * mul
+            stages[key] = q
+        return {"imgs": torch.stack(imgs), "proj_matrices": stages, "depth_values": depth_values,
+                "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}
+
+
+TANKS_SCANS = {     # scan -> (width, height) of the original images (datasets/tanks.py:24-48)
+    "intermediate": {"Family": (1920, 1080), "Francis": (1920, 1080), "Horse": (1920, 1080), "Lighthouse": (2048, 1080),
+                     "M60": (2048, 1080), "Panther": (2048, 1080), "Playground": (1920, 1080), "Train": (1920, 1080)},
+    "advanced": {"Auditorium": (1920, 1080), "Ballroom": (1920, 1080), "Courtroom": (1920, 1080), "Museum": (1920, 1080),
+                 "Palace": (1920, 1080), "Temple": (1920, 1080)},
+}
+
+
+class TanksDataset(torch.utils.data.Dataset):
+    """datasets/tanks.py ``MVSDataset``: <datapath>/<split>/<scan>/{pair.txt, cams_1/, images/}; every image is resized to
+    ``img_wh`` (no rounding to multiples of 32), the camera file's last line is ``depth_min depth_max`` and the ``ndepths``
+    planes span exactly that range.  ``scans`` restricts the split's scan list (the reference always walks all of them)."""
+
+    def __init__(self, datapath, split="intermediate", nviews=3, img_wh=(1920, 1056), ndepths=192, device="cuda:0", scans=None):
+        super().__init__()
+        self.datapath, self.split, self.nviews, self.img_wh, self.ndepths = datapath, split, nviews, img_wh, ndepths
+        self.device = torch.device(device)
+        self.image_sizes = dict(TANKS_SCANS[split])
+        self.scans = list(self.image_sizes) if scans is None else list(scans)
+        self.metas = []
+        for scan in self.scans:
+            for ref, srcs in scan_io.read_pair_file(os.path.join(datapath, split, scan, "pair.txt")):
+                self.metas.append((scan, ref, srcs, scan))
+
+    def __len__(self):
+        return len(self.metas)
+
+    @staticmethod
+    def read_cam_file(filename):
+        """-> intrinsics (first two rows / 4), extrinsics, depth_min, depth_max (datasets/tanks.py:66-80)."""
+        lines = scan_io._cam_lines(filename)
+        K, E = scan_io._matrix(lines[7:10], 3, 3), scan_io._matrix(lines[1:5], 4, 4)
+        K[:2, :] /= 4.0
+        tail = lines[11].split()
+        return K, E, float(tail[0]), float(tail[1])
+
+    def __getitem__(self, idx):
+        scan, ref_view, src_views, _ = self.metas[idx]
+        view_ids = [ref_view] + src_views[:self.nviews - 1]
+        new_w, new_h = self.img_wh
+        imgs, projs, depth_values = [], [], None
+        for i, vid in enumerate(view_ids):
+            folder = os.path.join(self.datapath, self.split, scan)
+            K, E, depth_min, depth_max = self.read_cam_file(os.path.join(folder, "cams_1/{:08d}_cam.txt".format(vid)))
+            raw = np.array(Image.open(os.path.join(folder, "images/{:08d}.jpg".format(vid))), dtype=np.uint8)
+            h0, w0 = raw.shape[:2]
+            K[0, :] *= 1.0 * new_w / w0
+            K[1, :] *= 1.0 * new_h / h0
+            imgs.append(prepare_image(raw, (int(new_h), int(new_w)), self.device))
+            p = np.zeros((2, 4, 4), dtype=np.float32)
+            p[0, :4, :4] = E
+            p[1, :3, :3] = K
+            projs.append(p)
+            if i == 0:
+                interval = (depth_max - depth_min) / (self.ndepths - 1)
+                depth_values = np.arange(depth_min, interval * (self.ndepths - 0.5) + depth_min, interval, dtype=np.float32)
         proj = np.stack(projs)
         stages = {"stage1": proj}
         for key, mul in (("stage2", 2), ("stage3", 4)):

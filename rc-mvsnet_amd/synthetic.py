@@ -246,3 +246,13 @@ def write_fusion_scan(scan, pair_folder, out_folder, image_ext="png", depth_line
         Image.fromarray(scan["img"][v]).save(os.path.join(out_folder, "images", "{:0>8}.jpg".format(v)), format=image_ext)
         save_pfm(os.path.join(out_folder, "depth_est", "{:0>8}.pfm".format(v)), scan["depth"][v])
         save_pfm(os.path.join(out_folder, "confidence", "{:0>8}.pfm".format(v)), scan["conf"][v])
+
+
+def write_tanks_scan(scan, folder, depth_line="300.0 1100.0"):
+    """The Tanks-and-Temples layout datasets/tanks.py reads: <folder>/{pair.txt, cams_1/<view:08d>_cam.txt, images/<view:08d>.jpg}
+    with ``depth_min depth_max`` on the camera file's last line."""
+    import os
+    import shutil
+    write_fusion_scan(scan, folder, folder, depth_line=depth_line)
+    shutil.rmtree(os.path.join(folder, "cams_1"), ignore_errors=True)
+    os.rename(os.path.join(folder, "cams"), os.path.join(folder, "cams_1"))

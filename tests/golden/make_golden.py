@@ -450,11 +450,27 @@ def dataset_fixture():
             arrays[tag + ":len"] = np.array(len(ds))
             for idx in (0, len(ds) - 1):
                 item = ds[idx]
-                arrays["%s:%d:imgs" % (tag, idx)] = np.stack([np.asarray(t) for t in item["imgs"]])
+                if idx == 0:                                              # keep the fixture small: pixels of the first item only
+                    arrays["%s:%d:imgs" % (tag, idx)] = np.stack([np.asarray(t) for t in item["imgs"]])
                 for k, v in item["proj_matrices"].items():
                     arrays["%s:%d:%s" % (tag, idx, k)] = v
                 arrays["%s:%d:depth_values" % (tag, idx)] = item["depth_values"]
                 arrays["%s:%d:filename" % (tag, idx)] = np.array(item["filename"])
+        # Tanks-and-Temples layout (datasets/tanks.py walks all eight "intermediate" scans; they share one synthetic scan)
+        tmod = importlib.import_module("datasets.tanks")
+        troot = os.path.join(d, "tt")
+        for name in ("Family", "Francis", "Horse", "Lighthouse", "M60", "Panther", "Playground", "Train"):
+            synthetic.write_tanks_scan(scan, os.path.join(troot, "intermediate", name))
+        tds = tmod.MVSDataset(troot, "intermediate", 3, (96, 64), 192)
+        arrays["t:len"] = np.array(len(tds))
+        for idx in (0, len(tds) - 1):
+            item = tds[idx]
+            if idx == 0:
+                arrays["t:%d:imgs" % idx] = np.stack([np.asarray(t) for t in item["imgs"]])
+            for k, v in item["proj_matrices"].items():
+                arrays["t:%d:%s" % (idx, k)] = v
+            arrays["t:%d:depth_values" % idx] = item["depth_values"]
+            arrays["t:%d:filename" % idx] = np.array(item["filename"])
     save("dataset", **arrays)
 
 
