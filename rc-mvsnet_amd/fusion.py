@@ -163,6 +163,59 @@ def filter_depth(pair_folder, scan_folder, out_folder, plyfilename, prob_thresho
     return xyz, rgb
 
 
+def filter_depth_tanks(scan_folder, out_folder, plyfilename, geo_pixel_thres, geo_depth_thres, photo_thres, img_wh, image_sizes,
+                       geo_mask_thres, n_views=None, scan="", device="cuda:0", save_masks=True, verbose=True):
+    """eval_rcmvsnet_tanks.py:269-380, the Tanks-and-Temples form of filter_depth: pair.txt, cams_1/ and images/ live in
+    ``scan_folder`` at the ORIGINAL image size ``image_sizes`` = (w, h); the depth maps under ``out_folder`` have the network
+    size ``img_wh`` = (w, h), so the intrinsics' first two rows are rescaled and the colour image is resized (cv2.resize's
+    rule, on the device).  Same kernels as filter_depth.  Returns (xyz (n,3) fp32, rgb (n,3) uint8)."""
+    from .mvs_dataset import prepare_image
+    dev = torch.device(device)
+    pairs = scan_io.read_pair_file(os.path.join(scan_folder, "pair.txt"))
+    views = sorted({v for ref, srcs in pairs for v in [ref] + list(srcs)})
+    slot = {v: i for i, v in enumerate(views)}
+    ow, oh = image_sizes
+    cams = {}
+    for v in views:
+        K, E = scan_io.read_camera_parameters(os.path.join(scan_folder, "cams_1/{:0>8}_cam.txt".format(v)))
+        K[0] *= img_wh[0] / ow
+        K[1] *= img_wh[1] / oh
+        cams[v] = (K, E)
+    depth_all = torch.from_numpy(np.stack([read_pfm(os.path.join(out_folder, "depth_est/{:0>8}.pfm".format(v)))[0] for v in views])).to(dev)
+    if tuple(depth_all.shape[1:]) != (img_wh[1], img_wh[0]):
+        raise _lib.RcmvsError(f"filter_depth_tanks: depth maps are {tuple(depth_all.shape[1:])}, img_wh says {(img_wh[1], img_wh[0])}")
+    if save_masks:
+        os.makedirs(os.path.join(out_folder, "mask"), exist_ok=True)
+    pts, cols = [], []
+    for ref, srcs in pairs:
+        if len(srcs) > MAX_SRC:
+            raise _lib.RcmvsError(f"filter_depth_tanks: view {ref} lists {len(srcs)} source views (at most {MAX_SRC})")
+        conf = torch.from_numpy(read_pfm(os.path.join(out_folder, "confidence/{:0>8}.pfm".format(ref)))[0]).to(dev)
+        from PIL import Image
+        raw = np.array(Image.open(os.path.join(scan_folder, "images/{:0>8}.jpg".format(ref))), dtype=np.uint8)
+        img = prepare_image(raw, (img_wh[1], img_wh[0]), dev, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)).permute(1, 2, 0).contiguous()
+        mats = torch.from_numpy(fusion_matrices(cams[ref][0], cams[ref][1], [cams[s][0] for s in srcs], [cams[s][1] for s in srcs])).to(dev)
+        r = fuse_view(depth_all, slot[ref], [slot[s] for s in srcs], conf, img, mats, photo_thres, geo_mask_thres, geo_pixel_thres, geo_depth_thres)
+        xyz, rgb = compact_points(r["masks"][2], r["xyz"], r["rgb"])
+        pts.append(xyz.cpu().numpy())
+        cols.append(rgb.cpu().numpy())
+        if save_masks or verbose:
+            m = r["masks"].cpu().numpy().astype(bool)
+            if save_masks:
+                for k, kind in enumerate(("photo", "geo", "final")):
+                    scan_io.save_mask(os.path.join(out_folder, "mask/{:0>8}_{}.png".format(ref, kind)), m[k])
+            if verbose:
+                print("processing {}, ref-view{:0>2}, geo_mask:{:3f} photo_mask:{:3f} final_mask: {:3f}".format(
+                    scan_folder, ref, m[1].mean(), m[0].mean(), m[2].mean()))
+    xyz, rgb = np.concatenate(pts, 0), np.concatenate(cols, 0)
+    os.makedirs(os.path.dirname(os.path.abspath(plyfilename)), exist_ok=True)
+    with open(plyfilename, "wb") as f:
+        f.write(ply_bytes(xyz, rgb))
+    if verbose:
+        print("saving the final model to", plyfilename)
+    return xyz, rgb
+
+
 def filter_scans(jobs, rank=None, world=None, **kwargs):
     """pcd_filter (eval_rcmvsnet_dtu.py:503-515) without the process pool: jobs = [dict of filter_depth arguments]; each rank
     (one process per GPU, RANK / WORLD_SIZE / LOCAL_RANK from the environment) takes every world-th scan, no collective."""

@@ -34,15 +34,16 @@ def scaled_size(h, w, max_h, max_w, base=32):
     return 1.0 * h // base * base, 1.0 * w // base * base
 
 
-def prepare_image(img_u8, out_hw, device):
-    """Decoded image (H,W,3) uint8 numpy -> (3,h,w) fp32 CUDA tensor, resized and normalised on the device."""
+def prepare_image(img_u8, out_hw, device, mean=MEAN, std=STD):
+    """Decoded image (H,W,3) uint8 numpy -> (3,h,w) fp32 CUDA tensor, resized and normalised on the device
+    (mean 0 / std 1 gives the plain resized image in [0,1])."""
     if img_u8.dtype != np.uint8 or img_u8.ndim != 3 or img_u8.shape[2] != 3:
         raise _lib.RcmvsError(f"prepare_image: expected an (H,W,3) uint8 image, got {img_u8.dtype} {img_u8.shape}")
     H, W = img_u8.shape[:2]
     h, w = int(out_hw[0]), int(out_hw[1])
     src = torch.from_numpy(np.ascontiguousarray(img_u8)).to(device, non_blocking=True)
     out = torch.empty((3, h, w), device=device, dtype=torch.float32)
-    mean, std = (ctypes.c_float * 3)(*MEAN), (ctypes.c_float * 3)(*STD)
+    mean, std = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     _lib.check(_lib.load().rcmvs_prepare_image(_chk(src, "src", torch.uint8), _chk(out, "out"), H, W, h, w,
                                                ctypes.cast(mean, ctypes.c_void_p), ctypes.cast(std, ctypes.c_void_p), _stream()),
                "prepare_image")

@@ -256,3 +256,30 @@ def write_tanks_scan(scan, folder, depth_line="300.0 1100.0"):
     write_fusion_scan(scan, folder, folder, depth_line=depth_line)
     shutil.rmtree(os.path.join(folder, "cams_1"), ignore_errors=True)
     os.rename(os.path.join(folder, "cams"), os.path.join(folder, "cams_1"))
+
+
+def tanks_fusion_scan(V=5, hw=(64, 96), orig_hw=(75, 100), seed=0, n_src=4):
+    """A fusion scan in the Tanks-and-Temples situation (eval_rcmvsnet_tanks.py:269-330): depth maps at the network size
+    ``hw`` while images and camera files describe the original size ``orig_hw`` (the filter rescales the intrinsics by
+    img_wh / original and resizes the colour image)."""
+    scan = fusion_scan(V=V, H=hw[0], W=hw[1], seed=seed, n_src=n_src)
+    K = scan["K"].astype(np.float64)
+    K[:, 0, :] *= orig_hw[1] / hw[1]
+    K[:, 1, :] *= orig_hw[0] / hw[0]
+    scan["K"] = K.astype(np.float32)
+    rng = np.random.default_rng(seed + 100)
+    scan["img"] = (255.0 * rng.random((V, orig_hw[0], orig_hw[1], 3))).astype(np.uint8)
+    return scan
+
+
+def write_tanks_fusion_scan(scan, scan_folder, out_folder):
+    """scan_folder: pair.txt, cams_1/, images/ ; out_folder: depth_est/, confidence/ (eval_rcmvsnet_tanks.py:269-300)."""
+    import os
+    import shutil
+    write_fusion_scan(scan, scan_folder, scan_folder)
+    shutil.rmtree(os.path.join(scan_folder, "cams_1"), ignore_errors=True)
+    os.rename(os.path.join(scan_folder, "cams"), os.path.join(scan_folder, "cams_1"))
+    for sub in ("depth_est", "confidence"):
+        os.makedirs(out_folder, exist_ok=True)
+        shutil.rmtree(os.path.join(out_folder, sub), ignore_errors=True)
+        shutil.move(os.path.join(scan_folder, sub), os.path.join(out_folder, sub))

@@ -340,7 +340,7 @@ def unsup_loss_fixture():
     save("unsup_loss", **arrays)
 
 
-def import_reference_eval():
+def import_reference_eval(name="eval_rcmvsnet_dtu"):
     """Import eval_rcmvsnet_dtu.py as a module (its argparse runs at import: give it an empty command line).  Absent
     third-party packages are stubbed: cv2.remap -> the oracle's restatement of OpenCV's published INTER_LINEAR remap (the one
     step of the fusion filter that is therefore NOT pinned by the reference, see oracle/fusion.py), plyfile -> a recorder of
@@ -351,6 +351,8 @@ def import_reference_eval():
     cv2 = sys.modules["cv2"]
     cv2.INTER_LINEAR = 1
     cv2.remap = lambda src, mx, my, interpolation=1: ofu.remap_linear(src, mx, my)
+    from oracle import dataset as ods
+    cv2.resize = lambda img, dsize, interpolation=1: ods.resize_linear(img, dsize)
     ply = types.ModuleType("plyfile")
     captured = {}
 
@@ -370,9 +372,9 @@ def import_reference_eval():
     ply.PlyElement, ply.PlyData = PlyElement, PlyData
     sys.modules["plyfile"] = ply
     sys.modules["torchvision"].transforms.Compose = lambda *a, **k: None
-    argv, sys.argv = sys.argv, ["eval_rcmvsnet_dtu.py"]
+    argv, sys.argv = sys.argv, [name + ".py"]
     try:
-        mod = importlib.import_module("eval_rcmvsnet_dtu")
+        mod = importlib.import_module(name)
     finally:
         sys.argv = argv
     return mod, captured
@@ -401,6 +403,20 @@ def fusion_fixture():
     vert = captured["vertex"]
     arrays["xyz"] = np.stack([vert["x"], vert["y"], vert["z"]], 1)
     arrays["rgb"] = np.stack([vert["red"], vert["green"], vert["blue"]], 1)
+    # Tanks-and-Temples form (eval_rcmvsnet_tanks.py:269-380): original-size cameras / images, network-size depth maps
+    tmod, captured = import_reference_eval("eval_rcmvsnet_tanks")
+    tscan = synthetic.tanks_fusion_scan(V=5, hw=(64, 96), orig_hw=(75, 100), seed=4, n_src=4)
+    arrays["tanks:dims"] = np.array([5, 64, 96, 75, 100, 4, 4])
+    arrays["tanks:thresholds"] = np.array([0.75, 0.01, 0.8, 3])
+    with tempfile.TemporaryDirectory() as d:
+        scan_folder, out_folder = os.path.join(d, "tt", "intermediate", "Horse"), os.path.join(d, "out", "Horse")
+        synthetic.write_tanks_fusion_scan(tscan, scan_folder, out_folder)
+        tmod.filter_depth(scan_folder, out_folder, os.path.join(d, "ply", "Horse.ply"), 0.75, 0.01, 0.8, (96, 64), (100, 75), 3, 5, "Horse")
+        for v in range(5):
+            arrays["tanks:mask:%d:final" % v] = np.array(Image.open(os.path.join(out_folder, "mask", "{:0>8}_final.png".format(v)))) > 0
+    vert = captured["vertex"]
+    arrays["tanks:xyz"] = np.stack([vert["x"], vert["y"], vert["z"]], 1)
+    arrays["tanks:rgb"] = np.stack([vert["red"], vert["green"], vert["blue"]], 1)
     save("fusion", **arrays)
 
 

@@ -40,11 +40,11 @@ def _p(a):
 
 
 def harness_prepare(h):
-    def prepare(img_u8, out_hw, device):
+    def prepare(img_u8, out_hw, device, mean=mvs_dataset.MEAN, std=mvs_dataset.STD):
         H, W = img_u8.shape[:2]
         out = np.empty((3, int(out_hw[0]), int(out_hw[1])), np.float32)
         img_u8 = np.ascontiguousarray(img_u8)
-        mean, std = np.array(mvs_dataset.MEAN, np.float32), np.array(mvs_dataset.STD, np.float32)
+        mean, std = np.array(mean, np.float32), np.array(std, np.float32)
         h.h_prepare_image(_p(img_u8), _p(out), H, W, out.shape[1], out.shape[2], _p(mean), _p(std))
         return torch.from_numpy(out)
     return prepare

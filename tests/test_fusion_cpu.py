@@ -169,3 +169,49 @@ def test_filter_scans_shards_scans_round_robin(monkeypatch):
     assert fusion.filter_scans(jobs, rank=0, world=2) == ["scan0.ply", "scan2.ply", "scan4.ply"]
     all_ranks = sorted(fusion.filter_scans(jobs, rank=r, world=3)[i] for r in range(3) for i in range(len(jobs[r::3])))
     assert all_ranks == sorted(j["plyfilename"] for j in jobs)
+
+
+def test_tanks_filter_host_logic_matches_reference(tmp_path, harness, monkeypatch):
+    """filter_depth_tanks (eval_rcmvsnet_tanks.py:269-380) end to end on the CPU, with the g++ harnesses standing in for the
+    three kernel launches: file layout, intrinsics rescaling, image resize, thresholds, vertex list."""
+    from PIL import Image
+    from rc_mvsnet_amd import mvs_dataset
+    V, h, w, oh, ow, seed, n_src = [int(x) for x in GOLD["tanks:dims"]]
+    pix, dth, photo, ncons = [float(x) for x in GOLD["tanks:thresholds"]]
+    s = synthetic.tanks_fusion_scan(V=V, hw=(h, w), orig_hw=(oh, ow), seed=seed, n_src=n_src)
+    scan_folder, out_folder = str(tmp_path / "tt" / "intermediate" / "Horse"), str(tmp_path / "out" / "Horse")
+    synthetic.write_tanks_fusion_scan(s, scan_folder, out_folder)
+    ip = str(tmp_path / "ip.so")
+    subprocess.run(["g++", "-O2", "-w", "-ffp-contract=off", "-shared", "-fPIC", "-o", ip, os.path.join(HERE, "harness", "image_prep_harness.cpp")], check=True)
+    ip = ctypes.CDLL(ip)
+
+    def prepare_cpu(img_u8, out_hw, device, mean=mvs_dataset.MEAN, std=mvs_dataset.STD):
+        out = np.empty((3, int(out_hw[0]), int(out_hw[1])), np.float32)
+        img_u8, mean, std = np.ascontiguousarray(img_u8), np.array(mean, np.float32), np.array(std, np.float32)
+        ip.h_prepare_image(_p(img_u8), _p(out), img_u8.shape[0], img_u8.shape[1], out.shape[1], out.shape[2], _p(mean), _p(std))
+        return torch.from_numpy(out)
+
+    def fuse_cpu(depth_all, ref_idx, src_idx, conf, img, mats, prob, ncons_, dist, depth_t, debug=False):
+        d, c, im, m = depth_all.numpy(), conf.numpy(), img.numpy(), mats.numpy()
+        N, (H, W) = len(src_idx), d.shape[1:]
+        masks, avg = np.empty((3, H, W), np.uint8), np.empty((H, W), np.float32)
+        xyz, rgb = np.empty((H, W, 3), np.float32), np.empty((H, W, 3), np.uint8)
+        idx = np.array(src_idx, np.int32)
+        harness.h_fuse_view(_p(d), int(ref_idx), _p(idx), _p(c), _p(im), _p(m), ctypes.c_float(prob), int(ncons_), ctypes.c_double(dist),
+                            ctypes.c_float(depth_t), _p(masks), _p(avg), _p(xyz), _p(rgb), None, None, None, N, H, W)
+        return {"masks": torch.from_numpy(masks), "depth_avg": torch.from_numpy(avg), "xyz": torch.from_numpy(xyz), "rgb": torch.from_numpy(rgb)}
+
+    monkeypatch.setattr(mvs_dataset, "prepare_image", prepare_cpu)
+    monkeypatch.setattr(fusion, "fuse_view", fuse_cpu)
+    monkeypatch.setattr(fusion, "compact_points", lambda mask, xyz, rgb=None: (xyz[mask.bool()], rgb[mask.bool()]))
+    ply = str(tmp_path / "ply" / "Horse.ply")
+    xyz, rgb = fusion.filter_depth_tanks(scan_folder, out_folder, ply, pix, dth, photo, (w, h), (ow, oh), int(ncons), V, "Horse",
+                                         device="cpu", verbose=False)
+    flips = 0
+    for v in range(V):
+        got = np.array(Image.open(os.path.join(out_folder, "mask", "{:0>8}_final.png".format(v)))) > 0
+        flips += int((got != GOLD["tanks:mask:%d:final" % v]).sum())
+    assert flips <= 2, flips
+    if flips == 0:
+        assert np.allclose(xyz, GOLD["tanks:xyz"], rtol=1e-5, atol=1e-3) and np.array_equal(rgb, GOLD["tanks:rgb"])
+    assert open(ply, "rb").read(3) == b"ply"

@@ -109,3 +109,27 @@ def test_fuse_view_argument_checks():
     # all-zero depth (division by zero in the relative test): nothing is consistent, nothing is NaN in the masks
     r = fusion.fuse_view(d, 0, [1], d[0], None, torch.ones(72, dtype=torch.float64, device=DEV), PROB, 1, DIST, DEPTH)
     assert int(r["masks"][1].sum()) == 0
+
+
+def test_filter_depth_tanks_matches_reference(tmp_path):
+    """The Tanks-and-Temples form (eval_rcmvsnet_tanks.py:269-380): original-size cameras and images, network-size depth maps."""
+    _lib.load()
+    from PIL import Image
+    V, h, w, oh, ow, seed, n_src = [int(x) for x in GOLD["tanks:dims"]]
+    pix, dth, photo, ncons = [float(x) for x in GOLD["tanks:thresholds"]]
+    s = synthetic.tanks_fusion_scan(V=V, hw=(h, w), orig_hw=(oh, ow), seed=seed, n_src=n_src)
+    scan_folder, out_folder = str(tmp_path / "tt" / "intermediate" / "Horse"), str(tmp_path / "out" / "Horse")
+    synthetic.write_tanks_fusion_scan(s, scan_folder, out_folder)
+    xyz, rgb = fusion.filter_depth_tanks(scan_folder, out_folder, str(tmp_path / "ply" / "Horse.ply"), pix, dth, photo, (w, h), (ow, oh),
+                                         int(ncons), V, "Horse", verbose=False)
+    flips = 0
+    for v in range(V):
+        got = np.array(Image.open(os.path.join(out_folder, "mask", "{:0>8}_final.png".format(v)))) > 0
+        flips += int((got != GOLD["tanks:mask:%d:final" % v]).sum())
+    assert flips <= 2, flips
+    if flips == 0:
+        assert np.allclose(xyz, GOLD["tanks:xyz"], rtol=1e-5, atol=1e-3)
+        assert (rgb.astype(int) - GOLD["tanks:rgb"].astype(int)).__abs__().max() <= 1      # colour: resize restated, 1 level of 255
+    with pytest.raises(_lib.RcmvsError):
+        fusion.filter_depth_tanks(scan_folder, out_folder, str(tmp_path / "x.ply"), pix, dth, photo, (w + 32, h), (ow, oh), int(ncons), V, "Horse",
+                                  verbose=False)
