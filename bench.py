@@ -16,6 +16,11 @@ The JSON line also carries
   cpu_baseline  the oracle's ATen op graph (= the reference's CPU path) timed on the host cores
                 of this box on a bounded sample, rank 0, N=1 only -- a reported baseline, plus
                 the depth-L1 parity of the HIP output against it on the same inputs.
+
+``--workload unsup_loss`` / ``--workload fusion`` time the two callers either side of the path that SURVEY.md section 8f ranks
+next (the self-supervised loss of the training step, the depth-map fusion filter of the evaluation) with the same contract and
+their own ``roofline`` / ``cpu_baseline`` objects; the default workload, and the only one BASELINE.json's metric is quoted
+on, is the cascade.
 """
 import argparse
 import json
@@ -60,8 +65,165 @@ def k1_algorithmic_bytes():
     return per_stage
 
 
+def timed_region(world, dev, warmup, steps, step):
+    """The contract's timing: W untimed steps, then exactly K steps between barrier + synchronize pairs, max over ranks."""
+    import torch.distributed as dist
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    return elapsed
+
+
+def event_ms(fn, reps=20):
+    """Average duration of ``fn`` (library launches on torch's current stream) from HIP events on that stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def bench_unsup_loss(args, rank, world, dev):
+    """SURVEY.md 8f-2.  Step = UnsupLossMultiStage forward + backward over the three stage depth maps of one sample of
+    BASELINE config 3's shape (batch 1, 4 views, 512x640); images / cameras / depth maps resident in HBM."""
+    from rc_mvsnet_amd import losses, synthetic
+    B, Vl = 1, 4
+    imgs, cams = synthetic.images(B, Vl, H, W, rank), synthetic.proj_matrices(B, Vl, H, W)
+    dep = {}
+    for i, sc in enumerate((4, 2, 1)):
+        h, w = H // sc, W // sc
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+        d = 620.0 + 110.0 * torch.sin(4.0 * xx + i) * torch.cos(3.0 * yy) + torch.randn(h, w, generator=torch.Generator().manual_seed(i))
+        dep["stage%d" % (i + 1)] = d.unsqueeze(0).repeat(B, 1, 1)
+    gi, gc = imgs.to(dev), {k: v.to(dev) for k, v in cams.items()}
+    gd = {k: v.to(dev) for k, v in dep.items()}
+    mod = losses.UnsupLossMultiStage()
+    last = {}
+
+    def step(i):
+        inputs = {k: {"depth": v.clone().requires_grad_(True)} for k, v in gd.items()}
+        total, _ = mod(inputs, gi, gc, dlossw=[0.5, 1.0, 2.0])
+        total.backward()
+        last["total"] = total
+
+    elapsed = timed_region(world, dev, args.warmup, args.steps, step)
+    if rank != 0:
+        return None
+    # dominant launch group: one full-resolution stage forward (rcmvs_unsup_loss_fwd, 2 Vs + 3 launches)
+    Vs = Vl - 1
+    ref = losses.stage_image(gi[:, 0], 2)
+    srcs = losses.nearest_reduce(gi[:, 1:], 1).permute(1, 0, 3, 4, 2).contiguous()
+    coef = losses.inverse_warp_coefs(gc["stage3"][:, 0], gc["stage3"][:, 1:])
+    ms = event_ms(lambda: losses.UnsupStageLossFn.apply(gd["stage3"], ref, srcs, coef))
+    alg = B * H * W * (Vs * (12 + 4 + 12 + 4 + 12 + 12 + 4) + 16 + 4 * Vs)      # warp r/w, terms reads, smoothness, best view
+    roofline = {"bound": "hbm", "kernel": "rcmvs_unsup_loss_fwd at 512x640 (inverse_warp + photo_terms per view, smooth_terms, best_view, finalize)",
+                "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg,
+                "us": round(ms * 1e3, 1), "note": "9 short launches over 0.33 M pixels: launch / latency bound, not bandwidth bound"}
+    result = {"metric": "loss steps/sec (UnsupLossMultiStage forward+backward, 4 views 512x640, 3 stages)", "value": round(world * args.steps / elapsed, 2),
+              "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "SURVEY 8f-2: losses/unsup_loss.py UnsupLossMultiStage on BASELINE configs[2] shapes (batch 1 per GPU)",
+                         "views": Vl, "height": H, "width": W, "parallelism": f"sample-per-gpu x{world}"},
+              "roofline": roofline}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import unsup_loss as O
+        nthreads = host_threads()
+        torch.set_num_threads(nthreads)
+        times = []
+        for _ in range(3):
+            c0 = time.perf_counter()
+            inputs = {k: {"depth": v.clone().requires_grad_(True)} for k, v in dep.items()}
+            ctotal, _ = O.unsup_loss_multi_stage(inputs, imgs, cams, dlossw=[0.5, 1.0, 2.0])
+            ctotal.backward()
+            times.append(time.perf_counter() - c0)
+        cpu_s = sorted(times[1:])[len(times[1:]) // 2]
+        result["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "steps/s", "cores": nthreads, "kind": "port",
+                                  "sample": f"median of 2 steps of the same workload after 1 warm-up, oracle/unsup_loss.py (the reference's op graph on PyTorch-CPU), {nthreads} threads"}
+        result["parity"] = {"loss_hip": float(last["total"]), "loss_oracle": float(ctotal),
+                            "rel": abs(float(last["total"]) - float(ctotal)) / abs(float(ctotal)), "tolerance": 2e-5}
+    return result
+
+
+def bench_fusion(args, rank, world, dev):
+    """SURVEY.md 8f-3.  Step = one reference view of the fusion filter at the reference's DTU evaluation shape (1184x1600 depth
+    maps, 10 source views): rcmvs_fuse_view + ordered compaction, every depth map of the scan resident in HBM."""
+    import numpy as np
+    from rc_mvsnet_amd import fusion, synthetic
+    Hf, Wf, n_src, Vf = 1184, 1600, 10, 11
+    s = synthetic.fusion_scan(V=Vf, H=Hf, W=Wf, seed=rank, n_src=n_src)
+    depth_all = torch.from_numpy(s["depth"]).to(dev)
+    jobs = []
+    for ref, srcs in s["pairs"]:
+        mats = torch.from_numpy(fusion.fusion_matrices(s["K"][ref], s["E"][ref], [s["K"][i] for i in srcs], [s["E"][i] for i in srcs])).to(dev)
+        jobs.append((ref, srcs, torch.from_numpy(s["conf"][ref]).to(dev), torch.from_numpy(s["img"][ref].astype(np.float32) / 255.0).to(dev), mats))
+    kept = {}
+
+    def fuse(i):
+        ref, srcs, conf, img, mats = jobs[i % len(jobs)]
+        return fusion.fuse_view(depth_all, ref, srcs, conf, img, mats, 0.8, 3, 0.5, 0.01)
+
+    def step(i):
+        r = fuse(i)
+        xyz, _ = fusion.compact_points(r["masks"][2], r["xyz"], r["rgb"])
+        kept["n"] = len(xyz)
+
+    elapsed = timed_region(world, dev, args.warmup, args.steps, step)
+    if rank != 0:
+        return None
+    ms = event_ms(lambda: fuse(0))
+    alg = Hf * Wf * (4 + 4 + 12 + 4 * n_src + 3 + 4 + 12 + 3)        # depth, conf, img, each source map once; masks, avg, xyz, rgb
+    roofline = {"bound": "hbm", "kernel": "rcmvs::fuse_view_kernel (1 launch per reference view)", "achieved": round(alg / (ms * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes": alg, "us": round(ms * 1e3, 1),
+                "note": "fp64 chain with fp32 cast points, ~250 fp64 operations per (pixel, source view): closer to the fp64 vector rate than to HBM"}
+    result = {"metric": "fused reference views/sec (filter_depth body, 1184x1600, 10 source views)", "value": round(world * args.steps / elapsed, 1),
+              "unit": "ref-views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": "SURVEY 8f-3: eval_rcmvsnet_dtu.py filter_depth per-reference-view body, DTU evaluation shape", "height": Hf,
+                         "width": Wf, "source_views": n_src, "points_kept": kept.get("n"), "parallelism": f"scan-per-gpu x{world}"},
+              "roofline": roofline}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import fusion as O
+        ref, srcs = s["pairs"][0]
+        times = []
+        for _ in range(2):
+            c0 = time.perf_counter()
+            o = O.fuse_view(s["depth"][ref], s["conf"][ref], s["img"][ref].astype(np.float32) / 255.0, s["K"][ref], s["E"][ref],
+                            [s["depth"][i] for i in srcs], [s["K"][i] for i in srcs], [s["E"][i] for i in srcs], 0.8, 3, 0.5, 0.01)
+            times.append(time.perf_counter() - c0)
+        g = fuse(0)
+        result["cpu_baseline"] = {"value": round(1.0 / min(times), 4), "unit": "ref-views/s", "cores": 1, "kind": "port",
+                                  "sample": "best of 2 reference views of the same workload, oracle/fusion.py (the reference's numpy path; numpy is "
+                                            "single-threaded here apart from BLAS in the 3xN matmuls)"}
+        result["parity"] = {"final_mask_mismatch_frac": float((g["masks"][2].cpu().numpy().astype(bool) != o["final"]).mean()), "tolerance": 1e-4}
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "unsup_loss", "fusion"],
+                    help="cascade = BASELINE.json's metric (default); the others are the SURVEY 8f rows either side of the path")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -82,6 +244,11 @@ def main():
     from rc_mvsnet_amd import _lib, ops, synthetic
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
     _lib.load()
+    if args.workload != "cascade":
+        result = (bench_unsup_loss if args.workload == "unsup_loss" else bench_fusion)(args, rank, world, dev)
+        if result is not None:
+            print(json.dumps(result))
+        return
 
     sd = synthetic.cascade_state_dict(0)
     model = CascadeMVSNet_eval(ndepths=list(NDEPTHS), depth_interals_ratio=list(RATIOS))

@@ -16,10 +16,15 @@ This package is the *checker*, never the product:
     stored as small ``.npz`` fixtures under ``tests/golden/``;
     ``tests/test_oracle_golden.py`` checks every oracle function against them.
 
+Later rows: ``unsup_loss`` (pinned to 1e-6 by the reference's own autograd), ``fusion`` and
+``dataset`` (pinned by the reference's filter_depth / MVSDataset run with restatements of the absent cv2.remap / cv2.resize --
+those two steps are "parity unpinned", see the module headers).  ``bench.py --workload unsup_loss|fusion`` times them as
+``cpu_baseline``; diagnostics that compare against the oracle live under ``tests/diag/``.
+
 Tolerances: the reference's own CPU path is not bit-reproducible across ATen builds
 (GCC contracts the AVX2 grid-sampler/conv code into FMAs in an unspecified order), so the
 fixtures are compared at a few fp32 ulp (rtol 2e-5 / atol 2e-6 on O(1) features), and the
 integer-valued confidence index is compared where it is not within rounding of a bin edge.
 """
 
-from . import warp, conv3d, depth_head, feature_net, cascade, render  # noqa: F401
+from . import warp, conv3d, depth_head, feature_net, cascade, render, unsup_loss, fusion, dataset  # noqa: F401

@@ -2,8 +2,8 @@
 """Diagnostic: error of the delegated FeatureNet (PyTorch-ROCm / MIOpen) against the CPU oracle at
 small and BASELINE config-2 sizes, and per-stage depth error of the cascade vs the reference golden."""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from conftest import load_golden
 from rc_mvsnet_amd import synthetic

@@ -2,7 +2,7 @@
 """Diagnostic (GPU box): isolate each HIP kernel's numerical error at BASELINE config-2 stage-1 size
 by feeding it the CPU oracle's exact inputs; fp64 CPU references give the 'true' values."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from rc_mvsnet_amd import synthetic, ops

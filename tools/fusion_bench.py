@@ -1,5 +1,6 @@
-"""Fusion filter at the reference's DTU evaluation shape (49 views of 1184 x 1600, 10 source views per reference view): ms per
-reference view on the HIP path (fuse + compaction, maps resident) beside the oracle (the reference's numpy path) on the CPU."""
+"""Fusion filter at the reference's DTU evaluation shape (1184 x 1600 depth maps, 10 source views per reference view): ms per
+reference view on the HIP path (fuse + compaction, maps resident) -- kernels only, e.g. under rocprofv3.  The CPU baseline
+beside it is ``python bench.py --workload fusion``."""
 import os
 import sys
 import time
@@ -8,7 +9,6 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import fusion as O                           # noqa: E402
 from rc_mvsnet_amd import _lib, fusion, synthetic        # noqa: E402
 
 
@@ -39,17 +39,8 @@ def main():
         n = run()
     torch.cuda.synchronize()
     hip_ms = (time.perf_counter() - t) * 1e3 / (reps * len(jobs))
-    if "--no-oracle" in sys.argv:                      # e.g. under rocprofv3: kernels only
-        print(f"fusion, {n_src} source views, {H}x{W}: HIP {hip_ms:.3f} ms per reference view")
-        return
-    ref, srcs = s["pairs"][0]
-    t = time.perf_counter()
-    O.fuse_view(s["depth"][ref], s["conf"][ref], s["img"][ref].astype(np.float32) / 255.0, s["K"][ref], s["E"][ref],
-                [s["depth"][i] for i in srcs], [s["K"][i] for i in srcs], [s["E"][i] for i in srcs], 0.8, 3, 0.5, 0.01)
-    cpu_ms = (time.perf_counter() - t) * 1e3
-    px = H * W
-    print(f"fusion, {n_src} source views, {H}x{W}: HIP {hip_ms:.3f} ms per reference view ({px * n_src / hip_ms / 1e6:.1f} G pixel-pairs/s, "
-          f"{n // len(jobs)} points kept) | oracle on CPU {cpu_ms:.0f} ms per reference view")
+    print(f"fusion, {n_src} source views, {H}x{W}: HIP {hip_ms:.3f} ms per reference view ({H * W * n_src / hip_ms / 1e6:.1f} G pixel-pairs/s, "
+          f"{n // len(jobs)} points kept)")
 
 
 if __name__ == "__main__":

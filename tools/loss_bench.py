@@ -1,13 +1,12 @@
 """Self-supervised loss at BASELINE config 3 shape (4 views, 512x640, batch 1): UnsupLossMultiStage forward + backward on
-the HIP path (ms, HIP events) beside the oracle (the reference's op graph) on the host CPU."""
+the HIP path (ms, HIP events) -- kernels only, e.g. under rocprofv3.  The CPU baseline beside it is
+``python bench.py --workload unsup_loss``."""
 import os
 import sys
-import time
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import unsup_loss as O                      # noqa: E402
 from rc_mvsnet_amd import _lib, losses, synthetic       # noqa: E402
 
 
@@ -46,16 +45,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     hip_ms = e0.elapsed_time(e1) / n
-    if "--no-oracle" in sys.argv:                      # e.g. under rocprofv3: kernels only
-        print(f"unsup loss 3 stages fwd+bwd: HIP {hip_ms:.3f} ms (loss {float(total):.6f})")
-        return
-    t = time.time()
-    inputs = {k: {"depth": d.clone().requires_grad_(True)} for k, d in dep.items()}
-    ctotal, _ = O.unsup_loss_multi_stage(inputs, imgs, cams, dlossw=[0.5, 1.0, 2.0])
-    ctotal.backward()
-    cpu_ms = (time.time() - t) * 1e3
-    print(f"unsup loss 3 stages fwd+bwd: HIP {hip_ms:.3f} ms (loss {float(total):.6f}) | oracle on CPU ({torch.get_num_threads()} threads) "
-          f"{cpu_ms:.1f} ms (loss {float(ctotal):.6f})")
+    print(f"unsup loss 3 stages fwd+bwd: HIP {hip_ms:.3f} ms (loss {float(total):.6f})")
 
 
 if __name__ == "__main__":

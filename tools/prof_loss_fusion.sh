@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/gpurun_out"
 export TMPDIR=/tmp
 cd /tmp
-timeout 60 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_loss" -o ls -- python "$R/tools/loss_bench.py" --no-oracle > "$R/gpurun_out/prof_loss.log" 2>&1
-timeout 80 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_fuse" -o fu -- python "$R/tools/fusion_bench.py" --no-oracle > "$R/gpurun_out/prof_fuse.log" 2>&1
+timeout 60 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_loss" -o ls -- python "$R/tools/loss_bench.py" > "$R/gpurun_out/prof_loss.log" 2>&1
+timeout 80 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_fuse" -o fu -- python "$R/tools/fusion_bench.py" > "$R/gpurun_out/prof_fuse.log" 2>&1
 cd "$R"
 for d in prof_loss prof_fuse; do
     tail -n 4 "gpurun_out/$d.log" | cut -c1-200
