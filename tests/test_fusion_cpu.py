@@ -215,3 +215,42 @@ def test_tanks_filter_host_logic_matches_reference(tmp_path, harness, monkeypatc
     if flips == 0:
         assert np.allclose(xyz, GOLD["tanks:xyz"], rtol=1e-5, atol=1e-3) and np.array_equal(rgb, GOLD["tanks:rgb"])
     assert open(ply, "rb").read(3) == b"ply"
+
+
+@pytest.mark.parametrize("case_name", ["zero_depth_holes", "source_out_of_frame", "sixteen_sources", "one_by_one"])
+def test_kernel_arithmetic_edge_cases(case_name, harness):
+    """Holes (depth 0: 0/0 in the relative test), a source camera that sees nothing, the maximum source count, a 1x1 map."""
+    s = synthetic.fusion_scan(V=5, H=(1 if case_name == "one_by_one" else 20), W=(1 if case_name == "one_by_one" else 28), seed=9, n_src=4)
+    ref, srcs = s["pairs"][0]
+    depth = s["depth"].copy()
+    K, E = s["K"].copy(), s["E"].copy()
+    if case_name == "zero_depth_holes":
+        depth[ref, 3:9, 5:11] = 0.0
+        depth[srcs[0], :, :7] = 0.0
+    if case_name == "source_out_of_frame":
+        E[srcs[1], :3, 3] += np.array([4.0e4, 0.0, 0.0], np.float32)
+    if case_name == "sixteen_sources":
+        srcs = (srcs * 4)[:16]
+    H, W = depth.shape[1:]
+    N = len(srcs)
+    img = np.ascontiguousarray(s["img"][ref].astype(np.float32) / 255.0)
+    mats = fusion.fusion_matrices(K[ref], E[ref], [K[i] for i in srcs], [E[i] for i in srcs])
+    masks, avg = np.empty((3, H, W), np.uint8), np.empty((H, W), np.float32)
+    xyz, rgb = np.empty((H, W, 3), np.float32), np.empty((H, W, 3), np.uint8)
+    dg = np.empty((N, H, W), np.uint8)
+    idx, conf, dall = np.array(srcs, np.int32), np.ascontiguousarray(s["conf"][ref]), np.ascontiguousarray(depth)
+    harness.h_fuse_view(_p(dall), ref, _p(idx), _p(conf), _p(img), _p(mats), ctypes.c_float(PROB), NCONS, ctypes.c_double(DIST),
+                        ctypes.c_float(DEPTH), _p(masks), _p(avg), _p(xyz), _p(rgb), None, _p(dg), None, N, H, W)
+    with np.errstate(all="ignore"):
+        r = O.fuse_view(depth[ref], s["conf"][ref], img, K[ref], E[ref], [depth[i] for i in srcs], [K[i] for i in srcs], [E[i] for i in srcs],
+                        PROB, NCONS, DIST, DEPTH)
+    assert np.array_equal(masks[0].astype(bool), r["photo"])
+    assert (masks[1].astype(bool) != r["geo"]).sum() <= 1 and (masks[2].astype(bool) != r["final"]).sum() <= 1
+    both = masks[2].astype(bool) & r["final"]
+    want = np.zeros((H, W, 3), np.float32)
+    want[r["final"]] = r["xyz"]
+    assert np.allclose(xyz[both], want[both], rtol=1e-5, atol=1e-3)
+    if case_name == "zero_depth_holes":
+        assert not masks[1][3:9, 5:11].any()                    # a hole in the reference map is never consistent
+    if case_name == "source_out_of_frame":
+        assert not dg[1].any()

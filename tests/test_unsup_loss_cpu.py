@@ -119,3 +119,52 @@ def test_losses_fail_loudly_without_a_gpu():
         losses.UnSupLoss()(imgs, cams["stage3"], torch.tensor(GOLD["a:depth:stage3"]), 2)
     with pytest.raises(_lib.RcmvsError):
         losses.SL1Loss()(torch.rand(4, 5), torch.rand(4, 5))
+
+
+def _harness_stage(harness, imgs, cams, depth, idx, gw):
+    B, V = imgs.shape[:2]
+    Vs = V - 1
+    ref = losses.stage_image(imgs[:, 0], idx)
+    srcs = losses.nearest_reduce(imgs[:, 1:], (4, 2, 1)[idx]).permute(1, 0, 3, 4, 2).contiguous()
+    coef = losses.inverse_warp_coefs(cams[:, 0], cams[:, 1:]).contiguous()
+    h, w = ref.shape[1:3]
+    d = depth.detach().contiguous()
+    warped, masks = torch.empty_like(srcs), torch.empty(Vs, B, h, w)
+    sums, counts, out = torch.empty(4 * Vs + 2, dtype=torch.float64), torch.empty(Vs, dtype=torch.int32), torch.empty(4 + Vs)
+    harness.h_unsup_loss_fwd(_p(ref), _p(srcs), _p(d), _p(coef), _p(warped), _p(masks), _p(sums), _p(counts), _p(out), B, Vs, h, w)
+    gd = torch.empty_like(d)
+    gw = gw.contiguous()
+    harness.h_unsup_loss_bwd(_p(ref), _p(srcs), _p(d), _p(coef), _p(warped), _p(masks), _p(counts), _p(gw), _p(gd), B, Vs, h, w)
+    return out, counts, masks, gd
+
+
+@pytest.mark.parametrize("case_name", ["one_source_view", "a_view_that_sees_nothing", "three_by_three", "five_source_views"])
+def test_kernel_arithmetic_edge_cases(case_name, harness):
+    """Edge cases of UnSupLoss.forward through the kernels' arithmetic: a single source view (SSIM of one view only), a source
+    camera that looks away (fully masked: it must win no pixel and contribute no gradient), the smallest image SSIM accepts,
+    and more views than the SSIM term uses (only the first two source views enter it, unsup_loss.py:70-72)."""
+    g = torch.Generator().manual_seed(7)
+    if case_name == "three_by_three":
+        B, V, H, W = 1, 3, 3, 3
+    elif case_name == "five_source_views":
+        B, V, H, W = 1, 6, 24, 32
+    else:
+        B, V, H, W = 2, (2 if case_name == "one_source_view" else 3), 24, 32
+    imgs = synthetic.images(B, V, H, W, 3)
+    cams = synthetic.proj_matrices(B, V, H, W)["stage3"].clone()
+    if case_name == "a_view_that_sees_nothing":
+        cams[:, 2, 0, :3, 3] += torch.tensor([5.0e4, 0.0, 0.0])          # translate source view 2 far off to the side
+    depth = (600.0 + 60.0 * torch.rand(B, H, W, generator=g)).requires_grad_(True)
+    r = O.unsup_loss(imgs, cams, depth, 2)
+    gw = torch.tensor([12.0, 6.0, 0.18])
+    r["loss"].backward()
+    out, counts, masks, gd = _harness_stage(harness, imgs, cams, depth, 2, gw)
+    for name, i in (("reconstr", 0), ("ssim", 1), ("smooth", 2), ("loss", 3)):
+        want = float(r[name])
+        assert abs(float(out[i]) - want) <= 2e-5 * max(abs(want), 1e-6), (case_name, name, float(out[i]), want)
+    scale = float(depth.grad.abs().max())
+    err = (gd - depth.grad).abs()
+    assert float(err.median()) <= 1e-5 * scale and float((err > 1e-3 * scale).float().mean()) <= 1e-2, (case_name, float(err.max()), scale)
+    if case_name == "a_view_that_sees_nothing":
+        assert float(masks[1].sum()) == 0.0 and int(counts[1]) == 0
+    assert int(counts.sum()) <= B * H * W
