@@ -163,6 +163,13 @@ int rcmvs_pack_conv2d_weight(const float* w, float* packed, int Co, int Ci, int 
  * Replaces Conv2d.forward = conv + BN(eval) + ReLU (modules.py:53-59) and the bare 1x1 / 3x3 output convs. */
 int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
                      float* y, int N, int H, int W, int Ci, int Co, int K, int stride, int relu, void* stream);
+/* Last FPN level in one launch: y = conv3x3(up2(up) + conv1x1(lat) + b_inner) without materialising the 32-channel
+ * intermediate (models/modules.py:448-462: `intra_feat = F.interpolate(intra_feat) + self.inner2(conv0)`,
+ * `self.out3(intra_feat)`).  lat (N,H,W,CL), up (N,H/2,W/2,CM), w_inner packed [1][CL][CM], b_inner (CM), w_out packed
+ * [9][CM][CO], y (N,H,W,CO); H, W even; channels 8 -> 32 -> 8.  Bit-identical to the two rcmvs_conv2d_fwd calls it replaces. */
+int rcmvs_fpn_out_fused(const float* lat, const float* up, const float* w_inner, const float* b_inner, const float* w_out,
+                        float* y, int N, int H, int W, int CL, int CM, int CO, void* stream);
+
 
 /* ---- K4: prob conv + softmax + soft-argmin + photometric confidence ---------------------- */
 /* replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression and the

@@ -124,6 +124,8 @@ class FeatureNet(nn.Module):
             if self.num_stage == 3:
                 plan["inner2"] = (ops.pack_conv2d_weight(self.inner2.weight), self.inner2.bias.detach().float().contiguous())
                 plan["out3"] = ops.pack_conv2d_weight(self.out3.weight)
+                plan["fuse_out3"] = (os.environ.get("RCMVS_FPN_FUSE", "0") == "1" and tuple(self.inner2.weight.shape[:2]) == (32, 8)
+                                     and tuple(self.out3.weight.shape[:2]) == (8, 32))
             self._plan, self._plan_key = plan, key
         return self._plan
 
@@ -154,8 +156,12 @@ class FeatureNet(nn.Module):
             intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
             out["stage2"] = (lambda t=intra: ops.conv2d(t, p["out2"]))
         if self.num_stage == 3:
-            intra = ops.conv2d(c0, p["inner2"][0], None, p["inner2"][1], up_add=intra)
-            out["stage3"] = (lambda t=intra: ops.conv2d(t, p["out3"]))
+            if p.get("fuse_out3") and c0.shape[1] % 2 == 0 and c0.shape[2] % 2 == 0:
+                # the full-resolution 32-channel merge is never stored: 1x1 lateral + up-add + 3x3 output conv in one launch
+                out["stage3"] = (lambda a=c0, b=intra: ops.fpn_out_fused(a, b, p["inner2"][0], p["inner2"][1], p["out3"]))
+            else:
+                intra = ops.conv2d(c0, p["inner2"][0], None, p["inner2"][1], up_add=intra)
+                out["stage3"] = (lambda t=intra: ops.conv2d(t, p["out3"]))
         return out if lazy else {k: f() for k, f in out.items()}
 
     # ---- training on the library: every layer as a one-plane volume on the 3-D conv family -----------------------

@@ -1,0 +1,110 @@
+// Last FPN level of FeatureNet in one kernel (models/modules.py:448-462, arch_mode='fpn'):
+//   intra = nearest_upsample_x2(prev) + inner2(conv0)        1x1 conv 8 -> 32 + bias, at full resolution
+//   out   = out3(intra)                                      3x3 conv 32 -> 8, no bias
+// Unfused, `intra` (32 channels at full resolution: 126 MB for three 512x640 views) is written by the merge kernel and read
+// back by the output conv -- more bytes than everything else FeatureNet moves.  Here the 3x3 conv's halo tile of `intra` is
+// formed on the fly in LDS, 8 channels at a time, from the 8-channel lateral map (staged once per block) and the half-
+// resolution previous level, so `intra` never exists in memory: reads 31 + 31 MB, writes 31 MB.  The arithmetic order of both
+// convolutions is the one of conv2d_lds_kernel (conv2d.hip), so the result is bit-identical to the two-kernel path.
+// gfx950 only.
+#include "common.h"
+
+namespace rcmvs {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int CL, int CM, int CO>
+__global__ __launch_bounds__(256) void fpn_out_fused_kernel(
+    const float* __restrict__ lat, const float* __restrict__ up, const float* __restrict__ w_in, const float* __restrict__ b_in,
+    const float* __restrict__ w_out, float* __restrict__ y, int H, int W, int tiles_w) {
+    static_assert(CL == 8 && CM % 8 == 0 && CO % 4 == 0, "lateral map has 8 channels");
+    constexpr int TH = 16, TW = 16, K = 3, HH = TH + 2, HW = TW + 2, NP = HH * HW;
+    constexpr int CK = 8, ST = CK + 4;                                  // channels per pass, floats per staged pixel
+    __shared__ __attribute__((aligned(16))) float lat_s[NP * ST];       // lateral halo tile, all 8 channels
+    __shared__ __attribute__((aligned(16))) float tile[NP * ST];        // 8 channels of intra
+    __shared__ float w_s[CL * CM];
+    __shared__ float b_s[CM];
+    const int n = blockIdx.y;
+    const unsigned t2 = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = t2 % tiles_w, th = t2 / tiles_w;
+    const int oy0 = th * TH, ox0 = tw * TW;
+    const int lx = threadIdx.x % TW, ly = threadIdx.x / TW;
+    const int Hh = H / 2, Wh = W / 2;
+    const float* lb = lat + (long long)n * H * W * CL;
+    const float* ub = up + (long long)n * Hh * Wh * CM;
+
+    for (int e = threadIdx.x; e < CL * CM; e += 256) w_s[e] = w_in[e];
+    if (threadIdx.x < CM) b_s[threadIdx.x] = b_in[threadIdx.x];
+    for (int e = threadIdx.x; e < NP * 2; e += 256) {
+        const int v = e >> 1, c4 = e & 1;
+        const int iy = oy0 - 1 + v / HW, ix = ox0 - 1 + v % HW;
+        f4v val = (f4v){0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = *reinterpret_cast<const f4v*>(lb + ((long long)iy * W + ix) * CL + c4 * 4);
+        *reinterpret_cast<f4v*>(lat_s + v * ST + c4 * 4) = val;
+    }
+
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+
+    for (int c0 = 0; c0 < CM; c0 += CK) {
+        __syncthreads();                                                // lat_s / w_s ready (first pass); tile free (later passes)
+        for (int e = threadIdx.x; e < NP * 2; e += 256) {
+            const int v = e >> 1, c4 = e & 1;
+            const int iy = oy0 - 1 + v / HW, ix = ox0 - 1 + v % HW;
+            f4v val = (f4v){0.f, 0.f, 0.f, 0.f};                        // the 3x3 conv zero-pads intra, not its inputs
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const f4v x0 = *reinterpret_cast<const f4v*>(lat_s + v * ST), x1 = *reinterpret_cast<const f4v*>(lat_s + v * ST + 4);
+                const f4v u4 = *reinterpret_cast<const f4v*>(ub + ((long long)(iy >> 1) * Wh + (ix >> 1)) * CM + c0 + c4 * 4);
+                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int co = c0 + c4 * 4 + k;
+                    float a = 0.0f;
+#pragma unroll
+                    for (int ci = 0; ci < CL; ++ci) a = fmaf(xs[ci], w_s[ci * CM + co], a);
+                    a = a + b_s[co];
+                    val[k] = u4[k] + a;
+                }
+            }
+            *reinterpret_cast<f4v*>(tile + v * ST + c4 * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll 1
+            for (int kx = 0; kx < K; ++kx) {
+                const float* wt = w_out + ((long long)(ky * K + kx) * CM + c0) * CO;
+#pragma unroll
+                for (int c4 = 0; c4 < CK / 4; ++c4) {
+                    const f4v xv = *reinterpret_cast<const f4v*>(tile + ((ly + ky) * HW + (lx + kx)) * ST + c4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv[j], wt[(c4 * 4 + j) * CO + co], acc[co]);
+                }
+            }
+        }
+    }
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy < H && ox < W) {
+        float* yp = y + (((long long)n * H + oy) * W + ox) * CO;
+#pragma unroll
+        for (int co = 0; co < CO; co += 4) *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+    }
+}
+
+}  // namespace rcmvs
+
+using namespace rcmvs;
+
+extern "C" int rcmvs_fpn_out_fused(const float* lat, const float* up, const float* w_inner, const float* b_inner, const float* w_out,
+                                   float* y, int N, int H, int W, int CL, int CM, int CO, void* stream) {
+    RCMVS_REQUIRE(lat && up && w_inner && b_inner && w_out && y, "fpn_out_fused: null pointer");
+    RCMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_out_fused: H and W must be even (got %d x %d)", H, W);
+    RCMVS_REQUIRE(CL == 8 && CM == 32 && CO == 8, "fpn_out_fused: unsupported channels %d -> %d -> %d (8 -> 32 -> 8 only)", CL, CM, CO);
+    const int tiles_w = (W + 15) / 16, tiles_h = (H + 15) / 16;
+    hipLaunchKernelGGL((fpn_out_fused_kernel<8, 32, 8>), dim3(tiles_w * tiles_h, N), dim3(256), 0, as_stream(stream), lat, up, w_inner,
+                       b_inner, w_out, y, H, W, tiles_w);
+    return launch_status("fpn_out_fused");
+}

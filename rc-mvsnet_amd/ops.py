@@ -245,6 +245,20 @@ def conv2d(x, w_packed, scale=None, shift=None, up_add=None, stride=1, relu=Fals
     return y
 
 
+def fpn_out_fused(lat, up, w_inner_packed, b_inner, w_out_packed):
+    """conv3x3(up2(up) + conv1x1(lat) + bias): lat (N,H,W,8), up (N,H/2,W/2,32) -> (N,H,W,8), the 32-channel merge never stored."""
+    N, H, W, CL = lat.shape
+    CM, CO = w_inner_packed.co, w_out_packed.co
+    if w_inner_packed.ci != CL or w_inner_packed.k != 1 or w_out_packed.ci != CM or w_out_packed.k != 3:
+        raise _lib.RcmvsError("fpn_out_fused: expected a 1x1 lateral conv followed by a 3x3 output conv on matching channels")
+    if tuple(up.shape) != (N, H // 2, W // 2, CM):
+        raise _lib.RcmvsError(f"fpn_out_fused: up {tuple(up.shape)} does not match half of {tuple(lat.shape)} with {CM} channels")
+    y = torch.empty((N, H, W, CO), device=lat.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_fpn_out_fused(_chk(lat, "lat"), _chk(up, "up"), _chk(w_inner_packed.blob, "w_inner"), _chk(b_inner, "b_inner"),
+                                               _chk(w_out_packed.blob, "w_out"), _chk(y, "y"), N, H, W, CL, CM, CO, _stream()), "fpn_out_fused")
+    return y
+
+
 # ------------------------------------------------------------------------------- K4
 def depth_head(x8, w_prob_packed, planes, want_prob=False):
     """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)]."""

@@ -629,3 +629,23 @@ def test_dtu_eval_shape(hip):
     assert torch.isfinite(out["depth"]).all() and torch.isfinite(out["photometric_confidence"]).all()
     c = out["photometric_confidence"]
     assert float(c.min()) >= 0.0 and float(c.max()) <= 1.0 + 1e-5
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 36, 44), (1, 16, 16), (3, 128, 160), (1, 18, 50)])
+def test_fpn_out_fused_is_bit_identical(N, H, W):
+    """rcmvs_fpn_out_fused (1x1 lateral + up-add + 3x3 output conv in one launch) against the two rcmvs_conv2d_fwd calls it
+    replaces: same arithmetic order, so the maps must be equal bit for bit (ragged tiles, image borders, several images)."""
+    from rc_mvsnet_amd import _lib, ops
+    _lib.load()
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    dev = "cuda:0"
+    lat = torch.randn(N, H, W, 8, generator=g).to(dev)
+    up = torch.randn(N, H // 2, W // 2, 32, generator=g).to(dev)
+    w_in = ops.pack_conv2d_weight((0.3 * torch.randn(32, 8, 1, 1, generator=g)).to(dev))
+    b_in = (0.1 * torch.randn(32, generator=g)).to(dev)
+    w_out = ops.pack_conv2d_weight((0.1 * torch.randn(8, 32, 3, 3, generator=g)).to(dev))
+    want = ops.conv2d(ops.conv2d(lat, w_in, None, b_in, up_add=up), w_out)
+    got = ops.fpn_out_fused(lat, up, w_in, b_in, w_out)
+    assert got.shape == want.shape and torch.equal(got, want)
+    with pytest.raises(_lib.RcmvsError):
+        ops.fpn_out_fused(lat[:, :-1], up, w_in, b_in, w_out)
