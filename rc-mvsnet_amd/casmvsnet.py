@@ -124,7 +124,7 @@ class FeatureNet(nn.Module):
             if self.num_stage == 3:
                 plan["inner2"] = (ops.pack_conv2d_weight(self.inner2.weight), self.inner2.bias.detach().float().contiguous())
                 plan["out3"] = ops.pack_conv2d_weight(self.out3.weight)
-                plan["fuse_out3"] = (os.environ.get("RCMVS_FPN_FUSE", "0") == "1" and tuple(self.inner2.weight.shape[:2]) == (32, 8)
+                plan["fuse_out3"] = (os.environ.get("RCMVS_FPN_FUSE", "1") != "0" and tuple(self.inner2.weight.shape[:2]) == (32, 8)
                                      and tuple(self.out3.weight.shape[:2]) == (8, 32))
             self._plan, self._plan_key = plan, key
         return self._plan
