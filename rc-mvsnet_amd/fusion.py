@@ -13,6 +13,7 @@ import os
 
 import numpy as np
 import torch
+from PIL import Image
 
 from . import _lib, scan_io
 from .data_io import read_pfm
@@ -191,7 +192,6 @@ def filter_depth_tanks(scan_folder, out_folder, plyfilename, geo_pixel_thres, ge
         if len(srcs) > MAX_SRC:
             raise _lib.RcmvsError(f"filter_depth_tanks: view {ref} lists {len(srcs)} source views (at most {MAX_SRC})")
         conf = torch.from_numpy(read_pfm(os.path.join(out_folder, "confidence/{:0>8}.pfm".format(ref)))[0]).to(dev)
-        from PIL import Image
         raw = np.array(Image.open(os.path.join(scan_folder, "images/{:0>8}.jpg".format(ref))), dtype=np.uint8)
         img = prepare_image(raw, (img_wh[1], img_wh[0]), dev, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)).permute(1, 2, 0).contiguous()
         mats = torch.from_numpy(fusion_matrices(cams[ref][0], cams[ref][1], [cams[s][0] for s in srcs], [cams[s][1] for s in srcs])).to(dev)

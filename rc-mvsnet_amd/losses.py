@@ -13,8 +13,6 @@ views, the photometric / gradient / SSIM / smoothness sums, the per-pixel best v
 device, and the backward produces d loss / d depth directly (the images carry no gradient -- asking for one raises).
 There is no CPU or eager fallback: tensors must live on the GPU and the library must be built.
 """
-import ctypes
-
 import numpy as np
 import torch
 import torch.nn as nn
