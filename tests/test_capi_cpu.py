@@ -78,3 +78,36 @@ def test_training_entry_points_validate_arguments(lib):
     assert b"stride" in lib.rcmvs_last_error_string()
     assert lib.rcmvs_composite_bwd(None, None, None, None, None, None, None, 4, 4, None) < 0
     assert lib.rcmvs_resize_planes_bwd(one, one, 1, 80, 80, 4, 8, 4, 4, None) < 0       # more channels than the kernel holds
+
+
+def test_loss_fusion_loader_entry_points_validate_arguments(lib):
+    """The SURVEY 8f entry points (self-supervised loss, fusion filter, image preparation, fused FPN level) reject bad
+    arguments on the host, before any launch, with a message."""
+    one = ctypes.c_void_p(16)
+    err = lib.rcmvs_last_error_string
+    assert lib.rcmvs_inverse_warp(one, one, None, one, one, 1, 8, 8, None) < 0 and b"null pointer" in err()
+    assert lib.rcmvs_inverse_warp(one, one, one, one, one, 1, 1, 8, None) < 0 and b"bad dims" in err()
+    assert lib.rcmvs_unsup_loss_fwd(one, one, one, one, one, one, one, one, one, 1, 0, 8, 8, None) < 0 and b"source views" in err()
+    assert lib.rcmvs_unsup_loss_fwd(one, one, one, one, one, one, one, one, one, 1, 9, 8, 8, None) < 0 and b"source views" in err()
+    assert lib.rcmvs_unsup_loss_fwd(one, one, one, one, one, one, one, one, one, 1, 2, 2, 8, None) < 0 and b"3x3" in err()
+    assert lib.rcmvs_unsup_loss_bwd(one, one, one, one, one, one, one, None, one, one, one, 1, 2, 8, 8, None) < 0 and b"null pointer" in err()
+    assert lib.rcmvs_masked_sl1_fwd(one, one, one, one, 0, None) < 0 and b"n=0" in err()
+    assert lib.rcmvs_masked_sl1_bwd(one, one, one, one, None, one, 4, None) < 0
+    idx = (ctypes.c_int * 17)(*range(17))
+    args = (one, 0, ctypes.cast(idx, ctypes.c_void_p), one, None, one, 0.8, 3, 0.5, 0.01, one, one, one, None, None, None, None)
+    assert lib.rcmvs_fuse_view(*args, 17, 8, 8, None) < 0 and b"source views" in err()
+    assert lib.rcmvs_fuse_view(*args, 0, 8, 8, None) < 0
+    bad = list(args)
+    bad[4] = one                                                    # img without rgb
+    assert lib.rcmvs_fuse_view(*bad, 2, 8, 8, None) < 0 and b"together" in err()
+    neg = (ctypes.c_int * 2)(1, -1)
+    args2 = (one, 0, ctypes.cast(neg, ctypes.c_void_p)) + args[3:]
+    assert lib.rcmvs_fuse_view(*args2, 2, 8, 8, None) < 0 and b"negative" in err()
+    assert lib.rcmvs_compact_points(one, one, None, one, None, one, 0, None) < 0 and b"n=0" in err()
+    assert lib.rcmvs_compact_points(one, one, one, one, None, one, 8, None) < 0 and b"together" in err()
+    mean, std0 = (ctypes.c_float * 3)(0.5, 0.5, 0.5), (ctypes.c_float * 3)(0.2, 0.0, 0.2)
+    assert lib.rcmvs_prepare_image(one, one, 8, 8, 4, 4, ctypes.cast(mean, ctypes.c_void_p), ctypes.cast(std0, ctypes.c_void_p), None) < 0
+    assert b"zero std" in err()
+    assert lib.rcmvs_prepare_image(one, one, 8, 8, 0, 4, ctypes.cast(mean, ctypes.c_void_p), ctypes.cast(mean, ctypes.c_void_p), None) < 0
+    assert lib.rcmvs_fpn_out_fused(one, one, one, one, one, one, 1, 15, 16, 8, 32, 8, None) < 0 and b"even" in err()
+    assert lib.rcmvs_fpn_out_fused(one, one, one, one, one, one, 1, 16, 16, 16, 32, 8, None) < 0 and b"unsupported" in err()
