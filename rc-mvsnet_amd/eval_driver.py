@@ -73,7 +73,7 @@ def save_reference_view(outdir, filename, cam, img):
 def run_scans(model, args, device, rank, world):
     """Real data: this rank's scans through the loader, the model, the writers and (``--filter``) the fusion step."""
     from . import fusion
-    from .mvs_dataset import MVSDataset
+    from .mvs_dataset import AsyncWriter, MVSDataset, prefetch
     with open(args.testlist) as f:
         scans = [line.rstrip() for line in f.readlines() if line.strip()]
     mine = shard_items(scans, rank, world)
@@ -82,9 +82,9 @@ def run_scans(model, args, device, rank, world):
     for scan in mine:
         ds = MVSDataset(args.testpath, [scan], "test", args.num_view, args.numdepth, args.interval_scale, device=device,
                         max_h=args.max_h, max_w=args.max_w)
-        with torch.no_grad():
-            for i in range(len(ds)):
-                item = ds[i]
+        # decoding runs ahead on worker threads, file writing trails on others: the GPU only waits for its own kernels
+        with torch.no_grad(), AsyncWriter(args.io_threads) as writer:
+            for item in prefetch(ds, workers=args.io_threads, depth=2 * args.io_threads):
                 imgs = item["imgs"].unsqueeze(0)
                 proj = {k: torch.from_numpy(v).unsqueeze(0).to(device) for k, v in item["proj_matrices"].items()}
                 dv = torch.from_numpy(item["depth_values"]).unsqueeze(0).to(device)
@@ -96,8 +96,9 @@ def run_scans(model, args, device, rank, world):
                 for kind, t in (("depth_est", out["depth"][0]), ("confidence", out["photometric_confidence"][0])):
                     path = os.path.join(args.outdir, name.format(kind, ".pfm"))
                     os.makedirs(os.path.dirname(path), exist_ok=True)
-                    save_pfm(path, t.float().cpu().numpy())
-                save_reference_view(args.outdir, name, item["proj_matrices"]["stage{}".format(nstage)][0], item["imgs"][0])
+                    writer.submit(save_pfm, path, t.float().cpu().numpy())
+                cam = item["proj_matrices"]["stage{}".format(nstage)][0]
+                writer.submit(save_reference_view, args.outdir, name, cam, item["imgs"][0].cpu())
         if args.filter:
             folder = os.path.join(args.outdir, scan)
             fusion.filter_depth(os.path.join(args.testpath, scan), folder, folder, os.path.join(args.outdir, scan + ".ply"),
@@ -118,6 +119,7 @@ def main(argv=None):
     ap.add_argument("--interval_scale", type=float, default=1.06)
     ap.add_argument("--max_h", type=int, default=1200)
     ap.add_argument("--max_w", type=int, default=1600)
+    ap.add_argument("--io_threads", type=int, default=4, help="threads decoding input images ahead / writing outputs behind the GPU")
     ap.add_argument("--filter", action="store_true", help="fuse each scan's depth maps into <outdir>/<scan>.ply afterwards")
     ap.add_argument("--prob_thres", type=float, default=0.8)
     ap.add_argument("--num_consistency", type=int, default=3)

@@ -137,3 +137,48 @@ def test_tanks_loader_items_match_reference(tanks_folder, harness, monkeypatch):
     _check_tanks(mvs_dataset.TanksDataset(tanks_folder, "intermediate", 3, (96, 64), 192, device="cpu"))
     one = mvs_dataset.TanksDataset(tanks_folder, "intermediate", 3, (96, 64), 192, device="cpu", scans=["Horse"])
     assert len(one) == 5 and one[0]["filename"].startswith("Horse/")
+
+
+def test_prefetch_keeps_order_and_propagates_errors(folder, harness, monkeypatch):
+    """prefetch(): host halves run ahead on threads, items come back in order and equal to direct indexing; a failing item
+    raises at its position."""
+    d, _ = folder
+    monkeypatch.setattr(mvs_dataset, "prepare_image", harness_prepare(harness))
+    ds = mvs_dataset.MVSDataset(d, ["scan1", "scan2"], "test", 3, 192, 1.06, device="cpu", max_h=1200, max_w=1600)
+    direct = [ds[i] for i in range(len(ds))]
+    for workers, depth in ((1, 1), (4, 8), (3, 2)):
+        got = list(mvs_dataset.prefetch(ds, workers=workers, depth=depth))
+        assert [g["filename"] for g in got] == [x["filename"] for x in direct]
+        assert all(torch.equal(g["imgs"], x["imgs"]) and np.array_equal(g["depth_values"], x["depth_values"]) for g, x in zip(got, direct))
+    assert [g["filename"] for g in mvs_dataset.prefetch(ds, indices=[7, 2])] == [direct[7]["filename"], direct[2]["filename"]]
+    orig = ds.load_host
+
+    def flaky(i):
+        if i == 3:
+            raise ValueError("broken image")
+        return orig(i)
+
+    monkeypatch.setattr(ds, "load_host", flaky)
+    seen = []
+    with pytest.raises(ValueError, match="broken image"):
+        for item in mvs_dataset.prefetch(ds, workers=4, depth=8):
+            seen.append(item["filename"])
+    assert seen == [x["filename"] for x in direct[:3]]
+
+
+def test_async_writer_flushes_and_reports_failures(tmp_path):
+    paths = [str(tmp_path / ("f%d.txt" % i)) for i in range(20)]
+    with mvs_dataset.AsyncWriter(3) as w:
+        for i, p in enumerate(paths):
+            w.submit(lambda p=p, i=i: open(p, "w").write(str(i)))
+    assert [open(p).read() for p in paths] == [str(i) for i in range(20)]        # everything is on disk once the block exits
+
+    def boom():
+        raise OSError("disk full")
+
+    w = mvs_dataset.AsyncWriter(2)
+    w.submit(boom)
+    w.submit(lambda: open(paths[0], "w").write("late"))
+    with pytest.raises(OSError, match="disk full"):
+        w.close()
+    assert open(paths[0]).read() == "late"                                        # the other jobs still ran
