@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, smoke, bench, rocprofv3 kernel stats.  Logs -> gpurun_out/.
 set -u
+exec < /dev/null          # nothing below may wait on stdin (an empty file list once turned `head` into a 7-minute hang)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 echo "== rocm-smi" ; rocm-smi --showproductname 2>/dev/null | head -8
@@ -20,6 +21,8 @@ echo "== train bench"
 timeout 300 python tools/train_bench.py 2>&1 | tail -4 | tee gpurun_out/train_bench.log
 echo "== rocprof"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1 )
-ls -R gpurun_out/prof | head -20
-f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && head -40 "$f"
+ls -R gpurun_out/prof 2>/dev/null | head -n 20
+f=$(find gpurun_out/prof -name "*kernel_stats.csv" 2>/dev/null | head -n 1)
+if [ -n "$f" ] && [ -f "$f" ]; then head -n 40 "$f"; fi
+find gpurun_out/prof -name "*kernel_trace.csv" -delete 2>/dev/null
+exit 0
