@@ -1,6 +1,8 @@
 #!/bin/bash
-# PMC counters for the K1 variants (separate passes; kernel-trace only, no other trace domains)
+# PMC counters for the K1 variants (separate passes; kernel-trace only, no other trace domains).
+# K1_VARIANTS="4 6" bash tools/k1_pmc.sh  profiles the LDS-staged variants (e.g. SQ_LDS_BANK_CONFLICT vs SQ_INSTS_LDS); default: production.
 set -u
+exec < /dev/null
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
 cd /tmp
@@ -9,7 +11,7 @@ for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_A
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
             "FETCH_SIZE" "WRITE_SIZE" ; do
   tag=$(echo $pass | cut -d' ' -f1)
-  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o k1_$tag -- python $GRAFT_REPO_ROOT/tools/k1_ablate.py 0 > $GRAFT_REPO_ROOT/gpurun_out/pmc/log_$tag.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc -o k1_$tag -- python $GRAFT_REPO_ROOT/tools/k1_ablate.py ${K1_VARIANTS:-0} > $GRAFT_REPO_ROOT/gpurun_out/pmc/log_$tag.txt 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
