@@ -35,3 +35,50 @@ def rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU emulation of the HIP kernels (tests/emu): the product's own Python path -- ops.*, the autograd Functions, the drop-in
+# modules -- runs on CPU tensors against librcmvs_emu.so, so kernel logic is checked against the oracle without a GPU.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="session")
+def emu_lib():
+    import ctypes
+    sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
+    import build as emu_build
+    from rc_mvsnet_amd import _lib
+    lib = ctypes.CDLL(emu_build.build_cached())
+    for name, argtypes in _lib.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _lib._RESTYPES.get(name, ctypes.c_int)
+    return lib
+
+
+@pytest.fixture
+def emu(emu_lib, monkeypatch):
+    """Route the package to the emulated library for one test: CPU tensors are accepted where the real path demands GPU ones,
+    the 'stream' is NULL, and the modules take their HIP branches regardless of the device."""
+    import ctypes
+    from rc_mvsnet_amd import _lib, casmvsnet, fusion, losses, mvs_dataset, ops, render_consist_net, train_ops
+
+    def chk(t, name, dtype=torch.float32):
+        if t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+            raise _lib.RcmvsError(f"{name}: emulation expects a contiguous CPU tensor of {dtype}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def opt(t, name):
+        return ctypes.c_void_p(0) if t is None else chk(t, name)
+
+    monkeypatch.setattr(_lib, "_lib", emu_lib)
+    for mod in (ops, fusion, losses, mvs_dataset, train_ops):
+        monkeypatch.setattr(mod, "_chk", chk)
+        monkeypatch.setattr(mod, "_stream", lambda: ctypes.c_void_p(0))
+    monkeypatch.setattr(ops, "_opt", opt)
+    monkeypatch.setattr(train_ops, "_opt", opt)
+    infer = lambda module, *tensors: (not module.training) and (not torch.is_grad_enabled())            # noqa: E731
+    train = lambda module, *tensors: module.training and os.environ.get("RCMVS_TRAIN", "hip") != "aten"  # noqa: E731
+    for mod in (casmvsnet, render_consist_net):
+        monkeypatch.setattr(mod, "_hip_inference", infer)
+        monkeypatch.setattr(mod, "_hip_training", train)
+    return emu_lib

@@ -1,0 +1,220 @@
+// CPU emulation of the slice of the HIP programming model that rc-mvsnet_amd/csrc/*.hip uses -- TEST INFRASTRUCTURE ONLY.
+//
+// tests/emu/build.py compiles the product's kernel sources, unmodified apart from the spelling of dynamic LDS declarations, with
+// the host clang++ against this header instead of <hip/hip_runtime.h>; the result (librcmvs_emu.so) exports the same C ABI as
+// librcmvs_hip.so and runs every launch on the CPU: one fiber (ucontext) per thread of a block, blocks one after another,
+// __syncthreads and the wave collectives (shuffles, ballots, readlane, DPP row shifts, MFMA) as rendezvous points between the
+// fibers of a block / a 64-lane wave.  It exists so that the `-m "not gpu"` suite can check kernel LOGIC (indexing, barriers,
+// collectives, launch geometry) against the oracle on a machine without a GPU; it says nothing about performance and it is
+// not bit-exact where the hardware is not IEEE (v_rcp_f32, the MFMA's internal summation order).  Nothing in the package loads it.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------- qualifiers / types
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+inline float2 make_float2(float a, float b) { return {a, b}; }
+inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+
+template <class T> inline T min(T a, T b) { return b < a ? b : a; }
+template <class T> inline T max(T a, T b) { return a < b ? b : a; }
+
+// ---------------------------------------------------------------------------------------------------- execution engine
+namespace shim {
+
+constexpr int WAVE = 64;
+enum State { RUNNABLE, AT_BLOCK, AT_WAVE, DONE };
+
+struct Fiber {
+    ucontext_t ctx;
+    State st;
+    dim3 tid;
+    int lin;               // linear thread id
+    uint64_t pub[2];       // value published to the wave (up to 16 bytes)
+    int pred;              // __syncthreads_count / ballot predicate
+};
+
+struct Engine {
+    std::vector<Fiber> fib;
+    std::vector<char> stacks;
+    ucontext_t sched;
+    dim3 grid, block, bid;
+    int nthreads = 0, cur = -1;
+    std::vector<char> dyn;
+    std::vector<uint64_t> snap;       // per thread: snapshot of the wave's published values at release
+    std::vector<int> snap_pred;
+    int block_count = 0;              // result of __syncthreads_count
+    std::function<void()> body;
+};
+Engine& eng();
+void run_grid(dim3 grid, dim3 block, size_t lds, std::function<void()> body);
+void yield(State s);
+
+inline Fiber& me() { Engine& e = eng(); return e.fib[e.cur]; }
+inline void* dyn_lds() { return eng().dyn.data(); }
+
+struct WaveView {                      // what a lane sees after a wave rendezvous
+    int base, lane, n;                 // first thread of the wave, own lane, lanes that exist in this wave
+    const uint64_t* pub(int l) const { return &eng().snap[(size_t)(base + l) * 2]; }
+    bool live(int l) const { return l >= 0 && l < n && eng().snap_pred[base + l] >= 0; }
+    int pred(int l) const { return eng().snap_pred[base + l]; }
+};
+template <class T> inline WaveView exchange(T v, int pred = 1) {
+    static_assert(sizeof(T) <= 16, "wave values are at most 16 bytes");
+    Fiber& f = me();
+    f.pub[0] = f.pub[1] = 0;
+    std::memcpy(f.pub, &v, sizeof(T));
+    f.pred = pred;
+    yield(AT_WAVE);
+    Engine& e = eng();
+    const int lin = e.fib[e.cur].lin;
+    WaveView w;
+    w.base = lin / WAVE * WAVE; w.lane = lin - w.base; w.n = min(WAVE, e.nthreads - w.base);
+    return w;
+}
+template <class T> inline T lane_value(const WaveView& w, int l, T own) {
+    if (!w.live(l)) return own;
+    T r;
+    std::memcpy(&r, w.pub(l), sizeof(T));
+    return r;
+}
+
+}  // namespace shim
+
+#define threadIdx (::shim::me().tid)
+#define blockIdx (::shim::eng().bid)
+#define blockDim (::shim::eng().block)
+#define gridDim (::shim::eng().grid)
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    ::shim::run_grid(dim3(grid), dim3(block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { ::shim::yield(::shim::AT_BLOCK); }
+inline int __syncthreads_count(int pred) {
+    ::shim::me().pred = pred ? 1 : 0;
+    ::shim::yield(::shim::AT_BLOCK);
+    return ::shim::eng().block_count;
+}
+
+// ---------------------------------------------------------------------------------------------------- wave collectives
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+    const auto w = ::shim::exchange(v);
+    const int l = w.lane ^ mask;
+    return (l / width == w.lane / width) ? ::shim::lane_value(w, l, v) : v;
+}
+template <class T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    const auto w = ::shim::exchange(v);
+    const int l = w.lane + (int)delta;
+    return (l / width == w.lane / width) ? ::shim::lane_value(w, l, v) : v;
+}
+template <class T> inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    const auto w = ::shim::exchange(v);
+    const int l = w.lane - (int)delta;
+    return (l >= 0 && l / width == w.lane / width) ? ::shim::lane_value(w, l, v) : v;
+}
+inline unsigned long long __ballot(int pred) {
+    const auto w = ::shim::exchange(0, pred ? 1 : 0);
+    unsigned long long m = 0;
+    for (int l = 0; l < w.n; ++l)
+        if (w.live(l) && w.pred(l) > 0) m |= 1ull << l;
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __builtin_amdgcn_readlane_emu(int v, int lane) { const auto w = ::shim::exchange(v); return ::shim::lane_value(w, lane, v); }
+inline int __builtin_amdgcn_readfirstlane_emu(int v) {
+    const auto w = ::shim::exchange(v);
+    for (int l = 0; l < w.n; ++l)
+        if (w.live(l)) return ::shim::lane_value(w, l, v);
+    return v;
+}
+// DPP row_shr:n (ctrl 0x111..0x11f) with bound_ctrl = 0: lane i of a 16-lane row reads lane i - n of the same row, else keeps `old`
+inline int __builtin_amdgcn_update_dpp_emu(int old, int src, int ctrl, int, int, bool) {
+    const auto w = ::shim::exchange(src);
+    if (ctrl >= 0x111 && ctrl <= 0x11f) {
+        const int n = ctrl - 0x110, l = w.lane - n;
+        return (w.lane % 16 >= n) ? ::shim::lane_value(w, l, old) : old;
+    }
+    std::fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl);
+    std::abort();
+}
+#define __builtin_amdgcn_readlane(v, l) __builtin_amdgcn_readlane_emu((v), (l))
+#define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu((v))
+#define __builtin_amdgcn_update_dpp(o, s, c, r, b, bc) __builtin_amdgcn_update_dpp_emu((o), (s), (c), (r), (b), (bc))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+
+// v_mfma_f32_16x16x4_f32: D (16x16) = A (16x4) B (4x16) + C.  Lane l holds a = A[l % 16][l / 16], b = B[l / 16][l % 16] and the
+// four elements D[4 (l / 16) + r][l % 16], r = 0..3 (MI355X_MICROARCH / CDNA3 ISA, section on MFMA register layouts).
+typedef float emu_v4f __attribute__((ext_vector_type(4)));
+inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x4f32_emu(float a, float b, emu_v4f c, int, int, int) {
+    struct AB { float a, b; } ab = {a, b};
+    const auto w = ::shim::exchange(ab);
+    const int j = w.lane % 16, g = w.lane / 16;
+    emu_v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float s = 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            const AB x = ::shim::lane_value(w, i + 16 * k, AB{0.f, 0.f}), y = ::shim::lane_value(w, j + 16 * k, AB{0.f, 0.f});
+            s = fmaf(x.a, y.b, s);
+        }
+        d[r] = c[r] + s;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x4f32_emu((a), (b), (c), (x), (y), (z))
+
+// ---------------------------------------------------------------------------------------------------- buffer resources
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num_records; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc_emu(const void* p, short, int num_records, int) {
+    return {reinterpret_cast<const char*>(p), (unsigned)num_records};
+}
+#define __builtin_amdgcn_make_buffer_rsrc(p, s, n, f) __builtin_amdgcn_make_buffer_rsrc_emu((p), (s), (n), (f))
+typedef unsigned emu_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned emu_v2u __attribute__((ext_vector_type(2)));
+// raw buffer loads return 0 for out-of-range offsets; "range" can only be emulated when the caller passes a real size: the
+// kernels here pass 0x7fffffff and steer invalid lanes to offsets >= 0x80000000, which the unsigned compare below catches
+inline emu_v4u __builtin_amdgcn_raw_buffer_load_b128_emu(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    const unsigned off = (unsigned)voffset + (unsigned)soffset;
+    emu_v4u v = {0u, 0u, 0u, 0u};
+    if (off < r.num_records && off + 16u <= r.num_records) std::memcpy(&v, r.base + off, 16);
+    return v;
+}
+inline emu_v2u __builtin_amdgcn_raw_buffer_load_b64_emu(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    const unsigned off = (unsigned)voffset + (unsigned)soffset;
+    emu_v2u v = {0u, 0u};
+    if (off < r.num_records && off + 8u <= r.num_records) std::memcpy(&v, r.base + off, 8);
+    return v;
+}
+#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b128_emu((r), (v), (s), (a))
+#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b64_emu((r), (v), (s), (a))
+
+// ---------------------------------------------------------------------------------------------------- atomics (one OS thread)
+template <class T> inline T unsafeAtomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }

@@ -1,0 +1,68 @@
+"""The HIP kernels themselves on the CPU: rc-mvsnet_amd/csrc/*.hip compiled against the emulation of tests/emu (fibers for
+threads, rendezvous for __syncthreads / wave collectives) and driven through the package's own Python path on CPU tensors,
+checked against the oracle and the reference's goldens.  Logic only -- indexing, barriers, collectives, launch geometry; the
+`-m gpu` tests remain the parity tests proper (the emulation's v_rcp and MFMA summation order are not the hardware's)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from rc_mvsnet_amd import synthetic
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_unsup_loss_multi_stage_on_emulated_kernels(emu):
+    from rc_mvsnet_amd import losses
+    G = np.load(os.path.join(HERE, "golden", "unsup_loss.npz"))
+    for tag in ("a", "b"):
+        B, V, H, W, seed = [int(x) for x in G[tag + ":dims"]]
+        imgs, cams = synthetic.images(B, V, H, W, seed), synthetic.proj_matrices(B, V, H, W)
+        inputs = {k: {"depth": torch.tensor(G[f"{tag}:depth:{k}"]).requires_grad_(True)} for k in ("stage1", "stage2", "stage3")}
+        total, scalars = losses.UnsupLossMultiStage()(inputs, imgs, cams, dlossw=[0.5, 1.0, 2.0])
+        total.backward()
+        assert abs(float(total.detach()) - float(G[tag + ":total"])) <= 2e-5 * abs(float(G[tag + ":total"]))
+        for k in inputs:
+            want = torch.tensor(G[f"{tag}:grad:{k}"])
+            err = (inputs[k]["depth"].grad - want).abs()
+            assert float(err.median()) <= 1e-5 * float(want.abs().max()) and float((err > 1e-3 * float(want.abs().max())).float().mean()) <= 5e-3
+
+
+def test_fused_fpn_level_and_conv2d_on_emulated_kernels(emu):
+    from rc_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(0)
+    lat, up = torch.randn(2, 36, 44, 8, generator=g), torch.randn(2, 18, 22, 32, generator=g)
+    w_in_t, b_in = 0.3 * torch.randn(32, 8, 1, 1, generator=g), 0.1 * torch.randn(32, generator=g)
+    w_out_t = 0.1 * torch.randn(8, 32, 3, 3, generator=g)
+    w_in, w_out = ops.pack_conv2d_weight(w_in_t), ops.pack_conv2d_weight(w_out_t)
+    two = ops.conv2d(ops.conv2d(lat, w_in, None, b_in, up_add=up), w_out)
+    one = ops.fpn_out_fused(lat, up, w_in, b_in, w_out)
+    assert torch.equal(one, two)
+    F = torch.nn.functional
+    intra = F.interpolate(up.permute(0, 3, 1, 2), scale_factor=2, mode="nearest") + F.conv2d(lat.permute(0, 3, 1, 2), w_in_t, b_in)
+    want = F.conv2d(intra, w_out_t, padding=1).permute(0, 2, 3, 1)
+    assert float((one - want).abs().max()) < 2e-5
+
+
+def test_cascade_eval_forward_on_emulated_kernels(emu):
+    """CascadeMVSNet_eval.forward through every inference kernel (FeatureNet 2-D convs incl. the MFMA / space-to-depth layers,
+    planes, homography, K1, the 3-D conv family, depth head) on the emulation, against the oracle -- __graft_entry__.smoke()'s
+    check without a GPU."""
+    from oracle import cascade
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    sd = synthetic.cascade_state_dict(0)
+    nd, ratios = (8, 8, 8), (4, 2, 1)
+    model = CascadeMVSNet_eval(ndepths=list(nd), depth_interals_ratio=list(ratios))
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 32, 64, 0)
+    with torch.no_grad():
+        out = model(imgs, pm, dv)
+    ref = cascade.forward_eval(imgs, pm, dv, sd, nd, ratios, impl="spec")
+    rng = float(dv[0, -1] - dv[0, 0])
+    for key in ("stage1", "stage2", "stage3"):
+        err = float((out[key]["depth"] - ref[key]["depth"]).abs().mean()) / rng
+        assert err < 1e-4, (key, err)
+    assert float((out["photometric_confidence"] - ref["photometric_confidence"]).abs().max()) < 5e-3
