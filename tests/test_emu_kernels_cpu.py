@@ -66,3 +66,32 @@ def test_cascade_eval_forward_on_emulated_kernels(emu):
         err = float((out[key]["depth"] - ref[key]["depth"]).abs().mean()) / rng
         assert err < 1e-4, (key, err)
     assert float((out["photometric_confidence"] - ref["photometric_confidence"]).abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize("C,D,h,w,V", [(32, 16, 12, 21, 3), (16, 8, 17, 30, 4), (8, 12, 16, 40, 2), (8, 8, 12, 24, 7), (16, 8, 10, 14, 5)])
+def test_k1_variants_on_emulated_kernels(C, D, h, w, V, emu):
+    """K1 forward: production two-phase kernel (compile-time 2 / 4 / 6 source views and the general path) against the
+    reference-order kernel and the LDS-staged variants (per-wave bounding boxes through DPP row shifts + readlane), and against
+    the oracle's variance volume."""
+    from oracle import warp
+    from rc_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(C + V)
+    feats = torch.randn(2, V, h, w, C, generator=g)
+    pm = synthetic.proj_matrices(2, V, h * 4, w * 4)["stage1"]
+    rot, trans = ops.compose_homography(pm)
+    planes = torch.stack((425.0 + 100.0 * torch.rand(2, h, w, generator=g), 2.0 + 8.0 * torch.rand(2, h, w, generator=g)), dim=-1).contiguous()
+    try:
+        emu.rcmvs_debug_k1_variant(2)
+        vref = ops.warp_variance(feats, rot, trans, planes, D)
+        outs = {}
+        for var in (0, 4, 6):
+            emu.rcmvs_debug_k1_variant(var)
+            outs[var] = ops.warp_variance(feats, rot, trans, planes, D)
+    finally:
+        emu.rcmvs_debug_k1_variant(0)
+    for var, v in outs.items():
+        assert float((v - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), var
+    samples = planes[..., 0].unsqueeze(1) + planes[..., 1].unsqueeze(1) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
+    want = warp.variance_volume([feats[:, v].permute(0, 3, 1, 2) for v in range(V)], pm, samples)        # (B,C,D,h,w)
+    got = outs[0].permute(0, 4, 1, 2, 3)
+    assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))

@@ -38,7 +38,8 @@ def test_unsup_loss_multi_stage_matches_reference(tag):
     inputs = {k: {"depth": torch.tensor(GOLD[f"{tag}:depth:{k}"]).to(DEV).requires_grad_(True)} for k in STAGES}
     total, scalars = losses.UnsupLossMultiStage()(inputs, imgs.to(DEV), {k: v.to(DEV) for k, v in cams.items()}, dlossw=DLOSSW)
     total.backward()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     assert abs(float(total) - float(GOLD[tag + ":total"])) <= 2e-5 * abs(float(GOLD[tag + ":total"]))
     for k, v in scalars.items():
         want = float(GOLD[f"{tag}:{k}"])

@@ -638,7 +638,7 @@ def test_fpn_out_fused_is_bit_identical(N, H, W):
     from rc_mvsnet_amd import _lib, ops
     _lib.load()
     g = torch.Generator().manual_seed(N * 1000 + H)
-    dev = "cuda:0"
+    dev = DEV
     lat = torch.randn(N, H, W, 8, generator=g).to(dev)
     up = torch.randn(N, H // 2, W // 2, 32, generator=g).to(dev)
     w_in = ops.pack_conv2d_weight((0.3 * torch.randn(32, 8, 1, 1, generator=g)).to(dev))

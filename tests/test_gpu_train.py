@@ -8,6 +8,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"          # tests/test_emu_gpu_suite_cpu.py re-runs a subset of this file on the CPU emulation with DEV = "cpu"
 
 
 def test_train_step_then_hip_inference():
@@ -15,7 +16,7 @@ def test_train_step_then_hip_inference():
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
     _lib.load()
     warnings.simplefilter("ignore")
-    dev = torch.device("cuda:0")
+    dev = torch.device(DEV)
     model, model_nerf, opt = ts.build(dev, ndepths=(16, 8, 8), n_samples=32)
     imgs, proj, dv, batch = ts.synthetic_sample(dev, H=128, W=160, V=4)
     model.eval()
@@ -51,7 +52,7 @@ def test_conv_bn_relu_block_forward_backward(ci, co, stride, transposed, relu, w
     import torch.nn.functional as F
     from rc_mvsnet_amd import _lib, train_ops
     _lib.load()
-    dev = "cuda:0"
+    dev = DEV
     g = torch.Generator().manual_seed(ci * 100 + co + stride)
     B, D, H, W = (2, 8, 8, 16) if relu else (1, 4, 6, 10)             # second shape: ragged width (Wo = 10 or 5)
     x = torch.randn(B, ci, D, H, W, generator=g)
@@ -99,7 +100,7 @@ def test_prob_depth_head_backward():
     import torch.nn.functional as F
     from rc_mvsnet_amd import _lib, train_ops
     _lib.load()
-    dev = "cuda:0"
+    dev = DEV
     g = torch.Generator().manual_seed(5)
     B, D, h, w = 2, 8, 16, 24
     x8 = torch.randn(B, 8, D, h, w, generator=g)
@@ -130,7 +131,7 @@ def test_cascade_train_native_vs_delegated_gradients(monkeypatch):
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet
     _lib.load()
     warnings.simplefilter("ignore")
-    dev = "cuda:0"
+    dev = DEV
     m1 = CascadeMVSNet(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1])
     m1.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=2.0), strict=True)
     m1 = m1.to(dev).train()
@@ -173,7 +174,7 @@ def test_neural_volume_net_train_native_vs_delegated(monkeypatch):
     from rc_mvsnet_amd.render_consist_net import Neural_Volume_Net
     _lib.load()
     warnings.simplefilter("ignore")
-    dev = "cuda:0"
+    dev = DEV
     torch.manual_seed(3)
     m1 = Neural_Volume_Net().to(dev).train()
     for mod in m1.modules():
@@ -209,7 +210,7 @@ def test_renderer_train_native_vs_delegated(monkeypatch):
     from rc_mvsnet_amd.render_consist_net import Rendering_Consistency_Net
     _lib.load()
     warnings.simplefilter("ignore")
-    dev = "cuda:0"
+    dev = DEV
     H, W, V, S = 64, 96, 4, 16
     m1 = Rendering_Consistency_Net(ts.render_args(S))
     m1.load_state_dict(synthetic.render_state_dict(1), strict=True)
@@ -265,7 +266,7 @@ def test_hip_training_path_vs_reference_gradients():
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet
     _lib.load()
     warnings.simplefilter("ignore")
-    dev = "cuda:0"
+    dev = DEV
     g = load_golden("train_grads")
     m = CascadeMVSNet(ndepths=[8, 8, 8], depth_interals_ratio=[4, 2, 1])
     m.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=2.0), strict=True)
@@ -301,7 +302,7 @@ def test_featurenet_train_native_vs_delegated(monkeypatch):
     from rc_mvsnet_amd.casmvsnet import FeatureNet
     _lib.load()
     warnings.simplefilter("ignore")
-    dev = "cuda:0"
+    dev = DEV
     torch.manual_seed(1)
     m1 = FeatureNet(base_channels=8, stride=4, num_stage=3, arch_mode="fpn").to(dev).train()
     for mod in m1.modules():
@@ -341,7 +342,7 @@ def test_sync_batchnorm_branch_with_simulated_replica(monkeypatch):
     import torch.distributed as dist
     from rc_mvsnet_amd import _lib, train_ops
     _lib.load()
-    dev = "cuda:0"
+    dev = DEV
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 8, 8, 16, 16, generator=g).to(dev)
     w = (torch.randn(16, 16, 3, 3, 3, generator=g) * 0.05).to(dev)
