@@ -6,6 +6,15 @@ namespace shim {
 static Engine g_engine;
 Engine& eng() { return g_engine; }
 
+// Scheduling order of the fibers between synchronisation points: 0 = ascending thread id, 1 = descending, 2 = waves descending
+// with lanes ascending.  A kernel whose result depends on it is missing a barrier (or relies on an unordered float atomic).
+static int g_order = 0;
+static inline int pick(int i, int n) {
+    if (g_order == 2 && n % WAVE == 0) return (n / WAVE - 1 - i / WAVE) * WAVE + i % WAVE;
+    if (g_order >= 1) return n - 1 - i;
+    return i;
+}
+
 constexpr size_t STACK = 256 * 1024;
 
 static void trampoline() {
@@ -71,7 +80,8 @@ static void run_block(Engine& e) {
     }
     for (;;) {
         bool progressed = false, live = false;
-        for (int t = 0; t < e.nthreads; ++t) {
+        for (int i = 0; i < e.nthreads; ++i) {
+            const int t = pick(i, e.nthreads);
             if (e.fib[t].st != RUNNABLE) continue;
             e.cur = t;
             swapcontext(&e.sched, &e.fib[t].ctx);
@@ -111,3 +121,5 @@ void run_grid(dim3 grid, dim3 block, size_t lds, std::function<void()> body) {
 }
 
 }  // namespace shim
+
+extern "C" void rcmvs_emu_set_order(int order) { shim::g_order = order; }

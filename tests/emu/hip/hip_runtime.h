@@ -147,26 +147,68 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
-inline int __builtin_amdgcn_readlane_emu(int v, int lane) { const auto w = ::shim::exchange(v); return ::shim::lane_value(w, lane, v); }
-inline int __builtin_amdgcn_readfirstlane_emu(int v) {
+template <class T> inline T __builtin_amdgcn_readlane_emu(T v, int lane) { const auto w = ::shim::exchange(v); return ::shim::lane_value(w, lane, v); }
+template <class T> inline T __builtin_amdgcn_readfirstlane_emu(T v) {
     const auto w = ::shim::exchange(v);
     for (int l = 0; l < w.n; ++l)
         if (w.live(l)) return ::shim::lane_value(w, l, v);
     return v;
 }
-// DPP row_shr:n (ctrl 0x111..0x11f) with bound_ctrl = 0: lane i of a 16-lane row reads lane i - n of the same row, else keeps `old`
-inline int __builtin_amdgcn_update_dpp_emu(int old, int src, int ctrl, int, int, bool) {
-    const auto w = ::shim::exchange(src);
-    if (ctrl >= 0x111 && ctrl <= 0x11f) {
-        const int n = ctrl - 0x110, l = w.lane - n;
-        return (w.lane % 16 >= n) ? ::shim::lane_value(w, l, old) : old;
-    }
+// DPP source lane for the controls the CDNA ISA defines on 64-lane waves; -1 = no source (bound_ctrl decides: keep `old` or 0)
+inline int emu_dpp_source(int lane, int ctrl) {
+    const int row = lane & ~15, i = lane & 15;
+    if (ctrl >= 0x000 && ctrl <= 0x0ff) return (lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3);            // quad_perm
+    if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; return i + n <= 15 ? lane + n : -1; }   // row_shl
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; return i >= n ? lane - n : -1; }        // row_shr
+    if (ctrl >= 0x121 && ctrl <= 0x12f) { const int n = ctrl - 0x120; return row + ((i - n) & 15); }          // row_ror
+    if (ctrl == 0x130) return lane + 1 <= 63 ? lane + 1 : -1;                                                  // wave_shl:1
+    if (ctrl == 0x138) return lane >= 1 ? lane - 1 : -1;                                                       // wave_shr:1
+    if (ctrl == 0x140) return row + (15 - i);                                                                  // row_mirror
+    if (ctrl == 0x141) return row + (i < 8 ? 7 - i : 23 - i);                                                  // row_half_mirror
+    if (ctrl == 0x142) return lane >= 16 ? row - 1 : -1;                                                       // row_bcast:15: lane 15 of the previous row
+    if (ctrl == 0x143) return lane >= 32 ? 31 : -1;                                                            // row_bcast:31
     std::fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl);
     std::abort();
 }
+template <class T> inline T __builtin_amdgcn_update_dpp_emu(T old, T src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const auto w = ::shim::exchange(src);
+    const bool enabled = ((row_mask >> (w.lane / 16)) & 1) && ((bank_mask >> ((w.lane & 15) / 4)) & 1);
+    if (!enabled) return old;
+    const int srcl = emu_dpp_source(w.lane, ctrl);
+    if (srcl < 0 || !w.live(srcl)) return bound_ctrl ? T(0) : old;
+    return ::shim::lane_value(w, srcl, old);
+}
+template <class T> inline T __builtin_amdgcn_ds_bpermute_emu(int addr, T src) {
+    const auto w = ::shim::exchange(src);
+    return ::shim::lane_value(w, (addr >> 2) & 63, T(0));
+}
+template <class T> inline T __shfl(T v, int src_lane, int width = 64) {
+    const auto w = ::shim::exchange(v);
+    return ::shim::lane_value(w, (w.lane / width) * width + (src_lane % width), v);
+}
+inline int __any(int pred) { return __ballot(pred) != 0ull; }
+inline int __all(int pred) { const auto w = ::shim::exchange(0, pred ? 1 : 0); for (int l = 0; l < w.n; ++l) if (w.live(l) && w.pred(l) <= 0) return 0; return 1; }
+inline unsigned long long __activemask() { return __ballot(1); }
+inline int __lane_id() { return ::shim::me().lin % ::shim::WAVE; }
 #define __builtin_amdgcn_readlane(v, l) __builtin_amdgcn_readlane_emu((v), (l))
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu((v))
 #define __builtin_amdgcn_update_dpp(o, s, c, r, b, bc) __builtin_amdgcn_update_dpp_emu((o), (s), (c), (r), (b), (bc))
+#define __builtin_amdgcn_mov_dpp(s, c, r, b, bc) __builtin_amdgcn_update_dpp_emu((s), (s), (c), (r), (b), (bc))
+#define __builtin_amdgcn_ds_bpermute(a, s) __builtin_amdgcn_ds_bpermute_emu((a), (s))
+// scheduling / counters: no effect on results
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __ldg(p) (*(p))
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+#define __fdividef(a, b) ((a) / (b))
+#define __frcp_rn(x) (1.0f / (x))
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
 // v_mfma_f32_16x16x4_f32: D (16x16) = A (16x4) B (4x16) + C.  Lane l holds a = A[l % 16][l / 16], b = B[l / 16][l % 16] and the
@@ -215,6 +257,41 @@ inline emu_v2u __builtin_amdgcn_raw_buffer_load_b64_emu(__amdgpu_buffer_rsrc_t r
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b128_emu((r), (v), (s), (a))
 #define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b64_emu((r), (v), (s), (a))
 
+// buffer_load ... lds (direct-to-LDS DMA): lane i of the wave writes `size` bytes at ldsptr + i * size.  Emulated synchronously,
+// which is what the data looks like once the s_waitcnt vmcnt(0) + barrier that must follow on hardware have passed.
+inline void __builtin_amdgcn_raw_ptr_buffer_load_lds_emu(__amdgpu_buffer_rsrc_t r, void* ldsptr, int size, int voffset, int soffset, int offset, int) {
+    const unsigned off = (unsigned)voffset + (unsigned)soffset + (unsigned)offset;
+    char* dst = reinterpret_cast<char*>(ldsptr) + (size_t)(::shim::me().lin % ::shim::WAVE) * size;
+    if (off < r.num_records && off + (unsigned)size <= r.num_records) std::memcpy(dst, r.base + off, size);
+    else std::memset(dst, 0, size);
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, p, n, v, s, o, a) __builtin_amdgcn_raw_ptr_buffer_load_lds_emu((r), (p), (n), (v), (s), (o), (a))
+
+// v_mfma_f32_32x32x2_f32: D (32x32) = A (32x2) B (2x32) + C; lane l holds a = A[l % 32][l / 32], b = B[l / 32][l % 32] and the
+// sixteen elements D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32], r = 0..15
+typedef float emu_v16f __attribute__((ext_vector_type(16)));
+inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x2f32_emu(float a, float b, emu_v16f c, int, int, int) {
+    struct AB { float a, b; } ab = {a, b};
+    const auto w = ::shim::exchange(ab);
+    const int j = w.lane % 32, g = w.lane / 32;
+    emu_v16f d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = 8 * (r / 4) + 4 * g + r % 4;
+        float s = 0.0f;
+        for (int k = 0; k < 2; ++k) {
+            const AB x = ::shim::lane_value(w, i + 32 * k, AB{0.f, 0.f}), y = ::shim::lane_value(w, j + 32 * k, AB{0.f, 0.f});
+            s = fmaf(x.a, y.b, s);
+        }
+        d[r] = c[r] + s;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x2f32_emu((a), (b), (c), (x), (y), (z))
+
 // ---------------------------------------------------------------------------------------------------- atomics (one OS thread)
 template <class T> inline T unsafeAtomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { const T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) { const T o = *p; if (o == cmp) *p = v; return o; }

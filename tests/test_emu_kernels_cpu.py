@@ -95,3 +95,54 @@ def test_k1_variants_on_emulated_kernels(C, D, h, w, V, emu):
     want = warp.variance_volume([feats[:, v].permute(0, 3, 1, 2) for v in range(V)], pm, samples)        # (B,C,D,h,w)
     got = outs[0].permute(0, 4, 1, 2, 3)
     assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_results_do_not_depend_on_the_thread_schedule(emu):
+    """Missing-barrier detector: between synchronisation points the emulation may run a block's threads in any order; ascending,
+    descending and wave-reversed schedules must give bit-identical results for kernels without float atomics (the whole inference
+    cascade, the fused FPN level, the LDS-staged K1 variant, ordered compaction) and equal results up to summation order for the
+    ones that accumulate with atomics (loss sums, K1 backward)."""
+    from rc_mvsnet_amd import fusion, losses, ops
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    model = CascadeMVSNet_eval(ndepths=[8, 8, 8], depth_interals_ratio=[4, 2, 1])
+    model.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
+    model.eval()
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 32, 64, 0)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(1, 3, 12, 20, 16, generator=g)
+    rot, trans = ops.compose_homography(synthetic.proj_matrices(1, 3, 48, 80)["stage1"])
+    planes = torch.stack((425.0 + 100.0 * torch.rand(1, 12, 20, generator=g), 2.0 + 8.0 * torch.rand(1, 12, 20, generator=g)), dim=-1).contiguous()
+    mask = (torch.rand(37, 53, generator=g) < 0.4).to(torch.uint8)
+    xyz = torch.randn(37, 53, 3, generator=g)
+    gvar = torch.randn(1, 8, 12, 20, 16, generator=g)
+    G = np.load(os.path.join(HERE, "golden", "unsup_loss.npz"))
+    B, V, H, W, seed = [int(x) for x in G["a:dims"]]
+    limgs, lcams = synthetic.images(B, V, H, W, seed), synthetic.proj_matrices(B, V, H, W)
+
+    def run():
+        with torch.no_grad():
+            out = model(imgs, pm, dv)
+            emu.rcmvs_debug_k1_variant(6)
+            staged = ops.warp_variance(feats, rot, trans, planes, 8)
+            emu.rcmvs_debug_k1_variant(0)
+            pts, _ = fusion.compact_points(mask, xyz)
+            gfe = ops.warp_variance_bwd(feats, rot, trans, planes, gvar, None)
+        inputs = {k: {"depth": torch.tensor(G[f"a:depth:{k}"]).requires_grad_(True)} for k in ("stage1", "stage2", "stage3")}
+        total, _ = losses.UnsupLossMultiStage()(inputs, limgs, lcams, dlossw=[0.5, 1.0, 2.0])
+        total.backward()
+        exact = {"depth": out["depth"], "conf": out["photometric_confidence"], "staged": staged, "pts": pts}
+        approx = {"k1_bwd": gfe, "loss": total.detach().reshape(1), "loss_grad": inputs["stage3"]["depth"].grad}
+        return exact, approx
+
+    try:
+        exact0, approx0 = run()
+        for order in (1, 2):
+            emu.rcmvs_emu_set_order(order)
+            exact, approx = run()
+            for k in exact0:
+                assert torch.equal(exact[k], exact0[k]), (order, k)
+            for k in approx0:
+                assert float((approx[k] - approx0[k]).abs().max()) <= 1e-5 * max(1e-6, float(approx0[k].abs().max())), (order, k)
+    finally:
+        emu.rcmvs_emu_set_order(0)
+        emu.rcmvs_debug_k1_variant(0)
