@@ -542,6 +542,211 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// K1, pipelined staged variant (debug variants 8 / 9; NOT measured yet -- logic verified bit-identical to the
+// reference-order kernel on the CPU emulation, tests/test_emu_kernels_cpu.py).  The LDS-staged kernel above loses to
+// the production kernel because every plane chunk is stage -> barrier -> gather (its waves wait half their cycles,
+// profiles/r1_k1_pmc_summary.txt).  Here one block owns a tile for ALL plane chunks and keeps two LDS sets
+// (tap table + source windows): while chunk i is blended out of set i & 1, the taps of chunk i + 1 are computed and
+// its windows are loaded straight into the other set with buffer_load ... lds (no VGPRs in flight, the only wait is
+// the vmcnt(0) in front of the barrier that publishes them).  Up to NV = 2 source views (config 2); anything else
+// stays on the other kernels.
+// ------------------------------------------------------------------------------------------
+template <int C, int DKB, bool FAST, int NV>
+__global__ __launch_bounds__(256) void warp_variance_ps_kernel(
+    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int patch_texels) {
+#pragma clang fp contract(off)
+    constexpr int LPP = C / 4;
+    constexpr int PIX = 256 / LPP;
+    constexpr int TH = 4, TW = PIX / TH;
+    constexpr int GRP = 256 / PIX;
+    constexpr int KPT = (DKB + GRP - 1) / GRP;
+    constexpr int C4 = C * 4;
+    constexpr int TAB = NV * DKB * PIX;
+    extern __shared__ __attribute__((aligned(16))) v4i lds_ps[];
+    const int patch_bytes = patch_texels * C4;
+    const int set_v4 = TAB * 2 + 4 * NV + NV * (patch_bytes / 16);           // v4i units per set: offsets, weights, boxes, windows
+    const int nv = V - 1;
+
+    const int b = blockIdx.z;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const int hw = h * w;
+    const int nch = (D + DKB - 1) / DKB;
+    K1Geom g;
+    g.w = w; g.h = h;
+    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
+    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
+    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
+    const float* fb = feats + (long long)b * V * hw * C;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
+
+    const int p = threadIdx.x / LPP;
+    const int q4b = (threadIdx.x % LPP) * 16;
+    const int x = tx0 + p % TW, y = ty0 + p / TW;
+    const bool inside = (x < w) && (y < h);
+    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
+    const float fV = (float)V, rV = rcp_nr(fV);
+    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
+    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
+    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
+    const float fxa = (float)xa, fya = (float)ya;
+    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
+    const int lane = threadIdx.x & 63;
+
+    // ---- phase A of chunk kc into set `st`: taps -> clamped coordinates + weights, per-wave bounding boxes
+    auto phase_a = [&](int kc, int st) {
+        v4i* lo = lds_ps + st * set_v4;
+        v4f* lw = reinterpret_cast<v4f*>(lo + TAB);
+        int* lbox = reinterpret_cast<int*>(lo + 2 * TAB);
+        const int k0 = kc * DKB;
+        for (int va = 0; va < nv; ++va) {
+            const float* r = rot + ((long long)b * (V - 1) + va) * 9;
+            const float* t = trans + ((long long)b * (V - 1) + va) * 3;
+            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
+            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
+            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
+            const float t0 = t[0], t1 = t[1], t2 = t[2];
+            int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) {
+                const int ka = ga + kk * GRP;
+                if (ka >= DKB) continue;
+                const float d = pla.x + (float)(k0 + ka) * pla.y;
+                v4f wt;
+                int xi, yi;
+                k1_chain(rx, ry, rz, t0, t1, t2, d, g, xi, yi, wt);
+                const int xc0 = min(max(xi, 0), w - 1), xc1 = min(max(xi + 1, 0), w - 1);
+                const int yc0 = min(max(yi, 0), h - 1), yc1 = min(max(yi + 1, 0), h - 1);
+                const bool any = (wt.x != 0.0f) || (wt.y != 0.0f) || (wt.z != 0.0f) || (wt.w != 0.0f);
+                const int idx = (va * DKB + ka) * PIX + pa;
+                v4i rec;
+                rec.x = xc0; rec.y = yc0; rec.z = (xc1 != xc0 ? 1 : 0) | (yc1 != yc0 ? 2 : 0) | (any ? 4 : 0); rec.w = 0;
+                lo[idx] = rec;
+                lw[idx] = wt;
+                if (any) { bx0 = min(bx0, xc0); bx1 = max(bx1, xc1); by0 = min(by0, yc0); by1 = max(by1, yc1); }
+            }
+            bx0 = wave_reduce_i32<true>(bx0); bx1 = wave_reduce_i32<false>(bx1);
+            by0 = wave_reduce_i32<true>(by0); by1 = wave_reduce_i32<false>(by1);
+            if (lane == 0) *reinterpret_cast<v4i*>(lbox + ((threadIdx.x >> 6) * NV + va) * 4) = (v4i){bx0, bx1, by0, by1};
+        }
+    };
+
+    // ---- phase A2 + S of set `st` (after a barrier): block bounding box, records -> byte offsets, windows -> LDS (direct loads)
+    auto stage = [&](int st, bool* fits) {
+        v4i* lo = lds_ps + st * set_v4;
+        const int* lbox = reinterpret_cast<const int*>(lo + 2 * TAB);
+        char* lpatch = reinterpret_cast<char*>(lo + 2 * TAB + 4 * NV);
+        const unsigned patch_base = (unsigned)(lpatch - reinterpret_cast<char*>(lds_ps));
+        int px0[NV], py0[NV], pw[NV], ph[NV];
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            v4i bb = *reinterpret_cast<const v4i*>(lbox + va * 4);
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) {
+                const v4i t = *reinterpret_cast<const v4i*>(lbox + (wv * NV + va) * 4);
+                bb.x = min(bb.x, t.x); bb.y = max(bb.y, t.y); bb.z = min(bb.z, t.z); bb.w = max(bb.w, t.w);
+            }
+            px0[va] = bb.x; py0[va] = bb.z;
+            pw[va] = bb.y - bb.x + 1; ph[va] = bb.w - bb.z + 1;
+            if (bb.y < 0) { px0[va] = 0; py0[va] = 0; pw[va] = 1; ph[va] = 1; }
+            fits[va] = (va < nv) && (pw[va] * ph[va] <= patch_texels);
+        }
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            if (va >= nv) continue;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) {
+                if (ga + kk * GRP >= DKB) continue;
+                const int idx = (va * DKB + ga + kk * GRP) * PIX + pa;
+                const v4i rec = lo[idx];
+                const bool any = rec.z & 4;
+                v4i o;
+                if (fits[va]) {
+                    const int lx = any ? rec.x - px0[va] : 0, ly = any ? rec.y - py0[va] : 0;
+                    const int base = (ly * pw[va] + lx) * C4 + (int)patch_base + va * patch_bytes;
+                    const int dx = (any && (rec.z & 1)) ? C4 : 0, dy = (any && (rec.z & 2)) ? pw[va] * C4 : 0;
+                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
+                } else {
+                    const int base = ((1 + va) * hw + rec.y * w + rec.x) * C4;
+                    const int dx = (rec.z & 1) ? C4 : 0, dy = (rec.z & 2) ? w * C4 : 0;
+                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
+                }
+                lo[idx] = o;
+            }
+        }
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            if (!fits[va]) continue;
+            const int row4 = pw[va] * LPP;                        // 16-byte pieces per window row
+            const int n4 = row4 * ph[va];
+            const int src0 = (((1 + va) * hw) + py0[va] * w + px0[va]) * C4;      // byte offset of the window's first texel
+            char* dst = lpatch + va * patch_bytes;
+            for (int e0 = (threadIdx.x & ~63); e0 < n4; e0 += 256) {              // one wave moves 64 consecutive pieces = 1 KB of LDS
+                const int e = e0 + lane;
+                if (e < n4) {
+                    const int row = e / row4, c4 = e - row * row4;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + (size_t)e0 * 16, 16, src0 + (row * w * C + c4 * 4) * 4, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- phase B of chunk kc out of set `st`
+    auto phase_b = [&](int kc, int st, const bool* fits) {
+        const v4i* lo = lds_ps + st * set_v4;
+        const v4f* lw = reinterpret_cast<const v4f*>(lo + TAB);
+        const char* lds_bytes = reinterpret_cast<const char*>(lds_ps) + q4b;
+        const int k0 = kc * DKB;
+        if (!inside) return;
+#pragma unroll
+        for (int k = 0; k < DKB; ++k) {
+            v4f a = ref, a2 = ref * ref;
+#pragma unroll
+            for (int va = 0; va < NV; ++va) {
+                if (va >= nv) continue;
+                const int idx = (va * DKB + k) * PIX + p;
+                const v4i o = lo[idx];
+                const v4f wt = lw[idx];
+                v4f ta, tb, tc, td;
+                if (fits[va]) {
+                    ta = *reinterpret_cast<const v4f*>(lds_bytes + o.x);
+                    tb = *reinterpret_cast<const v4f*>(lds_bytes + o.y);
+                    tc = *reinterpret_cast<const v4f*>(lds_bytes + o.z);
+                    td = *reinterpret_cast<const v4f*>(lds_bytes + o.w);
+                } else {
+                    ta = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
+                    tb = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
+                    tc = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
+                    td = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
+                }
+                v4f val = blend4<FAST>(ta, tb, tc, td, wt);
+                a = a + val;
+                if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
+            }
+            if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
+        }
+    };
+
+    bool fits_cur[NV], fits_next[NV];
+    phase_a(0, 0);
+    __syncthreads();
+    stage(0, fits_cur);
+    for (int kc = 0; kc < nch; ++kc) {
+        const int st = kc & 1;
+        if (kc + 1 < nch) phase_a(kc + 1, st ^ 1);
+        __builtin_amdgcn_s_waitcnt(0);                             // vmcnt(0): the windows of chunk kc have landed in LDS
+        __syncthreads();                                           // ... for every wave; tables and boxes of chunk kc + 1 are visible
+        if (kc + 1 < nch) stage(st ^ 1, fits_next);
+        phase_b(kc, st, fits_cur);
+        __syncthreads();                                           // set `st` is free for the taps of chunk kc + 2
+#pragma unroll
+        for (int va = 0; va < NV; ++va) fits_cur[va] = fits_next[va];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // train-variant extra: warped RGB of every source view ++ source-only variance / V, written in
 // the reference's NCDHW layout because the tensor crosses the module boundary
 // (CascadeMVSNet.forward returns it, models/casmvsnet.py:231).  One thread per (pixel, plane).
@@ -659,6 +864,33 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
             default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
         }
         return launch_status("warp_variance_fwd(lds)");
+    }
+    if (g_k1_variant == 8 || g_k1_variant == 9) {
+        // pipelined staged kernel (persistent over the plane chunks of a tile): 8 = exact, 9 = FMA blend; up to 2 source views
+        const bool fastm = g_k1_variant == 9;
+        RCMVS_REQUIRE(V - 1 <= 2, "warp_variance_fwd: debug variant %d handles at most 2 source views (V=%d)", g_k1_variant, V);
+        RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
+        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
+        const int LPP = C / 4, PIX = 256 / LPP;
+        const int dkb = (C == 8) ? 4 : (C == 16 ? 4 : 4);
+        const int ptex = (C == 32) ? 128 : (C == 16 ? 224 : 384);
+        const size_t set_bytes = (size_t)2 * dkb * PIX * 32 + 64 * 2 + (size_t)2 * ptex * C * 4;
+        const size_t lds = 2 * set_bytes;
+        const int TWl = PIX / 4;
+        const int txl = (w + TWl - 1) / TWl, tyl = (h + 3) / 4;
+        dim3 gridp(txl * tyl, 1, B);
+#define RCMVS_K1PS(CC, FF) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_ps_kernel<CC, 4, FF, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, 4, FF, 2>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
+#define RCMVS_K1PS_F(CC) do { if (fastm) RCMVS_K1PS(CC, true); else RCMVS_K1PS(CC, false); } while (0)
+        switch (C) {
+            case 8:  RCMVS_K1PS_F(8); break;
+            case 16: RCMVS_K1PS_F(16); break;
+            case 32: RCMVS_K1PS_F(32); break;
+            default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+        }
+        (void)dkb;
+        return launch_status("warp_variance_fwd(ps)");
     }
     if (g_k1_variant == 0 || g_k1_variant == 1) {
         // production kernel: variant 0 = exact arithmetic (default), 1 = FMA-contracted blend

@@ -146,3 +146,34 @@ def test_results_do_not_depend_on_the_thread_schedule(emu):
     finally:
         emu.rcmvs_emu_set_order(0)
         emu.rcmvs_debug_k1_variant(0)
+
+
+@pytest.mark.parametrize("C,D,h,w,V", [(32, 16, 12, 21, 3), (16, 8, 17, 30, 3), (8, 12, 16, 40, 2), (8, 10, 9, 140, 3), (32, 5, 6, 9, 2)])
+def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
+    """Debug variants 8 / 9 (persistent over plane chunks, double-buffered tap tables and windows, direct-to-LDS loads): the
+    exact build must equal the reference-order kernel bit for bit -- ragged plane counts, ragged tiles, windows that do not fit
+    the LDS budget (wide maps: global fallback), one and two source views -- under every thread schedule."""
+    from rc_mvsnet_amd import _lib, ops
+    g = torch.Generator().manual_seed(C + V + D)
+    feats = torch.randn(2, V, h, w, C, generator=g)
+    pm = synthetic.proj_matrices(2, V, h * 4, w * 4)["stage1"]
+    rot, trans = ops.compose_homography(pm)
+    planes = torch.stack((425.0 + 100.0 * torch.rand(2, h, w, generator=g), 2.0 + 8.0 * torch.rand(2, h, w, generator=g)), dim=-1).contiguous()
+    try:
+        emu.rcmvs_debug_k1_variant(2)
+        vref = ops.warp_variance(feats, rot, trans, planes, D)
+        for order in (0, 1, 2):
+            emu.rcmvs_emu_set_order(order)
+            emu.rcmvs_debug_k1_variant(8)
+            v8 = ops.warp_variance(feats, rot, trans, planes, D)
+            assert torch.equal(v8, vref), order
+        emu.rcmvs_emu_set_order(0)
+        emu.rcmvs_debug_k1_variant(9)
+        v9 = ops.warp_variance(feats, rot, trans, planes, D)
+        assert float((v9 - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max()))
+        emu.rcmvs_debug_k1_variant(8)
+        with pytest.raises(_lib.RcmvsError):
+            ops.warp_variance(torch.randn(1, 4, h, w, C), rot[:1].repeat(1, 2, 1)[:, :3], trans[:1].repeat(1, 2, 1)[:, :3], planes[:1], D)
+    finally:
+        emu.rcmvs_emu_set_order(0)
+        emu.rcmvs_debug_k1_variant(0)
