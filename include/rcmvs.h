@@ -65,6 +65,9 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
 
 /* profiling hook: select the K1 code variant (0 = default; see warp_variance.hip) */
 void rcmvs_debug_k1_variant(int variant);
+/* Tuning knobs of the pipelined staged K1 variant (debug variants 8 / 9): planes per chunk (2, 4 or 8) and the LDS window
+ * budget per source view in texels; 0 = built-in default.  Profiling only. */
+void rcmvs_debug_k1_ps_config(int dkb, int patch_texels);
 
 /* train-variant extra (models/casmvsnet.py:59,82,89-101): volume_feature_no_ref, NCDHW like
  * the reference returns it: out (B, 3(V-1)+C, D, h, w) = warped RGB of each source view

@@ -28,6 +28,7 @@ SIGNATURES = {
     "rcmvs_hypothesis_planes": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_k1_variant": [_i],
+    "rcmvs_debug_k1_ps_config": [_i, _i],
     "rcmvs_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_resize_planes_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_composite_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
@@ -70,7 +71,7 @@ SIGNATURES = {
     "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
 }
 _RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll, "rcmvs_nerf_workspace_floats": _ll,
-             "rcmvs_packed_weight_floats": _ll, "rcmvs_debug_force_direct_conv": None, "rcmvs_debug_k1_variant": None}
+             "rcmvs_packed_weight_floats": _ll, "rcmvs_debug_force_direct_conv": None, "rcmvs_debug_k1_variant": None, "rcmvs_debug_k1_ps_config": None}
 
 _lib = None
 

@@ -823,10 +823,12 @@ __global__ __launch_bounds__(256) void warp_noref_kernel(
 using namespace rcmvs;
 
 static int g_k1_variant = 0;     // profiling hook (rcmvs_debug_k1_variant)
+static int g_k1_ps_dkb = 0, g_k1_ps_ptex = 0;     // tuning knobs of the pipelined staged variant (rcmvs_debug_k1_ps_config), 0 = default
 
 extern "C" {
 
 void rcmvs_debug_k1_variant(int v) { g_k1_variant = v; }
+void rcmvs_debug_k1_ps_config(int dkb, int patch_texels) { g_k1_ps_dkb = dkb; g_k1_ps_ptex = patch_texels; }
 
 int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                             const float* planes, float* var,
@@ -872,24 +874,27 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
         const int LPP = C / 4, PIX = 256 / LPP;
-        const int dkb = (C == 8) ? 4 : (C == 16 ? 4 : 4);
-        const int ptex = (C == 32) ? 128 : (C == 16 ? 224 : 384);
+        const int dkb = g_k1_ps_dkb ? g_k1_ps_dkb : 4;
+        const int ptex = g_k1_ps_ptex ? g_k1_ps_ptex : ((C == 32) ? 128 : (C == 16 ? 224 : 384));
+        RCMVS_REQUIRE(dkb == 2 || dkb == 4 || dkb == 8, "warp_variance_fwd: pipelined variant: plane chunk %d (2, 4 or 8)", dkb);
+        RCMVS_REQUIRE(ptex >= 16 && (ptex * C * 4) % 16 == 0, "warp_variance_fwd: pipelined variant: window budget %d texels", ptex);
         const size_t set_bytes = (size_t)2 * dkb * PIX * 32 + 64 * 2 + (size_t)2 * ptex * C * 4;
         const size_t lds = 2 * set_bytes;
+        RCMVS_REQUIRE(lds <= 160 * 1024, "warp_variance_fwd: pipelined variant needs %zu bytes of LDS (chunk %d, %d texels)", lds, dkb, ptex);
         const int TWl = PIX / 4;
         const int txl = (w + TWl - 1) / TWl, tyl = (h + 3) / 4;
         dim3 gridp(txl * tyl, 1, B);
-#define RCMVS_K1PS(CC, FF) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_ps_kernel<CC, 4, FF, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, 4, FF, 2>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
-#define RCMVS_K1PS_F(CC) do { if (fastm) RCMVS_K1PS(CC, true); else RCMVS_K1PS(CC, false); } while (0)
+#define RCMVS_K1PS(CC, DD, FF) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_ps_kernel<CC, DD, FF, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, DD, FF, 2>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
+#define RCMVS_K1PS_D(CC, FF) do { if (dkb == 2) RCMVS_K1PS(CC, 2, FF); else if (dkb == 4) RCMVS_K1PS(CC, 4, FF); else RCMVS_K1PS(CC, 8, FF); } while (0)
+#define RCMVS_K1PS_F(CC) do { if (fastm) RCMVS_K1PS_D(CC, true); else RCMVS_K1PS_D(CC, false); } while (0)
         switch (C) {
             case 8:  RCMVS_K1PS_F(8); break;
             case 16: RCMVS_K1PS_F(16); break;
             case 32: RCMVS_K1PS_F(32); break;
             default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
         }
-        (void)dkb;
         return launch_status("warp_variance_fwd(ps)");
     }
     if (g_k1_variant == 0 || g_k1_variant == 1) {

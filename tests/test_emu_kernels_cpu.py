@@ -146,6 +146,7 @@ def test_results_do_not_depend_on_the_thread_schedule(emu):
     finally:
         emu.rcmvs_emu_set_order(0)
         emu.rcmvs_debug_k1_variant(0)
+        emu.rcmvs_debug_k1_ps_config(0, 0)
 
 
 @pytest.mark.parametrize("C,D,h,w,V", [(32, 16, 12, 21, 3), (16, 8, 17, 30, 3), (8, 12, 16, 40, 2), (8, 10, 9, 140, 3), (32, 5, 6, 9, 2)])
@@ -168,6 +169,10 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
             v8 = ops.warp_variance(feats, rot, trans, planes, D)
             assert torch.equal(v8, vref), order
         emu.rcmvs_emu_set_order(0)
+        for dkb, ptex in ((2, 0), (8, 64), (4, 16), (2, 64)):                       # other chunk depths; a budget small enough to force the global fallback
+            emu.rcmvs_debug_k1_ps_config(dkb, ptex)
+            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (dkb, ptex)
+        emu.rcmvs_debug_k1_ps_config(0, 0)
         emu.rcmvs_debug_k1_variant(9)
         v9 = ops.warp_variance(feats, rot, trans, planes, D)
         assert float((v9 - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max()))
@@ -177,3 +182,4 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
     finally:
         emu.rcmvs_emu_set_order(0)
         emu.rcmvs_debug_k1_variant(0)
+        emu.rcmvs_debug_k1_ps_config(0, 0)
