@@ -77,7 +77,9 @@ SLOW = {
          "test_cascade_batch_two_equals_two_singles"],
     GR: ["test_neural_volume_vs_golden", "test_render_forward_vs_reference_golden"],
     GT: ["test_conv_bn_relu_block_forward_backward", "test_neural_volume_net_train_native_vs_delegated",
-         "test_renderer_train_native_vs_delegated", "test_featurenet_train_native_vs_delegated"],
+         "test_renderer_train_native_vs_delegated", "test_featurenet_train_native_vs_delegated",
+         "test_cascade_train_native_vs_delegated_gradients", "test_hip_training_path_vs_reference_gradients",
+         "test_sync_batchnorm_branch_with_simulated_replica"],
     GF: ["test_compact_points_is_ordered_boolean_indexing"],
 }
 for _table, _slow in ((FAST, False), (SLOW, True)):
