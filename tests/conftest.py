@@ -52,6 +52,8 @@ def emu_lib():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _lib._RESTYPES.get(name, ctypes.c_int)
+    # RCMVS_EMU_ORDER=1|2 runs every block's threads in another order between synchronisation points: a whole-suite missing-barrier check
+    lib.rcmvs_emu_set_order(int(os.environ.get("RCMVS_EMU_ORDER", "0")))
     return lib
 
 
