@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
 // the vmcnt(0) in front of the barrier that publishes them).  Up to NV = 2 source views (config 2); anything else
 // stays on the other kernels.
 // ------------------------------------------------------------------------------------------
-template <int C, int DKB, bool FAST, int NV>
+template <int C, int DKB, bool FAST, int NV, bool DMA = true>
 __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int patch_texels) {
@@ -634,6 +634,9 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
     };
 
     // ---- phase A2 + S of set `st` (after a barrier): block bounding box, records -> byte offsets, windows -> LDS (direct loads)
+    constexpr int MAXP = 4;                                       // 16-byte pieces per thread and view in the register-staged form
+    v4f held[NV][MAXP];
+    int held_n4[NV], held_dst[NV];
     auto stage = [&](int st, bool* fits) {
         v4i* lo = lds_ps + st * set_v4;
         const int* lbox = reinterpret_cast<const int*>(lo + 2 * TAB);
@@ -683,11 +686,40 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
             const int n4 = row4 * ph[va];
             const int src0 = (((1 + va) * hw) + py0[va] * w + px0[va]) * C4;      // byte offset of the window's first texel
             char* dst = lpatch + va * patch_bytes;
-            for (int e0 = (threadIdx.x & ~63); e0 < n4; e0 += 256) {              // one wave moves 64 consecutive pieces = 1 KB of LDS
-                const int e = e0 + lane;
-                if (e < n4) {
+            if constexpr (DMA) {
+                for (int e0 = (threadIdx.x & ~63); e0 < n4; e0 += 256) {          // one wave moves 64 consecutive pieces = 1 KB of LDS
+                    const int e = e0 + lane;
+                    if (e < n4) {
+                        const int row = e / row4, c4 = e - row * row4;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + (size_t)e0 * 16, 16, src0 + (row * w * C + c4 * 4) * 4, 0, 0, 0);
+                    }
+                }
+            } else {
+                // register-staged form: the loads are issued now, the LDS writes follow the blend of the current chunk
+                held_n4[va] = n4;
+                held_dst[va] = (int)(dst - reinterpret_cast<char*>(lds_ps));
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i) {
+                    const int e = threadIdx.x + i * 256;
                     const int row = e / row4, c4 = e - row * row4;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + (size_t)e0 * 16, 16, src0 + (row * w * C + c4 * 4) * 4, 0, 0, 0);
+                    held[va][i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, e < n4 ? src0 + (row * w * C + c4 * 4) * 4 : (int)0x80000000, 0, 0));
+                }
+            }
+        }
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int va = 0; va < NV; ++va)
+                if (!fits[va]) held_n4[va] = 0;
+        }
+    };
+    auto stage_finish = [&]() {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int va = 0; va < NV; ++va) {
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i) {
+                    const int e = threadIdx.x + i * 256;
+                    if (e < held_n4[va]) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(lds_ps) + held_dst[va] + e * 16) = held[va][i];
                 }
             }
         }
@@ -730,9 +762,12 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
     };
 
     bool fits_cur[NV], fits_next[NV];
+#pragma unroll
+    for (int va = 0; va < NV; ++va) held_n4[va] = 0;
     phase_a(0, 0);
     __syncthreads();
     stage(0, fits_cur);
+    stage_finish();
     for (int kc = 0; kc < nch; ++kc) {
         const int st = kc & 1;
         if (kc + 1 < nch) phase_a(kc + 1, st ^ 1);
@@ -740,6 +775,7 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
         __syncthreads();                                           // ... for every wave; tables and boxes of chunk kc + 1 are visible
         if (kc + 1 < nch) stage(st ^ 1, fits_next);
         phase_b(kc, st, fits_cur);
+        if (kc + 1 < nch) stage_finish();                          // register-staged form only: windows of chunk kc + 1 -> LDS
         __syncthreads();                                           // set `st` is free for the taps of chunk kc + 2
 #pragma unroll
         for (int va = 0; va < NV; ++va) fits_cur[va] = fits_next[va];
@@ -867,9 +903,10 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         }
         return launch_status("warp_variance_fwd(lds)");
     }
-    if (g_k1_variant == 8 || g_k1_variant == 9) {
-        // pipelined staged kernel (persistent over the plane chunks of a tile): 8 = exact, 9 = FMA blend; up to 2 source views
-        const bool fastm = g_k1_variant == 9;
+    if (g_k1_variant >= 8 && g_k1_variant <= 11) {
+        // pipelined staged kernel (persistent over the plane chunks of a tile): 8 = exact, 9 = FMA blend, windows loaded straight
+        // into LDS; 10 / 11 = the same with the windows held in registers across the blend (no buffer_load ... lds); <= 2 source views
+        const bool fastm = g_k1_variant & 1, dma = g_k1_variant < 10;
         RCMVS_REQUIRE(V - 1 <= 2, "warp_variance_fwd: debug variant %d handles at most 2 source views (V=%d)", g_k1_variant, V);
         RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
@@ -884,9 +921,11 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         const int TWl = PIX / 4;
         const int txl = (w + TWl - 1) / TWl, tyl = (h + 3) / 4;
         dim3 gridp(txl * tyl, 1, B);
-#define RCMVS_K1PS(CC, DD, FF) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_ps_kernel<CC, DD, FF, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, DD, FF, 2>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
+        RCMVS_REQUIRE(dma || ptex * LPP <= 256 * 4, "warp_variance_fwd: register-staged variant holds at most %d texels per view (asked %d)", 1024 / LPP, ptex);
+#define RCMVS_K1PS_M(CC, DD, FF, MM) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_ps_kernel<CC, DD, FF, 2, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, DD, FF, 2, MM>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
+#define RCMVS_K1PS(CC, DD, FF) do { if (dma) RCMVS_K1PS_M(CC, DD, FF, true); else RCMVS_K1PS_M(CC, DD, FF, false); } while (0)
 #define RCMVS_K1PS_D(CC, FF) do { if (dkb == 2) RCMVS_K1PS(CC, 2, FF); else if (dkb == 4) RCMVS_K1PS(CC, 4, FF); else RCMVS_K1PS(CC, 8, FF); } while (0)
 #define RCMVS_K1PS_F(CC) do { if (fastm) RCMVS_K1PS_D(CC, true); else RCMVS_K1PS_D(CC, false); } while (0)
         switch (C) {

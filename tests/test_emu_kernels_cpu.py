@@ -165,17 +165,20 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
         vref = ops.warp_variance(feats, rot, trans, planes, D)
         for order in (0, 1, 2):
             emu.rcmvs_emu_set_order(order)
-            emu.rcmvs_debug_k1_variant(8)
-            v8 = ops.warp_variance(feats, rot, trans, planes, D)
-            assert torch.equal(v8, vref), order
+            for var in (8, 10):                                                       # windows by direct-to-LDS loads / held in registers
+                emu.rcmvs_debug_k1_variant(var)
+                assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, order)
         emu.rcmvs_emu_set_order(0)
         for dkb, ptex in ((2, 0), (8, 64), (4, 16), (2, 64)):                       # other chunk depths; a budget small enough to force the global fallback
             emu.rcmvs_debug_k1_ps_config(dkb, ptex)
-            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (dkb, ptex)
+            for var in (8, 10):
+                emu.rcmvs_debug_k1_variant(var)
+                assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex)
         emu.rcmvs_debug_k1_ps_config(0, 0)
-        emu.rcmvs_debug_k1_variant(9)
-        v9 = ops.warp_variance(feats, rot, trans, planes, D)
-        assert float((v9 - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max()))
+        for var in (9, 11):
+            emu.rcmvs_debug_k1_variant(var)
+            v9 = ops.warp_variance(feats, rot, trans, planes, D)
+            assert float((v9 - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), var
         emu.rcmvs_debug_k1_variant(8)
         with pytest.raises(_lib.RcmvsError):
             ops.warp_variance(torch.randn(1, 4, h, w, C), rot[:1].repeat(1, 2, 1)[:, :3], trans[:1].repeat(1, 2, 1)[:, :3], planes[:1], D)
