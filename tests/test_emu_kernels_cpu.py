@@ -169,7 +169,8 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
                 emu.rcmvs_debug_k1_variant(var)
                 assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, order)
         emu.rcmvs_emu_set_order(0)
-        for dkb, ptex in ((2, 0), (8, 64), (4, 16), (2, 64)):                       # other chunk depths; a budget small enough to force the global fallback
+        knobs = ((2, 0), (8, 64), (4, 16), (2, 64)) if (C, V) in ((32, 3), (8, 2)) else ((4, 16),)
+        for dkb, ptex in knobs:                                                       # other chunk depths; a budget small enough to force the global fallback
             emu.rcmvs_debug_k1_ps_config(dkb, ptex)
             for var in (8, 10):
                 emu.rcmvs_debug_k1_variant(var)
