@@ -649,3 +649,32 @@ def test_fpn_out_fused_is_bit_identical(N, H, W):
     assert got.shape == want.shape and torch.equal(got, want)
     with pytest.raises(_lib.RcmvsError):
         ops.fpn_out_fused(lat[:, :-1], up, w_in, b_in, w_out)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("RCMVS_TEST_PS", "0") != "1",
+                    reason="pipelined staged K1 variants 8-11: verified on the CPU emulation only so far; RCMVS_TEST_PS=1 runs them on the GPU")
+@pytest.mark.parametrize("C,D,h,w,V", [(32, 48, 128, 160, 3), (16, 32, 66, 90, 3), (8, 8, 120, 200, 3), (8, 10, 9, 140, 2), (32, 5, 6, 9, 2)])
+def test_warp_variance_pipelined_variants(hip, C, D, h, w, V):
+    """Debug variants 8 / 10 (exact) must be bit-identical to the reference-order kernel, 9 / 11 (FMA blend) within 2e-6, for
+    every chunk depth and a window budget small enough to force the global fallback."""
+    from rc_mvsnet_amd import _lib, synthetic
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C + V + D)
+    feats = gpu(torch.randn(2, V, h, w, C, generator=g))
+    rot, trans = hip.compose_homography(gpu(synthetic.proj_matrices(2, V, h * 4, w * 4)["stage1"]))
+    planes = gpu(torch.stack((425.0 + 100.0 * torch.rand(2, h, w, generator=g), 2.0 + 8.0 * torch.rand(2, h, w, generator=g)), dim=-1))
+    try:
+        lib.rcmvs_debug_k1_variant(2)
+        vref = hip.warp_variance(feats, rot, trans, planes, D)
+        for dkb, ptex in ((0, 0), (2, 0), (8, 64), (4, 16)):
+            lib.rcmvs_debug_k1_ps_config(dkb, ptex)
+            for var in (8, 10):
+                lib.rcmvs_debug_k1_variant(var)
+                assert torch.equal(hip.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex)
+            for var in (9, 11):
+                lib.rcmvs_debug_k1_variant(var)
+                vv = hip.warp_variance(feats, rot, trans, planes, D)
+                assert float((vv - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), (var, dkb, ptex)
+    finally:
+        lib.rcmvs_debug_k1_variant(0)
+        lib.rcmvs_debug_k1_ps_config(0, 0)
