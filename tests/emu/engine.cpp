@@ -109,7 +109,9 @@ void run_grid(dim3 grid, dim3 block, size_t lds, std::function<void()> body) {
         e.snap.resize((size_t)e.nthreads * 2);
         e.snap_pred.resize(e.nthreads);
     }
-    e.dyn.assign(lds + 64, 0);
+    constexpr size_t GUARD = 256;                         // canary behind the dynamic LDS: a kernel that writes past its allocation trips it
+    e.dyn.assign(lds + GUARD, 0);
+    std::memset(e.dyn.data() + lds, 0xA5, GUARD);
     e.body = std::move(body);
     for (unsigned z = 0; z < grid.z; ++z)
         for (unsigned y = 0; y < grid.y; ++y)
@@ -117,6 +119,11 @@ void run_grid(dim3 grid, dim3 block, size_t lds, std::function<void()> body) {
                 e.bid = dim3(x, y, z);
                 run_block(e);
             }
+    for (size_t i = 0; i < GUARD; ++i)
+        if ((unsigned char)e.dyn[lds + i] != 0xA5) {
+            std::fprintf(stderr, "emu: a kernel wrote %zu bytes past its %zu bytes of dynamic LDS\n", i + 1, lds);
+            std::abort();
+        }
     e.cur = -1;
 }
 
