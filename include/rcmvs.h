@@ -65,9 +65,10 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
 
 /* profiling hook: select the K1 code variant (0 = default; see warp_variance.hip) */
 void rcmvs_debug_k1_variant(int variant);
-/* Tuning knobs of the pipelined staged K1 variant (debug variants 8 / 9): planes per chunk (2, 4 or 8) and the LDS window
- * budget per source view in texels; 0 = built-in default.  Profiling only. */
-void rcmvs_debug_k1_ps_config(int dkb, int patch_texels);
+/* Tuning knobs of the pipelined staged K1 variant (debug variants 8-11): planes per chunk (2, 4 or 8), the LDS window budget
+ * per source view in texels, and (register-held forms 10 / 11 only) padding bytes per staged texel (0, 16, 32) against LDS bank
+ * conflicts; 0 = built-in default.  Profiling only. */
+void rcmvs_debug_k1_ps_config(int dkb, int patch_texels, int texel_pad_bytes);
 
 /* train-variant extra (models/casmvsnet.py:59,82,89-101): volume_feature_no_ref, NCDHW like
  * the reference returns it: out (B, 3(V-1)+C, D, h, w) = warped RGB of each source view

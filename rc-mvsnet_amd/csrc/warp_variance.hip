@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void warp_variance_lds_kernel(
 template <int C, int DKB, bool FAST, int NV, bool DMA = true>
 __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
-    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int patch_texels) {
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int patch_texels, int pad) {
 #pragma clang fp contract(off)
     constexpr int LPP = C / 4;
     constexpr int PIX = 256 / LPP;
@@ -564,7 +564,8 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
     constexpr int C4 = C * 4;
     constexpr int TAB = NV * DKB * PIX;
     extern __shared__ __attribute__((aligned(16))) v4i lds_ps[];
-    const int patch_bytes = patch_texels * C4;
+    const int cs = C4 + (DMA ? 0 : pad);                         // bytes per staged texel (padding spreads the gathers over the LDS banks)
+    const int patch_bytes = patch_texels * cs;
     const int set_v4 = TAB * 2 + 4 * NV + NV * (patch_bytes / 16);           // v4i units per set: offsets, weights, boxes, windows
     const int nv = V - 1;
 
@@ -668,8 +669,8 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
                 v4i o;
                 if (fits[va]) {
                     const int lx = any ? rec.x - px0[va] : 0, ly = any ? rec.y - py0[va] : 0;
-                    const int base = (ly * pw[va] + lx) * C4 + (int)patch_base + va * patch_bytes;
-                    const int dx = (any && (rec.z & 1)) ? C4 : 0, dy = (any && (rec.z & 2)) ? pw[va] * C4 : 0;
+                    const int base = (ly * pw[va] + lx) * cs + (int)patch_base + va * patch_bytes;
+                    const int dx = (any && (rec.z & 1)) ? cs : 0, dy = (any && (rec.z & 2)) ? pw[va] * cs : 0;
                     o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
                 } else {
                     const int base = ((1 + va) * hw + rec.y * w + rec.x) * C4;
@@ -719,7 +720,11 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
 #pragma unroll
                 for (int i = 0; i < MAXP; ++i) {
                     const int e = threadIdx.x + i * 256;
-                    if (e < held_n4[va]) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(lds_ps) + held_dst[va] + e * 16) = held[va][i];
+                    if (e < held_n4[va]) {
+                        // piece e = (texel t of the window, 16-byte quad q); texels sit cs bytes apart in LDS
+                        const int t = e / LPP, q = e - t * LPP;
+                        *reinterpret_cast<v4f*>(reinterpret_cast<char*>(lds_ps) + held_dst[va] + t * cs + q * 16) = held[va][i];
+                    }
                 }
             }
         }
@@ -859,12 +864,12 @@ __global__ __launch_bounds__(256) void warp_noref_kernel(
 using namespace rcmvs;
 
 static int g_k1_variant = 0;     // profiling hook (rcmvs_debug_k1_variant)
-static int g_k1_ps_dkb = 0, g_k1_ps_ptex = 0;     // tuning knobs of the pipelined staged variant (rcmvs_debug_k1_ps_config), 0 = default
+static int g_k1_ps_dkb = 0, g_k1_ps_ptex = 0, g_k1_ps_pad = 0;     // tuning knobs of the pipelined staged variant (rcmvs_debug_k1_ps_config), 0 = default
 
 extern "C" {
 
 void rcmvs_debug_k1_variant(int v) { g_k1_variant = v; }
-void rcmvs_debug_k1_ps_config(int dkb, int patch_texels) { g_k1_ps_dkb = dkb; g_k1_ps_ptex = patch_texels; }
+void rcmvs_debug_k1_ps_config(int dkb, int patch_texels, int texel_pad_bytes) { g_k1_ps_dkb = dkb; g_k1_ps_ptex = patch_texels; g_k1_ps_pad = texel_pad_bytes; }
 
 int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                             const float* planes, float* var,
@@ -915,7 +920,9 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         const int ptex = g_k1_ps_ptex ? g_k1_ps_ptex : ((C == 32) ? 128 : (C == 16 ? 224 : 384));
         RCMVS_REQUIRE(dkb == 2 || dkb == 4 || dkb == 8, "warp_variance_fwd: pipelined variant: plane chunk %d (2, 4 or 8)", dkb);
         RCMVS_REQUIRE(ptex >= 16 && (ptex * C * 4) % 16 == 0, "warp_variance_fwd: pipelined variant: window budget %d texels", ptex);
-        const size_t set_bytes = (size_t)2 * dkb * PIX * 32 + 64 * 2 + (size_t)2 * ptex * C * 4;
+        const int pad = dma ? 0 : g_k1_ps_pad;                  // direct-to-LDS loads land contiguously: padding only in the register-held form
+        RCMVS_REQUIRE(g_k1_ps_pad == 0 || g_k1_ps_pad == 16 || g_k1_ps_pad == 32, "warp_variance_fwd: pipelined variant: texel padding %d (0, 16 or 32 bytes)", g_k1_ps_pad);
+        const size_t set_bytes = (size_t)2 * dkb * PIX * 32 + 64 * 2 + (size_t)2 * ptex * (C * 4 + pad);
         const size_t lds = 2 * set_bytes;
         RCMVS_REQUIRE(lds <= 160 * 1024, "warp_variance_fwd: pipelined variant needs %zu bytes of LDS (chunk %d, %d texels)", lds, dkb, ptex);
         const int TWl = PIX / 4;
@@ -924,7 +931,7 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         RCMVS_REQUIRE(dma || ptex * LPP <= 256 * 4, "warp_variance_fwd: register-staged variant holds at most %d texels per view (asked %d)", 1024 / LPP, ptex);
 #define RCMVS_K1PS_M(CC, DD, FF, MM) do { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_ps_kernel<CC, DD, FF, 2, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, DD, FF, 2, MM>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
+        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, DD, FF, 2, MM>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex, pad); } while (0)
 #define RCMVS_K1PS(CC, DD, FF) do { if (dma) RCMVS_K1PS_M(CC, DD, FF, true); else RCMVS_K1PS_M(CC, DD, FF, false); } while (0)
 #define RCMVS_K1PS_D(CC, FF) do { if (dkb == 2) RCMVS_K1PS(CC, 2, FF); else if (dkb == 4) RCMVS_K1PS(CC, 4, FF); else RCMVS_K1PS(CC, 8, FF); } while (0)
 #define RCMVS_K1PS_F(CC) do { if (fastm) RCMVS_K1PS_D(CC, true); else RCMVS_K1PS_D(CC, false); } while (0)

@@ -146,7 +146,7 @@ def test_results_do_not_depend_on_the_thread_schedule(emu):
     finally:
         emu.rcmvs_emu_set_order(0)
         emu.rcmvs_debug_k1_variant(0)
-        emu.rcmvs_debug_k1_ps_config(0, 0)
+        emu.rcmvs_debug_k1_ps_config(0, 0, 0)
 
 
 @pytest.mark.parametrize("C,D,h,w,V", [(32, 16, 12, 21, 3), (16, 8, 17, 30, 3), (8, 12, 16, 40, 2), (8, 10, 9, 140, 3), (32, 5, 6, 9, 2)])
@@ -169,13 +169,13 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
                 emu.rcmvs_debug_k1_variant(var)
                 assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, order)
         emu.rcmvs_emu_set_order(0)
-        knobs = ((2, 0), (8, 64), (4, 16), (2, 64)) if (C, V) in ((32, 3), (8, 2)) else ((4, 16),)
-        for dkb, ptex in knobs:                                                       # other chunk depths; a budget small enough to force the global fallback
-            emu.rcmvs_debug_k1_ps_config(dkb, ptex)
+        knobs = ((2, 0, 0), (8, 64, 16), (4, 16, 0), (2, 64, 32), (4, 0, 16)) if (C, V) in ((32, 3), (8, 2)) else ((4, 16, 16),)
+        for dkb, ptex, pad in knobs:                                                       # other chunk depths; a budget small enough to force the global fallback
+            emu.rcmvs_debug_k1_ps_config(dkb, ptex, pad)
             for var in (8, 10):
                 emu.rcmvs_debug_k1_variant(var)
-                assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex)
-        emu.rcmvs_debug_k1_ps_config(0, 0)
+                assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex, pad)
+        emu.rcmvs_debug_k1_ps_config(0, 0, 0)
         for var in (9, 11):
             emu.rcmvs_debug_k1_variant(var)
             v9 = ops.warp_variance(feats, rot, trans, planes, D)
@@ -186,4 +186,4 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
     finally:
         emu.rcmvs_emu_set_order(0)
         emu.rcmvs_debug_k1_variant(0)
-        emu.rcmvs_debug_k1_ps_config(0, 0)
+        emu.rcmvs_debug_k1_ps_config(0, 0, 0)

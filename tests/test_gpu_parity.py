@@ -666,15 +666,15 @@ def test_warp_variance_pipelined_variants(hip, C, D, h, w, V):
     try:
         lib.rcmvs_debug_k1_variant(2)
         vref = hip.warp_variance(feats, rot, trans, planes, D)
-        for dkb, ptex in ((0, 0), (2, 0), (8, 64), (4, 16)):
-            lib.rcmvs_debug_k1_ps_config(dkb, ptex)
+        for dkb, ptex, pad in ((0, 0, 0), (2, 0, 16), (8, 64, 0), (4, 16, 32)):
+            lib.rcmvs_debug_k1_ps_config(dkb, ptex, pad)
             for var in (8, 10):
                 lib.rcmvs_debug_k1_variant(var)
-                assert torch.equal(hip.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex)
+                assert torch.equal(hip.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex, pad)
             for var in (9, 11):
                 lib.rcmvs_debug_k1_variant(var)
                 vv = hip.warp_variance(feats, rot, trans, planes, D)
-                assert float((vv - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), (var, dkb, ptex)
+                assert float((vv - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), (var, dkb, ptex, pad)
     finally:
         lib.rcmvs_debug_k1_variant(0)
-        lib.rcmvs_debug_k1_ps_config(0, 0)
+        lib.rcmvs_debug_k1_ps_config(0, 0, 0)

@@ -11,7 +11,7 @@ dev = "cuda:0"
 V, H, W = int(os.environ.get('K1_V', '3')), 512, 640
 names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 4: "lds exact", 5: "lds fma", 6: "lds exact deep", 7: "lds fma deep", 8: "pipelined staged exact", 9: "pipelined staged fma", 10: "pipelined staged exact (register-held windows)", 11: "pipelined staged fma (register-held windows)", 100: "torch zero_ (memset)"}
 variants = [int(a) for a in sys.argv[1:]] or [0, 1, 3, 4, 5, 6, 7]
-lib.rcmvs_debug_k1_ps_config(int(os.environ.get("K1_PS_DKB", "0")), int(os.environ.get("K1_PS_PTEX", "0")))    # variants 8 / 9 only
+lib.rcmvs_debug_k1_ps_config(int(os.environ.get("K1_PS_DKB", "0")), int(os.environ.get("K1_PS_PTEX", "0")), int(os.environ.get("K1_PS_PAD", "0")))    # variants 8 / 9 only
 dv = synthetic.depth_values(1).to(dev)
 tot = {v: 0.0 for v in variants}
 for (C, D, sc, key) in ((32, 48, 4, "stage1"), (16, 32, 2, "stage2"), (8, 8, 1, "stage3")):
