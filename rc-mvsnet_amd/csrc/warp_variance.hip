@@ -15,6 +15,7 @@
 // oracle/warp.py (itself the reference's op order) with fp contraction OFF and correctly rounded
 // divisions, so the kernel is bit-comparable with the oracle; taps outside the source image, and
 // non-finite coordinates (z == 0), contribute zero (grid_sample zeros padding, CUDA/HIP semantics).
+#include <type_traits>
 #include "common.h"
 #include "k1_taps.h"
 
@@ -730,13 +731,13 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
         }
     };
 
-    // ---- phase B of chunk kc out of set `st`
-    auto phase_b = [&](int kc, int st, const bool* fits) {
+    // ---- phase B of chunk kc out of set `st`: a fits-only body (ds_reads only) and a mixed body, see warp_variance_pss_kernel
+    auto phase_b_body = [&](int kc, int st, const bool* fits, auto mixed) {
+        constexpr bool MIXED = decltype(mixed)::value;
         const v4i* lo = lds_ps + st * set_v4;
         const v4f* lw = reinterpret_cast<const v4f*>(lo + TAB);
         const char* lds_bytes = reinterpret_cast<const char*>(lds_ps) + q4b;
         const int k0 = kc * DKB;
-        if (!inside) return;
 #pragma unroll
         for (int k = 0; k < DKB; ++k) {
             v4f a = ref, a2 = ref * ref;
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
                 const v4i o = lo[idx];
                 const v4f wt = lw[idx];
                 v4f ta, tb, tc, td;
-                if (fits[va]) {
+                if (!MIXED || fits[va]) {
                     ta = *reinterpret_cast<const v4f*>(lds_bytes + o.x);
                     tb = *reinterpret_cast<const v4f*>(lds_bytes + o.y);
                     tc = *reinterpret_cast<const v4f*>(lds_bytes + o.z);
@@ -764,6 +765,14 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
             }
             if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
         }
+    };
+    auto phase_b = [&](int kc, int st, const bool* fits) {
+        if (!inside) return;
+        bool all = true;
+#pragma unroll
+        for (int va = 0; va < NV; ++va) all = all && (va >= nv || fits[va]);
+        if (all) phase_b_body(kc, st, fits, std::false_type{});
+        else phase_b_body(kc, st, fits, std::true_type{});
     };
 
     bool fits_cur[NV], fits_next[NV];
@@ -784,6 +793,224 @@ __global__ __launch_bounds__(256) void warp_variance_ps_kernel(
         __syncthreads();                                           // set `st` is free for the taps of chunk kc + 2
 #pragma unroll
         for (int va = 0; va < NV; ++va) fits_cur[va] = fits_next[va];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1, pipelined staged variant with STATIC LDS sets (debug variants 12 / 13).  Same algorithm as warp_variance_ps_kernel with
+// direct-to-LDS loads, but the two sets are distinct __shared__ objects and the chunk loop is unrolled by two, so that every
+// access names its object at compile time.  Why it matters: SIInsertWaitcnts makes a ds_read wait (vmcnt) for every outstanding
+// buffer_load ... lds that MAY alias it; with one dynamic LDS block carved into sets it cannot tell the window being filled from
+// the window being gathered and serialises them (ISA of variant 8: s_waitcnt vmcnt(3..0) in front of the first gathers of every
+// chunk); with distinct objects it emits the loads and the gathers back to back (checked on the gfx950 ISA).  The window budget
+// is a compile-time constant here (PTEX texels per view); NOT measured yet.
+// ------------------------------------------------------------------------------------------
+template <int C, int DKB, bool FAST, int PTEX>
+__global__ __launch_bounds__(256) void warp_variance_pss_kernel(
+    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x) {
+#pragma clang fp contract(off)
+    constexpr int NV = 2;
+    constexpr int LPP = C / 4;
+    constexpr int PIX = 256 / LPP;
+    constexpr int TH = 4, TW = PIX / TH;
+    constexpr int GRP = 256 / PIX;
+    constexpr int KPT = (DKB + GRP - 1) / GRP;
+    constexpr int C4 = C * 4;
+    constexpr int TAB = NV * DKB * PIX;
+    constexpr int PATCH_BYTES = PTEX * C4;
+    __shared__ __attribute__((aligned(16))) v4i tab_o0[TAB];
+    __shared__ __attribute__((aligned(16))) v4i tab_o1[TAB];
+    __shared__ __attribute__((aligned(16))) v4f tab_w0[TAB];
+    __shared__ __attribute__((aligned(16))) v4f tab_w1[TAB];
+    __shared__ __attribute__((aligned(16))) int box0[16 * NV];
+    __shared__ __attribute__((aligned(16))) int box1[16 * NV];
+    __shared__ __attribute__((aligned(16))) char patch0[NV * PATCH_BYTES];
+    __shared__ __attribute__((aligned(16))) char patch1[NV * PATCH_BYTES];
+    const int nv = V - 1;
+
+    const int b = blockIdx.z;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const int hw = h * w;
+    const int nch = (D + DKB - 1) / DKB;
+    K1Geom g;
+    g.w = w; g.h = h;
+    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
+    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
+    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
+    const float* fb = feats + (long long)b * V * hw * C;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
+
+    const int p = threadIdx.x / LPP;
+    const int q4b = (threadIdx.x % LPP) * 16;
+    const int x = tx0 + p % TW, y = ty0 + p / TW;
+    const bool inside = (x < w) && (y < h);
+    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
+    const float fV = (float)V, rV = rcp_nr(fV);
+    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
+    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
+    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
+    const float fxa = (float)xa, fya = (float)ya;
+    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
+    const int lane = threadIdx.x & 63;
+
+    // every phase takes the arrays of ITS set as arguments; after inlining they are compile-time objects
+    auto phase_a = [&](int kc, v4i* lo, v4f* lw, int* lbox) {
+        const int k0 = kc * DKB;
+        for (int va = 0; va < nv; ++va) {
+            const float* r = rot + ((long long)b * (V - 1) + va) * 9;
+            const float* t = trans + ((long long)b * (V - 1) + va) * 3;
+            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
+            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
+            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
+            const float t0 = t[0], t1 = t[1], t2 = t[2];
+            int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) {
+                const int ka = ga + kk * GRP;
+                if (ka >= DKB) continue;
+                const float d = pla.x + (float)(k0 + ka) * pla.y;
+                v4f wt;
+                int xi, yi;
+                k1_chain(rx, ry, rz, t0, t1, t2, d, g, xi, yi, wt);
+                const int xc0 = min(max(xi, 0), w - 1), xc1 = min(max(xi + 1, 0), w - 1);
+                const int yc0 = min(max(yi, 0), h - 1), yc1 = min(max(yi + 1, 0), h - 1);
+                const bool any = (wt.x != 0.0f) || (wt.y != 0.0f) || (wt.z != 0.0f) || (wt.w != 0.0f);
+                const int idx = (va * DKB + ka) * PIX + pa;
+                v4i rec;
+                rec.x = xc0; rec.y = yc0; rec.z = (xc1 != xc0 ? 1 : 0) | (yc1 != yc0 ? 2 : 0) | (any ? 4 : 0); rec.w = 0;
+                lo[idx] = rec;
+                lw[idx] = wt;
+                if (any) { bx0 = min(bx0, xc0); bx1 = max(bx1, xc1); by0 = min(by0, yc0); by1 = max(by1, yc1); }
+            }
+            bx0 = wave_reduce_i32<true>(bx0); bx1 = wave_reduce_i32<false>(bx1);
+            by0 = wave_reduce_i32<true>(by0); by1 = wave_reduce_i32<false>(by1);
+            if (lane == 0) *reinterpret_cast<v4i*>(lbox + ((threadIdx.x >> 6) * NV + va) * 4) = (v4i){bx0, bx1, by0, by1};
+        }
+    };
+
+    // records -> byte offsets inside this set's window array (or global offsets), windows -> LDS by direct loads
+    auto stage = [&](v4i* lo, const int* lbox, char* lpatch, bool* fits) {
+        int px0[NV], py0[NV], pw[NV], ph[NV];
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            v4i bb = *reinterpret_cast<const v4i*>(lbox + va * 4);
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) {
+                const v4i t = *reinterpret_cast<const v4i*>(lbox + (wv * NV + va) * 4);
+                bb.x = min(bb.x, t.x); bb.y = max(bb.y, t.y); bb.z = min(bb.z, t.z); bb.w = max(bb.w, t.w);
+            }
+            px0[va] = bb.x; py0[va] = bb.z;
+            pw[va] = bb.y - bb.x + 1; ph[va] = bb.w - bb.z + 1;
+            if (bb.y < 0) { px0[va] = 0; py0[va] = 0; pw[va] = 1; ph[va] = 1; }
+            fits[va] = (va < nv) && (pw[va] * ph[va] <= PTEX);
+        }
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            if (va >= nv) continue;
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk) {
+                if (ga + kk * GRP >= DKB) continue;
+                const int idx = (va * DKB + ga + kk * GRP) * PIX + pa;
+                const v4i rec = lo[idx];
+                const bool any = rec.z & 4;
+                v4i o;
+                if (fits[va]) {
+                    const int lx = any ? rec.x - px0[va] : 0, ly = any ? rec.y - py0[va] : 0;
+                    const int base = (ly * pw[va] + lx) * C4 + va * PATCH_BYTES;
+                    const int dx = (any && (rec.z & 1)) ? C4 : 0, dy = (any && (rec.z & 2)) ? pw[va] * C4 : 0;
+                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
+                } else {
+                    const int base = ((1 + va) * hw + rec.y * w + rec.x) * C4;
+                    const int dx = (rec.z & 1) ? C4 : 0, dy = (rec.z & 2) ? w * C4 : 0;
+                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
+                }
+                lo[idx] = o;
+            }
+        }
+#pragma unroll
+        for (int va = 0; va < NV; ++va) {
+            if (!fits[va]) continue;
+            const int row4 = pw[va] * LPP;
+            const int n4 = row4 * ph[va];
+            const int src0 = (((1 + va) * hw) + py0[va] * w + px0[va]) * C4;
+            char* dst = lpatch + va * PATCH_BYTES;
+            for (int e0 = (threadIdx.x & ~63); e0 < n4; e0 += 256) {
+                const int e = e0 + lane;
+                if (e < n4) {
+                    const int row = e / row4, c4 = e - row * row4;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + (size_t)e0 * 16, 16, src0 + (row * w * C + c4 * 4) * 4, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // Two bodies: when every view's window fits (the block-uniform common case) the gathers are ds_reads only.  The mixed body
+    // also issues global gathers for a view whose window did not fit; keeping it apart matters because its buffer loads share
+    // destination registers with the ds_reads, which makes the compiler drain vmcnt -- and with it the windows in flight.
+    auto phase_b_body = [&](int kc, const v4i* lo, const v4f* lw, const char* lpatch, const bool* fits, auto mixed) {
+        constexpr bool MIXED = decltype(mixed)::value;
+        const int k0 = kc * DKB;
+        const char* pq = lpatch + q4b;
+#pragma unroll
+        for (int k = 0; k < DKB; ++k) {
+            v4f a = ref, a2 = ref * ref;
+#pragma unroll
+            for (int va = 0; va < NV; ++va) {
+                if (va >= nv) continue;
+                const int idx = (va * DKB + k) * PIX + p;
+                const v4i o = lo[idx];
+                const v4f wt = lw[idx];
+                v4f ta, tb, tc, td;
+                if (!MIXED || fits[va]) {
+                    ta = *reinterpret_cast<const v4f*>(pq + o.x);
+                    tb = *reinterpret_cast<const v4f*>(pq + o.y);
+                    tc = *reinterpret_cast<const v4f*>(pq + o.z);
+                    td = *reinterpret_cast<const v4f*>(pq + o.w);
+                } else {
+                    ta = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
+                    tb = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
+                    tc = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
+                    td = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
+                }
+                v4f val = blend4<FAST>(ta, tb, tc, td, wt);
+                a = a + val;
+                if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
+            }
+            if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
+        }
+    };
+    auto phase_b = [&](int kc, const v4i* lo, const v4f* lw, const char* lpatch, const bool* fits) {
+        if (!inside) return;
+        bool all = true;
+#pragma unroll
+        for (int va = 0; va < NV; ++va) all = all && (va >= nv || fits[va]);
+        if (all) phase_b_body(kc, lo, lw, lpatch, fits, std::false_type{});
+        else phase_b_body(kc, lo, lw, lpatch, fits, std::true_type{});
+    };
+
+    bool fits0[NV], fits1[NV];
+    phase_a(0, tab_o0, tab_w0, box0);
+    __syncthreads();
+    stage(tab_o0, box0, patch0, fits0);
+    for (int kc = 0; kc < nch; kc += 2) {
+        // ---- even chunk: blend set 0 while set 1 is prepared
+        if (kc + 1 < nch) phase_a(kc + 1, tab_o1, tab_w1, box1);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (kc + 1 < nch) stage(tab_o1, box1, patch1, fits1);
+        phase_b(kc, tab_o0, tab_w0, patch0, fits0);
+        __syncthreads();
+        if (kc + 1 >= nch) break;
+        // ---- odd chunk: blend set 1 while set 0 is prepared
+        if (kc + 2 < nch) phase_a(kc + 2, tab_o0, tab_w0, box0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (kc + 2 < nch) stage(tab_o0, box0, patch0, fits0);
+        phase_b(kc + 1, tab_o1, tab_w1, patch1, fits1);
+        __syncthreads();
     }
 }
 
@@ -907,6 +1134,28 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
             default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
         }
         return launch_status("warp_variance_fwd(lds)");
+    }
+    if (g_k1_variant == 12 || g_k1_variant == 13) {
+        // pipelined staged kernel with static LDS sets (compile-time window budget): 12 = exact, 13 = FMA blend; <= 2 source views
+        const bool fastm = g_k1_variant == 13;
+        RCMVS_REQUIRE(V - 1 <= 2, "warp_variance_fwd: debug variant %d handles at most 2 source views (V=%d)", g_k1_variant, V);
+        RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
+        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
+        const int dkb = g_k1_ps_dkb ? g_k1_ps_dkb : (C == 8 ? 2 : 4);        // C = 8: 128 pixels per block, the 4-plane tap tables alone are 64 KB
+        RCMVS_REQUIRE(dkb == 2 || dkb == 4, "warp_variance_fwd: static pipelined variant: plane chunk %d (2 or 4)", dkb);
+        const int PIXs = 256 / (C / 4), TWs = PIXs / 4;
+        const int txs = (w + TWs - 1) / TWs, tys = (h + 3) / 4;
+        dim3 grids(txs * tys, 1, B);
+        // window budgets (texels per view): two sets of tables + windows stay under 80 KB so that two blocks share a CU
+#define RCMVS_K1PSS(CC, DD, FF, PP) hipLaunchKernelGGL((warp_variance_pss_kernel<CC, DD, FF, PP>), grids, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, txs)
+#define RCMVS_K1PSS_F(CC, DD, PP) do { if (fastm) RCMVS_K1PSS(CC, DD, true, PP); else RCMVS_K1PSS(CC, DD, false, PP); } while (0)
+        switch (C) {
+            case 8:  if (dkb == 2) RCMVS_K1PSS_F(8, 2, 320); else RCMVS_K1PSS_F(8, 4, 256); break;
+            case 16: if (dkb == 2) RCMVS_K1PSS_F(16, 2, 224); else RCMVS_K1PSS_F(16, 4, 160); break;
+            case 32: if (dkb == 2) RCMVS_K1PSS_F(32, 2, 128); else RCMVS_K1PSS_F(32, 4, 112); break;
+            default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+        }
+        return launch_status("warp_variance_fwd(pss)");
     }
     if (g_k1_variant >= 8 && g_k1_variant <= 11) {
         // pipelined staged kernel (persistent over the plane chunks of a tile): 8 = exact, 9 = FMA blend, windows loaded straight

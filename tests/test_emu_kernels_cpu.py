@@ -165,7 +165,7 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
         vref = ops.warp_variance(feats, rot, trans, planes, D)
         for order in (0, 1, 2):
             emu.rcmvs_emu_set_order(order)
-            for var in (8, 10):                                                       # windows by direct-to-LDS loads / held in registers
+            for var in (8, 10, 12):                                                   # windows by direct-to-LDS loads / held in registers / static LDS sets
                 emu.rcmvs_debug_k1_variant(var)
                 assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, order)
         emu.rcmvs_emu_set_order(0)
@@ -176,7 +176,12 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
                 emu.rcmvs_debug_k1_variant(var)
                 assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex, pad)
         emu.rcmvs_debug_k1_ps_config(0, 0, 0)
-        for var in (9, 11):
+        for dkb in (2, 4):                                                            # static-set form: compile-time budgets per chunk depth
+            emu.rcmvs_debug_k1_ps_config(dkb, 0, 0)
+            emu.rcmvs_debug_k1_variant(12)
+            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), dkb
+        emu.rcmvs_debug_k1_ps_config(0, 0, 0)
+        for var in (9, 11, 13):
             emu.rcmvs_debug_k1_variant(var)
             v9 = ops.warp_variance(feats, rot, trans, planes, D)
             assert float((v9 - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), var
@@ -187,3 +192,39 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
         emu.rcmvs_emu_set_order(0)
         emu.rcmvs_debug_k1_variant(0)
         emu.rcmvs_debug_k1_ps_config(0, 0, 0)
+
+
+@pytest.mark.parametrize("C,interval", [(32, 40.0), (16, 60.0), (8, 400.0)])
+def test_k1_pipelined_variants_window_overflow_path(C, interval, emu):
+    """Plane spacing so wide that a chunk's source window exceeds the LDS budget: the block-uniform mixed body (global gathers for
+    the view that does not fit) of the pipelined variants, including the static-set form whose budget is a compile-time constant.
+    The test first shows, with the oracle's coordinates, that such windows do occur for these inputs."""
+    from oracle import warp
+    from rc_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(C)
+    V, D, h, w = 3, 8, 8, 200
+    budget, tile_w, chunk = {32: (112, 8, 4), 16: (160, 16, 4), 8: (320, 32, 2)}[C]          # the static form's PTEX, TW, DKB
+    feats = torch.randn(1, V, h, w, C, generator=g)
+    pm = synthetic.proj_matrices(1, V, h * 4, w * 4)["stage1"]
+    rot, trans = ops.compose_homography(pm)
+    planes = torch.stack((430.0 + 5.0 * torch.rand(1, h, w, generator=g), interval + 5.0 * torch.rand(1, h, w, generator=g)), dim=-1).contiguous()
+    samples = planes[..., 0].unsqueeze(1) + planes[..., 1].unsqueeze(1) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
+    largest = 0
+    for v in (1, 2):
+        r, t = warp.compose_homography(pm[:, v], pm[:, 0])
+        ix, iy = warp.warp_coords(r, t, samples, h, w)
+        x0, y0 = ix[0].floor().clamp(0, w - 1), iy[0].floor().clamp(0, h - 1)
+        for k0 in range(0, D, chunk):
+            for tx in range(0, w, tile_w):
+                xs, ys = x0[k0:k0 + chunk, 0:4, tx:tx + tile_w], y0[k0:k0 + chunk, 0:4, tx:tx + tile_w]
+                largest = max(largest, int((xs.max() - xs.min() + 2) * (ys.max() - ys.min() + 2)))
+    assert largest > budget, (largest, budget)
+    try:
+        emu.rcmvs_debug_k1_variant(2)
+        vref = ops.warp_variance(feats, rot, trans, planes, D)
+        assert float(vref.abs().max()) > 0
+        for var in (8, 10, 12):
+            emu.rcmvs_debug_k1_variant(var)
+            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), var
+    finally:
+        emu.rcmvs_debug_k1_variant(0)

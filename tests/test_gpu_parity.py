@@ -652,7 +652,7 @@ def test_fpn_out_fused_is_bit_identical(N, H, W):
 
 
 @pytest.mark.skipif(__import__("os").environ.get("RCMVS_TEST_PS", "0") != "1",
-                    reason="pipelined staged K1 variants 8-11: verified on the CPU emulation only so far; RCMVS_TEST_PS=1 runs them on the GPU")
+                    reason="pipelined staged K1 variants 8-13: verified on the CPU emulation only so far; RCMVS_TEST_PS=1 runs them on the GPU")
 @pytest.mark.parametrize("C,D,h,w,V", [(32, 48, 128, 160, 3), (16, 32, 66, 90, 3), (8, 8, 120, 200, 3), (8, 10, 9, 140, 2), (32, 5, 6, 9, 2)])
 def test_warp_variance_pipelined_variants(hip, C, D, h, w, V):
     """Debug variants 8 / 10 (exact) must be bit-identical to the reference-order kernel, 9 / 11 (FMA blend) within 2e-6, for
@@ -668,10 +668,10 @@ def test_warp_variance_pipelined_variants(hip, C, D, h, w, V):
         vref = hip.warp_variance(feats, rot, trans, planes, D)
         for dkb, ptex, pad in ((0, 0, 0), (2, 0, 16), (8, 64, 0), (4, 16, 32)):
             lib.rcmvs_debug_k1_ps_config(dkb, ptex, pad)
-            for var in (8, 10):
+            for var in (8, 10) + ((12,) if dkb in (0, 2, 4) else ()):
                 lib.rcmvs_debug_k1_variant(var)
                 assert torch.equal(hip.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex, pad)
-            for var in (9, 11):
+            for var in (9, 11) + ((13,) if dkb in (0, 2, 4) else ()):
                 lib.rcmvs_debug_k1_variant(var)
                 vv = hip.warp_variance(feats, rot, trans, planes, D)
                 assert float((vv - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), (var, dkb, ptex, pad)

@@ -9,7 +9,7 @@ from rc_mvsnet_amd import _lib, ops, synthetic
 lib = _lib.load()
 dev = "cuda:0"
 V, H, W = int(os.environ.get('K1_V', '3')), 512, 640
-names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 4: "lds exact", 5: "lds fma", 6: "lds exact deep", 7: "lds fma deep", 8: "pipelined staged exact", 9: "pipelined staged fma", 10: "pipelined staged exact (register-held windows)", 11: "pipelined staged fma (register-held windows)", 100: "torch zero_ (memset)"}
+names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 4: "lds exact", 5: "lds fma", 6: "lds exact deep", 7: "lds fma deep", 8: "pipelined staged exact", 9: "pipelined staged fma", 10: "pipelined staged exact (register-held windows)", 11: "pipelined staged fma (register-held windows)", 12: "pipelined staged exact (static LDS sets)", 13: "pipelined staged fma (static LDS sets)", 100: "torch zero_ (memset)"}
 variants = [int(a) for a in sys.argv[1:]] or [0, 1, 3, 4, 5, 6, 7]
 lib.rcmvs_debug_k1_ps_config(int(os.environ.get("K1_PS_DKB", "0")), int(os.environ.get("K1_PS_PTEX", "0")), int(os.environ.get("K1_PS_PAD", "0")))    # variants 8 / 9 only
 dv = synthetic.depth_values(1).to(dev)
