@@ -1152,7 +1152,13 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         switch (C) {
             case 8:  if (dkb == 2) RCMVS_K1PSS_F(8, 2, 320); else RCMVS_K1PSS_F(8, 4, 256); break;
             case 16: if (dkb == 2) RCMVS_K1PSS_F(16, 2, 224); else RCMVS_K1PSS_F(16, 4, 160); break;
-            case 32: if (dkb == 2) RCMVS_K1PSS_F(32, 2, 128); else RCMVS_K1PSS_F(32, 4, 112); break;
+            case 32:
+                // K1_PS_PTEX <= 72 selects the 72-texel budget: 16 KB of tables + 36 KB of windows = three blocks per CU; the window
+                // statistics put the median stage-1 window of a 4 x 8 tile over 4 planes at ~48 texels (profiles/r1_k1_window_stats.txt)
+                if (dkb == 2) RCMVS_K1PSS_F(32, 2, 128);
+                else if (g_k1_ps_ptex > 0 && g_k1_ps_ptex <= 72) RCMVS_K1PSS_F(32, 4, 72);
+                else RCMVS_K1PSS_F(32, 4, 112);
+                break;
             default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
         }
         return launch_status("warp_variance_fwd(pss)");

@@ -176,10 +176,10 @@ def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
                 emu.rcmvs_debug_k1_variant(var)
                 assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex, pad)
         emu.rcmvs_debug_k1_ps_config(0, 0, 0)
-        for dkb in (2, 4):                                                            # static-set form: compile-time budgets per chunk depth
-            emu.rcmvs_debug_k1_ps_config(dkb, 0, 0)
+        for dkb, ptex in ((2, 0), (4, 0), (4, 72)):                                   # static-set form: compile-time budgets per chunk depth
+            emu.rcmvs_debug_k1_ps_config(dkb, ptex, 0)
             emu.rcmvs_debug_k1_variant(12)
-            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), dkb
+            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (dkb, ptex)
         emu.rcmvs_debug_k1_ps_config(0, 0, 0)
         for var in (9, 11, 13):
             emu.rcmvs_debug_k1_variant(var)
