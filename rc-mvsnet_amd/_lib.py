@@ -85,16 +85,32 @@ def sources():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source into librcmvs_hip.so for gfx950 (cross-compiles without a GPU)."""
+    """Compile every HIP source into librcmvs_hip.so for gfx950 (cross-compiles without a GPU).  One object per source
+    (csrc/_obj/*.o, rebuilt when the source or any header is newer), compiled in parallel, then one link step."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + hdrs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 

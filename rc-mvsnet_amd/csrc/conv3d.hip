@@ -148,8 +148,18 @@ bool deconv3d_lds_supported(int Ci, int Co);
 int deconv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                         int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
 
-// packed weight blob = [27][Ci][Co] (direct kernels) followed by the MFMA image when the pair has one
+// conv3d_x3.hip (stride-1 layers on the bf16 matrix cores, three-way split operands)
+bool conv3d_x3_supported(int Ci, int Co);
+long long conv3d_x3_weight_floats(int Ci, int Co);
+int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int transposed, hipStream_t st);
+int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
+                     int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
+
+// packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 image
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
+static inline long long x3_image_offset(int Ci, int Co) {
+    return direct_weight_floats(Ci, Co) + (conv3d_mfma_supported(Ci, Co, 0) ? mfma_weight_floats_host(Ci, Co) : 0);
+}
 
 }  // namespace rcmvs
 
@@ -157,15 +167,17 @@ using namespace rcmvs;
 
 static int g_prefer_lds = 1;     // LDS/scalar-weight kernel before the MFMA kernel where both exist (debug bit 16 clears it)
 static int g_force_direct = 0;   // test/bench hook: route everything through the direct kernels
+static int g_no_x3 = 0;          // test/bench hook (bit 6): skip the split-bf16 MFMA kernels (A/B against the fp32 kernels)
 
 extern "C" {
 
-void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; g_prefer_lds = !(on & 16); conv3d_lds_set_config(((on >> 1) & 7) | (((on >> 5) & 1) << 3)); }
+void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; g_prefer_lds = !(on & 16); g_no_x3 = (on >> 6) & 1; conv3d_lds_set_config(((on >> 1) & 7) | (((on >> 5) & 1) << 3)); }
 
 long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;
     long long n = direct_weight_floats(Ci, Co);
     if (conv3d_mfma_supported(Ci, Co, 0)) n += mfma_weight_floats_host(Ci, Co);
+    if (conv3d_x3_supported(Ci, Co)) n += conv3d_x3_weight_floats(Ci, Co);
     return n;
 }
 
@@ -175,8 +187,11 @@ int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int 
     hipLaunchKernelGGL(pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, packed, Co, Ci, transposed);
     int rc = launch_status("pack_conv3d_weight");
     if (rc) return rc;
-    if (conv3d_mfma_supported(Ci, Co, 0))
-        return pack_weight_mfma_launch(w, packed + direct_weight_floats(Ci, Co), Co, Ci, transposed, as_stream(stream));
+    if (conv3d_mfma_supported(Ci, Co, 0)) {
+        rc = pack_weight_mfma_launch(w, packed + direct_weight_floats(Ci, Co), Co, Ci, transposed, as_stream(stream));
+        if (rc) return rc;
+    }
+    if (conv3d_x3_supported(Ci, Co)) return conv3d_x3_pack(w, packed + x3_image_offset(Ci, Co), Co, Ci, transposed, as_stream(stream));
     return 0;
 }
 
@@ -190,6 +205,8 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
     ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
+    if (stride == 1 && conv3d_x3_supported(Ci, Co) && !g_force_direct && !g_no_x3)
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
     if (g_prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !g_force_direct)
         return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
     if (conv3d_mfma_supported(Ci, Co, mode) && !g_force_direct)

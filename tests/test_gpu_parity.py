@@ -241,6 +241,43 @@ def test_conv3d_vs_oracle(hip, Ci, Co, stride):
     assert rel_err(y2.cpu().permute(0, 4, 1, 2, 3), ref2) < 2e-5
 
 
+@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 8), (32, 8), (16, 16)])
+@pytest.mark.parametrize("shape", [(2, 5, 11, 21), (1, 9, 37, 70), (1, 20, 8, 32)])
+def test_conv3d_x3_vs_fp64(hip, Ci, Co, shape):
+    """The split-bf16 MFMA kernels (csrc/conv3d_x3.hip: three bf16 pieces per fp32 operand, six MFMAs per product, fp32
+    accumulation) must be as close to an fp64 convolution as the fp32 FMA-chain kernels are: wide-dynamic-range inputs,
+    ragged tiles in x / y, z chunks, batch 2, full epilogue, and the flipped-tap (data gradient) weight image."""
+    g = torch.Generator().manual_seed(Ci * 7 + Co + shape[1])
+    B, D, H, W = shape
+    x = torch.randn(B, Ci, D, H, W, generator=g) * torch.exp(torch.randn(B, Ci, D, H, W, generator=g))
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+    scale, shift = 0.5 + torch.rand(Co, generator=g), 0.1 * torch.randn(Co, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
+    res = torch.randn(B, Co, D, H, W, generator=g)
+    ref2 = torch.relu(ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)) + res.double()
+    wp = hip.pack_conv3d_weight(gpu(w))
+    xcl = gpu(x.permute(0, 2, 3, 4, 1))
+    rcl = gpu(res.permute(0, 2, 3, 4, 1))
+    outs = {}
+    for name, cfg in (("x3", 0), ("fp32", 64)):
+        try:
+            hip.force_direct_conv(cfg)
+            outs[name] = (hip.conv3d(xcl, wp).cpu().permute(0, 4, 1, 2, 3).double(),
+                          hip.conv3d(xcl, wp, gpu(scale), gpu(shift), rcl, relu=True).cpu().permute(0, 4, 1, 2, 3).double())
+        finally:
+            hip.force_direct_conv(0)
+    e_x3 = float((outs["x3"][0] - ref).abs().max()), float((outs["x3"][1] - ref2).abs().max())
+    e_32 = float((outs["fp32"][0] - ref).abs().max()), float((outs["fp32"][1] - ref2).abs().max())
+    mag = float(ref.abs().max())
+    assert e_x3[0] <= 2.0 * e_32[0] + 1e-7 * mag and e_x3[1] <= 2.0 * e_32[1] + 1e-7 * mag, (e_x3, e_32, mag)
+    assert e_x3[0] < 3e-6 * mag
+    if Ci == Co:      # adjoint of a stride-1 conv (training dgrad): weight (Ci, Co, 27) with flipped taps
+        wt = torch.randn(Ci, Co, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+        refT = torch.nn.functional.conv_transpose3d(x.double(), wt.double(), padding=1)
+        yT = hip.conv3d(xcl, hip.pack_conv3d_weight(gpu(wt), transposed=2)).cpu().permute(0, 4, 1, 2, 3).double()
+        assert float((yT - refT).abs().max()) < 3e-6 * float(refT.abs().max())
+
+
 @pytest.mark.parametrize("Ci", [8, 16, 32, 44])
 def test_conv3d_lds_halo_kernel(hip, Ci):
     """Cout = 8 stride-1 layers run on the LDS-staged halo kernel: against the oracle (ragged tiles: sizes
