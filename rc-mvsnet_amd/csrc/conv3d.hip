@@ -148,17 +148,20 @@ bool deconv3d_lds_supported(int Ci, int Co);
 int deconv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                         int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
 
-// conv3d_x3.hip (stride-1 layers on the bf16 matrix cores, three-way split operands)
-bool conv3d_x3_supported(int Ci, int Co);
-long long conv3d_x3_weight_floats(int Ci, int Co);
-int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int transposed, hipStream_t st);
+// conv3d_x3.hip (bf16 matrix cores, three-way split operands); kind: 0 stride-1 conv, 1 stride-2 conv, 2 transposed stride-2
+bool conv3d_x3_supported(int Ci, int Co, int kind);
+long long conv3d_x3_weight_floats(int Ci, int Co, int kind);
+int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, hipStream_t st);
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
+                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st);
 
-// packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 image
+// packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 images of
+// the three kinds (each present when the pair has that kernel)
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
-static inline long long x3_image_offset(int Ci, int Co) {
-    return direct_weight_floats(Ci, Co) + (conv3d_mfma_supported(Ci, Co, 0) ? mfma_weight_floats_host(Ci, Co) : 0);
+static inline long long x3_image_offset(int Ci, int Co, int kind) {
+    long long off = direct_weight_floats(Ci, Co) + (conv3d_mfma_supported(Ci, Co, 0) ? mfma_weight_floats_host(Ci, Co) : 0);
+    for (int k = 0; k < kind; ++k) off += conv3d_x3_weight_floats(Ci, Co, k);
+    return off;
 }
 
 }  // namespace rcmvs
@@ -177,7 +180,7 @@ long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;
     long long n = direct_weight_floats(Ci, Co);
     if (conv3d_mfma_supported(Ci, Co, 0)) n += mfma_weight_floats_host(Ci, Co);
-    if (conv3d_x3_supported(Ci, Co)) n += conv3d_x3_weight_floats(Ci, Co);
+    for (int k = 0; k < 3; ++k) n += conv3d_x3_weight_floats(Ci, Co, k);
     return n;
 }
 
@@ -191,7 +194,11 @@ int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int 
         rc = pack_weight_mfma_launch(w, packed + direct_weight_floats(Ci, Co), Co, Ci, transposed, as_stream(stream));
         if (rc) return rc;
     }
-    if (conv3d_x3_supported(Ci, Co)) return conv3d_x3_pack(w, packed + x3_image_offset(Ci, Co), Co, Ci, transposed, as_stream(stream));
+    for (int k = 0; k < 3; ++k) {         // a ConvTranspose3d weight (transposed == 1) feeds the transposed kernel only, and vice versa
+        if (!conv3d_x3_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
+        rc = conv3d_x3_pack(w, packed + x3_image_offset(Ci, Co, k), Co, Ci, k, transposed, as_stream(stream));
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -205,8 +212,8 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
     ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
-    if (stride == 1 && conv3d_x3_supported(Ci, Co) && !g_force_direct && !g_no_x3)
-        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
+    if (conv3d_x3_supported(Ci, Co, mode) && !g_force_direct && !g_no_x3)
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st);
     if (g_prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !g_force_direct)
         return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
     if (conv3d_mfma_supported(Ci, Co, mode) && !g_force_direct)
@@ -225,6 +232,9 @@ int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
     RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
     ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
+    if (conv3d_x3_supported(Ci, Co, CONV_T2) && !g_force_direct && !g_no_x3)
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
+                                as_stream(stream));
     if (deconv3d_lds_supported(Ci, Co) && !g_force_direct)
         return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
     if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !g_force_direct)

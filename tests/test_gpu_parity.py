@@ -278,6 +278,42 @@ def test_conv3d_x3_vs_fp64(hip, Ci, Co, shape):
         assert float((yT - refT).abs().max()) < 3e-6 * float(refT.abs().max())
 
 
+@pytest.mark.parametrize("Ci,Co,kind", [(8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2")])
+@pytest.mark.parametrize("shape", [(2, 5, 11, 21), (1, 9, 37, 70), (1, 16, 8, 32)])
+def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
+    """Stride-2 and transposed stride-2 forms of the split-bf16 MFMA kernel against fp64 (odd sizes: the stride-2 output of an
+    odd extent, the last input cell of the transposed conv reading a neighbour outside the volume), full epilogue."""
+    g = torch.Generator().manual_seed(Ci * 7 + Co + shape[2])
+    B, D, H, W = shape
+    x = torch.randn(B, Ci, D, H, W, generator=g) * torch.exp(torch.randn(B, Ci, D, H, W, generator=g))
+    scale, shift = 0.5 + torch.rand(Co, generator=g), 0.1 * torch.randn(Co, generator=g)
+    if kind == "s2":
+        w = torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+        ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1, stride=2)
+        wp = hip.pack_conv3d_weight(gpu(w))
+        run = lambda *a, **k: hip.conv3d(gpu(x.permute(0, 2, 3, 4, 1)), wp, *a, stride=2, **k)
+    else:
+        w = torch.randn(Ci, Co, 3, 3, 3, generator=g) / (Ci * 27 / 8) ** 0.5
+        ref = torch.nn.functional.conv_transpose3d(x.double(), w.double(), padding=1, stride=2, output_padding=1)
+        wp = hip.pack_conv3d_weight(gpu(w), transposed=True)
+        run = lambda *a, **k: hip.deconv3d(gpu(x.permute(0, 2, 3, 4, 1)), wp, *a, **k)
+    res = torch.randn(ref.shape, generator=g)
+    ref2 = torch.relu(ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)) + res.double()
+    outs = {}
+    for name, cfg in (("x3", 0), ("fp32", 64)):
+        try:
+            hip.force_direct_conv(cfg)
+            outs[name] = (run().cpu().permute(0, 4, 1, 2, 3).double(),
+                          run(gpu(scale), gpu(shift), gpu(res.permute(0, 2, 3, 4, 1)), relu=True).cpu().permute(0, 4, 1, 2, 3).double())
+        finally:
+            hip.force_direct_conv(0)
+    assert outs["x3"][0].shape == ref.shape
+    mag = float(ref.abs().max())
+    for i, r in enumerate((ref, ref2)):
+        e_x3, e_32 = float((outs["x3"][i] - r).abs().max()), float((outs["fp32"][i] - r).abs().max())
+        assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
+
+
 @pytest.mark.parametrize("Ci", [8, 16, 32, 44])
 def test_conv3d_lds_halo_kernel(hip, Ci):
     """Cout = 8 stride-1 layers run on the LDS-staged halo kernel: against the oracle (ragged tiles: sizes
