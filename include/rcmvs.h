@@ -4,7 +4,7 @@
  * The reference (Boese0601/RC-MVSNet) has no FFI layer: its hot path is a composition of ATen
  * ops inside Python nn.Modules.  Each entry point below replaces one
  * such composition; the reference call site it replaces is cited (paths relative to the
- * reference repository root).  The Python modules in rc-mvsnet_amd/ bind these with ctypes.
+ * reference repository root).  The Python modules in rc_mvsnet_amd/ bind these with ctypes.
  *
  * Conventions
  *   - every function is extern "C", returns int: 0 = ok, <0 = bad argument (see

@@ -3,7 +3,7 @@
 This package is the *checker*, never the product:
 
   * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
-    import it; nothing under ``rc-mvsnet_amd/`` imports it and the product path raises when
+    import it; nothing under ``rc_mvsnet_amd/`` imports it and the product path raises when
     the HIP library is missing rather than falling back to anything here;
   * every function is written from the formulas of the reference (cited file:line, relative
     to ``/root/reference``) with plain PyTorch-CPU / numpy arithmetic in fp32 -- the fused

@@ -93,7 +93,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + hdrs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "_obj")
+    objdir = os.path.join(_HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     jobs, objs = [], []

@@ -39,6 +39,7 @@ typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int x3_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int x3_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned char x3_byte;
 
 enum { X3_S1 = 0, X3_S2 = 1, X3_T2 = 2 };        // stride-1 conv, stride-2 conv, transposed stride-2 conv
 enum { X3_XT = 0, X3_YT = 1, X3_PL = 2 };        // how an n-tile maps to voxels (see above)
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, X3Dims dm) {
     using C = X3<CIN, COUT, KIND>;
     constexpr int MT = C::MT, KSW = C::KSW, KSPLIT = C::KSPLIT, TP = C::TP, NSLOT = C::NSLOT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const partbase = smem + NSLOT * C::SLB;
+    extern __shared__ __attribute__((aligned(16))) x3_byte smem[];
+    x3_byte* const partbase = smem + NSLOT * C::SLB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= 4;
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             }
         };
         auto stash = [&](const x3_f32x4 (&pf)[C::NPF], int slot) {
-            unsigned char* sb = smem + slot * C::SLB;
+            x3_byte* sb = smem + slot * C::SLB;
 #pragma unroll
             for (int i = 0; i < C::NPF; ++i) {
                 if (loff[i] < 0) continue;

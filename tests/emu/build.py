@@ -16,13 +16,13 @@ DYN_LDS = re.compile(r"extern\s+__shared__\s+((?:__attribute__\(\(aligned\(\d+\)
 def build(out_dir, only=None, verbose=False):
     """-> path of librcmvs_emu.so under out_dir.  only: iterable of .hip base names to include (default: all)."""
     src_root = os.path.join(out_dir, "src")
-    csrc = os.path.join(src_root, "rc-mvsnet_amd", "csrc")
+    csrc = os.path.join(src_root, "rc_mvsnet_amd", "csrc")
     shutil.rmtree(src_root, ignore_errors=True)
     os.makedirs(csrc)
     os.makedirs(os.path.join(src_root, "include"))
     shutil.copy(os.path.join(REPO, "include", "rcmvs.h"), os.path.join(src_root, "include", "rcmvs.h"))
     units = []
-    for path in sorted(glob.glob(os.path.join(REPO, "rc-mvsnet_amd", "csrc", "*"))):
+    for path in sorted(glob.glob(os.path.join(REPO, "rc_mvsnet_amd", "csrc", "*"))):
         name = os.path.basename(path)
         text = open(path).read()
         text = DYN_LDS.sub(lambda m: f"{m.group(2)}* {m.group(3)} = reinterpret_cast<{m.group(2)}*>(::shim::dyn_lds());", text)
@@ -48,7 +48,7 @@ def build(out_dir, only=None, verbose=False):
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(REPO, "rc-mvsnet_amd", "csrc", "*")) + glob.glob(os.path.join(HERE, "*.cpp")) +
+    return sorted(glob.glob(os.path.join(REPO, "rc_mvsnet_amd", "csrc", "*")) + glob.glob(os.path.join(HERE, "*.cpp")) +
                   glob.glob(os.path.join(HERE, "hip", "*.h")) + [os.path.join(REPO, "include", "rcmvs.h"), os.path.abspath(__file__)])
 
 

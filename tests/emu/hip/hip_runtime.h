@@ -1,4 +1,4 @@
-// CPU emulation of the slice of the HIP programming model that rc-mvsnet_amd/csrc/*.hip uses -- TEST INFRASTRUCTURE ONLY.
+// CPU emulation of the slice of the HIP programming model that rc_mvsnet_amd/csrc/*.hip uses -- TEST INFRASTRUCTURE ONLY.
 //
 // tests/emu/build.py compiles the product's kernel sources, unmodified apart from the spelling of dynamic LDS declarations, with
 // the host clang++ against this header instead of <hip/hip_runtime.h>; the result (librcmvs_emu.so) exports the same C ABI as
@@ -231,6 +231,45 @@ inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x4f32_emu(float a, float b, emu_v4
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x4f32_emu((a), (b), (c), (x), (y), (z))
+
+// v_mfma_f32_16x16x32_bf16: D (16x16) = A (16x32) B (32x16) + C.  Lane l holds the eight bf16 A[l % 16][8 (l / 16) + e] and
+// B[8 (l / 16) + e][l % 16], e = 0..7, and the four D[4 (l / 16) + r][l % 16] (cdna_hip_programming.md, "Fragment layout").
+// Products of two bf16 are exact in fp32; the accumulation order inside the instruction is not architected -- plain fp32
+// sums here, callers compare with a tolerance.
+typedef __bf16 emu_v8bf __attribute__((ext_vector_type(8)));
+inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16_emu(emu_v8bf a, emu_v8bf b, emu_v4f c, int, int, int) {
+    struct H8 { unsigned short h[8]; } ha, hb;       // two exchanges: a wave value is at most 16 bytes
+    std::memcpy(ha.h, &a, 16);
+    std::memcpy(hb.h, &b, 16);
+    const auto wa = ::shim::exchange(ha);
+    const int j = wa.lane % 16, g = wa.lane / 16;
+    H8 xa[4][4];                                     // the A rows this lane's outputs need, copied before the next rendezvous overwrites the snapshot
+    for (int r = 0; r < 4; ++r)
+        for (int kq = 0; kq < 4; ++kq) xa[r][kq] = ::shim::lane_value(wa, 4 * g + r + 16 * kq, H8{});
+    const auto wb = ::shim::exchange(hb);
+    auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float v; std::memcpy(&v, &u, 4); return v; };
+    emu_v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        float s = 0.0f;
+        for (int kq = 0; kq < 4; ++kq) {
+            const H8 y = ::shim::lane_value(wb, j + 16 * kq, H8{});
+            for (int e = 0; e < 8; ++e) s += f(xa[r][kq].h[e]) * f(y.h[e]);
+        }
+        d[r] = c[r] + s;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16_emu((a), (b), (c), (x), (y), (z))
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {s0 (bytes 4..7), s1 (bytes 0..3)} (selectors 0..7 only)
+inline unsigned __builtin_amdgcn_perm_emu(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long v = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+}
+#define __builtin_amdgcn_perm(a, b, s) __builtin_amdgcn_perm_emu((a), (b), (s))
+inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 // ---------------------------------------------------------------------------------------------------- buffer resources
 struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num_records; };

@@ -1,6 +1,6 @@
-// CPU loop harness around rc-mvsnet_amd/csrc/fusion_math.h (the per-pixel arithmetic of fusion.hip) for
+// CPU loop harness around rc_mvsnet_amd/csrc/fusion_math.h (the per-pixel arithmetic of fusion.hip) for
 // tests/test_fusion_cpu.py.  Test infrastructure only -- nothing in the package loads this.
-#include "../../rc-mvsnet_amd/csrc/fusion_math.h"
+#include "../../rc_mvsnet_amd/csrc/fusion_math.h"
 
 using namespace rcmvs;
 

@@ -1,5 +1,5 @@
-// CPU loop harness around rc-mvsnet_amd/csrc/image_prep_math.h for tests/test_dataset_cpu.py.  Test infrastructure only.
-#include "../../rc-mvsnet_amd/csrc/image_prep_math.h"
+// CPU loop harness around rc_mvsnet_amd/csrc/image_prep_math.h for tests/test_dataset_cpu.py.  Test infrastructure only.
+#include "../../rc_mvsnet_amd/csrc/image_prep_math.h"
 
 extern "C" void h_prepare_image(const unsigned char* src, float* out, int H, int W, int h, int w, const float* mean, const float* stdv) {
     for (int c = 0; c < 3; ++c)

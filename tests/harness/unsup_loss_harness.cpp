@@ -1,9 +1,9 @@
-// CPU loop harness around rc-mvsnet_amd/csrc/unsup_loss_math.h: the same per-pixel arithmetic the HIP kernels of
+// CPU loop harness around rc_mvsnet_amd/csrc/unsup_loss_math.h: the same per-pixel arithmetic the HIP kernels of
 // unsup_loss.hip execute, driven by plain loops so tests/test_unsup_loss_cpu.py can compare it with the oracle on a
 // machine without a GPU.  Test infrastructure only -- nothing in the package loads this.
 #include <cstring>
 #include <vector>
-#include "../../rc-mvsnet_amd/csrc/unsup_loss_math.h"
+#include "../../rc_mvsnet_amd/csrc/unsup_loss_math.h"
 
 using namespace rcmvs;
 

@@ -1,4 +1,4 @@
-"""The HIP kernels themselves on the CPU: rc-mvsnet_amd/csrc/*.hip compiled against the emulation of tests/emu (fibers for
+"""The HIP kernels themselves on the CPU: rc_mvsnet_amd/csrc/*.hip compiled against the emulation of tests/emu (fibers for
 threads, rendezvous for __syncthreads / wave collectives) and driven through the package's own Python path on CPU tensors,
 checked against the oracle and the reference's goldens.  Logic only -- indexing, barriers, collectives, launch geometry; the
 `-m gpu` tests remain the parity tests proper (the emulation's v_rcp and MFMA summation order are not the hardware's)."""

@@ -1,6 +1,6 @@
 // Standalone developer harness for csrc/conv3d_x3.hip (GPU box, no torch): accuracy against an fp64 CPU convolution on small
 // volumes, then HIP-event timings at the config-2 layer shapes.   hipcc --offload-arch=gfx950 -O3 tools/dev/x3_test.hip -o x3_test
-#include "../../rc-mvsnet_amd/csrc/conv3d_x3.hip"
+#include "../../rc_mvsnet_amd/csrc/conv3d_x3.hip"
 #include <vector>
 #include <random>
 #include <cmath>

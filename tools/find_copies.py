@@ -23,6 +23,6 @@ import collections
 c = collections.Counter()
 for e in prof.events():
     if e.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy", "aten::cat", "aten::select", "aten::index"):
-        st = [s for s in (e.stack or []) if "rc-mvsnet_amd" in s or "rc_mvsnet_amd" in s]
+        st = [s for s in (e.stack or []) if "rc_mvsnet_amd" in s or "rc_mvsnet_amd" in s]
         c[(e.name, st[0] if st else "?")] += 1
 for k, v in c.most_common(30): print(v, k)
