@@ -227,6 +227,21 @@ int rcmvs_pack_nerf_weights(const float* const* wb, float* blob, void* stream);
 int rcmvs_nerf_mlp_fwd(const float* ndc, float* feat, int ldf, const float* dirs, const float* w2c_ref,
                        const float* weights, float* workspace, float* raw, int N, int S, void* stream);
 
+/* NeRF MLP in training (autograd of Renderer_ours.forward, models/render_models.py:192-220, called through
+ * run_network_mvs, models/renderer.py:42-63; replaces the 11 nn.Linear forward/backward pairs of the reference).
+ *   rcmvs_nerf_mlp_train_fwd: as rcmvs_nerf_mlp_fwd, but every layer's activations are kept in `workspace`
+ *     (rcmvs_nerf_train_workspace_floats(M) floats) for the backward pass.
+ *   rcmvs_nerf_mlp_bwd: wb = the 22 parameter pointers (host array, order of rcmvs_pack_nerf_weights); feat / tws / raw as
+ *     given to / filled by the forward call; draw (M,4) = gradient of raw; gws = scratch of
+ *     rcmvs_nerf_bwd_workspace_floats(M) floats; outputs (all written, not accumulated): dfeat (M,ldf) = gradient of the
+ *     feature columns, dwb = 22 device pointers receiving the weight / bias gradients in the parameters' own shapes. */
+long long rcmvs_nerf_train_workspace_floats(long long M);
+long long rcmvs_nerf_bwd_workspace_floats(long long M);
+int rcmvs_nerf_mlp_train_fwd(const float* ndc, float* feat, int ldf, const float* dirs, const float* w2c_ref,
+                             const float* weights, float* workspace, float* raw, int N, int S, void* stream);
+int rcmvs_nerf_mlp_bwd(const float* const* wb, const float* feat, int ldf, const float* tws, const float* raw, const float* draw,
+                       float* gws, float* dfeat, float* const* dwb, int N, int S, void* stream);
+
 /* compositing (models/renderer.py:18-26,65-93): alpha = 1-exp(-sigma), T = exclusive cumprod
  * of (1-alpha+1e-10), w = alpha*T;  rgb (N,3), depth (N), weights (N,S), alpha (N,S). */
 int rcmvs_composite_fwd(const float* raw, const float* z, float* rgb, float* depth,

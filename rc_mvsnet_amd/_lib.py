@@ -65,12 +65,16 @@ SIGNATURES = {
     "rcmvs_gu_sample_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_point_feats_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_nerf_mlp_fwd": [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p],
+    "rcmvs_nerf_mlp_train_fwd": [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p],
+    "rcmvs_nerf_mlp_bwd": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "rcmvs_nerf_train_workspace_floats": [_ll],
+    "rcmvs_nerf_bwd_workspace_floats": [_ll],
     "rcmvs_nerf_weight_floats": [],
     "rcmvs_nerf_workspace_floats": [_ll],
     "rcmvs_pack_nerf_weights": [_p, _p, _p],
     "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
 }
-_RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll, "rcmvs_nerf_workspace_floats": _ll,
+_RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll, "rcmvs_nerf_workspace_floats": _ll, "rcmvs_nerf_train_workspace_floats": _ll, "rcmvs_nerf_bwd_workspace_floats": _ll,
              "rcmvs_packed_weight_floats": _ll, "rcmvs_debug_force_direct_conv": None, "rcmvs_debug_k1_variant": None, "rcmvs_debug_k1_ps_config": None}
 
 _lib = None

@@ -294,8 +294,7 @@ class Rendering_Consistency_Net(nn.Module):
         volume network (train_ops.ConvBnReluFn ...), point features (PointFeatsFn: trilinear scatter), compositing
         (CompositeFn: reverse recurrence) run forward and backward on the library; the 11 plain GEMMs of the NeRF MLP
         and their gradients go through PyTorch-ROCm (hipBLASLt).  Rays, samples and image taps carry no gradient."""
-        from .train_ops import CompositeFn, PointFeatsFn
-        _note_delegation("RenderNet MLP (training)")
+        from .train_ops import CompositeFn, PointFeatsFn, nerf_mlp_train
         vol = self.MVSNet.forward_cl_train(vfw)[0]                                 # (128,h,w,8)
         with torch.no_grad():
             cam = torch.cat((intr[0].reshape(-1), c2ws[0].reshape(-1), w2cs[0].reshape(-1), intr[0].reshape(-1), nf[0])).contiguous()
@@ -303,11 +302,10 @@ class Rendering_Consistency_Net(nn.Module):
                                                               pix.to(torch.int32).contiguous(), eps.contiguous(), u.contiguous(), cam)
             imgs3 = imgs[0, -3:].contiguous()
             poses = torch.cat((w2cs[:3].reshape(3, 16), intr[:3].reshape(3, 9)), dim=1).contiguous()
-            angle = (dirs / torch.norm(dirs, dim=-1, keepdim=True)) @ w2cs[0][:3, :3].t()
         S = z.shape[1]
-        feat = PointFeatsFn.apply(vol, imgs3, poses, pts, ndc, 32)[:, :20].reshape(N_RAYS, S, 20)
-        x = torch.cat((_embed(ndc), feat, angle[:, None].expand(-1, S, -1)), dim=-1)
-        raw = self.network_fn(x.reshape(-1, x.shape[-1])).reshape(N_RAYS, S, 4)
+        feat32 = PointFeatsFn.apply(vol, imgs3, poses, pts, ndc, 32)               # (M,32), 20 used columns
+        raw = nerf_mlp_train(self.network_fn.nerf, ndc, feat32, dirs, w2cs[0])
+        feat = feat32[:, :20].reshape(N_RAYS, S, 20)
         rgb, depth, weights, alpha = CompositeFn.apply(raw, z)
         if self.white_bkgd:
             rgb = rgb + (1.0 - torch.sum(weights, -1)[..., None])

@@ -312,6 +312,62 @@ class CompositeFn(torch.autograd.Function):
         return graw, None
 
 
+class NerfMlpFn(torch.autograd.Function):
+    """The NeRF MLP (Renderer_ours.forward through run_network_mvs, models/render_models.py:192-220, renderer.py:42-63)
+    forward and backward on the MFMA kernels of csrc/nerf_mlp.hip: raw (N,S,4) = f(ndc, feat, dirs; 22 parameters),
+    differentiable w.r.t. the point features (first 20 columns of the (M,32) buffer) and every weight / bias; ndc and the
+    view directions are data.  Parameters are passed in ops.NERF_ORDER as (weight, bias) pairs."""
+
+    @staticmethod
+    def forward(ctx, ndc, feat, dirs, w2c_ref, *params):
+        import ctypes
+        lib = _lib.load()
+        N, S = ndc.shape[:2]
+        M = N * S
+        ps = [p.detach().contiguous().float() for p in params]
+        arr = (ctypes.c_void_p * 22)(*[_chk(t, "nerf weight").value for t in ps])
+        blob = torch.empty((lib.rcmvs_nerf_weight_floats(),), device=ndc.device, dtype=torch.float32)
+        _lib.check(lib.rcmvs_pack_nerf_weights(arr, _chk(blob, "blob"), _stream()), "pack_nerf_weights")
+        feat = feat.detach().contiguous().clone()            # the forward zeroes its padding columns in place
+        tws = torch.empty((lib.rcmvs_nerf_train_workspace_floats(M),), device=ndc.device, dtype=torch.float32)
+        raw = torch.empty((N, S, 4), device=ndc.device, dtype=torch.float32)
+        _lib.check(lib.rcmvs_nerf_mlp_train_fwd(_chk(ndc.contiguous(), "ndc"), _chk(feat, "feat"), feat.shape[1], _chk(dirs.contiguous(), "dirs"),
+                                                _chk(w2c_ref.contiguous(), "w2c_ref"), _chk(blob, "weights"), _chk(tws, "workspace"),
+                                                _chk(raw, "raw"), N, S, _stream()), "nerf_mlp_train_fwd")
+        ctx.save_for_backward(feat, tws, raw, *ps)
+        ctx.dims = (N, S)
+        return raw
+
+    @staticmethod
+    def backward(ctx, graw):
+        import ctypes
+        lib = _lib.load()
+        feat, tws, raw, *ps = ctx.saved_tensors
+        N, S = ctx.dims
+        M = N * S
+        graw = graw.contiguous().float()
+        gws = torch.empty((lib.rcmvs_nerf_bwd_workspace_floats(M),), device=raw.device, dtype=torch.float32)
+        dfeat = torch.empty_like(feat)
+        grads = [torch.empty_like(p) for p in ps]
+        warr = (ctypes.c_void_p * 22)(*[_chk(t, "nerf weight").value for t in ps])
+        garr = (ctypes.c_void_p * 22)(*[_chk(t, "nerf grad").value for t in grads])
+        _lib.check(lib.rcmvs_nerf_mlp_bwd(warr, _chk(feat, "feat"), feat.shape[1], _chk(tws, "workspace"), _chk(raw, "raw"), _chk(graw, "grad_raw"),
+                                          _chk(gws, "scratch"), _chk(dfeat, "grad_feat"), garr, N, S, _stream()), "nerf_mlp_bwd")
+        return (None, dfeat, None, None, *grads)
+
+
+def nerf_mlp_train(net, ndc, feat, dirs, w2c_ref):
+    """net: Renderer_ours (use_viewdirs head).  feat (M,32) point-feature buffer (20 used columns)."""
+    mods = {"pts_bias": net.pts_bias, "alpha_linear": net.alpha_linear, "feature_linear": net.feature_linear,
+            "views_linears.0": net.views_linears[0], "rgb_linear": net.rgb_linear}
+    for i in range(6):
+        mods[f"pts_linears.{i}"] = net.pts_linears[i]
+    params = []
+    for n in ops.NERF_ORDER:
+        params += [mods[n].weight, mods[n].bias]
+    return NerfMlpFn.apply(ndc, feat, dirs, w2c_ref, *params)
+
+
 # --------------------------------------------------------------------------------------- depth head
 class ProbDepthHeadFn(torch.autograd.Function):
     """x8 (B,D,h,w,8), prob weight (1,8,3,3,3), planes (B,h,w,2) -> depth (B,h,w) [differentiable],

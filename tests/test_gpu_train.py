@@ -370,3 +370,69 @@ def test_sync_batchnorm_branch_with_simulated_replica(monkeypatch):
     for n, a, b in zip(names, syn, ref):
         tol = 2e-4 if n == "running_var" else 1e-5                    # unbiased correction N/(N-1) sees the doubled count
         assert _rel(a, b) < tol, n
+
+
+@pytest.mark.parametrize("N,S", [(64, 16), (37, 5), (130, 33)])
+def test_nerf_mlp_train_forward_backward_vs_fp64_autograd(N, S):
+    """rcmvs_nerf_mlp_train_fwd / rcmvs_nerf_mlp_bwd (11 linear layers with the multiplicative feature bias, the skip
+    concatenation and the sigmoid / ReLU heads on the fp32 MFMA chain) against fp64 autograd of the oracle's restatement of
+    Renderer_ours.forward: outputs, the gradient of the point features and all 22 parameter gradients, per tensor."""
+    from oracle import render as orr
+    from rc_mvsnet_amd import ops, train_ops
+    from rc_mvsnet_amd.render_consist_net import Renderer_ours
+    g = torch.Generator().manual_seed(N * 100 + S)
+    torch.manual_seed(N * 100 + S)                     # the module's kaiming initialisation draws from the global generator
+    net = Renderer_ours(D=6, W=128, input_ch=63, input_ch_views=3, output_ch=4, input_ch_feat=20, skips=[4], use_viewdirs=True)
+    with torch.no_grad():
+        for p in net.parameters():                     # biases are zero-initialised: give every tensor signal
+            if p.dim() == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        net.pts_bias.bias.add_(1.0)                    # keeps the multiplicative bias away from 0 on most units
+    M = N * S
+    ndc = torch.rand(N, S, 3, generator=g)
+    feat = torch.zeros(M, 32)
+    feat[:, :20] = torch.randn(M, 20, generator=g)
+    dirs = torch.randn(N, 3, generator=g)
+    w2c = torch.eye(4)
+    w2c[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    graw = torch.randn(N, S, 4, generator=g)
+    # fp64 reference
+    sd = {"network_fn.nerf." + k: v.detach().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    f64 = feat[:, :20].double().requires_grad_(True)
+    angle = (dirs / dirs.norm(dim=-1, keepdim=True)).double() @ w2c[:3, :3].double().t()
+    x63 = orr.embed(ndc.double().reshape(M, 3))
+    ref = orr.nerf_mlp(x63, f64, angle[:, None].expand(-1, S, -1).reshape(M, 3), sd)
+    (ref * graw.double().reshape(M, 4)).sum().backward()
+    # the same graph in fp32 on the CPU: the yardstick for what single-precision sums over M points can deliver
+    sd32 = {k: v.detach().float().requires_grad_(True) for k, v in sd.items()}
+    f32 = feat[:, :20].clone().requires_grad_(True)
+    ref32 = orr.nerf_mlp(x63.float(), f32, angle.float()[:, None].expand(-1, S, -1).reshape(M, 3), sd32)
+    (ref32 * graw.reshape(M, 4)).sum().backward()
+    # HIP
+    net = net.to(DEV)
+    fh = feat.to(DEV).requires_grad_(True)
+    raw = train_ops.nerf_mlp_train(net, ndc.to(DEV), fh, dirs.to(DEV), w2c.to(DEV))
+    (raw * graw.to(DEV)).sum().backward()
+    scale = float(ref.detach().abs().max())
+    assert float((raw.detach().cpu().double().reshape(M, 4) - ref.detach()).abs().max()) < 2e-5 * scale
+    gf = fh.grad.cpu().double()
+    assert float(gf[:, 20:].abs().max()) == 0.0
+    assert float((gf[:, :20] - f64.grad).norm()) <= max(1e-5, 2.0 * float((f32.grad.double() - f64.grad).norm() / f64.grad.norm())) * float(f64.grad.norm())
+    assert float((gf[:, :20] - f64.grad).abs().max()) < 2e-5 * float(f64.grad.abs().max())
+    for name, p in net.named_parameters():
+        want = sd["network_fn.nerf." + name].grad
+        got = p.grad.cpu().double()
+        assert got.shape == want.shape, name
+        # relative Frobenius error: within 1e-5, or no worse than twice what fp32 autograd of the same graph reaches on the CPU
+        e_hip = float((got - want).norm() / want.norm())
+        e_32 = float((sd32["network_fn.nerf." + name].grad.double() - want).norm() / want.norm())
+        assert e_hip <= max(1e-5, 2.0 * e_32), (name, e_hip, e_32)
+        assert e_hip <= 5e-5, (name, e_hip)
+    # inference forward on the same weights agrees with the training forward
+    with torch.no_grad():
+        blob = ops.pack_nerf_weights({n: (m.weight, m.bias) for n, m in
+                                      [("pts_bias", net.pts_bias), ("alpha_linear", net.alpha_linear), ("feature_linear", net.feature_linear),
+                                       ("views_linears.0", net.views_linears[0]), ("rgb_linear", net.rgb_linear)] +
+                                      [(f"pts_linears.{i}", net.pts_linears[i]) for i in range(6)]})
+        raw_inf = ops.nerf_mlp(ndc.to(DEV), feat.to(DEV).clone(), dirs.to(DEV), w2c.to(DEV), blob)
+    assert torch.equal(raw_inf, raw.detach())
