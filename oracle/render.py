@@ -17,8 +17,8 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 # --------------------------------------------------------------------------------------
 def unpreprocess(imgs):
     """models/render_consist_net.py:44-51: (x - (-m/s)) / (1/s), per channel; imgs (N,V,3,H,W)."""
-    mean = torch.tensor([-m / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]).reshape(1, 1, 3, 1, 1)
-    std = torch.tensor([1 / s for s in IMAGENET_STD]).reshape(1, 1, 3, 1, 1)
+    mean = torch.tensor([-m / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)], device=imgs.device).reshape(1, 1, 3, 1, 1)
+    std = torch.tensor([1 / s for s in IMAGENET_STD], device=imgs.device).reshape(1, 1, 3, 1, 1)
     return (imgs - mean) / std
 
 
@@ -44,7 +44,7 @@ def gaussian_uniform_samples(rays_depth, near, far, eps, u):
     sigma = torch.min(torch.abs(far - rays_depth), torch.abs(rays_depth - near)) / 3
     g = rays_depth.unsqueeze(1) + sigma.unsqueeze(1) * eps
     g, _ = torch.sort(g, dim=1)
-    t = torch.linspace(0.0, 1.0, steps=S).reshape(1, S)
+    t = torch.linspace(0.0, 1.0, steps=S, device=eps.device).reshape(1, S)
     lin = near * (1.0 - t) + far * t
     mids = 0.5 * (lin[:, 1:] + lin[:, :-1])
     upper = torch.cat([mids, lin[:, -1:]], -1)
@@ -74,7 +74,7 @@ def build_rays(imgs, pseudo_depth, w2cs, c2ws, intrinsics, near_fars, pix, eps, 
     near, far = near_fars[0, 0], near_fars[0, 1]
     z = gaussian_uniform_samples(rays_depth, near, far, eps, u)
     pts = rays_o.reshape(1, 1, 3) + z.unsqueeze(-1) * rays_d.unsqueeze(1)
-    inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32)
+    inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32, device=pts.device)
     ndc = ndc_coordinate(w2cs[0], intrinsics[0], pts, inv_scale, near, far)
     N = xs.shape[0]
     return {"rays_pts": pts, "rays_dir": rays_d, "target_s": target, "rays_ndc": ndc,
@@ -95,7 +95,7 @@ def trilinear_gather_zeros(vol, ndc):
     ix, iy, iz = _unnorm(g[..., 0], W), _unnorm(g[..., 1], H), _unnorm(g[..., 2], D)
     x0, y0, z0 = ix.floor(), iy.floor(), iz.floor()
     flat = vol.reshape(C, -1)
-    out = torch.zeros(*ndc.shape[:2], C)
+    out = torch.zeros(*ndc.shape[:2], C, device=vol.device, dtype=vol.dtype)
     for dz in (0, 1):
         for dy in (0, 1):
             for dx in (0, 1):
@@ -119,7 +119,7 @@ def bilinear_gather_border(img, grid):
     iy = _unnorm(grid[..., 1], H).clamp(0, H - 1)
     x0, y0 = ix.floor(), iy.floor()
     flat = img.reshape(C, -1)
-    out = torch.zeros(*grid.shape[:2], C)
+    out = torch.zeros(*grid.shape[:2], C, device=img.device, dtype=img.dtype)
     for dy in (0, 1):
         for dx in (0, 1):
             xx, yy = x0 + dx, y0 + dy
@@ -139,7 +139,7 @@ def point_features(volume, imgs3, w2cs, intrinsics, rays_pts, rays_ndc):
     of the reference (render_consist_net.py:74 vs render_utils.py:260) reproduced as is.
     Returns (N,S,20): 8 volume channels then, per image, r, g, b, in-bounds mask."""
     _, Vc, _, H, W = imgs3.shape
-    inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32)
+    inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32, device=rays_pts.device)
     feats = [trilinear_gather_zeros(volume, rays_ndc)]
     for i in range(Vc):
         pix = ndc_coordinate(w2cs[i], intrinsics[i], rays_pts, inv_scale, 2, 6)
@@ -155,7 +155,7 @@ def point_features(volume, imgs3, w2cs, intrinsics, rays_pts, rays_ndc):
 def embed(x, multires=10):
     """Embedder.embed (models/render_models.py:45-49): [x, sin(x*2^j)..., cos(x*2^j)...], j<10,
     frequency-major then coordinate (63 values for 3-D x)."""
-    freqs = 2.0 ** torch.linspace(0.0, multires - 1, steps=multires)
+    freqs = 2.0 ** torch.linspace(0.0, multires - 1, steps=multires, device=x.device, dtype=x.dtype)
     scaled = (x.unsqueeze(-2) * freqs.reshape(*([1] * (x.dim() - 1)), -1, 1)).reshape(*x.shape[:-1], -1)
     return torch.cat((x, torch.sin(scaled), torch.cos(scaled)), dim=-1)
 
@@ -184,7 +184,7 @@ def composite(raw, z):
     (1 - alpha + 1e-10), w = alpha*T.  raw (N,S,4), z (N,S)."""
     sigma = raw[..., 3]
     alpha = 1.0 - torch.exp(-sigma)
-    trans = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    trans = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1, device=alpha.device, dtype=alpha.dtype), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
     w = alpha * trans
     rgb_map = torch.sum(w[..., None] * raw[..., :3], -2)
     depth_map = torch.sum(w * z, -1)

@@ -14,13 +14,11 @@ Execution:
     forward AND backward on the library through autograd Functions (ops.WarpVarianceFn,
     train_ops.ConvBnReluFn / ConvPlainFn / ProbDepthHeadFn: batch-statistics BatchNorm, data / weight
     gradients, K1 scatter); PyTorch supplies element-wise glue only;
-  * everything else -- CPU tensors, eval mode with autograd on, RCMVS_TRAIN=aten -- runs the
-    reference's op graph through the modules' own nn.Conv / BatchNorm children on PyTorch: an
-    explicit, logged delegation (RCMVS_STRICT=1 makes it an error), never a silent fallback of the
-    GPU paths above.
+  * anything else -- CPU tensors, eval mode with autograd enabled, a missing library -- raises RcmvsError: the modules are
+    parameter holders (reference ``state_dict`` names) plus HIP execution plans, there is no PyTorch op graph behind them.
+    (The reference's op graph with autograd lives in oracle/aten_graph.py, for the tests only.)
 """
 import os
-import warnings
 
 import torch
 import torch.nn as nn
@@ -28,8 +26,6 @@ import torch.nn.functional as F
 
 from . import ops
 from ._lib import RcmvsError
-
-Align_Corners_Range = False
 
 
 # ----------------------------------------------------------------------------------------------
@@ -46,12 +42,7 @@ class Conv2d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        x = self.conv(x)
-        if self.bn is not None:
-            x = self.bn(x)
-        if self.relu:
-            x = F.relu(x, inplace=True)
-        return x
+        _holder_only(self)
 
 
 class FeatureNet(nn.Module):
@@ -90,7 +81,9 @@ class FeatureNet(nn.Module):
         mods = [m for seq in (self.conv0, self.conv1, self.conv2) for m in seq]
         tens = []
         for m in mods:
-            tens += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+            # running statistics are updated by the kernels through raw pointers (no version bump): num_batches_tracked is
+            # incremented in place by every train-mode forward and stands in for them
+            tens += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.num_batches_tracked]
         extra = [self.out1.weight]
         if self.num_stage >= 2:
             extra += [self.inner1.weight, self.inner1.bias, self.out2.weight]
@@ -142,6 +135,9 @@ class FeatureNet(nn.Module):
                 _, w3, sc, sh = p[n]
                 return ops.conv3d(t.unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)
             if p[n][0] == "s2d_mfma3d":
+                if t.shape[1] % 2 or t.shape[2] % 2:
+                    raise RcmvsError(f"FeatureNet: image height and width must be multiples of 4 (got a {t.shape[1]}x{t.shape[2]} map "
+                                     "at the second stride-2 layer), as the reference's three-level pyramid requires")
                 _, w3, sc, sh = p[n]
                 return ops.conv3d(self._s2d(t).contiguous().unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)
             w, sc, sh, stride = p[n]
@@ -226,22 +222,16 @@ class FeatureNet(nn.Module):
         return out
 
     def forward(self, x):
-        conv0 = self.conv0(x)
-        conv1 = self.conv1(conv0)
-        conv2 = self.conv2(conv1)
-        intra = conv2
-        outputs = {"stage1": self.out1(intra)}
-        if self.num_stage >= 2:
-            intra = F.interpolate(intra, scale_factor=2, mode="nearest") + self.inner1(conv1)
-            outputs["stage2"] = self.out2(intra)
-        if self.num_stage == 3:
-            intra = F.interpolate(intra, scale_factor=2, mode="nearest") + self.inner2(conv0)
-            outputs["stage3"] = self.out3(intra)
-        return outputs
+        """x (N,3,H,W) -> {'stageK': (N,C,h,w)} like the reference module (models/modules.py:440-464), on the HIP kernels."""
+        if _hip_inference(self, x):
+            return {k: ops.to_channels_first(v) for k, v in self.forward_cl(x).items()}
+        if _hip_training(self, x):
+            return {k: v.permute(0, 3, 1, 2) for k, v in self.forward_train_cl(x).items()}
+        _unsupported(self, x)
 
 
 # ----------------------------------------------------------------------------------------------
-# 3-D blocks (models/modules.py:118-210) -- parameter holders + PyTorch-ROCm forward for autograd
+# 3-D blocks (models/modules.py:118-210) -- parameter holders (the HIP plans read their conv / bn children)
 # ----------------------------------------------------------------------------------------------
 class Conv3d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1, **kwargs):
@@ -256,8 +246,7 @@ class Conv3d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        x = self.bn(self.conv(x))
-        return F.relu(x, inplace=True) if self.relu else x
+        _holder_only(self)
 
 
 class Deconv3d(nn.Module):
@@ -272,8 +261,7 @@ class Deconv3d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        x = self.bn(self.conv(x))
-        return F.relu(x, inplace=True) if self.relu else x
+        _holder_only(self)
 
 
 def _bn_fold(bn):
@@ -311,7 +299,7 @@ class CostRegNet(nn.Module):
         ts = []
         for n in self._LAYERS:
             m = getattr(self, n)
-            ts += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+            ts += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.num_batches_tracked]
         return ts + [self.prob.weight]
 
     def hip_plan(self):
@@ -362,146 +350,44 @@ class CostRegNet(nn.Module):
             feat = self.features_cl(ops.to_channels_last(x.contiguous().float()))
             logits = ops.conv3d(feat, self.hip_plan()["prob"])
             return ops.to_channels_first(logits)
-        _note_delegation("CostRegNet")
-        conv0 = self.conv0(x)
-        conv2 = self.conv2(self.conv1(conv0))
-        conv4 = self.conv4(self.conv3(conv2))
-        t = self.conv6(self.conv5(conv4))
-        t = conv4 + self.conv7(t)
-        t = conv2 + self.conv9(t)
-        t = conv0 + self.conv11(t)
-        return self.prob(t)
+        _unsupported(self, x)
 
 
 # ----------------------------------------------------------------------------------------------
-_delegation_noted = set()
-
-
 def _hip_inference(module, *tensors):
-    """The native path is taken for inference: eval mode, autograd off, tensors on the GPU."""
+    """The inference path: eval mode, autograd off, tensors on the GPU."""
     return (not module.training) and (not torch.is_grad_enabled()) and all(t.is_cuda for t in tensors)
 
 
 def _hip_training(module, *tensors):
-    """Native training path: train mode on the GPU (RCMVS_TRAIN=aten forces the delegated op graph, e.g. to
-    cross-check gradients)."""
-    return module.training and all(t.is_cuda for t in tensors) and os.environ.get("RCMVS_TRAIN", "hip") != "aten"
+    """The training path (autograd Functions over the HIP kernels): train mode, tensors on the GPU."""
+    return module.training and all(t.is_cuda for t in tensors)
 
 
-def _note_delegation(what):
-    if os.environ.get("RCMVS_STRICT", "0") == "1":
-        raise RcmvsError(f"{what}: this call needs autograd / batch statistics / a CPU tensor, which the HIP path does "
-                         "not provide yet (RCMVS_STRICT=1 forbids delegating it to PyTorch ops)")
-    if what not in _delegation_noted:
-        _delegation_noted.add(what)
-        warnings.warn(f"rc_mvsnet_amd: {what} is running through PyTorch ops (delegated path: CPU tensors, autograd in "
-                      "eval mode, RCMVS_TRAIN=aten, or a block the HIP training path does not cover yet).")
+def _unsupported(module, *tensors):
+    name = type(module).__name__
+    if not all(t.is_cuda for t in tensors):
+        raise RcmvsError(f"{name}: the HIP path needs its tensors on the GPU (there is no CPU / eager fallback)")
+    raise RcmvsError(f"{name}: eval-mode forward with autograd enabled is not provided -- wrap inference in torch.no_grad(), "
+                     "or put the module in train() mode for the differentiable HIP path")
 
 
-def depth_regression(p, depth_values):
-    if depth_values.dim() <= 2:
-        depth_values = depth_values.view(*depth_values.shape, 1, 1)
-    return torch.sum(p * depth_values, 1)
-
-
-def homo_warping(src_fea, src_proj, ref_proj, depth_values):
-    """Reference-contract warp (models/modules.py:304-339) through PyTorch ops -- used only by the
-    delegated (autograd) path below; inference uses the fused HIP kernel."""
-    batch, channels = src_fea.shape[0], src_fea.shape[1]
-    num_depth = depth_values.shape[1]
-    height, width = src_fea.shape[2], src_fea.shape[3]
-    with torch.no_grad():
-        proj = torch.matmul(src_proj, torch.inverse(ref_proj))
-        rot, trans = proj[:, :3, :3], proj[:, :3, 3:4]
-        y, x = torch.meshgrid([torch.arange(0, height, dtype=torch.float32, device=src_fea.device),
-                               torch.arange(0, width, dtype=torch.float32, device=src_fea.device)], indexing="ij")
-        xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(height * width, device=src_fea.device)))
-        rot_xyz = torch.matmul(rot, xyz.unsqueeze(0).repeat(batch, 1, 1))
-        rot_depth_xyz = rot_xyz.unsqueeze(2).repeat(1, 1, num_depth, 1) * depth_values.reshape(batch, 1, num_depth, -1)
-        proj_xyz = rot_depth_xyz + trans.view(batch, 3, 1, 1)
-        proj_xy = proj_xyz[:, :2] / proj_xyz[:, 2:3]
-        gx = proj_xy[:, 0] / ((width - 1) / 2) - 1
-        gy = proj_xy[:, 1] / ((height - 1) / 2) - 1
-        grid = torch.stack((gx, gy), dim=3)
-    warped = F.grid_sample(src_fea, grid.view(batch, num_depth * height, width, 2), mode="bilinear", padding_mode="zeros",
-                           align_corners=True)
-    return warped.view(batch, channels, num_depth, height, width)
-
-
-def get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth=192.0, min_depth=0.0):
-    cur_depth_min = cur_depth - ndepth / 2 * depth_inteval_pixel
-    cur_depth_max = cur_depth + ndepth / 2 * depth_inteval_pixel
-    new_interval = (cur_depth_max - cur_depth_min) / (ndepth - 1)
-    k = torch.arange(0, ndepth, device=cur_depth.device, dtype=cur_depth.dtype).reshape(1, -1, 1, 1)
-    return cur_depth_min.unsqueeze(1) + k * new_interval.unsqueeze(1)
-
-
-def get_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, device, dtype, shape, max_depth=192.0, min_depth=0.0):
-    if cur_depth.dim() == 2:
-        cur_depth_min, cur_depth_max = cur_depth[:, 0], cur_depth[:, -1]
-        new_interval = (cur_depth_max - cur_depth_min) / (ndepth - 1)
-        s = cur_depth_min.unsqueeze(1) + torch.arange(0, ndepth, device=device, dtype=dtype).reshape(1, -1) * new_interval.unsqueeze(1)
-        return s.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, shape[1], shape[2])
-    return get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth, min_depth)
+def _holder_only(module):
+    raise RcmvsError(f"{type(module).__name__} is a parameter holder: its conv / bn children are executed by the enclosing "
+                     "network's HIP plan (CascadeMVSNet.forward, CostRegNet.forward, FeatureNet.forward)")
 
 
 class DepthNet(nn.Module):
-    """Per-stage cost volume + depth head (models/casmvsnet.py:45-124 / :234-311).  Parameter-free,
-    kept as a child module for API compatibility; `train_variant` adds volume_feature_no_ref."""
+    """Parameter-free child kept for API / checkpoint compatibility (models/casmvsnet.py:45-124, 234-311): the per-stage cost
+    volume + depth head it stands for run inside _CascadeBase._forward_hip / _forward_train_hip (warp+variance kernel K1,
+    cost regularisation, fused depth head)."""
 
     def __init__(self, train_variant):
         super().__init__()
         self.train_variant = train_variant
 
-    # delegated (autograd) path: reference op graph on PyTorch-ROCm
-    def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, imgs, pad=0, prob_volume_init=None):
-        _note_delegation("DepthNet")
-        proj_matrices = torch.unbind(proj_matrices, 1)
-        assert len(features) == len(proj_matrices), "Different number of images and projection matrices"
-        assert depth_values.shape[1] == num_depth
-        V = len(features)
-        B = imgs.shape[0]
-        _, C, H, W = features[0].shape
-        ref_feature, src_features = features[0], features[1:]
-        ref_proj, src_projs = proj_matrices[0], proj_matrices[1:]
-        ref_new = ref_proj[:, 0].clone()
-        ref_new[:, :3, :4] = torch.matmul(ref_proj[:, 1, :3, :3], ref_proj[:, 0, :3, :4])
-        vs = ref_feature.unsqueeze(2).repeat(1, 1, num_depth, 1, 1)
-        vq = vs ** 2
-        out_noref = None
-        if self.train_variant:
-            small = F.interpolate(imgs.view(B * V, *imgs.shape[2:]), (H, W), mode="bilinear", align_corners=False)
-            small = small.view(B, V, -1, H, W).permute(1, 0, 2, 3, 4)
-            out_noref = torch.empty((B, 3 * (V - 1) + C, num_depth, H, W), device=imgs.device, dtype=torch.float)
-            s_nr, q_nr = 0, 0
-        for i, (src_fea, src_proj) in enumerate(zip(src_features, src_projs)):
-            src_new = src_proj[:, 0].clone()
-            src_new[:, :3, :4] = torch.matmul(src_proj[:, 1, :3, :3], src_proj[:, 0, :3, :4])
-            warped = homo_warping(src_fea, src_new, ref_new, depth_values)
-            vs = vs + warped
-            vq = vq + warped ** 2
-            if self.train_variant:
-                out_noref[:, i * 3:(i + 1) * 3] = homo_warping(small[i + 1], src_new, ref_new, depth_values)
-                wn = warped if self.training else warped ** 2      # eval-mode quirk, casmvsnet.py:92-96
-                s_nr = s_nr + wn
-                q_nr = q_nr + wn ** 2
-        var = vq.div(V).sub((vs.div(V)) ** 2)
-        if self.train_variant:
-            out_noref[:, -C:] = q_nr.div(V).sub((s_nr.div(V)) ** 2)
-        pre = cost_regularization(var).squeeze(1)
-        if prob_volume_init is not None:
-            pre = pre + prob_volume_init
-        prob = F.softmax(pre, dim=1)
-        depth = depth_regression(prob, depth_values=depth_values)
-        with torch.no_grad():
-            sum4 = 4 * F.avg_pool3d(F.pad(prob.unsqueeze(1), pad=(0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1, padding=0).squeeze(1)
-            idx = depth_regression(prob, depth_values=torch.arange(num_depth, device=prob.device, dtype=torch.float)).long()
-            idx = idx.clamp(min=0, max=num_depth - 1)
-            conf = torch.gather(sum4, 1, idx.unsqueeze(1)).squeeze(1)
-        out = {"depth": depth, "photometric_confidence": conf}
-        if self.train_variant:
-            out["volume_feature_no_ref"] = out_noref
-        return out
+    def forward(self, *args, **kwargs):
+        _holder_only(self)
 
 
 class _CascadeBase(nn.Module):
@@ -584,20 +470,14 @@ class _CascadeBase(nn.Module):
         """Train mode with autograd: the feature pyramid and every op of the three cascade stages -- warp + variance (and
         the train variant's volume_feature_no_ref), the cost regularisation with batch-statistics BatchNorm, prob conv +
         softmax + soft-argmin -- run forward AND backward on the HIP kernels (ops.WarpVarianceFn, train_ops.*).  The
-        pyramid sees all V views in one pass but normalises them per view, like models/casmvsnet.py:364-366
-        (RCMVS_TRAIN_FPN=aten keeps it on the module's own nn.Conv2d / BatchNorm2d children)."""
+        pyramid sees all V views in one pass but normalises them per view, like models/casmvsnet.py:364-366."""
         from . import train_ops
         B, V, _, H, W = imgs.shape
         imgs = imgs.float()
         depth_values = depth_values.contiguous().float()
-        native_fpn = self.feature.arch_mode == "fpn" and os.environ.get("RCMVS_TRAIN_FPN", "hip") != "aten"
-        if native_fpn:
-            # all V views in one pass, normalised per view (segments) like the reference's per-view calls (casmvsnet.py:364-366)
-            fv = self.feature.forward_train_cl(imgs.transpose(0, 1).reshape(V * B, 3, H, W), segments=V)
-            features = [{k: f[v * B:(v + 1) * B] for k, f in fv.items()} for v in range(V)]
-        else:
-            _note_delegation("FeatureNet (training)")
-            features = [{k: f.permute(0, 2, 3, 1) for k, f in self.feature(imgs[:, v]).items()} for v in range(V)]
+        # all V views in one pass, normalised per view (segments) like the reference's per-view calls (casmvsnet.py:364-366)
+        fv = self.feature.forward_train_cl(imgs.transpose(0, 1).reshape(V * B, 3, H, W), segments=V)
+        features = [{k: f[v * B:(v + 1) * B] for k, f in fv.items()} for v in range(V)]
         outputs = {}
         depth = None
         for s in range(self.num_stage):
@@ -611,7 +491,7 @@ class _CascadeBase(nn.Module):
                 prev = None
                 if depth is not None:
                     if self.grad_method != "detach":
-                        raise RcmvsError("grad_method='undetach' is not supported by the HIP training path (RCMVS_TRAIN=aten)")
+                        raise RcmvsError("grad_method='undetach' (models/casmvsnet.py:192: gradient through the previous stage's depth into the plane positions) is not provided by the HIP training path; the shipped configuration is 'detach'")
                     prev = depth.detach()
                 planes = ops.hypothesis_planes(prev, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
                 small_cl = None
@@ -630,44 +510,12 @@ class _CascadeBase(nn.Module):
             outputs.update(out)
         return outputs
 
-    # ---------------------------------------------------------------- delegated (autograd) path
-    def _forward_aten(self, imgs, proj_matrices, depth_values):
-        depth_min = depth_values[0, 0]
-        depth_max = depth_values[0, -1]
-        depth_interval = (depth_max.double() - depth_min.double()) / depth_values.size(1)
-        features = [self.feature(imgs[:, v]) for v in range(imgs.size(1))]
-        img = imgs[:, 0]
-        outputs = {}
-        depth = None
-        for s in range(self.num_stage):
-            key = "stage{}".format(s + 1)
-            features_stage = [f[key] for f in features]
-            scale = int(self.stage_infos[key]["scale"])
-            if depth is not None:
-                cur = depth.detach() if self.grad_method == "detach" else depth
-                cur = F.interpolate(cur.unsqueeze(1), [img.shape[2], img.shape[3]], mode="bilinear",
-                                    align_corners=Align_Corners_Range).squeeze(1)
-            else:
-                cur = depth_values
-            itv = self.depth_interals_ratio[s] * depth_interval        # 0-dim double, like the reference's python float
-            samples = get_depth_range_samples(cur_depth=cur, ndepth=self.ndepths[s], depth_inteval_pixel=itv,
-                                              dtype=img[0].dtype, device=img[0].device,
-                                              shape=[img.shape[0], img.shape[2], img.shape[3]])
-            samples = F.interpolate(samples.unsqueeze(1), [self.ndepths[s], img.shape[2] // scale, img.shape[3] // scale],
-                                    mode="trilinear", align_corners=Align_Corners_Range).squeeze(1)
-            out = self.DepthNet(features_stage, proj_matrices[key], depth_values=samples, num_depth=self.ndepths[s],
-                                cost_regularization=self._cr(s), imgs=imgs)
-            depth = out["depth"]
-            outputs[key] = out
-            outputs.update(out)
-        return outputs
-
     def _run(self, imgs, proj_matrices, depth_values):
         if _hip_inference(self, imgs, depth_values):
             return self._forward_hip(imgs, proj_matrices, depth_values)
         if _hip_training(self, imgs, depth_values):
             return self._forward_train_hip(imgs, proj_matrices, depth_values)
-        return self._forward_aten(imgs, proj_matrices, depth_values)
+        _unsupported(self, imgs, depth_values)
 
 
 class CascadeMVSNet_eval(_CascadeBase):

@@ -3,7 +3,10 @@ datasets/dtu_test.py:11-229 and the Tanks-and-Temples one of datasets/tanks.py:1
 per-image work moved to the GPU.
 
 Same constructor arguments, item order and item dict (``imgs`` (V,3,h,w), ``proj_matrices`` {stage1..3: (V,2,4,4)},
-``depth_values`` (ndepths,), ``filename``) as the reference, so ``eval_rcmvsnet_dtu.py:174-197`` iterates it unchanged.  The
+``depth_values`` (ndepths,), ``filename``) as the reference, so the loop of ``eval_rcmvsnet_dtu.py:174-197`` consumes the
+items unchanged -- with ``DataLoader(num_workers=0)`` or the ``prefetch()`` iterator below: ``__getitem__`` launches HIP
+kernels, so a forked loader worker (the reference's ``num_workers=1``) cannot run it ("Cannot re-initialize CUDA in forked
+subprocess").  The
 host parses the text files and decodes the JPEG; ``/255``, the ``cv2.resize`` of ``scale_mvs_input`` / the common-size resize,
 ``ToTensor`` and ``Normalize`` are one kernel per image (``rcmvs_prepare_image``) on the uploaded bytes -- that work costs the
 reference's single loader worker ~10x the network's time per item.  ``imgs`` is therefore a CUDA tensor; everything else is
@@ -56,7 +59,10 @@ class MVSDataset(torch.utils.data.Dataset):
         assert mode == "test"
         self.datapath, self.listfile, self.mode, self.nviews, self.ndepths = datapath, listfile, mode, nviews, ndepths
         self.max_h, self.max_w = kwargs["max_h"], kwargs["max_w"]
-        self.fix_res = kwargs.get("fix_res", False)      # accepted for signature parity; see __getitem__ on mixed sizes
+        if kwargs.get("fix_res", False):
+            raise ValueError("fix_res=True (one resolution latched for the whole list, datasets/dtu_test.py:201-205) is not provided: "
+                             "every item is scaled by its own size, the reference's default")
+        self.fix_res = False
         self.device = torch.device(device)
         self.interval_scale = {scan: (interval_scale if isinstance(interval_scale, float) else interval_scale[scan]) for scan in listfile}
         self.metas = self.build_list()

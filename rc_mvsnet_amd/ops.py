@@ -131,6 +131,7 @@ class WarpVarianceFn(torch.autograd.Function):
         feats = feats.contiguous()
         ctx.save_for_backward(feats, rot, trans, planes)
         ctx.ndepth = ndepth
+        ctx.set_materialize_grads(False)      # an unused output (stage 2/3 no-ref volumes) must not cost a zero-filled gradient tensor
         var = warp_variance(feats, rot, trans, planes, ndepth)
         if imgs is None:
             return var
@@ -141,6 +142,8 @@ class WarpVarianceFn(torch.autograd.Function):
     def backward(ctx, gvar, gnoref=None):
         feats, rot, trans, planes = ctx.saved_tensors
         C = feats.shape[-1]
+        if gvar is None and gnoref is None:
+            return None, None, None, None, None, None
         if gvar is None:
             gvar = torch.zeros((feats.shape[0], ctx.ndepth, *feats.shape[2:]), device=feats.device)
         gnr = None

@@ -10,9 +10,9 @@ Same constructor (``args`` namespace; ``args.feat_dim`` is written like the refe
 Execution mirrors casmvsnet.py: eval() under no_grad runs on the HIP kernels (plane resize,
 neural-volume U-Net on the 3-D conv family without ReLU, Gaussian-Uniform sampler, point features,
 MFMA MLP, wave-scan compositing).  In train mode on the GPU the volume network, the point-feature
-gather / scatter and the compositing run forward and backward on the library through autograd
-Functions (train_ops.py); the plain GEMMs of the NeRF MLP go through PyTorch-ROCm (hipBLASLt).
-CPU tensors / RCMVS_TRAIN=aten run the reference's op graph on PyTorch (logged delegation).
+gather / scatter, the NeRF MLP (forward, data and weight gradients on the MFMA chain) and the compositing run forward and
+backward on the library through autograd Functions (train_ops.py).  CPU tensors or eval mode with autograd enabled raise
+RcmvsError: there is no PyTorch op graph behind these modules (the tests' comparator lives in oracle/aten_graph.py).
 Random draws (pixel indices, Gaussian eps, stratified u) come from torch's generator on the device and
 are passed INTO the sampler kernel -- the RNG contract of SURVEY.md 8a-9; ``forward`` accepts them
 through the optional ``randoms=(pix, eps, u)`` argument so tests can inject the reference's draws.
@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .casmvsnet import _bn_fold, _hip_inference, _hip_training, _note_delegation
+from .casmvsnet import _bn_fold, _hip_inference, _hip_training, _holder_only, _unsupported
 
 N_RAYS = 1024                               # hard-coded in the reference (render_consist_net.py:68)
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -38,7 +38,7 @@ class ConvBnReLU3D(nn.Module):
         self.bn = norm_act(out_channels)
 
     def forward(self, x):
-        return self.bn(self.conv(x))
+        _holder_only(self)
 
 
 class CostReg(nn.Module):
@@ -72,6 +72,8 @@ class CostReg(nn.Module):
         for n in self._LAYERS:
             conv, bn, _ = self._conv_bn(n)
             ts += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            if getattr(bn, "num_batches_tracked", None) is not None:      # bumped by every train-mode forward (the kernels update the statistics in place)
+                ts.append(bn.num_batches_tracked)
         key = tuple((t.data_ptr(), t._version) for t in ts)
         if self._plan is None or key != self._plan_key:
             plan = {}
@@ -113,13 +115,14 @@ class CostReg(nn.Module):
         return blk("conv11", t, residual=conv0)
 
     def forward(self, x):
-        conv0 = self.conv0(x)
-        conv2 = self.conv2(self.conv1(conv0))
-        conv4 = self.conv4(self.conv3(conv2))
-        x = self.conv6(self.conv5(conv4))
-        x = conv4 + self.conv7(x)
-        x = conv2 + self.conv9(x)
-        return conv0 + self.conv11(x)
+        """x (B,C,D,h,w) -> (B,8,D,h,w) like the reference module (models/render_models.py:720-734), on the HIP kernels."""
+        if _hip_inference(self, x):
+            C = x.shape[1]
+            xcl = ops.to_channels_last(x.contiguous().float())
+            if C % 4:
+                xcl = F.pad(xcl, (0, 4 - C % 4))
+            return ops.to_channels_first(self.forward_cl(xcl))
+        _unsupported(self, x)
 
 
 class Neural_Volume_Net(nn.Module):
@@ -159,11 +162,7 @@ class Neural_Volume_Net(nn.Module):
         if self.hip_trainable(volume_feature):
             v = self.forward_cl_train(volume_feature).permute(0, 4, 1, 2, 3)      # NCDHW view of the channels-last result
             return v.reshape(1, -1, *v.shape[2:])
-        _note_delegation("Neural_Volume_Net")
-        B, C, _, H, W = volume_feature.shape
-        v = F.interpolate(volume_feature, size=[128, H, W], mode="trilinear", align_corners=True)
-        v = self.cost_reg_2(v)
-        return v.reshape(1, -1, *v.shape[2:])
+        _unsupported(self, volume_feature)
 
 
 class Renderer_ours(nn.Module):
@@ -190,19 +189,7 @@ class Renderer_ours(nn.Module):
                 nn.init.zeros_(m.bias.data)
 
     def forward(self, x):
-        in_ch_feat = x.shape[-1] - self.in_ch_pts - self.in_ch_views
-        pts, feats, views = torch.split(x, [self.in_ch_pts, in_ch_feat, self.in_ch_views], dim=-1)
-        h = pts
-        bias = self.pts_bias(feats)
-        for i in range(len(self.pts_linears)):
-            h = F.relu(self.pts_linears[i](h) * bias)
-            if i in self.skips:
-                h = torch.cat([pts, h], -1)
-        alpha = torch.relu(self.alpha_linear(h))
-        feature = self.feature_linear(h)
-        h = F.relu(self.views_linears[0](torch.cat([feature, views], -1)))
-        rgb = torch.sigmoid(self.rgb_linear(h))
-        return torch.cat([rgb, alpha], -1)
+        _holder_only(self)       # the eleven layers run as one MFMA chain: ops.nerf_mlp / train_ops.nerf_mlp_train
 
 
 class RenderNet(nn.Module):
@@ -231,13 +218,7 @@ class RenderNet(nn.Module):
         return self._blob
 
     def forward(self, x):
-        return self.nerf(x)
-
-
-def _embed(x, multires=10):
-    freqs = 2.0 ** torch.linspace(0.0, multires - 1, steps=multires, device=x.device)
-    scaled = (x.unsqueeze(-2) * freqs.reshape(*([1] * (x.dim() - 1)), -1, 1)).reshape(*x.shape[:-1], -1)
-    return torch.cat((x, torch.sin(scaled), torch.cos(scaled)), dim=-1)
+        _holder_only(self)
 
 
 class Rendering_Consistency_Net(nn.Module):
@@ -285,15 +266,14 @@ class Rendering_Consistency_Net(nn.Module):
             return self._forward_hip(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
         if self.MVSNet.hip_trainable(volume_feature_warp) and pseudo.is_cuda:
             return self._forward_train_hip(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
-        _note_delegation("Rendering_Consistency_Net")
-        return self._forward_aten(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
+        _unsupported(self, volume_feature_warp, pseudo)
 
-    # ---- training path: HIP kernels with autograd, MLP GEMMs through hipBLASLt ----------------------------
+    # ---- training path: HIP kernels with autograd ---------------------------------------------------------
     def _forward_train_hip(self, vfw, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u):
         """Same data flow as ``_forward_hip``.  Differentiable w.r.t. the warped volume feature and every parameter:
         volume network (train_ops.ConvBnReluFn ...), point features (PointFeatsFn: trilinear scatter), compositing
-        (CompositeFn: reverse recurrence) run forward and backward on the library; the 11 plain GEMMs of the NeRF MLP
-        and their gradients go through PyTorch-ROCm (hipBLASLt).  Rays, samples and image taps carry no gradient."""
+        (CompositeFn: reverse recurrence) and the NeRF MLP (NerfMlpFn: eleven layers, data and weight gradients on the MFMA
+        chain) run forward and backward on the library.  Rays, samples and image taps carry no gradient."""
         from .train_ops import CompositeFn, PointFeatsFn, nerf_mlp_train
         vol = self.MVSNet.forward_cl_train(vfw)[0]                                 # (128,h,w,8)
         with torch.no_grad():
@@ -325,57 +305,3 @@ class Rendering_Consistency_Net(nn.Module):
         rgb, depth, weights, alpha = ops.composite(raw, z)
         S = z.shape[1]
         return rgb, feat[:, :20].reshape(N_RAYS, S, 20), weights, depth, alpha, {}, rdepth, target
-
-    # ---- delegated path (autograd): the reference's op graph on PyTorch-ROCm -------------------------
-    def _forward_aten(self, vfw, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u):
-        _, V, _, H, W = imgs.shape
-        S = eps.shape[1]
-        volume = self.MVSNet(vfw)
-        xs, ys = pix[0].float(), pix[1].float()
-        K, c2w = intr[0], c2ws[0]
-        dirs = torch.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], torch.ones_like(xs)], -1)
-        rays_d = dirs @ c2w[:3, :3].t()
-        rays_o = c2w[:3, -1]
-        target = imgs[0, 0][:, pix[1], pix[0]].permute(1, 0)
-        rdepth = pseudo[pix[1], pix[0]]
-        near, far = nf[0, 0], nf[0, 1]
-        half = N_RAYS // 2
-        sigma = torch.min(torch.abs(far - rdepth), torch.abs(rdepth - near)) / 3
-        g, _ = torch.sort(rdepth.unsqueeze(1) + sigma.unsqueeze(1) * eps, dim=1)
-        t = torch.linspace(0.0, 1.0, steps=S, device=eps.device).reshape(1, S)
-        lin = near * (1.0 - t) + far * t
-        mids = 0.5 * (lin[:, 1:] + lin[:, :-1])
-        upper, lower = torch.cat([mids, lin[:, -1:]], -1), torch.cat([lin[:, :1], mids], -1)
-        z = torch.cat((g[:half], lower + (upper - lower) * u), dim=0)
-        pts = rays_o.reshape(1, 1, 3) + z.unsqueeze(-1) * rays_d.unsqueeze(1)
-        inv_scale = torch.tensor([W - 1, H - 1], dtype=torch.float32, device=pts.device)
-
-        def ndc_of(w2c, Kk, p, nr, fr):
-            q = (p.reshape(-1, 3) @ w2c[:3, :3].t() + w2c[:3, 3].reshape(1, 3)) @ Kk.t()
-            xy = (q[:, :2] / q[:, 2:3] + 0.0) / inv_scale.reshape(1, 2)
-            return torch.cat((xy, ((q[:, 2] - nr) / (fr - nr)).unsqueeze(1)), dim=1).reshape(p.shape)
-
-        ndc = ndc_of(w2cs[0], intr[0], pts, near, far)
-        grid = ndc.view(-1, 1, N_RAYS, S, 3) * 2 - 1.0
-        vfeat = F.grid_sample(volume, grid, align_corners=True, mode="bilinear")[:, :, 0].permute(2, 3, 0, 1).squeeze()
-        feats = [vfeat]
-        imgs3 = imgs[:, -3:]
-        for i in range(3):
-            gxy = ndc_of(w2cs[i], intr[i], pts, 2, 6)[None][..., :2] * 2.0 - 1.0
-            data = F.grid_sample(imgs3[:, i], gxy, align_corners=True, mode="bilinear", padding_mode="border")
-            inb = (gxy > -1.0) * (gxy < 1.0)
-            mask = (inb[..., 0] * inb[..., 1]).float()
-            feats.append(torch.cat((data, mask.unsqueeze(1)), dim=1)[0].permute(1, 2, 0))
-        feat = torch.cat(feats, dim=-1)
-        cos = torch.norm(rays_d, dim=-1)
-        angle = (rays_d / cos.unsqueeze(-1)) @ w2cs[0][:3, :3].t()
-        x = torch.cat((_embed(ndc), feat, angle[:, None].expand(-1, S, -1)), dim=-1)
-        raw = self.network_fn(x.reshape(-1, x.shape[-1])).reshape(N_RAYS, S, 4)
-        alpha = 1.0 - torch.exp(-raw[..., 3])
-        T = torch.cumprod(torch.cat([torch.ones(N_RAYS, 1, device=alpha.device), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
-        weights = alpha * T
-        rgb = torch.sum(weights[..., None] * raw[..., :3], -2)
-        depth = torch.sum(weights * z, -1)
-        if self.white_bkgd:
-            rgb = rgb + (1.0 - torch.sum(weights, -1)[..., None])
-        return rgb, feat, weights, depth, alpha, {}, rdepth, target

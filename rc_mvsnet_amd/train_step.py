@@ -3,16 +3,15 @@
 volume_feature_no_ref), forward #2 on augmented images, Rendering_Consistency_Net.forward on the detached
 pseudo depth, ONE backward over the summed losses, optimizer step.
 
-On the GPU the losses are the reference's own (rc_mvsnet_amd/losses.py: UnsupLossMultiStage on forward #1,
-AugLossMultiStage against the detached pseudo depth on forward #2, MSE + SL1Loss on the rendered rays), each a fused HIP
-call.  On a CPU (tests/test_train_step_cpu.py, which only checks that the delegated op graph reaches every parameter)
-simple surrogates with the same data flow stand in for them, because the HIP losses have no CPU fallback.
+The losses are the reference's own (rc_mvsnet_amd/losses.py: UnsupLossMultiStage on forward #1, AugLossMultiStage against
+the detached pseudo depth on forward #2, MSE + SL1Loss on the rendered rays), each a fused HIP call.  Everything runs on the
+HIP library; there is no CPU path (tools/train_bench.py can swap the two network forwards for the oracle's op graph to
+time the PyTorch-ROCm equivalent).
 The renderer is hard-wired to 4 views (1 ref + 3 src; SURVEY.md header note 2).
 """
 import types
 
 import torch
-import torch.nn.functional as F
 
 from . import synthetic
 from .casmvsnet import CascadeMVSNet
@@ -46,58 +45,29 @@ def synthetic_sample(device, H=512, W=640, V=4, seed=0):
 DLOSSW = (0.5, 1.0, 2.0)      # --dlossw default, train_rcmvsnet.py:61
 
 
-def train_step_hip_losses(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.01):
-    """One iteration with the reference's losses on the HIP path (train_rcmvsnet.py:279-312,330-376,397-446)."""
+def train_step(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.01, cascade_fn=None, render_fn=None):
+    """One iteration with the reference's losses (train_rcmvsnet.py:279-312,330-376,397-446); returns a dict of scalar losses
+    (python floats).  cascade_fn(model, imgs, proj, depth_values) / render_fn(model_nerf, volume_feature, pseudo_depth, batch)
+    default to the modules' own forward."""
     from . import losses
+    cascade_fn = cascade_fn or (lambda m, *a: m(*a))
+    render_fn = render_fn or (lambda m, *a: m(*a))
     model.train()
     model_nerf.train()
     opt.zero_grad(set_to_none=True)
     dlossw = list(DLOSSW)
-    outputs, volume_feature = model(imgs, proj, depth_values)                      # forward #1 (:342)
+    outputs, volume_feature = cascade_fn(model, imgs, proj, depth_values)          # forward #1 (:342)
     loss_base, _ = losses.UnsupLossMultiStage()(outputs, imgs, proj, dlossw=dlossw)  # (:345)
     pseudo_depth = outputs["depth"].detach()
     ref_img, filter_mask = losses.random_image_mask(imgs[:, 0], (imgs.shape[3] // 3, imgs.shape[4] // 3))   # (:412)
     imgs_aug = torch.cat((ref_img.unsqueeze(1), imgs[:, 1:]), dim=1)
-    outputs_aug, _ = model(imgs_aug, proj, depth_values)                           # forward #2 (:415)
+    outputs_aug, _ = cascade_fn(model, imgs_aug, proj, depth_values)               # forward #2 (:415)
     loss_aug, _ = losses.AugLossMultiStage()(outputs_aug, pseudo_depth, None, filter_mask, dlossw=dlossw)
     loss_aug = loss_aug * w_aug                                                    # (:420-424)
-    rgb, _, _, depth_pred, _, _, rays_depth, target = model_nerf(volume_feature, pseudo_depth, dict(batch))   # (:285)
+    rgb, _, _, depth_pred, _, _, rays_depth, target = render_fn(model_nerf, volume_feature, pseudo_depth, dict(batch))   # (:285)
     img_loss = torch.mean((rgb - target) ** 2)                                     # img2mse (:291)
     depth_loss = losses.SL1Loss()(depth_pred, rays_depth, rays_depth > 0)          # (:295-297)
     loss = loss_base + loss_aug + img_loss + depth_loss
     loss.backward()                                                                # one backward over both forwards (:311)
     opt.step()
     return {"loss": float(loss), "base": float(loss_base), "aug": float(loss_aug), "render": float(img_loss + depth_loss)}
-
-
-def train_step(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.01, real_losses=None):
-    """One iteration; returns a dict of scalar losses (python floats).  real_losses: None = the reference's losses on a GPU,
-    surrogates on a CPU."""
-    if real_losses is None:
-        real_losses = imgs.is_cuda
-    if real_losses:
-        return train_step_hip_losses(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug)
-    model.train()
-    model_nerf.train()
-    opt.zero_grad(set_to_none=True)
-    # ---- forward #1 (train_rcmvsnet.py:342) + surrogate base loss
-    outputs, volume_feature = model(imgs, proj, depth_values)
-    loss_base = 0.0
-    for k, wgt in (("stage1", 0.5), ("stage2", 1.0), ("stage3", 2.0)):
-        d = outputs[k]["depth"]
-        loss_base = loss_base + wgt * ((d[:, 1:] - d[:, :-1]).abs().mean() + (d[:, :, 1:] - d[:, :, :-1]).abs().mean())
-    pseudo_depth = outputs["depth"].detach()
-    # ---- forward #2 on masked images (train_rcmvsnet.py:412-423)
-    g = torch.Generator(device="cpu").manual_seed(1)
-    mask = (torch.rand(imgs.shape[0], 1, 1, imgs.shape[3] // 8, imgs.shape[4] // 8, generator=g) > 0.1).float().to(imgs.device)
-    mask = F.interpolate(mask[:, 0], size=imgs.shape[-2:], mode="nearest").unsqueeze(1)
-    imgs_aug = torch.cat((imgs[:, :1] * mask, imgs[:, 1:]), dim=1)
-    outputs_aug, _ = model(imgs_aug, proj, depth_values)
-    loss_aug = w_aug * (outputs_aug["depth"] - pseudo_depth).abs().mean()
-    # ---- rendering-consistency branch (train_rcmvsnet.py:285-298)
-    rgb, _, _, depth_pred, _, _, rays_depth, target = model_nerf(volume_feature, pseudo_depth, dict(batch))
-    loss_render = F.mse_loss(rgb, target) + F.smooth_l1_loss(depth_pred, rays_depth)
-    loss = loss_base + loss_aug + loss_render
-    loss.backward()                                           # one backward over both forwards (:311)
-    opt.step()
-    return {"loss": float(loss), "base": float(loss_base), "aug": float(loss_aug), "render": float(loss_render)}

@@ -41,8 +41,8 @@ def rel_err(a, b):
 # CPU emulation of the HIP kernels (tests/emu): the product's own Python path -- ops.*, the autograd Functions, the drop-in
 # modules -- runs on CPU tensors against librcmvs_emu.so, so kernel logic is checked against the oracle without a GPU.
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="session")
-def emu_lib():
+def load_emu_lib():
+    """ctypes handle of librcmvs_emu.so (built on demand under tests/emu/_build) with the product's signature table."""
     import ctypes
     sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
     import build as emu_build
@@ -57,10 +57,10 @@ def emu_lib():
     return lib
 
 
-@pytest.fixture
-def emu(emu_lib, monkeypatch):
-    """Route the package to the emulated library for one test: CPU tensors are accepted where the real path demands GPU ones,
-    the 'stream' is NULL, and the modules take their HIP branches regardless of the device."""
+def route_to_emulation(lib, setattr_):
+    """Point the package at the emulated library: CPU tensors are accepted where the real path demands GPU ones, the 'stream'
+    is NULL, and the modules take their HIP branches regardless of the device.  setattr_(obj, name, value) does the patching
+    (monkeypatch.setattr in a test, plain setattr in a spawned worker process)."""
     import ctypes
     from rc_mvsnet_amd import _lib, casmvsnet, fusion, losses, mvs_dataset, ops, render_consist_net, train_ops
 
@@ -72,15 +72,26 @@ def emu(emu_lib, monkeypatch):
     def opt(t, name):
         return ctypes.c_void_p(0) if t is None else chk(t, name)
 
-    monkeypatch.setattr(_lib, "_lib", emu_lib)
+    setattr_(_lib, "_lib", lib)
     for mod in (ops, fusion, losses, mvs_dataset, train_ops):
-        monkeypatch.setattr(mod, "_chk", chk)
-        monkeypatch.setattr(mod, "_stream", lambda: ctypes.c_void_p(0))
-    monkeypatch.setattr(ops, "_opt", opt)
-    monkeypatch.setattr(train_ops, "_opt", opt)
+        setattr_(mod, "_chk", chk)
+        setattr_(mod, "_stream", lambda: ctypes.c_void_p(0))
+    setattr_(ops, "_opt", opt)
+    setattr_(train_ops, "_opt", opt)
     infer = lambda module, *tensors: (not module.training) and (not torch.is_grad_enabled())            # noqa: E731
-    train = lambda module, *tensors: module.training and os.environ.get("RCMVS_TRAIN", "hip") != "aten"  # noqa: E731
+    train = lambda module, *tensors: module.training                                                      # noqa: E731
     for mod in (casmvsnet, render_consist_net):
-        monkeypatch.setattr(mod, "_hip_inference", infer)
-        monkeypatch.setattr(mod, "_hip_training", train)
+        setattr_(mod, "_hip_inference", infer)
+        setattr_(mod, "_hip_training", train)
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    return load_emu_lib()
+
+
+@pytest.fixture
+def emu(emu_lib, monkeypatch):
+    """Route the package to the emulated library for one test (see route_to_emulation)."""
+    route_to_emulation(emu_lib, monkeypatch.setattr)
     return emu_lib

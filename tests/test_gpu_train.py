@@ -123,10 +123,12 @@ def test_prob_depth_head_backward():
     assert e_dx < 1e-4 and e_dw < 1e-4
 
 
-def test_cascade_train_native_vs_delegated_gradients(monkeypatch):
+def test_cascade_train_native_vs_delegated_gradients():
     """CascadeMVSNet in train mode: the HIP training path (WarpVarianceFn + ConvBnReluFn + ProbDepthHeadFn) and the
-    delegated PyTorch-ROCm op graph produce the same outputs, parameter gradients and running statistics."""
+    reference's op graph with autograd (oracle/aten_graph.py, same device) produce the same outputs, parameter gradients
+    and running statistics."""
     import copy
+    from oracle import aten_graph
     from rc_mvsnet_amd import _lib, synthetic
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet
     _lib.load()
@@ -140,15 +142,14 @@ def test_cascade_train_native_vs_delegated_gradients(monkeypatch):
     imgs, dv = imgs.to(dev), dv.to(dev)
     pm = {k: v.to(dev) for k, v in pm.items()}
 
-    def run(model):
-        out, noref = model(imgs, pm, dv)
+    def run(model, forward):
+        out, noref = forward(model, imgs, pm, dv)
         loss = sum((out[f"stage{s}"]["depth"] - 600.0).abs().mean() for s in (1, 2, 3)) + 1e-2 * noref.pow(2).mean()
         loss.backward()
         return out, noref, loss
 
-    out1, nr1, l1 = run(m1)
-    monkeypatch.setenv("RCMVS_TRAIN", "aten")
-    out2, nr2, l2 = run(m2)
+    out1, nr1, l1 = run(m1, lambda m, *a: m(*a))
+    out2, nr2, l2 = run(m2, aten_graph.cascade_forward)
     assert _rel(out1["stage1"]["depth"], out2["stage1"]["depth"]) < 1e-4
     assert _rel(nr1, nr2) < 1e-4
     worst = ("", 0.0)
@@ -166,10 +167,11 @@ def test_cascade_train_native_vs_delegated_gradients(monkeypatch):
             assert _rel(b1[n2], b) < 1e-4, n2
 
 
-def test_neural_volume_net_train_native_vs_delegated(monkeypatch):
+def test_neural_volume_net_train_native_vs_delegated():
     """Rendering branch, a8 in train mode: plane resize + CostReg (conv + batch-stat norm, no ReLU, 41 -> 44 padded
-    input channels) on the HIP kernels vs the delegated op graph: volume, input gradient, parameter gradients."""
+    input channels) on the HIP kernels vs the reference op graph over the module's children (oracle/aten_graph.py): volume, input gradient, parameter gradients."""
     import copy
+    from oracle import aten_graph
     from rc_mvsnet_amd import _lib
     from rc_mvsnet_amd.render_consist_net import Neural_Volume_Net
     _lib.load()
@@ -186,26 +188,26 @@ def test_neural_volume_net_train_native_vs_delegated(monkeypatch):
     x = torch.randn(1, 41, 12, 16, 24, generator=g).to(dev)
     G = torch.randn(1, 8, 128, 16, 24, generator=g).to(dev)
 
-    def run(model):
+    def run(model, forward):
         xi = x.clone().requires_grad_(True)
-        v = model(xi)
+        v = forward(model, xi)
         (v * G).sum().backward()
         return v.detach(), xi.grad
 
-    v1, gx1 = run(m1)
-    monkeypatch.setenv("RCMVS_TRAIN", "aten")
-    v2, gx2 = run(m2)
+    v1, gx1 = run(m1, lambda m, t: m(t))
+    v2, gx2 = run(m2, aten_graph.neural_volume)
     e_v, e_gx = _rel(v1, v2), _rel(gx1, gx2)
     worst = max(_rel(p1.grad, p2.grad) for p1, p2 in zip(m1.parameters(), m2.parameters()))
     print(f"Neural_Volume_Net train: volume {e_v:.1e}  d/d input {e_gx:.1e}  worst param grad {worst:.1e}")
     assert e_v < 1e-4 and e_gx < 1e-3 and worst < 1e-3
 
 
-def test_renderer_train_native_vs_delegated(monkeypatch):
+def test_renderer_train_native_vs_delegated():
     """Rendering_Consistency_Net in train mode with injected draws: HIP training path (volume network, point-feature
-    scatter, compositing recurrence native; MLP GEMMs on hipBLASLt) vs the delegated op graph -- outputs, gradient
-    w.r.t. the warped volume feature, parameter gradients."""
+    scatter, NeRF MLP, compositing recurrence -- all on the library) vs the reference's op graph with autograd
+    (oracle/aten_graph.py) -- outputs, gradient w.r.t. the warped volume feature, parameter gradients."""
     import copy
+    from oracle import aten_graph
     from rc_mvsnet_amd import _lib, synthetic, train_step as ts
     from rc_mvsnet_amd.render_consist_net import Rendering_Consistency_Net
     _lib.load()
@@ -225,17 +227,16 @@ def test_renderer_train_native_vs_delegated(monkeypatch):
     vfw = (0.5 * torch.randn(1, 41, 12, H // 4, W // 4, generator=g)).to(dev)
     pseudo = (500.0 + 300.0 * torch.rand(1, H, W, generator=g)).to(dev)
 
-    def run(model):
+    def run(model, forward):
         x = vfw.clone().requires_grad_(True)
-        rgb, feat, wts, dpred, alpha, _, rdepth, target = model(x, pseudo, dict(batch), randoms=(pix, eps, u))
+        rgb, feat, wts, dpred, alpha, _, rdepth, target = forward(model, x, pseudo, dict(batch), (pix, eps, u))
         loss = torch.nn.functional.mse_loss(rgb, target) + 1e-3 * torch.nn.functional.smooth_l1_loss(dpred, rdepth) + \
             1e-2 * wts.pow(2).mean() + 1e-2 * alpha.mean()
         loss.backward()
         return (rgb.detach(), dpred.detach(), wts.detach()), x.grad, loss
 
-    o1, gx1, l1 = run(m1)
-    monkeypatch.setenv("RCMVS_TRAIN", "aten")
-    o2, gx2, l2 = run(m2)
+    o1, gx1, l1 = run(m1, lambda m, x, p, b, r: m(x, p, b, randoms=r))
+    o2, gx2, l2 = run(m2, aten_graph.render_forward)
     e_out = max(_rel(a, b) for a, b in zip(o1, o2))
     e_gx = _rel(gx1, gx2)
     worst = ("", 0.0)
@@ -293,11 +294,12 @@ def test_hip_training_path_vs_reference_gradients():
     assert _rel(bufs["cost_regularization.0.conv0.bn.running_var"].cpu(), torch.as_tensor(g["running_var_conv0"])) < 1e-4
 
 
-def test_featurenet_train_native_vs_delegated(monkeypatch):
+def test_featurenet_train_native_vs_delegated():
     """FeatureNet in train mode on the library (every layer as a one-plane volume on the 3-D conv family, 5x5 stride-2
-    layers as space-to-depth + 3x3) vs the module's own nn.Conv2d / BatchNorm2d graph: feature maps, input-independent
-    parameter gradients, running statistics."""
+    layers as space-to-depth + 3x3) vs the reference graph over the module's nn.Conv2d / BatchNorm2d children
+    (oracle/aten_graph.feature_pyramid): feature maps, input-independent parameter gradients, running statistics."""
     import copy
+    from oracle import aten_graph
     from rc_mvsnet_amd import _lib
     from rc_mvsnet_amd.casmvsnet import FeatureNet
     _lib.load()
@@ -316,7 +318,7 @@ def test_featurenet_train_native_vs_delegated(monkeypatch):
     # two "views" of one image each, normalised separately: one batched call with segments=2 vs two module calls
     o1 = m1.forward_train_cl(x, segments=2)
     sum((o1[k] * G[k]).sum() for k in G).backward()
-    oa, ob = m2(x[:1]), m2(x[1:])
+    oa, ob = aten_graph.feature_pyramid(m2, x[:1]), aten_graph.feature_pyramid(m2, x[1:])
     o2 = {k: torch.cat((oa[k], ob[k])) for k in oa}
     sum((o2[k].permute(0, 2, 3, 1) * G[k]).sum() for k in G).backward()
     for k in G:

@@ -52,37 +52,125 @@ def _ddp_worker(rank, world, port, q):
     from torch.nn.parallel import DistributedDataParallel as DDP
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from rc_mvsnet_amd.parallel import flat_allreduce_hook, allreduce_gradients
+    from oracle import aten_graph
+    from rc_mvsnet_amd.parallel import GradSync, flat_allreduce_hook
     from rc_mvsnet_amd.casmvsnet import CostRegNet
+
+    class Graph(nn.Module):                      # the product module refuses CPU tensors: run its parameters through the oracle graph
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            return aten_graph.unet3d(self.net, x, self.net.prob)
+
     torch.manual_seed(0)
     net = CostRegNet(8, 8)                       # a real sub-module of the path (3-D U-Net, BN included)
     ref = CostRegNet(8, 8)
     ref.load_state_dict(net.state_dict())
-    ddp = DDP(net)
+    ddp = DDP(Graph(net))
     ddp.register_comm_hook(state=None, hook=flat_allreduce_hook)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(1, 8, 16, 16, 16, generator=g)
     ddp(x).square().mean().backward()
-    ref(x).square().mean().backward()
-    allreduce_gradients([ref])                   # manual flat all-reduce must agree with the hook
+    sync = GradSync([ref])                       # one flat buffer, .grad are views into it
+    assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in ref.parameters())
+    Graph(ref)(x).square().mean().backward()
+    local = [p.grad.clone() for p in ref.parameters()]
+    sync.sync()                                  # must agree with the DDP hook
     err = max(float((a.grad - b.grad).abs().max()) for a, b in zip(net.parameters(), ref.parameters()))
+    # and with the plain average of the two ranks' local gradients
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [t.numpy() for t in local])
+    mean = [sum(torch.as_tensor(gathered[r][i]) for r in range(world)) / world for i in range(len(local))]
+    err = max(err, max(float((p.grad - m).abs().max()) for p, m in zip(ref.parameters(), mean)))
     gsum = float(sum(p.grad.abs().sum() for p in net.parameters()))
-    q.put((rank, err, gsum))
+    sync.zero()
+    zeroed = all(float(p.grad.abs().max()) == 0.0 for p in ref.parameters())
+    next(ref.parameters()).grad = torch.zeros_like(next(ref.parameters()))
+    try:
+        sync.sync()
+        detected = False
+    except RuntimeError:
+        detected = True
+    q.put((rank, err, gsum, zeroed and detected))
     dist.destroy_process_group()
 
 
 def test_flat_allreduce_hook_world2():
-    """DDP over gloo, world size 2: the flat-buffer comm hook averages gradients across ranks (every rank
-    ends with identical gradients) and matches the manual flat all-reduce."""
+    """Gradient exchange over gloo, world size 2: the DDP comm hook and GradSync (one flat buffer for all parameters, .grad
+    views into it) both leave every rank with the average of the ranks' gradients; GradSync.zero() clears through the views
+    and a replaced .grad is detected."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(err < 1e-6 for _, err, _ in res), res
+    assert all(err < 1e-6 for _, err, _, _ in res), res
+    assert all(ok for _, _, _, ok in res), res
     assert abs(res[0][2] - res[1][2]) < 1e-4 * max(1.0, res[0][2])      # same averaged gradients on both ranks
+
+
+def _syncbn_worker(rank, world, port, q):
+    """Two ranks, each with HALF of a batch, run the product's train-mode conv -> SyncBatchNorm -> ReLU block (HIP kernels on
+    the CPU emulation; the batch statistics and the backward sums go through train_ops' fp64 all-reduce over gloo)."""
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import conftest
+    conftest.route_to_emulation(conftest.load_emu_lib(), setattr)
+    import torch.nn as nn
+    from rc_mvsnet_amd import train_ops
+    from rc_mvsnet_amd.casmvsnet import Conv3d
+    torch.manual_seed(0)
+    blk = nn.SyncBatchNorm.convert_sync_batchnorm(Conv3d(16, 16, padding=1)).train()
+    g = torch.Generator().manual_seed(7)
+    x_all = torch.randn(2, 4, 8, 8, 16, generator=g)            # channels-last (B,D,H,W,C), one batch item per rank
+    G_all = torch.randn(2, 4, 8, 8, 16, generator=g)
+    x = x_all[rank:rank + 1].clone().requires_grad_(True)
+    z = train_ops.conv_bn_train(blk.conv, blk.bn, x, relu=True)
+    (z * G_all[rank:rank + 1]).sum().backward()
+    q.put((rank, z.detach().numpy(), x.grad.numpy(), blk.conv.weight.grad.numpy(), blk.bn.weight.grad.numpy(),
+           blk.bn.running_mean.numpy().copy(), blk.bn.running_var.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_statistics_world2():
+    """SyncBatchNorm-converted block (train_rcmvsnet.py:524-525) over two gloo ranks == the same block with plain BatchNorm on
+    the concatenated batch: outputs, input gradients and running statistics per rank; the parameter gradients of the ranks
+    sum to the full-batch ones (what the gradient all-reduce then averages)."""
+    import numpy as np
+    import torch.nn.functional as F
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # full-batch reference in fp64 with torch ops (same seeds as the workers)
+    from rc_mvsnet_amd.casmvsnet import Conv3d
+    torch.manual_seed(0)
+    blk = Conv3d(16, 16, padding=1).double().train()
+    g = torch.Generator().manual_seed(7)
+    x_all = torch.randn(2, 4, 8, 8, 16, generator=g)
+    G_all = torch.randn(2, 4, 8, 8, 16, generator=g)
+    x = x_all.double().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    z = torch.relu(blk.bn(blk.conv(x)))
+    (z * G_all.double().permute(0, 4, 1, 2, 3)).sum().backward()
+    rel = lambda a, b: float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+    for rank, zr, gx, gw, gg, rm, rv in res:
+        assert rel(zr[0], z[rank].detach().permute(1, 2, 3, 0).numpy()) < 1e-5
+        assert rel(gx[0], x.grad[rank].permute(1, 2, 3, 0).numpy()) < 1e-4
+        assert rel(rm, blk.bn.running_mean.numpy()) < 1e-5 and rel(rv, blk.bn.running_var.numpy()) < 1e-4
+    assert rel(res[0][3] + res[1][3], blk.conv.weight.grad.numpy()) < 1e-4
+    assert rel(res[0][4] + res[1][4], blk.bn.weight.grad.numpy()) < 1e-4

@@ -1,4 +1,4 @@
-"""Per-tensor gradient mismatch of the HIP training path and of the delegated op graph (both on the GPU) against the
+"""Per-tensor gradient mismatch of the HIP training path and of the reference op graph (oracle/aten_graph.py; both on the GPU) against the
 reference-autograd golden (tests/golden/train_grads.npz)."""
 import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,13 +12,14 @@ _lib.load()
 dev = "cuda:0"
 g = load_golden("train_grads")
 res = {}
+from oracle import aten_graph
 for mode in ("hip", "aten"):
-    os.environ["RCMVS_TRAIN"] = mode
     m = CascadeMVSNet(ndepths=[8, 8, 8], depth_interals_ratio=[4, 2, 1])
     m.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=2.0), strict=True)
     m = m.to(dev).train()
     imgs, pm, dv = synthetic.cascade_inputs(1, 3, 64, 96, 0)
-    outputs, noref = m(imgs.to(dev), {k: v.to(dev) for k, v in pm.items()}, dv.to(dev))
+    fwd = (lambda mm, *a: mm(*a)) if mode == "hip" else aten_graph.cascade_forward
+    outputs, noref = fwd(m, imgs.to(dev), {k: v.to(dev) for k, v in pm.items()}, dv.to(dev))
     loss = ((outputs["stage1"]["depth"] - 600.0) ** 2).mean() / 1e4 + 1e-2 * (noref ** 2).mean()
     loss.backward()
     params = dict(m.named_parameters())
