@@ -17,6 +17,10 @@ The JSON line also carries
                 of this box on a bounded sample, rank 0, N=1 only -- a reported baseline, plus
                 the depth-L1 parity of the HIP output against it on the same inputs.
 
+``--workload train_step`` times one training iteration of BASELINE config 3 (train_rcmvsnet.py's call sequence: two
+CascadeMVSNet passes over 4 views at 512x640, D = 48/32/8, the rendering-consistency branch on 1024 rays x 128 samples, the
+reference's losses, one backward, Adam) -- with N > 1 ranks as data-parallel training (config 4): SyncBatchNorm-converted
+models, gradients of both models averaged with ONE reduce-scatter + all-gather message over RCCL (parallel.GradSync).
 ``--workload unsup_loss`` / ``--workload fusion`` time the two callers either side of the path that SURVEY.md section 8f ranks
 next (the self-supervised loss of the training step, the depth-map fusion filter of the evaluation) with the same contract and
 their own ``roofline`` / ``cpu_baseline`` objects; the default workload, and the only one BASELINE.json's metric is quoted
@@ -220,15 +224,82 @@ def bench_fusion(args, rank, world, dev):
     return result
 
 
+def bench_train_step(args, rank, world, dev):
+    """BASELINE configs[2] (N = 1) / configs[3] (N > 1, one sample per GPU, RCCL gradient exchange).  Step = one training
+    iteration (rc_mvsnet_amd/train_step.py = train_rcmvsnet.py:279-312,330-446) on synthetic inputs resident in HBM."""
+    import torch.distributed as dist
+    from rc_mvsnet_amd import ops, train_step as ts, parallel
+    Vt = 4
+    model, model_nerf, opt = ts.build(dev, seed=0)
+    sync = None
+    if world > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)                   # train_rcmvsnet.py:524-525
+        model_nerf = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model_nerf)
+        opt = torch.optim.Adam(list(model.parameters()) + list(model_nerf.parameters()), lr=1e-4, betas=(0.9, 0.999))
+        sync = parallel.GradSync([model, model_nerf])
+    imgs, proj, dv, batch = ts.synthetic_sample(dev, H=H, W=W, V=Vt, seed=rank)
+    last = {}
+
+    def step(i):
+        last.update(ts.train_step(model, model_nerf, opt, imgs, proj, dv, batch, grad_sync=sync))
+
+    elapsed = timed_region(world, dev, args.warmup, args.steps, step)
+    if rank != 0:
+        return None
+    # dominant memory-bound kernel of the iteration: the K1 backward scatter at stage 3 (two calls per iteration)
+    C, D, h, w = FEAT_C[2], NDEPTHS[2], H, W
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(1, Vt, h, w, C, generator=g).to(dev)
+    rot, trans = ops.compose_homography(proj["stage3"].contiguous().float())
+    prev = (600.0 + 100.0 * torch.rand(1, h // 2, w // 2, generator=g)).to(dev)
+    planes = ops.hypothesis_planes(prev, dv, (H, W), 1, D, 1.0)
+    gvar = torch.randn(1, D, h, w, C, generator=g).to(dev)
+    ms = event_ms(lambda: ops.warp_variance_bwd(feats, rot, trans, planes, gvar, None), reps=10)
+    alg = 4 * (C * D * h * w + 2 * Vt * C * h * w + 2 * D * h * w)       # gradient volume in, feature maps in, feature gradients out, planes
+    roofline = {"bound": "hbm", "kernel": "rcmvs::warp_variance_bwd (K1 backward scatter, stage 3: 8 planes x 512x640 x 8 channels, 3 source views)",
+                "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg, "us": round(ms * 1e3, 1),
+                "note": "4 fp32 atomics per (tap, channel quad): atomic-rate bound, not bandwidth bound"}
+    result = {"metric": "training iterations/sec (DTU-shaped 4 views 512x640, D=48/32/8, rendering branch 1024 rays x 128 samples)",
+              "value": round(world * args.steps / elapsed, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+              "data": "synthetic",
+              "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: train_rcmvsnet.py iteration (2 x CascadeMVSNet.forward, "
+                                     "Rendering_Consistency_Net.forward, UnsupLoss + AugLoss + render losses, backward, Adam), batch 1 per GPU",
+                         "views": Vt, "height": H, "width": W, "ndepths": list(NDEPTHS), "rays": 1024, "samples": 128,
+                         "parallelism": f"dp{world}" + (" (SyncBatchNorm + one reduce-scatter/all-gather gradient message over RCCL)" if world > 1 else ""),
+                         "rccl_ranks": world},
+              "roofline": roofline, "losses": {k: round(v, 5) for k, v in last.items()}}
+    if world == 1 and not args.no_cpu_baseline:
+        # bounded sample of the reference's CPU path: forward + backward of ONE of the iteration's two CascadeMVSNet passes
+        # (oracle/aten_graph.py on the host cores); the iteration has two of them plus the renderer and the losses, so
+        # 1 / (2 t) is an upper bound of the CPU rate
+        from oracle import aten_graph
+        nthreads = host_threads()
+        torch.set_num_threads(nthreads)
+        cm, _, _ = ts.build(torch.device("cpu"), seed=0)
+        cm.train()
+        ci, cp, cd = imgs.cpu(), {k: v.cpu() for k, v in proj.items()}, dv.cpu()
+        c0 = time.perf_counter()
+        out, noref = aten_graph.cascade_forward(cm, ci, cp, cd)
+        (sum(out[f"stage{s}"]["depth"].mean() for s in (1, 2, 3)) + noref.mean()).backward()
+        t = time.perf_counter() - c0
+        result["cpu_baseline"] = {"value": round(1.0 / (2.0 * t), 5), "unit": "iterations/s", "cores": nthreads, "kind": "port",
+                                  "sample": f"one CascadeMVSNet forward+backward at the full config-3 size through oracle/aten_graph.py ({t:.1f} s, "
+                                            f"{nthreads} threads, no warm-up); an iteration holds two such passes plus the renderer and the losses, "
+                                            "so the value 1/(2 t) is an upper bound of the reference's CPU rate"}
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="cascade", choices=["cascade", "unsup_loss", "fusion"],
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "train_step", "unsup_loss", "fusion"],
                     help="cascade = BASELINE.json's metric (default); the others are the SURVEY 8f rows either side of the path")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=600, help="timed steps (default: ~1 s of cascade forwards)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scenes", type=int, default=3, help="scenes timed on the CPU baseline (bounded sample)")
+    ap.add_argument("--cpu-scenes", type=int, default=5, help="scenes timed on the CPU baseline after 2 warm-ups (bounded sample, BASELINE.md section 3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,7 +316,9 @@ def main():
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
     _lib.load()
     if args.workload != "cascade":
-        result = (bench_unsup_loss if args.workload == "unsup_loss" else bench_fusion)(args, rank, world, dev)
+        if args.workload == "train_step" and args.steps == 600 and args.warmup == 20:
+            args.steps, args.warmup = 10, 3                       # an iteration is ~80 ms: the defaults of the cascade workload are overkill
+        result = {"unsup_loss": bench_unsup_loss, "fusion": bench_fusion, "train_step": bench_train_step}[args.workload](args, rank, world, dev)
         if result is not None:
             print(json.dumps(result))
         return
@@ -342,21 +415,26 @@ def main():
         times = []
         with torch.no_grad():
             budget_t0 = time.perf_counter()
-            for i in range(1 + args.cpu_scenes):              # first pass = warm-up unless it is all we can afford
+            for i in range(2 + args.cpu_scenes):              # 2 warm-ups + >= 5 timed passes, median
                 c0 = time.perf_counter()
                 ref = cascade.forward_eval(imgs, pm, dv, sd, NDEPTHS, RATIOS, impl="aten")
                 times.append(time.perf_counter() - c0)
-                if time.perf_counter() - budget_t0 > 25.0:    # bounded sample: ~10-30 s of CPU work
+                if time.perf_counter() - budget_t0 > 40.0:    # bounded sample
                     break
+            torch.set_num_threads(1)                           # the 1-thread figure: one pass
+            c0 = time.perf_counter()
+            cascade.forward_eval(imgs, pm, dv, sd, NDEPTHS, RATIOS, impl="aten")
+            one_thread_s = time.perf_counter() - c0
+            torch.set_num_threads(nthreads)
             hip = model(*scenes[0])
-        timed = times[1:] if len(times) > 1 else times
+        timed = times[2:] if len(times) > 2 else times[-1:]
         cpu_s = sorted(timed)[len(timed) // 2]
         rng = float(dv[0, -1] - dv[0, 0])
         dd = (hip["depth"].cpu() - ref["depth"]).abs()
         result["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "ref-scenes/s", "cores": nthreads, "kind": "port",
-                                  "sample": f"median of {len(timed)} scene(s) of the same config-2 workload"
-                                            f"{' after 1 warm-up' if len(times) > 1 else ' (cold, no warm-up fit the time bound)'}, "
-                                            f"oracle impl='aten' (reference op graph on PyTorch-CPU), {nthreads} threads"}
+                                  "sample": f"median of {len(timed)} scene(s) of the same config-2 workload after {len(times) - len(timed)} warm-up(s), "
+                                            f"oracle impl='aten' (reference op graph on PyTorch-CPU), {nthreads} threads",
+                                  "one_thread": {"value": round(1.0 / one_thread_s, 4), "unit": "ref-scenes/s", "sample": "one scene, 1 thread"}}
         result["parity"] = {"depth_l1_over_range": float(dd.mean()) / rng, "depth_l1_mm": float(dd.mean()),
                             "depth_max_abs_mm": float(dd.max()), "frac_pixels_over_0.1mm": float((dd > 0.1).float().mean()),
                             "tolerance": 1e-4}

@@ -45,16 +45,20 @@ def synthetic_sample(device, H=512, W=640, V=4, seed=0):
 DLOSSW = (0.5, 1.0, 2.0)      # --dlossw default, train_rcmvsnet.py:61
 
 
-def train_step(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.01, cascade_fn=None, render_fn=None):
+def train_step(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.01, cascade_fn=None, render_fn=None, grad_sync=None):
     """One iteration with the reference's losses (train_rcmvsnet.py:279-312,330-376,397-446); returns a dict of scalar losses
     (python floats).  cascade_fn(model, imgs, proj, depth_values) / render_fn(model_nerf, volume_feature, pseudo_depth, batch)
-    default to the modules' own forward."""
+    default to the modules' own forward.  grad_sync: a parallel.GradSync over both models (data-parallel training: the
+    gradients live in its flat buffer and are averaged over the ranks with one message before the optimizer step)."""
     from . import losses
     cascade_fn = cascade_fn or (lambda m, *a: m(*a))
     render_fn = render_fn or (lambda m, *a: m(*a))
     model.train()
     model_nerf.train()
-    opt.zero_grad(set_to_none=True)
+    if grad_sync is not None:
+        grad_sync.zero()
+    else:
+        opt.zero_grad(set_to_none=True)
     dlossw = list(DLOSSW)
     outputs, volume_feature = cascade_fn(model, imgs, proj, depth_values)          # forward #1 (:342)
     loss_base, _ = losses.UnsupLossMultiStage()(outputs, imgs, proj, dlossw=dlossw)  # (:345)
@@ -69,5 +73,7 @@ def train_step(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.
     depth_loss = losses.SL1Loss()(depth_pred, rays_depth, rays_depth > 0)          # (:295-297)
     loss = loss_base + loss_aug + img_loss + depth_loss
     loss.backward()                                                                # one backward over both forwards (:311)
+    if grad_sync is not None:
+        grad_sync.sync()
     opt.step()
     return {"loss": float(loss), "base": float(loss_base), "aug": float(loss_aug), "render": float(img_loss + depth_loss)}

@@ -438,3 +438,37 @@ def test_nerf_mlp_train_forward_backward_vs_fp64_autograd(N, S):
                                       [(f"pts_linears.{i}", net.pts_linears[i]) for i in range(6)]})
         raw_inf = ops.nerf_mlp(ndc.to(DEV), feat.to(DEV).clone(), dirs.to(DEV), w2c.to(DEV), blob)
     assert torch.equal(raw_inf, raw.detach())
+
+
+def test_train_step_full_size_config3():
+    """BASELINE configs[2] at its full size under the driver's eyes: ONE training iteration with 4 views at 512x640,
+    D = 48/32/8 and 1024 rays x 128 samples on the HIP path -- finite losses, finite gradients for every parameter of both
+    models, BatchNorm running statistics and step counters updated, weights changed by the optimizer.  The self-supervised loss
+    of forward #1 is cross-checked against the reference op graph (oracle/aten_graph.py on the host cores, forward only, same
+    weights): the seeded network is chaotic (prob head x20), so the bound is loose; the tight per-block and per-tensor
+    checks are the tests above."""
+    import copy
+    from oracle import aten_graph
+    from rc_mvsnet_amd import losses, train_step as ts, _lib
+    _lib.load()
+    warnings.simplefilter("ignore")
+    dev = torch.device(DEV)
+    model, model_nerf, opt = ts.build(dev)
+    imgs, proj, dv, batch = ts.synthetic_sample(dev, H=512, W=640, V=4)
+    m2 = copy.deepcopy(model).cpu().train()                     # on the host cores: a fresh GPU box would spend a minute in MIOpen's kernel search
+    with torch.no_grad():
+        out2, _ = aten_graph.cascade_forward(m2, imgs.cpu(), {k: v.cpu() for k, v in proj.items()}, dv.cpu())
+        out2 = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in out2.items()}
+        base2 = float(losses.UnsupLossMultiStage()(out2, imgs, proj, dlossw=list(ts.DLOSSW))[0])
+    del m2, out2
+    bn = model.cost_regularization[2].conv0.bn
+    rm0, w0 = bn.running_mean.clone(), model.cost_regularization[0].conv0.conv.weight.detach().clone()
+    l1 = ts.train_step(model, model_nerf, opt, imgs, proj, dv, batch)
+    print("HIP iteration", l1, "| reference-graph forward #1 loss", base2)
+    assert all(v == v and abs(v) < 1e9 for v in l1.values()), l1
+    for n, p in list(model.named_parameters()) + list(model_nerf.named_parameters()):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    assert float((bn.running_mean - rm0).abs().max()) > 0.0
+    assert int(bn.num_batches_tracked) == 2                                    # two cascade passes per iteration
+    assert float((model.cost_regularization[0].conv0.conv.weight.detach() - w0).abs().max()) > 0.0
+    assert abs(l1["base"] - base2) <= 5e-2 * abs(base2), (l1["base"], base2)
