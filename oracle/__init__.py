@@ -18,7 +18,9 @@ This package is the *checker*, never the product:
 
 Later rows: ``unsup_loss`` (pinned to 1e-6 by the reference's own autograd), ``fusion`` and
 ``dataset`` (pinned by the reference's filter_depth / MVSDataset run with restatements of the absent cv2.remap / cv2.resize --
-those two steps are "parity unpinned", see the module headers).  ``bench.py --workload unsup_loss|fusion`` times them as
+those two restatements are pinned by known answers worked out from OpenCV's published algorithm,
+tests/test_cv_known_answers_cpu.py), ``aten_graph`` (the reference's op graph with autograd over a product module's parameters:
+the comparator of the gradient tests, pinned by gradients of the imported reference, tests/golden/train_grads.npz).  ``bench.py --workload unsup_loss|fusion`` times them as
 ``cpu_baseline``; diagnostics that compare against the oracle live under ``tests/diag/``.
 
 Tolerances: the reference's own CPU path is not bit-reproducible across ATen builds
@@ -27,4 +29,4 @@ fixtures are compared at a few fp32 ulp (rtol 2e-5 / atol 2e-6 on O(1) features)
 integer-valued confidence index is compared where it is not within rounding of a bin edge.
 """
 
-from . import warp, conv3d, depth_head, feature_net, cascade, render, unsup_loss, fusion, dataset  # noqa: F401
+from . import warp, conv3d, depth_head, feature_net, cascade, render, unsup_loss, fusion, dataset, aten_graph  # noqa: F401

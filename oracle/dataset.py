@@ -4,9 +4,12 @@ Test infrastructure (see oracle/__init__.py): numpy restatement of datasets/dtu_
 scale_mvs_input, ToTensor + Normalize, the per-view loop of __getitem__ and the three-stage projection matrices).  Pinned by
 tests/golden/dataset.npz, produced by tests/golden/make_golden.py --only-dataset from the reference's MVSDataset.
 
-PARITY UNPINNED for one step: ``cv2.resize`` (opencv-python 4.5.5.62, requirements.txt:31) is absent from the reference tree
-and from this image; ``resize_linear`` restates its published float32 INTER_LINEAR algorithm (modules/imgproc/src/resize.cpp)
-and the golden generator hands it to the reference as ``cv2.resize``.  torchvision's ToTensor / Normalize (also absent) are a
+One step cannot be pinned by running the reference: ``cv2.resize`` (opencv-python 4.5.5.62, requirements.txt:31) is absent from
+the reference tree and from this image; ``resize_linear`` restates its published float32 INTER_LINEAR algorithm
+(modules/imgproc/src/resize.cpp, resizeGeneric_ with HResizeLinear / VResizeLinear: fx = (dx + 0.5) * scale - 0.5, floor,
+border clamps with fx = 0, taps {1 - fx, fx}, horizontal pass then vertical), the golden generator hands it to the reference as
+``cv2.resize``, and the restatement is pinned by KNOWN ANSWERS derived from that algorithm (exact halving, identity, border
+replication and interior taps of an enlargement, a linear ramp at non-integer scales): tests/test_cv_known_answers_cpu.py.  torchvision's ToTensor / Normalize (also absent) are a
 transpose and ``(x - mean) / std`` in float32.
 """
 import numpy as np

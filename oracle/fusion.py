@@ -6,11 +6,14 @@ kept as the reference has it (float32 camera matrices inverted / multiplied in f
 float32 casts at the same places).  Pinned by tests/golden/fusion.npz, which tests/golden/make_golden.py --only-fusion
 produced by importing the reference's eval script.
 
-PARITY UNPINNED for one step: the reference samples the source depth with ``cv2.remap(..., INTER_LINEAR)``; opencv-python
-(4.5.5.62, requirements.txt:31) is a third-party dependency absent from the reference tree and from this image, so
-``remap_linear`` below restates its published algorithm (modules/imgproc/src/imgwarp.cpp: coordinates rounded to 1/32 pixel
-with round-half-even, a float32 weight table, BORDER_CONSTANT value 0) and the golden generator hands the same function to
-the reference as ``cv2.remap``.  Everything around that call is pinned by the reference's own code.
+One step cannot be pinned by running the reference: it samples the source depth with ``cv2.remap(..., INTER_LINEAR)``, and
+opencv-python (4.5.5.62, requirements.txt:31) is a third-party dependency absent from the reference tree and from this image.
+``remap_linear`` below restates its published algorithm (modules/imgproc/src/imgwarp.cpp, cv::remap -> remapBilinear with the
+initInterTab2D tables: coordinates rounded to 1/32 pixel with cvRound = round-half-even, a 32 x 32 float32 weight table,
+BORDER_CONSTANT value 0), the golden generator hands the same function to the reference as ``cv2.remap``, and the restatement
+is pinned by KNOWN ANSWERS worked out from that algorithm in exact arithmetic (integer / 1-32nd-grid coordinates, ties,
+half-outside footprints, non-finite coordinates): tests/test_cv_known_answers_cpu.py.  Everything around that call is pinned
+by the reference's own code.
 """
 import numpy as np
 

@@ -28,11 +28,13 @@ from rc_mvsnet_amd import synthetic  # noqa: E402
 
 
 def import_reference():
-    cv2 = types.ModuleType("cv2")
+    # idempotent: the reference's modules keep a reference to the FIRST cv2 stub (`from models import *`), so a second call
+    # must hand back that same object for later attribute patches (cv2.remap / cv2.resize) to be seen
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
     cv2.COLORMAP_JET = 2
     sys.modules["cv2"] = cv2
     for n in ("torchvision", "torchvision.transforms", "torchvision.utils"):
-        sys.modules[n] = types.ModuleType(n)
+        sys.modules.setdefault(n, types.ModuleType(n))
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -122,6 +124,9 @@ def main():
     save("costreg_train", x=x, out=net(x))
     raw = torch.nn.Conv3d(8, 16, 3, stride=2, padding=1, bias=False)
     rawt = torch.nn.ConvTranspose3d(16, 8, 3, stride=2, padding=1, output_padding=1, bias=False)
+    gw = torch.Generator().manual_seed(1234)                 # own generator: seeded weights without shifting the draws of `g`
+    raw.weight.data = torch.randn(raw.weight.shape, generator=gw) / (8 * 27) ** 0.5
+    rawt.weight.data = torch.randn(rawt.weight.shape, generator=gw) / (16 * 27 / 8) ** 0.5
     xo = torch.randn(2, 8, 5, 7, 9, generator=g)             # odd sizes, batch 2
     yo = raw(xo)
     save("conv_raw", x=xo, w=raw.weight, y=yo, wt=rawt.weight, yt=rawt(yo))
