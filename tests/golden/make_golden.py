@@ -145,7 +145,7 @@ def main():
     # ---- a6: end-to-end cascades -----------------------------------------------------------
     sd = synthetic.cascade_state_dict(0)
 
-    def run_eval(H, W, nd, ratio, V=3):
+    def run_eval(H, W, nd, ratio, V=3, sd=sd):
         m = models.CascadeMVSNet_eval(ndepths=list(nd), depth_interals_ratio=list(ratio), cr_base_chs=[8] * len(nd))
         keep = {k: v for k, v in sd.items() if not k.startswith("cost_regularization.") or int(k.split(".")[1]) < len(nd)}
         if len(nd) == 1:                                    # a 1-stage FeatureNet has no lateral / out2 / out3 convs
@@ -167,6 +167,11 @@ def main():
     if args.full:
         o = run_eval(512, 640, (48, 32, 8), (4, 2, 1))      # BASELINE config 2
         save("cascade_c2", H=512, W=640, V=3, ndepths=(48, 32, 8), ratios=(4, 2, 1), depth=o["depth"],
+             conf=o["photometric_confidence"], depth1=o["stage1"]["depth"], depth2=o["stage2"]["depth"])
+        # the same configuration with a trained-like, well-conditioned probability head (prob.weight x1 instead of x20): the
+        # soft-argmin then varies smoothly with the logits and the end-to-end comparison is not hostage to knife-edge pixels
+        o = run_eval(512, 640, (48, 32, 8), (4, 2, 1), sd=synthetic.cascade_state_dict(0, prob_gain=1.0))
+        save("cascade_c2_smooth", H=512, W=640, V=3, ndepths=(48, 32, 8), ratios=(4, 2, 1), prob_gain=1.0, depth=o["depth"],
              conf=o["photometric_confidence"], depth1=o["stage1"]["depth"], depth2=o["stage2"]["depth"])
 
     # ---- train variant: volume_feature_no_ref (train mode and the eval-mode quirk) ---------

@@ -469,7 +469,7 @@ def _run_cascade(name, train_variant=False):
     g = load_golden(name)
     H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
     nd, ra = [int(v) for v in g["ndepths"]], [int(v) for v in g["ratios"]]
-    sd = synthetic.cascade_state_dict(0)
+    sd = synthetic.cascade_state_dict(0, prob_gain=float(g["prob_gain"])) if "prob_gain" in g else synthetic.cascade_state_dict(0)
     if len(nd) == 1:
         sd = {k: v for k, v in sd.items() if not (k.startswith("feature.inner") or k.startswith("feature.out2")
                                                    or k.startswith("feature.out3") or k.startswith("cost_regularization.1")
@@ -502,6 +502,79 @@ def test_cascade_vs_reference_golden(hip, name):
     cd = (out["photometric_confidence"].cpu() - g["conf"]).abs()
     assert float((cd[stable] > 1e-3).float().mean()) < (0.08 if name == "cascade_c2" else 0.02)
     assert set(out.keys()) >= {"depth", "photometric_confidence", "stage1"}
+
+
+def test_cascade_c2_smooth_head_vs_reference_golden(hip):
+    """BASELINE config 2 at full size against the imported reference (tests/golden/cascade_c2_smooth.npz, make_golden.py --full)
+    with a well-conditioned, trained-like probability head (prob.weight x1): the soft-argmin then follows the logits smoothly, so
+    the headline parity is not hostage to knife-edge pixels -- depth L1 an order of magnitude inside the 1e-4 tolerance and
+    >= 99 % of the pixels within 0.05 mm, confidences agreeing on those."""
+    g, out, rng = _run_cascade("cascade_c2_smooth")
+    dd = (out["depth"].cpu() - g["depth"]).abs()
+    err = float(dd.mean()) / rng
+    stable = dd < 0.05
+    cd = (out["photometric_confidence"].cpu() - g["conf"]).abs()
+    print(f"cascade_c2_smooth: depth L1/range = {err:.3e}  max|dd| = {float(dd.max()):.3e} mm  stable = {float(stable.float().mean()):.5f}  "
+          f"conf max diff on stable = {float(cd[stable].max()):.2e}")
+    assert err < 1e-5
+    assert float(stable.float().mean()) >= 0.99
+    assert float((cd[stable] > 1e-3).float().mean()) < 0.01
+
+
+def test_reference_fp32_homography_depends_on_the_backend(hip):
+    """Why the product does not chase the reference's fp32 `torch.inverse` homography (models/modules.py:314-316) bit for bit:
+    the reference's own value depends on where it runs.  On 300 random DTU-like rigs the fp32 composition is evaluated with
+    LAPACK on the host (what the golden fixtures hold) and with PyTorch-ROCm's inverse on this GPU (what the reference would
+    compute on this box); both land ~1e-5 pixel from the exact (fp64) homography and as far from EACH OTHER as from the truth,
+    so no single fp32 operation order is "the reference".  The product's composer (fp64 inside the kernel, rounded once) is
+    the exact homography to fp32 rounding."""
+    from oracle import warp
+    g = torch.Generator().manual_seed(300)
+    n = 300
+    # random rigs: intrinsics around the DTU ones, rotations up to ~0.3 rad, centres within ~150 mm
+    K = torch.eye(3).repeat(n, 1, 1)
+    K[:, 0, 0] = 360.0 + 20.0 * torch.rand(n, generator=g)
+    K[:, 1, 1] = K[:, 0, 0] * (1.0 + 0.01 * torch.randn(n, generator=g))
+    K[:, 0, 2], K[:, 1, 2] = 80.0 + 2.0 * torch.randn(n, generator=g), 64.0 + 2.0 * torch.randn(n, generator=g)
+
+    def extrinsic(scale):
+        w = scale * torch.randn(n, 3, generator=g)
+        th = w.norm(dim=1, keepdim=True).clamp_min(1e-9)
+        k = w / th
+        Kx = torch.zeros(n, 3, 3)
+        Kx[:, 0, 1], Kx[:, 0, 2], Kx[:, 1, 0], Kx[:, 1, 2], Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+        R = torch.eye(3) + torch.sin(th)[:, :, None] * Kx + (1 - torch.cos(th))[:, :, None] * (Kx @ Kx)
+        E = torch.eye(4).repeat(n, 1, 1)
+        E[:, :3, :3] = R
+        E[:, :3, 3] = (-R @ (150.0 * torch.randn(n, 3, 1, generator=g))).squeeze(-1)
+        return E
+
+    proj = torch.zeros(n, 2, 2, 4, 4)
+    for v in range(2):
+        proj[:, v, 0] = extrinsic(0.02 if v == 0 else 0.15)
+        proj[:, v, 1, :3, :3] = K
+    rot_t, trans_t = warp.compose_homography(proj[:, 1].double(), proj[:, 0].double())           # exact to fp64 rounding
+    rot_c, trans_c = warp.compose_homography(proj[:, 1], proj[:, 0])                               # fp32, LAPACK on the host
+    pg = gpu(proj)
+    rot_g, trans_g = warp.compose_homography(pg[:, 1], pg[:, 0])                                   # fp32, PyTorch-ROCm on this GPU
+    rot_h, trans_h = hip.compose_homography(pg)                                                    # product
+
+    def pixels(rot, trans):          # source pixel of the reference image corner at the far plane, in fp64
+        rot, trans = rot.double().cpu().reshape(n, 3, 3), trans.double().cpu().reshape(n, 3)
+        p = rot @ torch.tensor([159.0, 127.0, 1.0], dtype=torch.float64) * 935.0 + trans
+        return p[:, :2] / p[:, 2:3]
+
+    truth = pixels(rot_t, trans_t)
+    e_cpu = (pixels(rot_c, trans_c) - truth).norm(dim=1)
+    e_gpu = (pixels(rot_g, trans_g) - truth).norm(dim=1)
+    e_hip = (pixels(rot_h, trans_h) - truth).norm(dim=1)
+    d_ref = (pixels(rot_c, trans_c) - pixels(rot_g, trans_g)).norm(dim=1)
+    print(f"pixel error vs exact homography (median / max over {n} rigs): host fp32 {float(e_cpu.median()):.2e} / {float(e_cpu.max()):.2e}, "
+          f"GPU fp32 {float(e_gpu.median()):.2e} / {float(e_gpu.max()):.2e}, product {float(e_hip.median()):.2e} / {float(e_hip.max()):.2e}; "
+          f"host fp32 vs GPU fp32 {float(d_ref.median()):.2e} / {float(d_ref.max()):.2e}")
+    assert float(e_hip.max()) < 2e-4 and float(e_hip.median()) <= float(e_cpu.median())           # the product is the most exact of the three
+    assert float(d_ref.median()) > 0.2 * float(e_cpu.median())                                    # the two "references" disagree at the level of their own error
+    assert float((d_ref > 0).float().mean()) > 0.9
 
 
 def test_cascade_c2_hot_path_isolated(hip):
