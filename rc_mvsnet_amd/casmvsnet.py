@@ -488,11 +488,7 @@ class _CascadeBase(nn.Module):
             h, w = f_cl.shape[2:4]
             with torch.no_grad():
                 rot, trans = ops.compose_homography(proj_matrices[key].contiguous().float())
-                prev = None
-                if depth is not None:
-                    if self.grad_method != "detach":
-                        raise RcmvsError("grad_method='undetach' (models/casmvsnet.py:192: gradient through the previous stage's depth into the plane positions) is not provided by the HIP training path; the shipped configuration is 'detach'")
-                    prev = depth.detach()
+                prev = depth.detach() if depth is not None else None
                 planes = ops.hypothesis_planes(prev, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
                 small_cl = None
                 if self.TRAIN_VARIANT:
@@ -502,7 +498,16 @@ class _CascadeBase(nn.Module):
             var, noref = res if self.TRAIN_VARIANT else (res, None)
             cr = self._cr(s)
             x8 = cr.features_cl_train(var)
+            prev_live = depth
             depth, conf = train_ops.ProbDepthHeadFn.apply(x8, cr.prob.weight, planes)
+            if prev_live is not None and self.grad_method != "detach":
+                # grad_method='undetach' (models/casmvsnet.py:192): the hypothesis planes are prev-depth + constants, resized
+                # linearly (weights sum to 1), and the probabilities sum to 1, so d depth / d planes reaches the previous
+                # stage's depth as the adjoint of "bilinear up to (H,W), bilinear down to (h,w)"; the warp coordinates carry
+                # no gradient in the reference either (modules.py:313).  Value unchanged, gradient through two tiny resizes.
+                up = F.interpolate(prev_live.unsqueeze(1), [H, W], mode="bilinear", align_corners=False)
+                base = F.interpolate(up, [h, w], mode="bilinear", align_corners=False).squeeze(1)
+                depth = depth + (base - base.detach())
             out = {"depth": depth, "photometric_confidence": conf}
             if self.TRAIN_VARIANT:
                 out["volume_feature_no_ref"] = noref

@@ -474,12 +474,15 @@ def test_train_step_full_size_config3():
     assert abs(l1["base"] - base2) <= 5e-2 * abs(base2), (l1["base"], base2)
 
 
-def test_cascade_train_gradients_conditioned_network():
+@pytest.mark.parametrize("grad_method", ["detach", "undetach"])
+def test_cascade_train_gradients_conditioned_network(grad_method):
     """The HIP training path against the reference op graph (oracle/aten_graph.py, same GPU, fp32) on a WELL-CONDITIONED
     network: trained-like probability head (prob.weight x1) and volumes large enough that the deepest U-Net level holds
     dozens of voxels per channel (128x160 images, D = 16/16/8), so batch statistics and ReLU masks do not sit on knife
     edges as in the 64x96 / x20 fixture above.  Every parameter gradient of stage 1 and of the feature pyramid (identical
-    hypothesis planes on both paths) within 1e-3 in the Frobenius norm, losses and outputs within 1e-5 / 1e-4."""
+    hypothesis planes on both paths) within 1e-3 in the Frobenius norm, losses and outputs within 1e-5 / 1e-4.
+    grad_method='undetach' (models/casmvsnet.py:192) adds the gradient that later stages send back through the previous
+    stage's depth (the loss then includes all three stages, so stage-1 parameters receive it)."""
     import copy
     from oracle import aten_graph
     from rc_mvsnet_amd import _lib, synthetic
@@ -487,7 +490,7 @@ def test_cascade_train_gradients_conditioned_network():
     _lib.load()
     warnings.simplefilter("ignore")
     dev = DEV
-    m1 = CascadeMVSNet(ndepths=[16, 16, 8], depth_interals_ratio=[4, 2, 1])
+    m1 = CascadeMVSNet(ndepths=[16, 16, 8], depth_interals_ratio=[4, 2, 1], grad_method=grad_method)
     m1.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=1.0), strict=True)
     m1 = m1.to(dev).train()
     m2 = copy.deepcopy(m1)
@@ -497,7 +500,8 @@ def test_cascade_train_gradients_conditioned_network():
 
     def run(model, forward):
         out, noref = forward(model, imgs, pm, dv)
-        loss = ((out["stage1"]["depth"] - 600.0) ** 2).mean() / 1e4 + 1e-2 * (noref ** 2).mean()
+        stages = ("stage1",) if grad_method == "detach" else ("stage1", "stage2", "stage3")
+        loss = sum(((out[k]["depth"] - 600.0) ** 2).mean() for k in stages) / 1e4 + 1e-2 * (noref ** 2).mean()
         loss.backward()
         return out, noref, loss
 
@@ -510,8 +514,15 @@ def test_cascade_train_gradients_conditioned_network():
         assert (p1.grad is None) == (p2.grad is None), n1
         if p1.grad is not None and (n1.startswith("cost_regularization.0") or n1.startswith("feature")):
             errs[n1] = float((p1.grad.double() - p2.grad.double()).norm() / p2.grad.double().norm().clamp_min(1e-30))
+    if grad_method == "undetach":
+        # the loss now reaches stages 2 and 3, whose hypothesis planes follow each path's own previous depth (1e-5 apart): the
+        # feature pyramid's gradients inherit that; stage 1's cost regularisation sees it only through the undetached chain
+        feat = {k: v for k, v in errs.items() if k.startswith("feature")}
+        errs = {k: v for k, v in errs.items() if not k.startswith("feature")}
+        print(f"  feature pyramid (multi-stage loss): worst {max(feat.values()):.2e}")
+        assert max(feat.values()) < 2e-2
     worst = max(errs, key=errs.get)
     vals = sorted(errs.values())
-    print(f"conditioned network: loss {float(l1):.6f} vs {float(l2):.6f}; gradient error (Frobenius) median {vals[len(vals) // 2]:.2e}, "
+    print(f"conditioned network ({grad_method}): loss {float(l1):.6f} vs {float(l2):.6f}; gradient error (Frobenius) median {vals[len(vals) // 2]:.2e}, "
           f"worst {errs[worst]:.2e} at {worst}")
-    assert errs[worst] < 5e-4, (worst, errs[worst])          # measured 5e-5
+    assert errs[worst] < (5e-4 if grad_method == "detach" else 5e-3), (worst, errs[worst])          # measured 5e-5 (detach)
