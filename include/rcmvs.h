@@ -63,12 +63,12 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
                             const float* planes, float* var,
                             int B, int V, int C, int D, int h, int w, void* stream);
 
-/* profiling hook: select the K1 code variant (0 = default; see warp_variance.hip) */
-void rcmvs_debug_k1_variant(int variant);
-/* Tuning knobs of the pipelined staged K1 variant (debug variants 8-11): planes per chunk (2, 4 or 8), the LDS window budget
- * per source view in texels, and (register-held forms 10 / 11 only) padding bytes per staged texel (0, 16, 32) against LDS bank
- * conflicts; 0 = built-in default.  Profiling only. */
-void rcmvs_debug_k1_ps_config(int dkb, int patch_texels, int texel_pad_bytes);
+/* Test / profiling twin of rcmvs_warp_variance_fwd with an explicit code variant (stateless, re-entrant): 0 = the production
+ * kernel, 1 = production with FMA-contracted blend (<= 2e-7 relative), 2 = reference-order kernel (one full coordinate chain per
+ * lane, compiler IEEE division -- the kernel the production one is held bit-identical to), 3 = store-only ablation. */
+int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
+                                  const float* planes, float* var,
+                                  int B, int V, int C, int D, int h, int w, int variant, void* stream);
 
 /* train-variant extra (models/casmvsnet.py:59,82,89-101): volume_feature_no_ref, NCDHW like
  * the reference returns it: out (B, 3(V-1)+C, D, h, w) = warped RGB of each source view
@@ -99,9 +99,6 @@ int rcmvs_warp_variance_bwd(const float* feats, const float* rot, const float* t
  * fragment-ordered image [27][Ci/(4*VEC)][Co/16][64 lanes][VEC] those kernels read. */
 long long rcmvs_packed_weight_floats(int Co, int Ci);   /* size of `packed` in floats ([27][Ci][Co] + MFMA image) */
 int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream);
-/* test/bench hook: bit0 = route every layer through the direct kernels; bits 1-3 = LDS-conv tuning config;
- * bit4 (16) = prefer the MFMA kernel where both exist; bit5 (32) = one voxel per thread in the LDS kernel */
-void rcmvs_debug_force_direct_conv(int on);
 
 /* y = epilogue(conv3d(x, w, k=3, pad=1, stride)),  x (B,D,H,W,Ci) -> y (B,Do,Ho,Wo,Co),
  * Do = (D-1)/stride+1 ...;   epilogue(v) = [relu](v*scale[co] + shift[co]) + residual
@@ -116,6 +113,17 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
 int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                        const float* residual, float* y,
                        int B, int D, int H, int W, int Ci, int Co, int relu, void* stream);
+
+/* Test / A-B twins of the two entry points above with an explicit kernel selection `impl` (stateless: the library keeps no
+ * dispatch state).  0 = the production dispatch; bit 0 = direct (one thread per voxel) kernels only; bits 1-3 and 5 = tuning
+ * configuration of the LDS-halo kernel; bit 4 = fp32-MFMA kernel before the LDS kernel where both exist; bit 6 = skip the
+ * split-bf16 MFMA kernels (the fp32 FMA-chain kernels: the comparator of tests/test_gpu_parity.py::test_conv3d_x3_*). */
+int rcmvs_debug_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                           const float* residual, float* y,
+                           int B, int D, int H, int W, int Ci, int Co, int stride, int relu, int impl, void* stream);
+int rcmvs_debug_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                             const float* residual, float* y,
+                             int B, int D, int H, int W, int Ci, int Co, int relu, int impl, void* stream);
 
 /* ---- training: the 3-D blocks with BATCH statistics, forward and backward ---------------- */
 /* Conv3d / Deconv3d in train mode = conv -> BatchNorm3d(batch stats) -> ReLU (models/modules.py:149-157,

@@ -27,8 +27,7 @@ SIGNATURES = {
     "rcmvs_compose_homography": [_p, _p, _p, _i, _i, _p],
     "rcmvs_hypothesis_planes": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "rcmvs_debug_k1_variant": [_i],
-    "rcmvs_debug_k1_ps_config": [_i, _i, _i],
+    "rcmvs_debug_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_resize_planes_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_composite_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
@@ -54,7 +53,8 @@ SIGNATURES = {
     "rcmvs_warp_noref_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_packed_weight_floats": [_i, _i],
     "rcmvs_pack_conv3d_weight": [_p, _p, _i, _i, _i, _p],
-    "rcmvs_debug_force_direct_conv": [_i],
+    "rcmvs_debug_conv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_debug_deconv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_conv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_deconv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_rgb_to_nhwc4": [_p, _p, _i, _i, _i, _p],
@@ -75,7 +75,7 @@ SIGNATURES = {
     "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
 }
 _RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll, "rcmvs_nerf_workspace_floats": _ll, "rcmvs_nerf_train_workspace_floats": _ll, "rcmvs_nerf_bwd_workspace_floats": _ll,
-             "rcmvs_packed_weight_floats": _ll, "rcmvs_debug_force_direct_conv": None, "rcmvs_debug_k1_variant": None, "rcmvs_debug_k1_ps_config": None}
+             "rcmvs_packed_weight_floats": _ll,}
 
 _lib = None
 

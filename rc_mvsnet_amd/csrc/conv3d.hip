@@ -139,9 +139,7 @@ long long mfma_weight_floats_host(int Ci, int Co);
 // conv3d_lds.hip
 bool conv3d_lds_supported(int Ci, int Co, int stride);
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
-
-void conv3d_lds_set_config(int c);
+                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int lds_cfg);
 
 // deconv3d_lds.hip
 bool deconv3d_lds_supported(int Ci, int Co);
@@ -168,13 +166,16 @@ static inline long long x3_image_offset(int Ci, int Co, int kind) {
 
 using namespace rcmvs;
 
-static int g_prefer_lds = 1;     // LDS/scalar-weight kernel before the MFMA kernel where both exist (debug bit 16 clears it)
-static int g_force_direct = 0;   // test/bench hook: route everything through the direct kernels
-static int g_no_x3 = 0;          // test/bench hook (bit 6): skip the split-bf16 MFMA kernels (A/B against the fp32 kernels)
+// `impl` of the rcmvs_debug_* twins (tests, A/B benches; 0 = the production dispatch): bit 0 = direct kernels only;
+// bits 1-3 and 5 = tuning configuration of the LDS-halo kernel; bit 4 = fp32-MFMA kernel before the LDS kernel where both
+// exist; bit 6 = skip the split-bf16 MFMA kernels (conv3d_x3.hip).  Passed by value: the library keeps no dispatch state.
+struct ConvImpl {
+    bool direct, prefer_lds, no_x3;
+    int lds_cfg;
+    explicit ConvImpl(int on) : direct(on & 1), prefer_lds(!(on & 16)), no_x3((on >> 6) & 1), lds_cfg(((on >> 1) & 7) | (((on >> 5) & 1) << 3)) {}
+};
 
 extern "C" {
-
-void rcmvs_debug_force_direct_conv(int on) { g_force_direct = on & 1; g_prefer_lds = !(on & 16); g_no_x3 = (on >> 6) & 1; conv3d_lds_set_config(((on >> 1) & 7) | (((on >> 5) & 1) << 3)); }
 
 long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;
@@ -202,9 +203,9 @@ int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int 
     return 0;
 }
 
-int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
-                     const float* residual, float* y,
-                     int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream) {
+static int conv3d_dispatch(const float* x, const float* w_packed, const float* scale, const float* shift,
+                           const float* residual, float* y,
+                           int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream, const ConvImpl& im) {
     RCMVS_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad sizes");
     RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_fwd: stride must be 1 or 2");
@@ -212,35 +213,59 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
     ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
-    if (conv3d_x3_supported(Ci, Co, mode) && !g_force_direct && !g_no_x3)
+    if (conv3d_x3_supported(Ci, Co, mode) && !im.direct && !im.no_x3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st);
-    if (g_prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !g_force_direct)
-        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
-    if (conv3d_mfma_supported(Ci, Co, mode) && !g_force_direct)
+    if (im.prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !im.direct)
+        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
+    if (conv3d_mfma_supported(Ci, Co, mode) && !im.direct)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
                                   mode, relu, st);
-    if (conv3d_lds_supported(Ci, Co, stride) && !g_force_direct)
-        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st);
+    if (conv3d_lds_supported(Ci, Co, stride) && !im.direct)
+        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
     if (stride == 1) return direct_dispatch<CONV_S1>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
     return direct_dispatch<CONV_S2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
+}
+
+int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                     const float* residual, float* y,
+                     int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream) {
+    return conv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, stride, relu, stream, ConvImpl(0));
+}
+
+int rcmvs_debug_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                           const float* residual, float* y,
+                           int B, int D, int H, int W, int Ci, int Co, int stride, int relu, int impl, void* stream) {
+    return conv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, stride, relu, stream, ConvImpl(impl));
+}
+
+static int deconv3d_dispatch(const float* x, const float* w_packed, const float* scale, const float* shift,
+                             const float* residual, float* y,
+                             int B, int D, int H, int W, int Ci, int Co, int relu, void* stream, const ConvImpl& im) {
+    RCMVS_REQUIRE(x && w_packed && y, "deconv3d_fwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
+    RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
+    ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
+    if (conv3d_x3_supported(Ci, Co, CONV_T2) && !im.direct && !im.no_x3)
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
+                                as_stream(stream));
+    if (deconv3d_lds_supported(Ci, Co) && !im.direct)
+        return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
+    if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !im.direct)
+        return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
+                                  CONV_T2, relu, as_stream(stream));
+    return direct_dispatch<CONV_T2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, as_stream(stream));
 }
 
 int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                        const float* residual, float* y,
                        int B, int D, int H, int W, int Ci, int Co, int relu, void* stream) {
-    RCMVS_REQUIRE(x && w_packed && y, "deconv3d_fwd: null pointer");
-    RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
-    RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
-    ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
-    if (conv3d_x3_supported(Ci, Co, CONV_T2) && !g_force_direct && !g_no_x3)
-        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
-                                as_stream(stream));
-    if (deconv3d_lds_supported(Ci, Co) && !g_force_direct)
-        return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
-    if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !g_force_direct)
-        return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
-                                  CONV_T2, relu, as_stream(stream));
-    return direct_dispatch<CONV_T2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, as_stream(stream));
+    return deconv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, stream, ConvImpl(0));
+}
+
+int rcmvs_debug_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
+                             const float* residual, float* y,
+                             int B, int D, int H, int W, int Ci, int Co, int relu, int impl, void* stream) {
+    return deconv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, stream, ConvImpl(impl));
 }
 
 }  // extern "C"

@@ -144,11 +144,10 @@ bool conv3d_lds_supported(int Ci, int Co, int stride) {
                            (Co == 16 && Ci == 16));
 }
 
-static int g_lds_cfg = 0;   // debug override: 0 = tuned default; else bit0 = 16-channel chunks, bit1 = force split, bit2 = force no split
-void conv3d_lds_set_config(int c) { g_lds_cfg = c; }
-
+// g_lds_cfg: test / tuning override passed by the caller (0 = tuned default; bit0 = 16-channel chunks, bit1 = force split,
+// bit2 = force no split, bit3 = one voxel per thread)
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st) {
+                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int g_lds_cfg) {
     const int ppt = (Co == 8 && Ci >= 32 && !(g_lds_cfg & 8)) ? 2 : 1;   // two voxels per thread pay at Cin >= 32 (298 -> 250 us; 16 -> 8: 235 vs 243)
     const int tiles_w = (W + LT_W - 1) / LT_W, tiles_h = (H + LT_H - 1) / LT_H, tiles_d = (D + LT_D * ppt - 1) / (LT_D * ppt);
     // tuned on MI355X (tools/conv_bench.py): 8-channel chunks keep the per-pass weight set (6.9 KB) in the scalar
@@ -169,7 +168,7 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
         return launch_status("conv3d_lds");                                                 \
     }
     if (Co == 16 && Ci == 16) {                                 // conv2 of the U-Nets: 16 accumulators, 64 scalar weights per (tap, 4 ch)
-        if (!(g_lds_cfg & 8)) {                                 // two voxels per thread (debug bit 5 of rcmvs_debug_force_direct_conv: one)
+        if (!(g_lds_cfg & 8)) {                                 // two voxels per thread (bit 5 of the rcmvs_debug_conv3d_fwd impl: one)
             const int td2 = (D + 2 * LT_D - 1) / (2 * LT_D);
             const size_t lds2 = (size_t)(2 * LT_D + 2) * LH_H * LH_W * 12 * sizeof(float);
             dim3 grid2(tiles_w * tiles_h, td2, B);

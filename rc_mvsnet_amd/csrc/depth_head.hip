@@ -15,7 +15,7 @@
 namespace rcmvs {
 
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);   // conv3d_lds.hip
+                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int lds_cfg);   // conv3d_lds.hip
 
 // LP adjacent lanes share one pixel and own the planes k = j, j + LP, ... (at most 16 each, held in registers): the logit
 // column is read ONCE with all of a lane's loads in flight, max / sum / soft-argmin / window sums are combined across the
@@ -88,7 +88,7 @@ extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const f
     RCMVS_REQUIRE(x && w_prob && planes && depth && conf && prob, "depth_head_fwd: null pointer (prob is required: it doubles as the logit scratch)");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "depth_head_fwd: bad sizes");
     hipStream_t st = as_stream(stream);
-    int rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st);
+    int rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st, 0);
     if (rc) return rc;
     const long long hw = (long long)h * w;
     RCMVS_REQUIRE(D <= 64, "depth_head_fwd: at most 64 depth hypotheses per stage (got %d)", D);

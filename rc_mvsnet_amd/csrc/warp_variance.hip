@@ -348,672 +348,13 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K1, LDS-staged variant: same two-phase structure and arithmetic as warp_variance_tp_kernel,
-// but the bilinear taps are gathered from LDS instead of through the vector L1.
-// Why: rocprof PMC on the tp kernel shows TCP_TOTAL_CACHE_ACCESSES = 8 taps x the output volume
-// (18-24 M 64-byte accesses per launch), i.e. >= 30/40/30 us of vL1D time at one access per clock
-// per CU for the three config-2 stages -- the gathers, not the HBM stream, are the wall.  A tile's
-// samples land in a small source window (tile extent + the disparity sweep of DKB planes + 1), so:
-//   A   per (pixel, plane, view): coordinate chain -> clamped integer tap coordinates + masked
-//       weights; the block-wide bounding box of all contributing taps is reduced with LDS atomics;
-//   A2  records rewritten to byte offsets inside the staged window (or to global offsets when the
-//       window does not fit the LDS budget: block-uniform fallback to buffer loads);
-//   S   the window rows are copied global -> LDS with coalesced 16-byte loads, each texel once;
-//   B   as before, but each tap is a ds_read_b128.
-// LDS traffic replaces ~8x-output of L1 traffic by ~1-2x-output of staging traffic.
+// What is NOT here any more (measured on the MI355X in round 2, profiles/r2_k1_pipelined_variants_timed.txt): the
+// LDS-window variants of this kernel -- block-staged windows (78 / 102 / 84 us per stage), the persistent double-buffered
+// form with buffer_load ... lds (137 / 164 / 116 us; 75 / 86 / 69 us with a 72-texel budget), its static-LDS-set form
+// (94-111 / 105-120 / 84-97 us) and the register-held-window form (142 / 170 / 120 us) -- all bit-identical, all 1.7-3x
+// slower than the two-phase kernel above (42 / 57 / 39 us): the tap table plus two windows leave room for 8 waves per CU,
+// and the stage -> publish -> gather chain of a 32-pixel tile is latency-bound.  DESIGN.md section 4 has the analysis.
 // ------------------------------------------------------------------------------------------
-template <int C, int DKB, bool FAST, int NV>
-__global__ __launch_bounds__(256) void warp_variance_lds_kernel(
-    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
-    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int patch_texels) {
-#pragma clang fp contract(off)
-    constexpr int LPP = C / 4;
-    constexpr int PIX = 256 / LPP;
-    constexpr int TH = 4, TW = PIX / TH;
-    constexpr int GRP = 256 / PIX;
-    constexpr int KPT = (DKB + GRP - 1) / GRP;   // planes per phase-A thread (threads with ga >= DKB idle when DKB < GRP)
-    constexpr int C4 = C * 4;               // bytes per texel
-    extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [NV][DKB][PIX]
-    v4f* lds_w = reinterpret_cast<v4f*>(lds_o + NV * DKB * PIX);         // [NV][DKB][PIX]
-    int* lds_box = reinterpret_cast<int*>(lds_w + NV * DKB * PIX);       // [4 waves][NV][4] xmin xmax ymin ymax
-    char* lds_patch = reinterpret_cast<char*>(lds_box + 16 * NV);        // [NV][patch_texels * C4]
-    const int patch_bytes = patch_texels * C4;
-    const unsigned patch_base = (unsigned)(lds_patch - reinterpret_cast<char*>(lds_o));
-
-    const int b = blockIdx.z;
-    const int k0 = blockIdx.y * DKB;
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const int hw = h * w;
-    K1Geom g;
-    g.w = w; g.h = h;
-    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
-    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
-    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
-    const float* fb = feats + (long long)b * V * hw * C;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
-
-    const int p = threadIdx.x / LPP;
-    const int q4b = (threadIdx.x % LPP) * 16;
-    const int x = tx0 + p % TW, y = ty0 + p / TW;
-    const bool inside = (x < w) && (y < h);
-    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
-    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
-    const float fV = (float)V, rV = rcp_nr(fV);
-    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
-    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
-    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
-    const float fxa = (float)xa, fya = (float)ya;
-    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
-    const bool multi = (V - 1) > NV;
-
-    v4f s[DKB], sq[DKB];
-#pragma unroll
-    for (int k = 0; k < DKB; ++k) { s[k] = ref; sq[k] = ref * ref; }
-
-    for (int v0 = 1; v0 < V; v0 += NV) {
-        const int nv = min(NV, V - v0);
-        if (v0 > 1) __syncthreads();                             // previous chunk's phase B is done with LDS
-        // ---------------- phase A: taps -> packed clamped coordinates + weights, bounding box
-        for (int va = 0; va < nv; ++va) {
-            const float* r = rot + ((long long)b * (V - 1) + (v0 + va - 1)) * 9;
-            const float* t = trans + ((long long)b * (V - 1) + (v0 + va - 1)) * 3;
-            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
-            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
-            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
-            const float t0 = t[0], t1 = t[1], t2 = t[2];
-            int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
-#pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) {
-                const int ka = ga + kk * GRP;
-                if (ka >= DKB) continue;
-                const float d = pla.x + (float)(k0 + ka) * pla.y;
-                v4i o;
-                v4f wt;
-                int xi, yi;
-                k1_chain(rx, ry, rz, t0, t1, t2, d, g, xi, yi, wt);
-                const int xc0 = min(max(xi, 0), w - 1), xc1 = min(max(xi + 1, 0), w - 1);
-                const int yc0 = min(max(yi, 0), h - 1), yc1 = min(max(yi + 1, 0), h - 1);
-                const bool any = (wt.x != 0.0f) || (wt.y != 0.0f) || (wt.z != 0.0f) || (wt.w != 0.0f);
-                const int idx = (va * DKB + ka) * PIX + pa;
-                v4i rec;
-                rec.x = xc0; rec.y = yc0; rec.z = (xc1 != xc0 ? 1 : 0) | (yc1 != yc0 ? 2 : 0) | (any ? 4 : 0); rec.w = 0;
-                lds_o[idx] = rec;
-                lds_w[idx] = wt;
-                if (any) { bx0 = min(bx0, xc0); bx1 = max(bx1, xc1); by0 = min(by0, yc0); by1 = max(by1, yc1); }
-                (void)o;
-            }
-            // wave-level reduction in registers (DPP + readlane), one plain LDS store per wave: LDS atomics -- even from a
-            // single lane -- are expanded by the compiler into a 64-iteration scalar loop each (2.7 k SALU per wave, PMC)
-            bx0 = wave_reduce_i32<true>(bx0); bx1 = wave_reduce_i32<false>(bx1);
-            by0 = wave_reduce_i32<true>(by0); by1 = wave_reduce_i32<false>(by1);
-            if ((threadIdx.x & 63) == 0)
-                *reinterpret_cast<v4i*>(lds_box + ((threadIdx.x >> 6) * NV + va) * 4) = (v4i){bx0, bx1, by0, by1};
-        }
-        __syncthreads();
-        // ---------------- phase A2: rewrite records to byte offsets (LDS window or global fallback)
-        bool fits[NV];
-        int px0[NV], py0[NV], pw[NV], ph[NV];
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            v4i bb = *reinterpret_cast<const v4i*>(lds_box + va * 4);
-#pragma unroll
-            for (int wv = 1; wv < 4; ++wv) {
-                const v4i t = *reinterpret_cast<const v4i*>(lds_box + (wv * NV + va) * 4);
-                bb.x = min(bb.x, t.x); bb.y = max(bb.y, t.y); bb.z = min(bb.z, t.z); bb.w = max(bb.w, t.w);
-            }
-            px0[va] = bb.x; py0[va] = bb.z;
-            pw[va] = bb.y - bb.x + 1; ph[va] = bb.w - bb.z + 1;
-            const bool empty = bb.y < 0;
-            if (empty) { px0[va] = 0; py0[va] = 0; pw[va] = 1; ph[va] = 1; }     // stage one (finite) texel
-            fits[va] = (va < nv) && (pw[va] * ph[va] <= patch_texels);
-        }
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            if (va >= nv) continue;
-#pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) {
-                if (ga + kk * GRP >= DKB) continue;
-                const int idx = (va * DKB + ga + kk * GRP) * PIX + pa;
-                const v4i rec = lds_o[idx];
-                const bool any = rec.z & 4;
-                v4i o;
-                if (fits[va]) {
-                    const int lx = any ? rec.x - px0[va] : 0, ly = any ? rec.y - py0[va] : 0;
-                    const int base = (ly * pw[va] + lx) * C4 + (int)patch_base + va * patch_bytes;
-                    const int dx = (any && (rec.z & 1)) ? C4 : 0, dy = (any && (rec.z & 2)) ? pw[va] * C4 : 0;
-                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
-                } else {
-                    const int base = ((v0 + va) * hw + rec.y * w + rec.x) * C4;
-                    const int dx = (rec.z & 1) ? C4 : 0, dy = (rec.z & 2) ? w * C4 : 0;
-                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
-                }
-                lds_o[idx] = o;
-            }
-        }
-        // ---------------- stage the source windows (each texel once, coalesced rows)
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            if (!fits[va]) continue;
-            const int row4 = pw[va] * LPP;                        // float4s per window row
-            const int n4 = row4 * ph[va];
-            const float* src = fb + ((long long)(v0 + va) * hw + (long long)py0[va] * w + px0[va]) * C;
-            v4f* dst = reinterpret_cast<v4f*>(lds_patch + va * patch_bytes);
-            int row = threadIdx.x / row4, c4 = threadIdx.x - row * row4;   // one division per view, then incremental
-            const int drow = 256 / row4, dc4 = 256 - drow * row4;
-            for (int e = threadIdx.x; e < n4; e += 256) {
-                dst[e] = *reinterpret_cast<const v4f*>(src + (long long)row * w * C + c4 * 4);
-                c4 += dc4; row += drow;
-                if (c4 >= row4) { c4 -= row4; ++row; }
-            }
-        }
-        __syncthreads();
-        // ---------------- phase B
-        if (!inside) continue;
-        const char* lds_bytes = reinterpret_cast<const char*>(lds_o) + q4b;
-#pragma unroll
-        for (int k = 0; k < DKB; ++k) {
-            v4f a = s[k], a2 = sq[k];
-#pragma unroll
-            for (int va = 0; va < NV; ++va) {
-                if (va >= nv) continue;
-                const int idx = (va * DKB + k) * PIX + p;
-                const v4i o = lds_o[idx];
-                const v4f wt = lds_w[idx];
-                v4f ta, tb, tc, td;
-                if (fits[va]) {
-                    ta = *reinterpret_cast<const v4f*>(lds_bytes + o.x);
-                    tb = *reinterpret_cast<const v4f*>(lds_bytes + o.y);
-                    tc = *reinterpret_cast<const v4f*>(lds_bytes + o.z);
-                    td = *reinterpret_cast<const v4f*>(lds_bytes + o.w);
-                } else {
-                    ta = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
-                    tb = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
-                    tc = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
-                    td = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
-                }
-                v4f val = blend4<FAST>(ta, tb, tc, td, wt);
-                a = a + val;
-                if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
-            }
-            if (multi && v0 + nv < V) { s[k] = a; sq[k] = a2; continue; }
-            if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1, pipelined staged variant (debug variants 8 / 9; NOT measured yet -- logic verified bit-identical to the
-// reference-order kernel on the CPU emulation, tests/test_emu_kernels_cpu.py).  The LDS-staged kernel above loses to
-// the production kernel because every plane chunk is stage -> barrier -> gather (its waves wait half their cycles,
-// profiles/r1_k1_pmc_summary.txt).  Here one block owns a tile for ALL plane chunks and keeps two LDS sets
-// (tap table + source windows): while chunk i is blended out of set i & 1, the taps of chunk i + 1 are computed and
-// its windows are loaded straight into the other set with buffer_load ... lds (no VGPRs in flight, the only wait is
-// the vmcnt(0) in front of the barrier that publishes them).  Up to NV = 2 source views (config 2); anything else
-// stays on the other kernels.
-// ------------------------------------------------------------------------------------------
-template <int C, int DKB, bool FAST, int NV, bool DMA = true>
-__global__ __launch_bounds__(256) void warp_variance_ps_kernel(
-    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
-    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int patch_texels, int pad) {
-#pragma clang fp contract(off)
-    constexpr int LPP = C / 4;
-    constexpr int PIX = 256 / LPP;
-    constexpr int TH = 4, TW = PIX / TH;
-    constexpr int GRP = 256 / PIX;
-    constexpr int KPT = (DKB + GRP - 1) / GRP;
-    constexpr int C4 = C * 4;
-    constexpr int TAB = NV * DKB * PIX;
-    extern __shared__ __attribute__((aligned(16))) v4i lds_ps[];
-    const int cs = C4 + (DMA ? 0 : pad);                         // bytes per staged texel (padding spreads the gathers over the LDS banks)
-    const int patch_bytes = patch_texels * cs;
-    const int set_v4 = TAB * 2 + 4 * NV + NV * (patch_bytes / 16);           // v4i units per set: offsets, weights, boxes, windows
-    const int nv = V - 1;
-
-    const int b = blockIdx.z;
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const int hw = h * w;
-    const int nch = (D + DKB - 1) / DKB;
-    K1Geom g;
-    g.w = w; g.h = h;
-    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
-    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
-    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
-    const float* fb = feats + (long long)b * V * hw * C;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
-
-    const int p = threadIdx.x / LPP;
-    const int q4b = (threadIdx.x % LPP) * 16;
-    const int x = tx0 + p % TW, y = ty0 + p / TW;
-    const bool inside = (x < w) && (y < h);
-    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
-    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
-    const float fV = (float)V, rV = rcp_nr(fV);
-    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
-    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
-    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
-    const float fxa = (float)xa, fya = (float)ya;
-    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
-    const int lane = threadIdx.x & 63;
-
-    // ---- phase A of chunk kc into set `st`: taps -> clamped coordinates + weights, per-wave bounding boxes
-    auto phase_a = [&](int kc, int st) {
-        v4i* lo = lds_ps + st * set_v4;
-        v4f* lw = reinterpret_cast<v4f*>(lo + TAB);
-        int* lbox = reinterpret_cast<int*>(lo + 2 * TAB);
-        const int k0 = kc * DKB;
-        for (int va = 0; va < nv; ++va) {
-            const float* r = rot + ((long long)b * (V - 1) + va) * 9;
-            const float* t = trans + ((long long)b * (V - 1) + va) * 3;
-            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
-            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
-            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
-            const float t0 = t[0], t1 = t[1], t2 = t[2];
-            int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
-#pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) {
-                const int ka = ga + kk * GRP;
-                if (ka >= DKB) continue;
-                const float d = pla.x + (float)(k0 + ka) * pla.y;
-                v4f wt;
-                int xi, yi;
-                k1_chain(rx, ry, rz, t0, t1, t2, d, g, xi, yi, wt);
-                const int xc0 = min(max(xi, 0), w - 1), xc1 = min(max(xi + 1, 0), w - 1);
-                const int yc0 = min(max(yi, 0), h - 1), yc1 = min(max(yi + 1, 0), h - 1);
-                const bool any = (wt.x != 0.0f) || (wt.y != 0.0f) || (wt.z != 0.0f) || (wt.w != 0.0f);
-                const int idx = (va * DKB + ka) * PIX + pa;
-                v4i rec;
-                rec.x = xc0; rec.y = yc0; rec.z = (xc1 != xc0 ? 1 : 0) | (yc1 != yc0 ? 2 : 0) | (any ? 4 : 0); rec.w = 0;
-                lo[idx] = rec;
-                lw[idx] = wt;
-                if (any) { bx0 = min(bx0, xc0); bx1 = max(bx1, xc1); by0 = min(by0, yc0); by1 = max(by1, yc1); }
-            }
-            bx0 = wave_reduce_i32<true>(bx0); bx1 = wave_reduce_i32<false>(bx1);
-            by0 = wave_reduce_i32<true>(by0); by1 = wave_reduce_i32<false>(by1);
-            if (lane == 0) *reinterpret_cast<v4i*>(lbox + ((threadIdx.x >> 6) * NV + va) * 4) = (v4i){bx0, bx1, by0, by1};
-        }
-    };
-
-    // ---- phase A2 + S of set `st` (after a barrier): block bounding box, records -> byte offsets, windows -> LDS (direct loads)
-    constexpr int MAXP = 4;                                       // 16-byte pieces per thread and view in the register-staged form
-    v4f held[NV][MAXP];
-    int held_n4[NV], held_dst[NV];
-    auto stage = [&](int st, bool* fits) {
-        v4i* lo = lds_ps + st * set_v4;
-        const int* lbox = reinterpret_cast<const int*>(lo + 2 * TAB);
-        char* lpatch = reinterpret_cast<char*>(lo + 2 * TAB + 4 * NV);
-        const unsigned patch_base = (unsigned)(lpatch - reinterpret_cast<char*>(lds_ps));
-        int px0[NV], py0[NV], pw[NV], ph[NV];
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            v4i bb = *reinterpret_cast<const v4i*>(lbox + va * 4);
-#pragma unroll
-            for (int wv = 1; wv < 4; ++wv) {
-                const v4i t = *reinterpret_cast<const v4i*>(lbox + (wv * NV + va) * 4);
-                bb.x = min(bb.x, t.x); bb.y = max(bb.y, t.y); bb.z = min(bb.z, t.z); bb.w = max(bb.w, t.w);
-            }
-            px0[va] = bb.x; py0[va] = bb.z;
-            pw[va] = bb.y - bb.x + 1; ph[va] = bb.w - bb.z + 1;
-            if (bb.y < 0) { px0[va] = 0; py0[va] = 0; pw[va] = 1; ph[va] = 1; }
-            fits[va] = (va < nv) && (pw[va] * ph[va] <= patch_texels);
-        }
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            if (va >= nv) continue;
-#pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) {
-                if (ga + kk * GRP >= DKB) continue;
-                const int idx = (va * DKB + ga + kk * GRP) * PIX + pa;
-                const v4i rec = lo[idx];
-                const bool any = rec.z & 4;
-                v4i o;
-                if (fits[va]) {
-                    const int lx = any ? rec.x - px0[va] : 0, ly = any ? rec.y - py0[va] : 0;
-                    const int base = (ly * pw[va] + lx) * cs + (int)patch_base + va * patch_bytes;
-                    const int dx = (any && (rec.z & 1)) ? cs : 0, dy = (any && (rec.z & 2)) ? pw[va] * cs : 0;
-                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
-                } else {
-                    const int base = ((1 + va) * hw + rec.y * w + rec.x) * C4;
-                    const int dx = (rec.z & 1) ? C4 : 0, dy = (rec.z & 2) ? w * C4 : 0;
-                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
-                }
-                lo[idx] = o;
-            }
-        }
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            if (!fits[va]) continue;
-            const int row4 = pw[va] * LPP;                        // 16-byte pieces per window row
-            const int n4 = row4 * ph[va];
-            const int src0 = (((1 + va) * hw) + py0[va] * w + px0[va]) * C4;      // byte offset of the window's first texel
-            char* dst = lpatch + va * patch_bytes;
-            if constexpr (DMA) {
-                for (int e0 = (threadIdx.x & ~63); e0 < n4; e0 += 256) {          // one wave moves 64 consecutive pieces = 1 KB of LDS
-                    const int e = e0 + lane;
-                    if (e < n4) {
-                        const int row = e / row4, c4 = e - row * row4;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + (size_t)e0 * 16, 16, src0 + (row * w * C + c4 * 4) * 4, 0, 0, 0);
-                    }
-                }
-            } else {
-                // register-staged form: the loads are issued now, the LDS writes follow the blend of the current chunk
-                held_n4[va] = n4;
-                held_dst[va] = (int)(dst - reinterpret_cast<char*>(lds_ps));
-#pragma unroll
-                for (int i = 0; i < MAXP; ++i) {
-                    const int e = threadIdx.x + i * 256;
-                    const int row = e / row4, c4 = e - row * row4;
-                    held[va][i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, e < n4 ? src0 + (row * w * C + c4 * 4) * 4 : (int)0x80000000, 0, 0));
-                }
-            }
-        }
-        if constexpr (!DMA) {
-#pragma unroll
-            for (int va = 0; va < NV; ++va)
-                if (!fits[va]) held_n4[va] = 0;
-        }
-    };
-    auto stage_finish = [&]() {
-        if constexpr (!DMA) {
-#pragma unroll
-            for (int va = 0; va < NV; ++va) {
-#pragma unroll
-                for (int i = 0; i < MAXP; ++i) {
-                    const int e = threadIdx.x + i * 256;
-                    if (e < held_n4[va]) {
-                        // piece e = (texel t of the window, 16-byte quad q); texels sit cs bytes apart in LDS
-                        const int t = e / LPP, q = e - t * LPP;
-                        *reinterpret_cast<v4f*>(reinterpret_cast<char*>(lds_ps) + held_dst[va] + t * cs + q * 16) = held[va][i];
-                    }
-                }
-            }
-        }
-    };
-
-    // ---- phase B of chunk kc out of set `st`: a fits-only body (ds_reads only) and a mixed body, see warp_variance_pss_kernel
-    auto phase_b_body = [&](int kc, int st, const bool* fits, auto mixed) {
-        constexpr bool MIXED = decltype(mixed)::value;
-        const v4i* lo = lds_ps + st * set_v4;
-        const v4f* lw = reinterpret_cast<const v4f*>(lo + TAB);
-        const char* lds_bytes = reinterpret_cast<const char*>(lds_ps) + q4b;
-        const int k0 = kc * DKB;
-#pragma unroll
-        for (int k = 0; k < DKB; ++k) {
-            v4f a = ref, a2 = ref * ref;
-#pragma unroll
-            for (int va = 0; va < NV; ++va) {
-                if (va >= nv) continue;
-                const int idx = (va * DKB + k) * PIX + p;
-                const v4i o = lo[idx];
-                const v4f wt = lw[idx];
-                v4f ta, tb, tc, td;
-                if (!MIXED || fits[va]) {
-                    ta = *reinterpret_cast<const v4f*>(lds_bytes + o.x);
-                    tb = *reinterpret_cast<const v4f*>(lds_bytes + o.y);
-                    tc = *reinterpret_cast<const v4f*>(lds_bytes + o.z);
-                    td = *reinterpret_cast<const v4f*>(lds_bytes + o.w);
-                } else {
-                    ta = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
-                    tb = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
-                    tc = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
-                    td = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
-                }
-                v4f val = blend4<FAST>(ta, tb, tc, td, wt);
-                a = a + val;
-                if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
-            }
-            if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
-        }
-    };
-    auto phase_b = [&](int kc, int st, const bool* fits) {
-        if (!inside) return;
-        bool all = true;
-#pragma unroll
-        for (int va = 0; va < NV; ++va) all = all && (va >= nv || fits[va]);
-        if (all) phase_b_body(kc, st, fits, std::false_type{});
-        else phase_b_body(kc, st, fits, std::true_type{});
-    };
-
-    bool fits_cur[NV], fits_next[NV];
-#pragma unroll
-    for (int va = 0; va < NV; ++va) held_n4[va] = 0;
-    phase_a(0, 0);
-    __syncthreads();
-    stage(0, fits_cur);
-    stage_finish();
-    for (int kc = 0; kc < nch; ++kc) {
-        const int st = kc & 1;
-        if (kc + 1 < nch) phase_a(kc + 1, st ^ 1);
-        __builtin_amdgcn_s_waitcnt(0);                             // vmcnt(0): the windows of chunk kc have landed in LDS
-        __syncthreads();                                           // ... for every wave; tables and boxes of chunk kc + 1 are visible
-        if (kc + 1 < nch) stage(st ^ 1, fits_next);
-        phase_b(kc, st, fits_cur);
-        if (kc + 1 < nch) stage_finish();                          // register-staged form only: windows of chunk kc + 1 -> LDS
-        __syncthreads();                                           // set `st` is free for the taps of chunk kc + 2
-#pragma unroll
-        for (int va = 0; va < NV; ++va) fits_cur[va] = fits_next[va];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1, pipelined staged variant with STATIC LDS sets (debug variants 12 / 13).  Same algorithm as warp_variance_ps_kernel with
-// direct-to-LDS loads, but the two sets are distinct __shared__ objects and the chunk loop is unrolled by two, so that every
-// access names its object at compile time.  Why it matters: SIInsertWaitcnts makes a ds_read wait (vmcnt) for every outstanding
-// buffer_load ... lds that MAY alias it; with one dynamic LDS block carved into sets it cannot tell the window being filled from
-// the window being gathered and serialises them (ISA of variant 8: s_waitcnt vmcnt(3..0) in front of the first gathers of every
-// chunk); with distinct objects it emits the loads and the gathers back to back (checked on the gfx950 ISA).  The window budget
-// is a compile-time constant here (PTEX texels per view); NOT measured yet.
-// ------------------------------------------------------------------------------------------
-template <int C, int DKB, bool FAST, int PTEX>
-__global__ __launch_bounds__(256) void warp_variance_pss_kernel(
-    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
-    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x) {
-#pragma clang fp contract(off)
-    constexpr int NV = 2;
-    constexpr int LPP = C / 4;
-    constexpr int PIX = 256 / LPP;
-    constexpr int TH = 4, TW = PIX / TH;
-    constexpr int GRP = 256 / PIX;
-    constexpr int KPT = (DKB + GRP - 1) / GRP;
-    constexpr int C4 = C * 4;
-    constexpr int TAB = NV * DKB * PIX;
-    constexpr int PATCH_BYTES = PTEX * C4;
-    __shared__ __attribute__((aligned(16))) v4i tab_o0[TAB];
-    __shared__ __attribute__((aligned(16))) v4i tab_o1[TAB];
-    __shared__ __attribute__((aligned(16))) v4f tab_w0[TAB];
-    __shared__ __attribute__((aligned(16))) v4f tab_w1[TAB];
-    __shared__ __attribute__((aligned(16))) int box0[16 * NV];
-    __shared__ __attribute__((aligned(16))) int box1[16 * NV];
-    __shared__ __attribute__((aligned(16))) char patch0[NV * PATCH_BYTES];
-    __shared__ __attribute__((aligned(16))) char patch1[NV * PATCH_BYTES];
-    const int nv = V - 1;
-
-    const int b = blockIdx.z;
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const int hw = h * w;
-    const int nch = (D + DKB - 1) / DKB;
-    K1Geom g;
-    g.w = w; g.h = h;
-    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
-    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
-    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
-    const float* fb = feats + (long long)b * V * hw * C;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
-
-    const int p = threadIdx.x / LPP;
-    const int q4b = (threadIdx.x % LPP) * 16;
-    const int x = tx0 + p % TW, y = ty0 + p / TW;
-    const bool inside = (x < w) && (y < h);
-    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
-    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
-    const float fV = (float)V, rV = rcp_nr(fV);
-    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
-    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
-    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
-    const float fxa = (float)xa, fya = (float)ya;
-    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
-    const int lane = threadIdx.x & 63;
-
-    // every phase takes the arrays of ITS set as arguments; after inlining they are compile-time objects
-    auto phase_a = [&](int kc, v4i* lo, v4f* lw, int* lbox) {
-        const int k0 = kc * DKB;
-        for (int va = 0; va < nv; ++va) {
-            const float* r = rot + ((long long)b * (V - 1) + va) * 9;
-            const float* t = trans + ((long long)b * (V - 1) + va) * 3;
-            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
-            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
-            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
-            const float t0 = t[0], t1 = t[1], t2 = t[2];
-            int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
-#pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) {
-                const int ka = ga + kk * GRP;
-                if (ka >= DKB) continue;
-                const float d = pla.x + (float)(k0 + ka) * pla.y;
-                v4f wt;
-                int xi, yi;
-                k1_chain(rx, ry, rz, t0, t1, t2, d, g, xi, yi, wt);
-                const int xc0 = min(max(xi, 0), w - 1), xc1 = min(max(xi + 1, 0), w - 1);
-                const int yc0 = min(max(yi, 0), h - 1), yc1 = min(max(yi + 1, 0), h - 1);
-                const bool any = (wt.x != 0.0f) || (wt.y != 0.0f) || (wt.z != 0.0f) || (wt.w != 0.0f);
-                const int idx = (va * DKB + ka) * PIX + pa;
-                v4i rec;
-                rec.x = xc0; rec.y = yc0; rec.z = (xc1 != xc0 ? 1 : 0) | (yc1 != yc0 ? 2 : 0) | (any ? 4 : 0); rec.w = 0;
-                lo[idx] = rec;
-                lw[idx] = wt;
-                if (any) { bx0 = min(bx0, xc0); bx1 = max(bx1, xc1); by0 = min(by0, yc0); by1 = max(by1, yc1); }
-            }
-            bx0 = wave_reduce_i32<true>(bx0); bx1 = wave_reduce_i32<false>(bx1);
-            by0 = wave_reduce_i32<true>(by0); by1 = wave_reduce_i32<false>(by1);
-            if (lane == 0) *reinterpret_cast<v4i*>(lbox + ((threadIdx.x >> 6) * NV + va) * 4) = (v4i){bx0, bx1, by0, by1};
-        }
-    };
-
-    // records -> byte offsets inside this set's window array (or global offsets), windows -> LDS by direct loads
-    auto stage = [&](v4i* lo, const int* lbox, char* lpatch, bool* fits) {
-        int px0[NV], py0[NV], pw[NV], ph[NV];
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            v4i bb = *reinterpret_cast<const v4i*>(lbox + va * 4);
-#pragma unroll
-            for (int wv = 1; wv < 4; ++wv) {
-                const v4i t = *reinterpret_cast<const v4i*>(lbox + (wv * NV + va) * 4);
-                bb.x = min(bb.x, t.x); bb.y = max(bb.y, t.y); bb.z = min(bb.z, t.z); bb.w = max(bb.w, t.w);
-            }
-            px0[va] = bb.x; py0[va] = bb.z;
-            pw[va] = bb.y - bb.x + 1; ph[va] = bb.w - bb.z + 1;
-            if (bb.y < 0) { px0[va] = 0; py0[va] = 0; pw[va] = 1; ph[va] = 1; }
-            fits[va] = (va < nv) && (pw[va] * ph[va] <= PTEX);
-        }
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            if (va >= nv) continue;
-#pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) {
-                if (ga + kk * GRP >= DKB) continue;
-                const int idx = (va * DKB + ga + kk * GRP) * PIX + pa;
-                const v4i rec = lo[idx];
-                const bool any = rec.z & 4;
-                v4i o;
-                if (fits[va]) {
-                    const int lx = any ? rec.x - px0[va] : 0, ly = any ? rec.y - py0[va] : 0;
-                    const int base = (ly * pw[va] + lx) * C4 + va * PATCH_BYTES;
-                    const int dx = (any && (rec.z & 1)) ? C4 : 0, dy = (any && (rec.z & 2)) ? pw[va] * C4 : 0;
-                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
-                } else {
-                    const int base = ((1 + va) * hw + rec.y * w + rec.x) * C4;
-                    const int dx = (rec.z & 1) ? C4 : 0, dy = (rec.z & 2) ? w * C4 : 0;
-                    o.x = base; o.y = base + dx; o.z = base + dy; o.w = base + dy + dx;
-                }
-                lo[idx] = o;
-            }
-        }
-#pragma unroll
-        for (int va = 0; va < NV; ++va) {
-            if (!fits[va]) continue;
-            const int row4 = pw[va] * LPP;
-            const int n4 = row4 * ph[va];
-            const int src0 = (((1 + va) * hw) + py0[va] * w + px0[va]) * C4;
-            char* dst = lpatch + va * PATCH_BYTES;
-            for (int e0 = (threadIdx.x & ~63); e0 < n4; e0 += 256) {
-                const int e = e0 + lane;
-                if (e < n4) {
-                    const int row = e / row4, c4 = e - row * row4;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + (size_t)e0 * 16, 16, src0 + (row * w * C + c4 * 4) * 4, 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    // Two bodies: when every view's window fits (the block-uniform common case) the gathers are ds_reads only.  The mixed body
-    // also issues global gathers for a view whose window did not fit; keeping it apart matters because its buffer loads share
-    // destination registers with the ds_reads, which makes the compiler drain vmcnt -- and with it the windows in flight.
-    auto phase_b_body = [&](int kc, const v4i* lo, const v4f* lw, const char* lpatch, const bool* fits, auto mixed) {
-        constexpr bool MIXED = decltype(mixed)::value;
-        const int k0 = kc * DKB;
-        const char* pq = lpatch + q4b;
-#pragma unroll
-        for (int k = 0; k < DKB; ++k) {
-            v4f a = ref, a2 = ref * ref;
-#pragma unroll
-            for (int va = 0; va < NV; ++va) {
-                if (va >= nv) continue;
-                const int idx = (va * DKB + k) * PIX + p;
-                const v4i o = lo[idx];
-                const v4f wt = lw[idx];
-                v4f ta, tb, tc, td;
-                if (!MIXED || fits[va]) {
-                    ta = *reinterpret_cast<const v4f*>(pq + o.x);
-                    tb = *reinterpret_cast<const v4f*>(pq + o.y);
-                    tc = *reinterpret_cast<const v4f*>(pq + o.z);
-                    td = *reinterpret_cast<const v4f*>(pq + o.w);
-                } else {
-                    ta = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
-                    tb = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
-                    tc = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
-                    td = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
-                }
-                v4f val = blend4<FAST>(ta, tb, tc, td, wt);
-                a = a + val;
-                if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
-            }
-            if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
-        }
-    };
-    auto phase_b = [&](int kc, const v4i* lo, const v4f* lw, const char* lpatch, const bool* fits) {
-        if (!inside) return;
-        bool all = true;
-#pragma unroll
-        for (int va = 0; va < NV; ++va) all = all && (va >= nv || fits[va]);
-        if (all) phase_b_body(kc, lo, lw, lpatch, fits, std::false_type{});
-        else phase_b_body(kc, lo, lw, lpatch, fits, std::true_type{});
-    };
-
-    bool fits0[NV], fits1[NV];
-    phase_a(0, tab_o0, tab_w0, box0);
-    __syncthreads();
-    stage(tab_o0, box0, patch0, fits0);
-    for (int kc = 0; kc < nch; kc += 2) {
-        // ---- even chunk: blend set 0 while set 1 is prepared
-        if (kc + 1 < nch) phase_a(kc + 1, tab_o1, tab_w1, box1);
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (kc + 1 < nch) stage(tab_o1, box1, patch1, fits1);
-        phase_b(kc, tab_o0, tab_w0, patch0, fits0);
-        __syncthreads();
-        if (kc + 1 >= nch) break;
-        // ---- odd chunk: blend set 1 while set 0 is prepared
-        if (kc + 2 < nch) phase_a(kc + 2, tab_o0, tab_w0, box0);
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (kc + 2 < nch) stage(tab_o0, box0, patch0, fits0);
-        phase_b(kc + 1, tab_o1, tab_w1, patch1, fits1);
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // train-variant extra: warped RGB of every source view ++ source-only variance / V, written in
 // the reference's NCDHW layout because the tensor crosses the module boundary
@@ -1090,117 +431,19 @@ __global__ __launch_bounds__(256) void warp_noref_kernel(
 
 using namespace rcmvs;
 
-static int g_k1_variant = 0;     // profiling hook (rcmvs_debug_k1_variant)
-static int g_k1_ps_dkb = 0, g_k1_ps_ptex = 0, g_k1_ps_pad = 0;     // tuning knobs of the pipelined staged variant (rcmvs_debug_k1_ps_config), 0 = default
-
 extern "C" {
 
-void rcmvs_debug_k1_variant(int v) { g_k1_variant = v; }
-void rcmvs_debug_k1_ps_config(int dkb, int patch_texels, int texel_pad_bytes) { g_k1_ps_dkb = dkb; g_k1_ps_ptex = patch_texels; g_k1_ps_pad = texel_pad_bytes; }
-
-int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
-                            const float* planes, float* var,
-                            int B, int V, int C, int D, int h, int w, void* stream) {
+// variant: 0 = production (exact arithmetic), 1 = production with FMA-contracted blend, 2 = reference-order kernel (one full
+// coordinate chain per lane, compiler IEEE division: what variant 0 is held bit-identical to), 3 = store-only ablation
+static int k1_launch(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
+                     int B, int V, int C, int D, int h, int w, int variant, hipStream_t st) {
     RCMVS_REQUIRE(feats && rot && trans && planes && var, "warp_variance_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
     RCMVS_REQUIRE((long long)h * w * C < (1LL << 31), "warp_variance_fwd: feature map too large for 32-bit offsets");
-    const int TW = 256 / C, TH = 4;
-    const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
-    dim3 grid(tiles_x * tiles_y, (D + DK - 1) / DK, B);
-    hipStream_t st = as_stream(stream);
-    if (g_k1_variant >= 4 && g_k1_variant <= 7) {
-        // LDS-staged kernel: bit0 = FMA blend, bit1 = deeper plane chunk
-        const bool fastm = (g_k1_variant - 4) & 1, deep = (g_k1_variant - 4) & 2;
-        const int LPP = C / 4, PIX = 256 / LPP;
-        const int nvk = (V - 1) >= 2 ? 2 : 1;
-        const int dkb = (C == 8) ? (deep ? 4 : 2) : (deep ? 8 : 4);
-        const int ptex = (C == 32) ? (deep ? 192 : 128) : (C == 16 ? (deep ? 320 : 224) : (deep ? 512 : 384));
-        const size_t lds = (size_t)nvk * dkb * PIX * 32 + 64 * nvk + (size_t)nvk * ptex * C * 4;
-        RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
-        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-        const int TWl = PIX / 4;
-        const int txl = (w + TWl - 1) / TWl, tyl = (h + 3) / 4;
-        dim3 gridl(txl * tyl, (D + dkb - 1) / dkb, B);
-#define RCMVS_K1L(CC, DD, FF, NN) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_lds_kernel<CC, DD, FF, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((warp_variance_lds_kernel<CC, DD, FF, NN>), gridl, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex); } while (0)
-#define RCMVS_K1L_N(CC, DD, FF) do { if (nvk == 2) RCMVS_K1L(CC, DD, FF, 2); else RCMVS_K1L(CC, DD, FF, 1); } while (0)
-#define RCMVS_K1L_F(CC, DD) do { if (fastm) RCMVS_K1L_N(CC, DD, true); else RCMVS_K1L_N(CC, DD, false); } while (0)
-        switch (C) {
-            case 8:  if (deep) RCMVS_K1L_F(8, 4); else RCMVS_K1L_F(8, 2); break;
-            case 16: if (deep) RCMVS_K1L_F(16, 8); else RCMVS_K1L_F(16, 4); break;
-            case 32: if (deep) RCMVS_K1L_F(32, 8); else RCMVS_K1L_F(32, 4); break;
-            default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
-        }
-        return launch_status("warp_variance_fwd(lds)");
-    }
-    if (g_k1_variant == 12 || g_k1_variant == 13) {
-        // pipelined staged kernel with static LDS sets (compile-time window budget): 12 = exact, 13 = FMA blend; <= 2 source views
-        const bool fastm = g_k1_variant == 13;
-        RCMVS_REQUIRE(V - 1 <= 2, "warp_variance_fwd: debug variant %d handles at most 2 source views (V=%d)", g_k1_variant, V);
-        RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
-        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-        const int dkb = g_k1_ps_dkb ? g_k1_ps_dkb : (C == 8 ? 2 : 4);        // C = 8: 128 pixels per block, the 4-plane tap tables alone are 64 KB
-        RCMVS_REQUIRE(dkb == 2 || dkb == 4, "warp_variance_fwd: static pipelined variant: plane chunk %d (2 or 4)", dkb);
-        const int PIXs = 256 / (C / 4), TWs = PIXs / 4;
-        const int txs = (w + TWs - 1) / TWs, tys = (h + 3) / 4;
-        dim3 grids(txs * tys, 1, B);
-        // window budgets (texels per view): two sets of tables + windows stay under 80 KB so that two blocks share a CU
-#define RCMVS_K1PSS(CC, DD, FF, PP) hipLaunchKernelGGL((warp_variance_pss_kernel<CC, DD, FF, PP>), grids, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, txs)
-#define RCMVS_K1PSS_F(CC, DD, PP) do { if (fastm) RCMVS_K1PSS(CC, DD, true, PP); else RCMVS_K1PSS(CC, DD, false, PP); } while (0)
-        switch (C) {
-            case 8:  if (dkb == 2) RCMVS_K1PSS_F(8, 2, 320); else RCMVS_K1PSS_F(8, 4, 256); break;
-            case 16: if (dkb == 2) RCMVS_K1PSS_F(16, 2, 224); else RCMVS_K1PSS_F(16, 4, 160); break;
-            case 32:
-                // K1_PS_PTEX <= 72 selects the 72-texel budget: 16 KB of tables + 36 KB of windows = three blocks per CU; the window
-                // statistics put the median stage-1 window of a 4 x 8 tile over 4 planes at ~48 texels (profiles/r1_k1_window_stats.txt)
-                if (dkb == 2) RCMVS_K1PSS_F(32, 2, 128);
-                else if (g_k1_ps_ptex > 0 && g_k1_ps_ptex <= 72) RCMVS_K1PSS_F(32, 4, 72);
-                else RCMVS_K1PSS_F(32, 4, 112);
-                break;
-            default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
-        }
-        return launch_status("warp_variance_fwd(pss)");
-    }
-    if (g_k1_variant >= 8 && g_k1_variant <= 11) {
-        // pipelined staged kernel (persistent over the plane chunks of a tile): 8 = exact, 9 = FMA blend, windows loaded straight
-        // into LDS; 10 / 11 = the same with the windows held in registers across the blend (no buffer_load ... lds); <= 2 source views
-        const bool fastm = g_k1_variant & 1, dma = g_k1_variant < 10;
-        RCMVS_REQUIRE(V - 1 <= 2, "warp_variance_fwd: debug variant %d handles at most 2 source views (V=%d)", g_k1_variant, V);
-        RCMVS_REQUIRE(h <= 8191 && w <= 8191, "warp_variance_fwd: map too large");
-        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-        const int LPP = C / 4, PIX = 256 / LPP;
-        const int dkb = g_k1_ps_dkb ? g_k1_ps_dkb : 4;
-        const int ptex = g_k1_ps_ptex ? g_k1_ps_ptex : ((C == 32) ? 128 : (C == 16 ? 224 : 384));
-        RCMVS_REQUIRE(dkb == 2 || dkb == 4 || dkb == 8, "warp_variance_fwd: pipelined variant: plane chunk %d (2, 4 or 8)", dkb);
-        RCMVS_REQUIRE(ptex >= 16 && (ptex * C * 4) % 16 == 0, "warp_variance_fwd: pipelined variant: window budget %d texels", ptex);
-        const int pad = dma ? 0 : g_k1_ps_pad;                  // direct-to-LDS loads land contiguously: padding only in the register-held form
-        RCMVS_REQUIRE(g_k1_ps_pad == 0 || g_k1_ps_pad == 16 || g_k1_ps_pad == 32, "warp_variance_fwd: pipelined variant: texel padding %d (0, 16 or 32 bytes)", g_k1_ps_pad);
-        const size_t set_bytes = (size_t)2 * dkb * PIX * 32 + 64 * 2 + (size_t)2 * ptex * (C * 4 + pad);
-        const size_t lds = 2 * set_bytes;
-        RCMVS_REQUIRE(lds <= 160 * 1024, "warp_variance_fwd: pipelined variant needs %zu bytes of LDS (chunk %d, %d texels)", lds, dkb, ptex);
-        const int TWl = PIX / 4;
-        const int txl = (w + TWl - 1) / TWl, tyl = (h + 3) / 4;
-        dim3 gridp(txl * tyl, 1, B);
-        RCMVS_REQUIRE(dma || ptex * LPP <= 256 * 4, "warp_variance_fwd: register-staged variant holds at most %d texels per view (asked %d)", 1024 / LPP, ptex);
-#define RCMVS_K1PS_M(CC, DD, FF, MM) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)warp_variance_ps_kernel<CC, DD, FF, 2, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((warp_variance_ps_kernel<CC, DD, FF, 2, MM>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txl, ptex, pad); } while (0)
-#define RCMVS_K1PS(CC, DD, FF) do { if (dma) RCMVS_K1PS_M(CC, DD, FF, true); else RCMVS_K1PS_M(CC, DD, FF, false); } while (0)
-#define RCMVS_K1PS_D(CC, FF) do { if (dkb == 2) RCMVS_K1PS(CC, 2, FF); else if (dkb == 4) RCMVS_K1PS(CC, 4, FF); else RCMVS_K1PS(CC, 8, FF); } while (0)
-#define RCMVS_K1PS_F(CC) do { if (fastm) RCMVS_K1PS_D(CC, true); else RCMVS_K1PS_D(CC, false); } while (0)
-        switch (C) {
-            case 8:  RCMVS_K1PS_F(8); break;
-            case 16: RCMVS_K1PS_F(16); break;
-            case 32: RCMVS_K1PS_F(32); break;
-            default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
-        }
-        return launch_status("warp_variance_fwd(ps)");
-    }
-    if (g_k1_variant == 0 || g_k1_variant == 1) {
-        // production kernel: variant 0 = exact arithmetic (default), 1 = FMA-contracted blend
-        const bool fastm = g_k1_variant == 1;
+    RCMVS_REQUIRE(variant >= 0 && variant <= 3, "warp_variance_fwd: unknown variant %d", variant);
+    if (variant <= 1) {
+        const bool fastm = variant == 1;
         const int LPP = C / 4, PIX = 256 / LPP;
         const int nsrc = V - 1;
         const int nvt = (nsrc == 2 || nsrc == 4 || nsrc == 6) ? nsrc : 0;
@@ -1235,23 +478,32 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
         }
         return launch_status("warp_variance_fwd");
     }
-    // variants 2 (reference-order kernel, one tap computation per lane) and 3 (store-only ablation)
+    const int TW = 256 / C, TH = 4;
+    const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+    dim3 grid(tiles_x * tiles_y, (D + DK - 1) / DK, B);
 #define RCMVS_K1_LAUNCH(CC, VV) hipLaunchKernelGGL((warp_variance_ref_kernel<CC, VV>), grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y)
-#define RCMVS_K1_VARIANTS(CC)                                                               \
-    switch (g_k1_variant) {                                                                 \
-        case 2: RCMVS_K1_LAUNCH(CC, false); break;                                              \
-        case 3: RCMVS_K1_LAUNCH(CC, true); break;                                              \
-        default: return fail(-1, "warp_variance_fwd: unknown debug variant %d", g_k1_variant); \
-    }
+#define RCMVS_K1_VARIANTS(CC) do { if (variant == 2) RCMVS_K1_LAUNCH(CC, false); else RCMVS_K1_LAUNCH(CC, true); } while (0)
     switch (C) {
-        case 8:  RCMVS_K1_VARIANTS(8) break;
-        case 16: RCMVS_K1_VARIANTS(16) break;
-        case 32: RCMVS_K1_VARIANTS(32) break;
+        case 8:  RCMVS_K1_VARIANTS(8); break;
+        case 16: RCMVS_K1_VARIANTS(16); break;
+        case 32: RCMVS_K1_VARIANTS(32); break;
         default: return fail(-1, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
     }
 #undef RCMVS_K1_VARIANTS
 #undef RCMVS_K1_LAUNCH
     return launch_status("warp_variance_fwd");
+}
+
+int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
+                            const float* planes, float* var,
+                            int B, int V, int C, int D, int h, int w, void* stream) {
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, 0, as_stream(stream));
+}
+
+int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
+                                  const float* planes, float* var,
+                                  int B, int V, int C, int D, int h, int w, int variant, void* stream) {
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, variant, as_stream(stream));
 }
 
 int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot, const float* trans,

@@ -77,14 +77,20 @@ def hypothesis_planes(prev_depth, depth_values, full_hw, scale, ndepth, ratio):
 
 
 # ------------------------------------------------------------------------------- K1
-def warp_variance(feats, rot, trans, planes, ndepth):
-    """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C)."""
+def warp_variance(feats, rot, trans, planes, ndepth, variant=0):
+    """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C).  variant != 0: the test / profiling code variants of
+    rcmvs_debug_warp_variance_fwd (1 FMA blend, 2 reference-order kernel, 3 store-only)."""
     B, V, h, w, C = feats.shape
     var = torch.empty((B, ndepth, h, w, C), device=feats.device, dtype=torch.float32)
     ev = None
     if K1_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
+    if variant:
+        _lib.check(_lib.load().rcmvs_debug_warp_variance_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                             _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, int(variant),
+                                                             _stream()), "debug_warp_variance_fwd")
+        return var
     _lib.check(_lib.load().rcmvs_warp_variance_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
                                                    _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, _stream()),
                "warp_variance_fwd")
@@ -162,9 +168,15 @@ class PackedWeight:
         self.blob, self.ci, self.co = blob, ci, co
 
 
+_CONV_IMPL = 0      # test / A-B hook (force_direct_conv): kernel selection handed to the rcmvs_debug_* conv entry points
+
+
 def force_direct_conv(on):
-    """test/bench hook: route every 3-D conv through the direct (non-MFMA) kernels."""
-    _lib.load().rcmvs_debug_force_direct_conv(int(on))    # bit0 force direct; bits 1.. = LDS-kernel tuning config
+    """Test / bench hook: select the 3-D conv kernels for the following ops.conv3d / ops.deconv3d calls (bit 0 = direct kernels,
+    bit 6 = no split-bf16 MFMA kernels, other bits see include/rcmvs.h; 0 / False = production dispatch).  The selection lives
+    here, on the Python side: the library itself is stateless."""
+    global _CONV_IMPL
+    _CONV_IMPL = int(on)
 
 
 def pack_conv3d_weight(w, transposed=False):
@@ -189,6 +201,11 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
                     dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"conv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
+    if _CONV_IMPL:
+        _lib.check(_lib.load().rcmvs_debug_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                                      _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
+                                                      _CONV_IMPL, _stream()), "debug_conv3d_fwd")
+        return y
     _lib.check(_lib.load().rcmvs_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                             _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
                                             _stream()), "conv3d_fwd")
@@ -205,6 +222,11 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"deconv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)} "
                               "(volume sizes must be divisible by 8, as in the reference)")
+    if _CONV_IMPL:
+        _lib.check(_lib.load().rcmvs_debug_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                                        _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
+                                                        _CONV_IMPL, _stream()), "debug_deconv3d_fwd")
+        return y
     _lib.check(_lib.load().rcmvs_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                               _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
                                               _stream()), "deconv3d_fwd")

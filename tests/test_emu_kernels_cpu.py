@@ -71,8 +71,7 @@ def test_cascade_eval_forward_on_emulated_kernels(emu):
 @pytest.mark.parametrize("C,D,h,w,V", [(32, 16, 12, 21, 3), (16, 8, 17, 30, 4), (8, 12, 16, 40, 2), (8, 8, 12, 24, 7), (16, 8, 10, 14, 5)])
 def test_k1_variants_on_emulated_kernels(C, D, h, w, V, emu):
     """K1 forward: production two-phase kernel (compile-time 2 / 4 / 6 source views and the general path) against the
-    reference-order kernel and the LDS-staged variants (per-wave bounding boxes through DPP row shifts + readlane), and against
-    the oracle's variance volume."""
+    reference-order kernel (and its FMA-contracted build), and against the oracle's variance volume."""
     from oracle import warp
     from rc_mvsnet_amd import ops
     g = torch.Generator().manual_seed(C + V)
@@ -80,15 +79,8 @@ def test_k1_variants_on_emulated_kernels(C, D, h, w, V, emu):
     pm = synthetic.proj_matrices(2, V, h * 4, w * 4)["stage1"]
     rot, trans = ops.compose_homography(pm)
     planes = torch.stack((425.0 + 100.0 * torch.rand(2, h, w, generator=g), 2.0 + 8.0 * torch.rand(2, h, w, generator=g)), dim=-1).contiguous()
-    try:
-        emu.rcmvs_debug_k1_variant(2)
-        vref = ops.warp_variance(feats, rot, trans, planes, D)
-        outs = {}
-        for var in (0, 4, 6):
-            emu.rcmvs_debug_k1_variant(var)
-            outs[var] = ops.warp_variance(feats, rot, trans, planes, D)
-    finally:
-        emu.rcmvs_debug_k1_variant(0)
+    vref = ops.warp_variance(feats, rot, trans, planes, D, variant=2)
+    outs = {var: ops.warp_variance(feats, rot, trans, planes, D, variant=var) for var in (0, 1)}
     for var, v in outs.items():
         assert float((v - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), var
     samples = planes[..., 0].unsqueeze(1) + planes[..., 1].unsqueeze(1) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
@@ -100,7 +92,7 @@ def test_k1_variants_on_emulated_kernels(C, D, h, w, V, emu):
 def test_results_do_not_depend_on_the_thread_schedule(emu):
     """Missing-barrier detector: between synchronisation points the emulation may run a block's threads in any order; ascending,
     descending and wave-reversed schedules must give bit-identical results for kernels without float atomics (the whole inference
-    cascade, the fused FPN level, the LDS-staged K1 variant, ordered compaction) and equal results up to summation order for the
+    cascade, the fused FPN level, K1, ordered compaction) and equal results up to summation order for the
     ones that accumulate with atomics (loss sums, K1 backward)."""
     from rc_mvsnet_amd import fusion, losses, ops
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
@@ -122,9 +114,7 @@ def test_results_do_not_depend_on_the_thread_schedule(emu):
     def run():
         with torch.no_grad():
             out = model(imgs, pm, dv)
-            emu.rcmvs_debug_k1_variant(6)
             staged = ops.warp_variance(feats, rot, trans, planes, 8)
-            emu.rcmvs_debug_k1_variant(0)
             pts, _ = fusion.compact_points(mask, xyz)
             gfe = ops.warp_variance_bwd(feats, rot, trans, planes, gvar, None)
         inputs = {k: {"depth": torch.tensor(G[f"a:depth:{k}"]).requires_grad_(True)} for k in ("stage1", "stage2", "stage3")}
@@ -145,86 +135,3 @@ def test_results_do_not_depend_on_the_thread_schedule(emu):
                 assert float((approx[k] - approx0[k]).abs().max()) <= 1e-5 * max(1e-6, float(approx0[k].abs().max())), (order, k)
     finally:
         emu.rcmvs_emu_set_order(0)
-        emu.rcmvs_debug_k1_variant(0)
-        emu.rcmvs_debug_k1_ps_config(0, 0, 0)
-
-
-@pytest.mark.parametrize("C,D,h,w,V", [(32, 16, 12, 21, 3), (16, 8, 17, 30, 3), (8, 12, 16, 40, 2), (8, 10, 9, 140, 3), (32, 5, 6, 9, 2)])
-def test_k1_pipelined_staged_variant_on_emulated_kernels(C, D, h, w, V, emu):
-    """Debug variants 8 / 9 (persistent over plane chunks, double-buffered tap tables and windows, direct-to-LDS loads): the
-    exact build must equal the reference-order kernel bit for bit -- ragged plane counts, ragged tiles, windows that do not fit
-    the LDS budget (wide maps: global fallback), one and two source views -- under every thread schedule."""
-    from rc_mvsnet_amd import _lib, ops
-    g = torch.Generator().manual_seed(C + V + D)
-    feats = torch.randn(2, V, h, w, C, generator=g)
-    pm = synthetic.proj_matrices(2, V, h * 4, w * 4)["stage1"]
-    rot, trans = ops.compose_homography(pm)
-    planes = torch.stack((425.0 + 100.0 * torch.rand(2, h, w, generator=g), 2.0 + 8.0 * torch.rand(2, h, w, generator=g)), dim=-1).contiguous()
-    try:
-        emu.rcmvs_debug_k1_variant(2)
-        vref = ops.warp_variance(feats, rot, trans, planes, D)
-        for order in (0, 1, 2):
-            emu.rcmvs_emu_set_order(order)
-            for var in (8, 10, 12):                                                   # windows by direct-to-LDS loads / held in registers / static LDS sets
-                emu.rcmvs_debug_k1_variant(var)
-                assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, order)
-        emu.rcmvs_emu_set_order(0)
-        knobs = ((2, 0, 0), (8, 64, 16), (4, 16, 0), (2, 64, 32), (4, 0, 16)) if (C, V) in ((32, 3), (8, 2)) else ((4, 16, 16),)
-        for dkb, ptex, pad in knobs:                                                       # other chunk depths; a budget small enough to force the global fallback
-            emu.rcmvs_debug_k1_ps_config(dkb, ptex, pad)
-            for var in (8, 10):
-                emu.rcmvs_debug_k1_variant(var)
-                assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (var, dkb, ptex, pad)
-        emu.rcmvs_debug_k1_ps_config(0, 0, 0)
-        for dkb, ptex in ((2, 0), (4, 0), (4, 72)):                                   # static-set form: compile-time budgets per chunk depth
-            emu.rcmvs_debug_k1_ps_config(dkb, ptex, 0)
-            emu.rcmvs_debug_k1_variant(12)
-            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), (dkb, ptex)
-        emu.rcmvs_debug_k1_ps_config(0, 0, 0)
-        for var in (9, 11, 13):
-            emu.rcmvs_debug_k1_variant(var)
-            v9 = ops.warp_variance(feats, rot, trans, planes, D)
-            assert float((v9 - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), var
-        emu.rcmvs_debug_k1_variant(8)
-        with pytest.raises(_lib.RcmvsError):
-            ops.warp_variance(torch.randn(1, 4, h, w, C), rot[:1].repeat(1, 2, 1)[:, :3], trans[:1].repeat(1, 2, 1)[:, :3], planes[:1], D)
-    finally:
-        emu.rcmvs_emu_set_order(0)
-        emu.rcmvs_debug_k1_variant(0)
-        emu.rcmvs_debug_k1_ps_config(0, 0, 0)
-
-
-@pytest.mark.parametrize("C,interval", [(32, 40.0), (16, 60.0), (8, 400.0)])
-def test_k1_pipelined_variants_window_overflow_path(C, interval, emu):
-    """Plane spacing so wide that a chunk's source window exceeds the LDS budget: the block-uniform mixed body (global gathers for
-    the view that does not fit) of the pipelined variants, including the static-set form whose budget is a compile-time constant.
-    The test first shows, with the oracle's coordinates, that such windows do occur for these inputs."""
-    from oracle import warp
-    from rc_mvsnet_amd import ops
-    g = torch.Generator().manual_seed(C)
-    V, D, h, w = 3, 8, 8, 200
-    budget, tile_w, chunk = {32: (112, 8, 4), 16: (160, 16, 4), 8: (320, 32, 2)}[C]          # the static form's PTEX, TW, DKB
-    feats = torch.randn(1, V, h, w, C, generator=g)
-    pm = synthetic.proj_matrices(1, V, h * 4, w * 4)["stage1"]
-    rot, trans = ops.compose_homography(pm)
-    planes = torch.stack((430.0 + 5.0 * torch.rand(1, h, w, generator=g), interval + 5.0 * torch.rand(1, h, w, generator=g)), dim=-1).contiguous()
-    samples = planes[..., 0].unsqueeze(1) + planes[..., 1].unsqueeze(1) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
-    largest = 0
-    for v in (1, 2):
-        r, t = warp.compose_homography(pm[:, v], pm[:, 0])
-        ix, iy = warp.warp_coords(r, t, samples, h, w)
-        x0, y0 = ix[0].floor().clamp(0, w - 1), iy[0].floor().clamp(0, h - 1)
-        for k0 in range(0, D, chunk):
-            for tx in range(0, w, tile_w):
-                xs, ys = x0[k0:k0 + chunk, 0:4, tx:tx + tile_w], y0[k0:k0 + chunk, 0:4, tx:tx + tile_w]
-                largest = max(largest, int((xs.max() - xs.min() + 2) * (ys.max() - ys.min() + 2)))
-    assert largest > budget, (largest, budget)
-    try:
-        emu.rcmvs_debug_k1_variant(2)
-        vref = ops.warp_variance(feats, rot, trans, planes, D)
-        assert float(vref.abs().max()) > 0
-        for var in (8, 10, 12):
-            emu.rcmvs_debug_k1_variant(var)
-            assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), vref), var
-    finally:
-        emu.rcmvs_debug_k1_variant(0)

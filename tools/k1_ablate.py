@@ -9,9 +9,8 @@ from rc_mvsnet_amd import _lib, ops, synthetic
 lib = _lib.load()
 dev = "cuda:0"
 V, H, W = int(os.environ.get('K1_V', '3')), 512, 640
-names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 4: "lds exact", 5: "lds fma", 6: "lds exact deep", 7: "lds fma deep", 8: "pipelined staged exact", 9: "pipelined staged fma", 10: "pipelined staged exact (register-held windows)", 11: "pipelined staged fma (register-held windows)", 12: "pipelined staged exact (static LDS sets)", 13: "pipelined staged fma (static LDS sets)", 100: "torch zero_ (memset)"}
-variants = [int(a) for a in sys.argv[1:]] or [0, 1, 3, 4, 5, 6, 7]
-lib.rcmvs_debug_k1_ps_config(int(os.environ.get("K1_PS_DKB", "0")), int(os.environ.get("K1_PS_PTEX", "0")), int(os.environ.get("K1_PS_PAD", "0")))    # variants 8 / 9 only
+names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 100: "torch zero_ (memset)"}
+variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 100]
 dv = synthetic.depth_values(1).to(dev)
 tot = {v: 0.0 for v in variants}
 for (C, D, sc, key) in ((32, 48, 4, "stage1"), (16, 32, 2, "stage2"), (8, 8, 1, "stage3")):
@@ -30,8 +29,7 @@ for (C, D, sc, key) in ((32, 48, 4, "stage1"), (16, 32, 2, "stage2"), (8, 8, 1, 
         if v == 100:
             run = lambda: outbuf.zero_()
         else:
-            lib.rcmvs_debug_k1_variant(v)
-            run = lambda: ops.warp_variance(feats, rot, trans, planes, D)
+            run = lambda v=v: ops.warp_variance(feats, rot, trans, planes, D, variant=v)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,6 +43,5 @@ for (C, D, sc, key) in ((32, 48, 4, "stage1"), (16, 32, 2, "stage2"), (8, 8, 1, 
         us = e0.elapsed_time(e1) * 1e3 / R
         tot[v] += us
         print(f"C={C:2d} D={D:2d} {h}x{w}  variant {v} ({names[v]:24s}): {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s")
-lib.rcmvs_debug_k1_variant(0)
 for v in variants:
     print(f"variant {v} ({names[v]}): total {tot[v]:.1f} us/scene -> {457441280 / tot[v] / 1e3:.0f} GB/s = {457441280 / tot[v] / 1e3 / 8000:.3f} of 8 TB/s")
