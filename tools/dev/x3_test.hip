@@ -39,7 +39,7 @@ static void ref_conv(int kind, const std::vector<float>& x, const std::vector<fl
     }
 }
 
-static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, int reps) {
+static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, int reps, int blocks = 0) {
     const bool nores = getenv("X3_NORES") != nullptr;
     std::mt19937 rng(Ci * 131 + Co * 7 + D + H + W + kind);
     std::normal_distribution<float> nd(0.f, 1.f);
@@ -61,7 +61,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     CK(hipMemcpy(dres, res.data(), ny * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dy, 0xff, ny * 4));
     if (conv3d_x3_pack(dw, dimg, Co, Ci, kind, kind == 2 ? 1 : 0, 0)) return 1;
-    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0)) return 1;
+    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks)) return 1;
     CK(hipDeviceSynchronize());
     int bad = 0;
     if (check) {
@@ -78,9 +78,9 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     }
     if (reps > 0) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0);
+        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks);
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0);
+        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         double us = ms * 1e3 / reps, fl = 2.0 * 27 * Ci * Co * (kind == 2 ? (double)D * H * W : (double)Do * Ho * Wo);
@@ -97,8 +97,15 @@ int main(int argc, char** argv) {
         bad |= run_case(p[0], p[1], p[2], 8, 8, 32, true, 0);
         bad |= run_case(p[0], p[1], p[2], 11, 13, 45, true, 0);     // ragged: partial tiles in x and y, z not a multiple of the chunk
         bad |= run_case(p[0], p[1], p[2], 3, 20, 70, true, 0);
+        bad |= run_case(p[0], p[1], p[2], 10, 21, 70, true, 0, 3);     // three persistent blocks: several items per block, hand-over across tiles and z chunks
     }
     if (argc > 1 && atoi(argv[1]) == 0) return bad;
+    if (argc > 1 && atoi(argv[1]) == 3) {
+        const int blk = getenv("X3_BLOCKS") ? atoi(getenv("X3_BLOCKS")) : 0;
+        run_case(0, 32, 8, 48, 128, 160, false, 20, blk); run_case(0, 16, 8, 32, 256, 320, false, 20, blk); run_case(0, 8, 8, 8, 512, 640, false, 20, blk);
+        run_case(0, 16, 16, 16, 128, 160, false, 20, blk); run_case(1, 8, 16, 32, 256, 320, false, 20, blk); run_case(2, 16, 8, 16, 128, 160, false, 20, blk);
+        return 0;
+    }
     run_case(0, 32, 8, 48, 128, 160, false, 20);
     run_case(0, 16, 8, 32, 256, 320, false, 20);
     run_case(0, 8, 8, 8, 512, 640, false, 20);
