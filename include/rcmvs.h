@@ -117,7 +117,8 @@ int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale
 /* Test / A-B twins of the two entry points above with an explicit kernel selection `impl` (stateless: the library keeps no
  * dispatch state).  0 = the production dispatch; bit 0 = direct (one thread per voxel) kernels only; bits 1-3 and 5 = tuning
  * configuration of the LDS-halo kernel; bit 4 = fp32-MFMA kernel before the LDS kernel where both exist; bit 6 = skip the
- * split-bf16 MFMA kernels (the fp32 FMA-chain kernels: the comparator of tests/test_gpu_parity.py::test_conv3d_x3_*). */
+ * split-bf16 MFMA kernels (the fp32 FMA-chain kernels: the comparator of tests/test_gpu_parity.py::test_conv3d_x3_*);
+ * bits 8-15 = cap on the persistent blocks of the split-bf16 kernels (0 = one per CU). */
 int rcmvs_debug_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                            const float* residual, float* y,
                            int B, int D, int H, int W, int Ci, int Co, int stride, int relu, int impl, void* stream);

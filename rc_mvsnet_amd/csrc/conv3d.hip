@@ -151,7 +151,7 @@ bool conv3d_x3_supported(int Ci, int Co, int kind);
 long long conv3d_x3_weight_floats(int Ci, int Co, int kind);
 int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, hipStream_t st);
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st);
+                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks);
 
 // packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 images of
 // the three kinds (each present when the pair has that kernel)
@@ -171,8 +171,9 @@ using namespace rcmvs;
 // exist; bit 6 = skip the split-bf16 MFMA kernels (conv3d_x3.hip).  Passed by value: the library keeps no dispatch state.
 struct ConvImpl {
     bool direct, prefer_lds, no_x3;
-    int lds_cfg;
-    explicit ConvImpl(int on) : direct(on & 1), prefer_lds(!(on & 16)), no_x3((on >> 6) & 1), lds_cfg(((on >> 1) & 7) | (((on >> 5) & 1) << 3)) {}
+    int lds_cfg, x3_blocks;
+    explicit ConvImpl(int on) : direct(on & 1), prefer_lds(!(on & 16)), no_x3((on >> 6) & 1), lds_cfg(((on >> 1) & 7) | (((on >> 5) & 1) << 3)),
+                                x3_blocks((on >> 8) & 0xff) {}
 };
 
 extern "C" {
@@ -214,7 +215,7 @@ static int conv3d_dispatch(const float* x, const float* w_packed, const float* s
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
     if (conv3d_x3_supported(Ci, Co, mode) && !im.direct && !im.no_x3)
-        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st);
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks);
     if (im.prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !im.direct)
         return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
     if (conv3d_mfma_supported(Ci, Co, mode) && !im.direct)
@@ -247,7 +248,7 @@ static int deconv3d_dispatch(const float* x, const float* w_packed, const float*
     ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
     if (conv3d_x3_supported(Ci, Co, CONV_T2) && !im.direct && !im.no_x3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
-                                as_stream(stream));
+                                as_stream(stream), im.x3_blocks);
     if (deconv3d_lds_supported(Ci, Co) && !im.direct)
         return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
     if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !im.direct)

@@ -33,6 +33,11 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+// the emulated device has 6 compute units: persistent kernels that size their grid by the CU count walk several work items
+// per block on the test volumes (and 6 is not a multiple of the 8 XCDs: the round-robin item order is the one exercised)
+struct hipDeviceProp_t { int multiProcessorCount; };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 6; return hipSuccess; }
 
 struct dim3 {
     unsigned x, y, z;

@@ -299,6 +299,35 @@ def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
         assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
 
 
+@pytest.mark.parametrize("Ci,Co,kind", [(8, 8, "s1"), (16, 8, "s1"), (32, 8, "s1"), (16, 16, "s1"), (8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2")])
+def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
+    """The split-bf16 kernel is persistent: one block walks several (batch, tile, z chunk) work items with the LDS ring running
+    across item boundaries.  Whatever the block count (3: many items per block, round robin; 8 / 16: the XCD-contiguous order;
+    default: one block per CU), every output voxel sees the same arithmetic: results must be bit-identical."""
+    g = torch.Generator().manual_seed(Ci + Co)
+    B, D, H, W = 2, 4, 9, 35
+    x = gpu((torch.randn(B, D, H, W, Ci, generator=g) * torch.exp(torch.randn(B, D, H, W, Ci, generator=g))).contiguous())
+    scale, shift = gpu(0.5 + torch.rand(Co, generator=g)), gpu(0.1 * torch.randn(Co, generator=g))
+    if kind == "t2":
+        wp = hip.pack_conv3d_weight(gpu(torch.randn(Ci, Co, 3, 3, 3, generator=g) / (Ci * 27 / 8) ** 0.5), transposed=True)
+        res = gpu(torch.randn(B, 2 * D, 2 * H, 2 * W, Co, generator=g))
+        run = lambda: hip.deconv3d(x, wp, scale, shift, res, relu=True)
+    else:
+        st = 2 if kind == "s2" else 1
+        wp = hip.pack_conv3d_weight(gpu(torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5))
+        res = gpu(torch.randn(B, (D - 1) // st + 1, (H - 1) // st + 1, (W - 1) // st + 1, Co, generator=g))
+        run = lambda: hip.conv3d(x, wp, scale, shift, res, stride=st, relu=True)
+    base = run().cpu()
+    assert torch.isfinite(base).all()
+    for blocks in (3, 8, 16, 1):
+        try:
+            hip.force_direct_conv(blocks << 8)          # bits 8-15 of the debug selector: cap on the x3 block count
+            y = run().cpu()
+        finally:
+            hip.force_direct_conv(0)
+        assert torch.equal(y, base), (blocks, float((y - base).abs().max()))
+
+
 @pytest.mark.parametrize("Ci", [8, 16, 32, 44])
 def test_conv3d_lds_halo_kernel(hip, Ci):
     """Cout = 8 stride-1 layers run on the LDS-staged halo kernel: against the oracle (ragged tiles: sizes

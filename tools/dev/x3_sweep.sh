@@ -1,4 +1,4 @@
 #!/bin/bash
-for env in "X3_NORES=1" "X3_NORES=1 X3_DBG=1" "X3_NORES=1 X3_DBG=2" "X3_NORES=1 X3_DBG=3" "X3_NORES=1 X3_DBG=4" "X3_NORES=1 X3_DBG=7" "X3_NORES=1 X3_ZC=4" "X3_NORES=1 X3_ZC=16" "X3_NORES=1 X3_ZC=48"; do
-  echo "== $env"; env $env timeout 100 tools/dev/x3_test 2 2>&1 | grep time
+for env in "X3_DBG=0" "X3_DBG=1" "X3_DBG=3" "X3_DBG=7" "X3_DBG=2" "X3_DBG=4"; do
+  echo "== $env"; X3_NORES=1 env $env timeout 20 tools/dev/x3_test 3 2>&1 | grep "time" | head -4
 done
