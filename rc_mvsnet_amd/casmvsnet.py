@@ -96,10 +96,10 @@ class FeatureNet(nn.Module):
             for n, m in zip(names, mods):
                 pad_to = 4 if m.conv.in_channels == 3 else None
                 w = m.conv.weight
-                if w.shape[0] == 32 and w.shape[1] == 32 and w.shape[2] == 3 and m.stride == 1:
-                    # 32 -> 32 3x3: the scalar-weight VALU kernel runs at ~15 TF here; as a one-plane 3-D conv the layer goes
-                    # to the MFMA implicit-GEMM kernel (which skips the two out-of-range tap planes)
-                    w3 = w.detach().new_zeros(32, 32, 3, 3, 3)
+                if tuple(w.shape) in ((8, 8, 3, 3), (16, 16, 3, 3), (32, 32, 3, 3)) and m.stride == 1:
+                    # square 3x3 layers: as a one-plane 3-D conv the layer goes to the planar form of the split-bf16 matrix-core
+                    # kernel (csrc/conv3d_x3.hip, kd = 1 taps only); the scalar-weight VALU kernel runs these at 15-25 TF
+                    w3 = w.detach().new_zeros(w.shape[0], w.shape[1], 3, 3, 3)
                     w3[:, :, 1] = w.detach()
                     plan[n] = ("mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
                     continue

@@ -146,7 +146,9 @@ bool deconv3d_lds_supported(int Ci, int Co);
 int deconv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                         int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st);
 
-// conv3d_x3.hip (bf16 matrix cores, three-way split operands); kind: 0 stride-1 conv, 1 stride-2 conv, 2 transposed stride-2
+// conv3d_x3.hip (bf16 matrix cores, three-way split operands); kind: 0 stride-1 conv, 1 stride-2 conv, 2 transposed stride-2,
+// 3 planar stride-1 (the kd = 1 taps only: every z-plane on its own -- exact for a one-plane volume)
+enum { X3_KIND_PLANAR = 3, X3_NKINDS = 4 };
 bool conv3d_x3_supported(int Ci, int Co, int kind);
 long long conv3d_x3_weight_floats(int Ci, int Co, int kind);
 int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, hipStream_t st);
@@ -154,7 +156,7 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
                      int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks);
 
 // packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 images of
-// the three kinds (each present when the pair has that kernel)
+// the four kinds (each present when the pair has that kernel)
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
 static inline long long x3_image_offset(int Ci, int Co, int kind) {
     long long off = direct_weight_floats(Ci, Co) + (conv3d_mfma_supported(Ci, Co, 0) ? mfma_weight_floats_host(Ci, Co) : 0);
@@ -182,7 +184,7 @@ long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;
     long long n = direct_weight_floats(Ci, Co);
     if (conv3d_mfma_supported(Ci, Co, 0)) n += mfma_weight_floats_host(Ci, Co);
-    for (int k = 0; k < 3; ++k) n += conv3d_x3_weight_floats(Ci, Co, k);
+    for (int k = 0; k < X3_NKINDS; ++k) n += conv3d_x3_weight_floats(Ci, Co, k);
     return n;
 }
 
@@ -196,7 +198,7 @@ int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int 
         rc = pack_weight_mfma_launch(w, packed + direct_weight_floats(Ci, Co), Co, Ci, transposed, as_stream(stream));
         if (rc) return rc;
     }
-    for (int k = 0; k < 3; ++k) {         // a ConvTranspose3d weight (transposed == 1) feeds the transposed kernel only, and vice versa
+    for (int k = 0; k < X3_NKINDS; ++k) {         // a ConvTranspose3d weight (transposed == 1) feeds the transposed kernel only, and vice versa
         if (!conv3d_x3_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
         rc = conv3d_x3_pack(w, packed + x3_image_offset(Ci, Co, k), Co, Ci, k, transposed, as_stream(stream));
         if (rc) return rc;
@@ -214,6 +216,8 @@ static int conv3d_dispatch(const float* x, const float* w_packed, const float* s
     ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
+    if (stride == 1 && D == 1 && conv3d_x3_supported(Ci, Co, X3_KIND_PLANAR) && !im.direct && !im.no_x3)      // one plane: the kd = 0, 2 taps only see padding
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, X3_KIND_PLANAR), scale, shift, residual, y, B, D, H, W, Ci, Co, X3_KIND_PLANAR, relu, st, im.x3_blocks);
     if (conv3d_x3_supported(Ci, Co, mode) && !im.direct && !im.no_x3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks);
     if (im.prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !im.direct)

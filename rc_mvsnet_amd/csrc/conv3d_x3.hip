@@ -41,18 +41,21 @@ typedef unsigned int x3_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int x3_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned char x3_byte;
 
-enum { X3_S1 = 0, X3_S2 = 1, X3_T2 = 2 };        // stride-1 conv, stride-2 conv, transposed stride-2 conv
+// stride-1 conv, stride-2 conv, transposed stride-2 conv, planar stride-1 conv (kd = 1 taps only: a 3x3 conv of every z-plane,
+// what a 3x3x3 conv of a one-plane volume reduces to -- the FeatureNet layers, models/modules.py:413-424)
+enum { X3_S1 = 0, X3_S2 = 1, X3_T2 = 2, X3_P1 = 3, X3_KINDS = 4 };
+__host__ __device__ constexpr bool x3_unit(int kind) { return kind == X3_S1 || kind == X3_P1; }       // stride-1 geometry in the plane
 enum { X3_XT = 0, X3_YT = 1, X3_PL = 2 };        // how an n-tile maps to voxels (see above)
 
 template <int CIN, int COUT, int KIND>
 struct X3 {
-    static constexpr int MAP = (KIND == X3_S1 && COUT == 8) ? (CIN == 8 ? X3_XT : X3_YT) : X3_PL;
+    static constexpr int MAP = (x3_unit(KIND) && COUT == 8) ? (CIN == 8 ? X3_XT : X3_YT) : X3_PL;
     static constexpr int MROWS = (KIND == X3_T2) ? 8 * COUT : (COUT == 8 ? 16 : COUT);
     static constexpr int MT_ALL = MROWS / 16;                            // 16-row tiles of A
     static constexpr int VB = CIN * 2;                                   // bytes per voxel per piece plane
     static constexpr int PPS = (CIN >= 32) ? 1 : 32 / CIN;               // tap positions per K step
     static constexpr int HALVES = (CIN > 32) ? CIN / 32 : 1;            // K steps per position
-    static constexpr int NKD = (KIND == X3_T2) ? 2 : 3;                  // input z-planes one output step reads
+    static constexpr int NKD = (KIND == X3_T2) ? 2 : (KIND == X3_P1 ? 1 : 3);                  // input z-planes one output step reads
     static constexpr int QR = (KIND == X3_T2) ? 2 : (MAP == X3_YT ? 4 : 3);   // position grid of one plane: rows ...
     static constexpr int QC = (KIND == X3_T2) ? 2 : (MAP == X3_XT ? 4 : 3);   // ... and columns
     static constexpr int PPKD = QR * QC;
@@ -63,12 +66,12 @@ struct X3 {
     static constexpr int KSPLIT = (WREG / MSPLIT > 256) ? 4 / MSPLIT : ((WREG / MSPLIT > 128) ? 2 : 1);
     static constexpr int MT = MT_ALL / MSPLIT;                           // m-tiles per consumer wave
     static constexpr int KSW = (KSTEPS + KSPLIT - 1) / KSPLIT;          // K steps per consumer wave
-    static constexpr int TX = ((KIND == X3_S1 && CIN >= 32) || (KIND == X3_S2 && CIN >= 16)) ? 16 : 32;
+    static constexpr int TX = ((x3_unit(KIND) && CIN >= 32) || (KIND == X3_S2 && CIN >= 16)) ? 16 : 32;
     static constexpr int TY = (MAP == X3_XT) ? 8 : ((KIND == X3_S2) ? 2 : 4);
     static constexpr int CS = (MAP == X3_XT || KIND == X3_S2) ? 2 : 1;   // voxels between neighbouring columns
     static constexpr int RS = (MAP == X3_YT || KIND == X3_S2) ? 2 : 1;   // halo rows between neighbouring tile rows
-    static constexpr int TYP = (KIND == X3_S1) ? TY + 2 : (KIND == X3_S2 ? 2 * TY + 1 : TY + 1);
-    static constexpr int TXP = (KIND == X3_S1) ? TX + 2 : (KIND == X3_S2 ? 2 * TX + 1 : TX + 1);
+    static constexpr int TYP = x3_unit(KIND) ? TY + 2 : (KIND == X3_S2 ? 2 * TY + 1 : TY + 1);
+    static constexpr int TXP = x3_unit(KIND) ? TX + 2 : (KIND == X3_S2 ? 2 * TX + 1 : TX + 1);
     static constexpr int ROWB = TXP * VB;                                // bytes per halo row
     static constexpr int PLB = TYP * ROWB;                               // bytes per piece plane
     static constexpr int SLB = 3 * PLB;                                  // bytes per z-slice (h, m, l planes)
@@ -103,7 +106,7 @@ __host__ __device__ inline void x3_kslot(int js, int kk, int& q, int& ci0) {
 // of the LDS cycles.  Flipping bit 1 of the 16-byte slot on every second group of four columns makes all four groups
 // conflict-free for each of the three tap columns (exhaustive check in DESIGN.md); other layouts read conflict-free as they are.
 template <class C, int CIN, int KIND>
-__host__ __device__ inline int x3_swz(int hc) { return (CIN == 32 && KIND == X3_S1) ? ((hc >> 2) & 1) * 32 : 0; }
+__host__ __device__ inline int x3_swz(int hc) { return (CIN == 32 && x3_unit(KIND)) ? ((hc >> 2) & 1) * 32 : 0; }
 
 // ---- weight image: [K step][piece][m-tile][lane][8 bf16], the A fragment of v_mfma_f32_16x16x32_bf16 (row = lane & 15,
 // k = 8 * (lane >> 4) + e), pieces split by truncation like the activations.
@@ -123,7 +126,7 @@ __global__ void x3_pack_kernel(const float* __restrict__ w, unsigned short* __re
     float v = 0.0f;
     if (q < C::PPKD) {
         const int r = q / C::QC, c = q % C::QC;
-        int co, td, th, tw;       // output channel and tap per axis
+        int co, td, th, tw;       // output channel and tap per axis (planar: kd is the centre plane of the 3x3x3 weight)
         if (KIND == X3_T2) {
             const int p = m / COUT;
             co = m % COUT;
@@ -131,6 +134,7 @@ __global__ void x3_pack_kernel(const float* __restrict__ w, unsigned short* __re
         } else if (C::MAP == X3_XT) { co = m & 7; td = kd; th = r; tw = c - (m >> 3); }
         else if (C::MAP == X3_YT) { co = m & 7; td = kd; th = r - (m >> 3); tw = c; }
         else { co = m; td = kd; th = r; tw = c; }
+        if (KIND == X3_P1) td = 1;
         if (td >= 0 && td < 3 && th >= 0 && th < 3 && tw >= 0 && tw < 3 && co < COUT) {
             const int tap = (td * 3 + th) * 3 + tw;
             v = transposed ? w[((long long)ci * COUT + co) * 27 + (transposed == 2 ? 26 - tap : tap)] : w[((long long)co * CIN + ci) * 27 + tap];
@@ -411,8 +415,8 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             if (t.it == goff_item) return;
             goff_item = t.it;
             const X3Item& w = t.w;
-            const int hy0 = (KIND == X3_S1) ? w.y0 - 1 : (KIND == X3_S2 ? 2 * w.y0 - 1 : w.y0);
-            const int hx0 = (KIND == X3_S1) ? w.x0 - 1 : (KIND == X3_S2 ? 2 * w.x0 - 1 : w.x0);
+            const int hy0 = x3_unit(KIND) ? w.y0 - 1 : (KIND == X3_S2 ? 2 * w.y0 - 1 : w.y0);
+            const int hx0 = x3_unit(KIND) ? w.x0 - 1 : (KIND == X3_S2 ? 2 * w.x0 - 1 : w.x0);
             const int base = (w.b * dm.D * dm.H + hy0) * dm.W * CIN * 4 + hx0 * CIN * 4;
 #pragma unroll
             for (int i = 0; i < C::NPF; ++i) {
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                 *reinterpret_cast<x3_u32x2*>(sb + 2 * C::PLB + loff[i]) = l;
             }
         };
-        auto zin0 = [&](int z) { return (KIND == X3_S1) ? z - 1 : (KIND == X3_S2 ? 2 * z - 1 : z); };   // first input plane of step z
+        auto zin0 = [&](int z) { return (KIND == X3_S1) ? z - 1 : (KIND == X3_S2 ? 2 * z - 1 : z); };      // (planar: the plane itself)   // first input plane of step z
         // the planes a step adds to the ring: all NKD on the first step of an item, the last ZADV afterwards
         auto new_planes = [&](const X3Step<C>& t, int& first_plane) { first_plane = t.first ? zin0(t.z) : zin0(t.z) + NKD - ZADV; return t.first ? NKD : ZADV; };
         // finish the K-split tiles of a step: sum the partial tiles, BN scale/shift, ReLU, skip-add, store.  Two halves: epi_open at
@@ -544,7 +548,8 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-#define RCMVS_X3_LIST(X) X(8, 8, X3_S1) X(16, 8, X3_S1) X(32, 8, X3_S1) X(16, 16, X3_S1) X(8, 16, X3_S2) X(16, 32, X3_S2) X(16, 8, X3_T2)
+#define RCMVS_X3_LIST(X) X(8, 8, X3_S1) X(16, 8, X3_S1) X(32, 8, X3_S1) X(16, 16, X3_S1) X(8, 16, X3_S2) X(16, 32, X3_S2) X(16, 8, X3_T2) \
+    X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1)
 
 bool conv3d_x3_supported(int Ci, int Co, int kind) {
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;
@@ -594,12 +599,12 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
         /* one persistent block per CU walks its share of the (batch, tile, z chunk) items: pick the chunk length that minimises the \
            longest block (items per block x (steps per item + ~1.5 steps for the extra planes an item start loads)) */ \
         long long best = -1; int zchunk = dm.Dt; \
-        for (int zc = dm.Dt; zc >= 2; --zc) { \
+        for (int zc = dm.Dt; zc >= (C::NKD > 1 ? 2 : 1); --zc) { \
             const int nch = (dm.Dt + zc - 1) / zc; \
             if (nch > 1 && (dm.Dt + nch - 1) / nch != zc) continue;            /* only balanced splits */ \
             const long long items = (long long)B * dm.ntiles * nch; \
             const long long per_blk = (items + n_blk - 1) / n_blk; \
-            const long long cost = per_blk * (2 * zc + 3); \
+            const long long cost = per_blk * (2 * zc + (C::NKD > 1 ? 3 : 0)); \
             if (best < 0 || cost < best) { best = cost; zchunk = zc; } \
         } \
         dm.zchunk = zchunk; dm.nchunks = (dm.Dt + zchunk - 1) / zchunk; \

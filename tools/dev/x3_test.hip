@@ -12,17 +12,19 @@ int fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnpri
 using namespace rcmvs;
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
 
-// kind 0/1: w (Co,Ci,27), stride 1/2.  kind 2: ConvTranspose3d stride 2, pad 1, output_padding 1, w (Ci,Co,27)
+// kind 0/1: w (Co,Ci,27), stride 1/2.  kind 2: ConvTranspose3d stride 2, pad 1, output_padding 1, w (Ci,Co,27).  kind 3: planar (kd = 1 taps only)
 static void ref_conv(int kind, const std::vector<float>& x, const std::vector<float>& w, const std::vector<float>& sc, const std::vector<float>& sh,
                      const std::vector<float>& res, std::vector<double>& y, std::vector<float>& y32, int D, int H, int W, int Do, int Ho, int Wo, int Ci, int Co, int relu) {
     for (int z = 0; z < Do; ++z) for (int yy = 0; yy < Ho; ++yy) for (int xx = 0; xx < Wo; ++xx) for (int co = 0; co < Co; ++co) {
         double a = 0; float a32 = 0.f;
         for (int kd = 0; kd < 3; ++kd) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
             int iz, iy, ix;
+            if (kind == 3 && kd != 1) continue;
             if (kind == 2) {
                 int nz = z + 1 - kd, ny = yy + 1 - kh, nx = xx + 1 - kw;
                 if (nz < 0 || ny < 0 || nx < 0 || (nz & 1) || (ny & 1) || (nx & 1)) continue;
                 iz = nz >> 1; iy = ny >> 1; ix = nx >> 1;
+            } else if (kind == 3) { iz = z; iy = yy + kh - 1; ix = xx + kw - 1;
             } else { int s = kind == 1 ? 2 : 1; iz = s * z + kd - 1; iy = s * yy + kh - 1; ix = s * xx + kw - 1; }
             if (iz < 0 || iz >= D || iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
             for (int ci = 0; ci < Ci; ++ci) {
@@ -83,7 +85,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
         for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        double us = ms * 1e3 / reps, fl = 2.0 * 27 * Ci * Co * (kind == 2 ? (double)D * H * W : (double)Do * Ho * Wo);
+        double us = ms * 1e3 / reps, fl = 2.0 * (kind == 3 ? 9 : 27) * Ci * Co * (kind == 2 ? (double)D * H * W : (double)Do * Ho * Wo);
         printf("time  kind=%d Ci=%d Co=%d %dx%dx%d: %8.1f us  %6.1f TF (fp32-equivalent)\n", kind, Ci, Co, D, H, W, us, fl / us / 1e6);
     }
     hipFree(dx); hipFree(dw); hipFree(dimg); hipFree(dsc); hipFree(dsh); hipFree(dres); hipFree(dy);
@@ -92,7 +94,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
 
 int main(int argc, char** argv) {
     int bad = 0;
-    const int cases[7][3] = {{0, 8, 8}, {0, 16, 8}, {0, 32, 8}, {0, 16, 16}, {1, 8, 16}, {1, 16, 32}, {2, 16, 8}};
+    const int cases[10][3] = {{0, 8, 8}, {0, 16, 8}, {0, 32, 8}, {0, 16, 16}, {1, 8, 16}, {1, 16, 32}, {2, 16, 8}, {3, 8, 8}, {3, 16, 16}, {3, 32, 32}};
     for (auto& p : cases) {
         bad |= run_case(p[0], p[1], p[2], 8, 8, 32, true, 0);
         bad |= run_case(p[0], p[1], p[2], 11, 13, 45, true, 0);     // ragged: partial tiles in x and y, z not a multiple of the chunk
@@ -100,6 +102,10 @@ int main(int argc, char** argv) {
         bad |= run_case(p[0], p[1], p[2], 10, 21, 70, true, 0, 3);     // three persistent blocks: several items per block, hand-over across tiles and z chunks
     }
     if (argc > 1 && atoi(argv[1]) == 0) return bad;
+    if (argc > 1 && atoi(argv[1]) == 4) {        // FeatureNet layers: 3 views as planes
+        run_case(3, 8, 8, 3, 512, 640, false, 20); run_case(3, 16, 16, 3, 256, 320, false, 20); run_case(3, 32, 32, 3, 128, 160, false, 20);
+        return 0;
+    }
     if (argc > 1 && atoi(argv[1]) == 3) {
         const int blk = getenv("X3_BLOCKS") ? atoi(getenv("X3_BLOCKS")) : 0;
         run_case(0, 32, 8, 48, 128, 160, false, 20, blk); run_case(0, 16, 8, 32, 256, 320, false, 20, blk); run_case(0, 8, 8, 8, 512, 640, false, 20, blk);
