@@ -62,12 +62,16 @@ struct X3 {
     static constexpr int SPK = ((PPKD + PPS - 1) / PPS) * HALVES;       // K steps per plane (a step never straddles planes)
     static constexpr int KSTEPS = NKD * SPK;
     static constexpr int WREG = KSTEPS * MT_ALL * 12;                    // registers the whole weight image would take
+    // wave roles: 4 consumer + 4 producer waves; layers whose weight image exceeds 4 x 128 registers take 6 consumer waves (K cut
+    // three ways, M two ways) and 2 producer waves -- their volumes are small and the producers have little to do
+    static constexpr int NCW = (WREG > 512) ? 6 : 4;
+    static constexpr int NPW = 8 - NCW;
     static constexpr int MSPLIT = (MT_ALL >= 2 && WREG > 128) ? 2 : 1;
-    static constexpr int KSPLIT = (WREG / MSPLIT > 256) ? 4 / MSPLIT : ((WREG / MSPLIT > 128) ? 2 : 1);
+    static constexpr int KSPLIT = (NCW == 6) ? 3 : ((WREG / MSPLIT > 256) ? 4 / MSPLIT : ((WREG / MSPLIT > 128) ? 2 : 1));
     static constexpr int MT = MT_ALL / MSPLIT;                           // m-tiles per consumer wave
     static constexpr int KSW = (KSTEPS + KSPLIT - 1) / KSPLIT;          // K steps per consumer wave
-    static constexpr int TX = ((x3_unit(KIND) && CIN >= 32) || (KIND == X3_S2 && CIN >= 16)) ? 16 : 32;
-    static constexpr int TY = (MAP == X3_XT) ? 8 : ((KIND == X3_S2) ? 2 : 4);
+    static constexpr int TX = ((x3_unit(KIND) && CIN >= 32) || (KIND == X3_S2 && CIN >= 16) || NCW == 6) ? 16 : 32;
+    static constexpr int TY = (MAP == X3_XT) ? 8 : ((KIND == X3_S2 || NCW == 6) ? 2 : 4);
     static constexpr int CS = (MAP == X3_XT || KIND == X3_S2) ? 2 : 1;   // voxels between neighbouring columns
     static constexpr int RS = (MAP == X3_YT || KIND == X3_S2) ? 2 : 1;   // halo rows between neighbouring tile rows
     static constexpr int TYP = x3_unit(KIND) ? TY + 2 : (KIND == X3_S2 ? 2 * TY + 1 : TY + 1);
@@ -79,15 +83,15 @@ struct X3 {
     static constexpr int NSLOT = 2 * NKD;                                // ring: the planes being read + the ones being written (up to NKD when the next item starts)
     static constexpr int NTX = (MAP == X3_XT) ? TX / 32 : TX / 16;       // n-tiles along x
     static constexpr int NTILE = ((MAP == X3_YT) ? TY / 2 : TY) * NTX;
-    static constexpr int NG = 4 / (KSPLIT * MSPLIT);                     // consumer waves that own different n-tiles
+    static constexpr int NG = NCW / (KSPLIT * MSPLIT);                     // consumer waves that own different n-tiles
     static constexpr int NTW = NTILE / NG;                               // n-tiles per consumer wave
     static constexpr int TP = (MT <= 2 && NTW % 2 == 0) ? 2 : 1;         // n-tiles in flight (independent accumulators)
     static constexpr int Q4 = CIN / 4;                                   // float4 per voxel
     static constexpr int NLOAD = TYP * TXP * Q4;                         // float4 per z-slice
-    static constexpr int NPF = (NLOAD + 255) / 256;                      // float4 per producer thread per z-slice
+    static constexpr int NPF = (NLOAD + NPW * 64 - 1) / (NPW * 64);                      // float4 per producer thread per z-slice
     static constexpr int PARTB = (KSPLIT > 1) ? NTILE * MT_ALL * KSPLIT * 1024 : 0;   // one buffer of partial output tiles
     static constexpr int LDSB = NSLOT * SLB + 2 * PARTB;
-    static_assert(KSPLIT * MSPLIT <= 4 && WREG / (KSPLIT * MSPLIT) <= 128, "weight slice per wave");
+    static_assert(NCW % (KSPLIT * MSPLIT) == 0 && WREG / (KSPLIT * MSPLIT) <= 128, "weight slice per wave");
     static_assert(NTILE % NG == 0 && NTW % TP == 0, "tiles per wave");
     static_assert(MAP != X3_XT || PPS == 4, "XT packs the four kw' positions of 8 channels into one K step");
     static_assert(LDSB <= 160 * 1024, "LDS budget");
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     x3_byte* const partbase = smem + NSLOT * C::SLB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave >= 4;
+    const bool producer = wave >= C::NCW;
     const int n = lane & 15, kk = lane >> 4;
     // item order: with a block count that is a multiple of 8 the blocks of one XCD (every 8th block id, MI355X_MICROARCH
     // "workgroup dispatch") take one contiguous eighth of the items, so neighbouring tiles share that XCD's L2; otherwise plain
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         }
     } else {
         // =============================== producer
-        const int pw = wave - 4, ptid = tid - 256;
+        const int pw = wave - C::NCW, ptid = tid - C::NCW * 64;
         constexpr int OOB = 0x7ffffff0;
         const long long vol = (long long)dm.B * dm.D * dm.H * dm.W * CIN * 4;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)vol, 0x00020000);
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         int hrc[C::NPF], grel[C::NPF], loff[C::NPF], goff[C::NPF];
 #pragma unroll
         for (int i = 0; i < C::NPF; ++i) {
-            const int e = ptid + i * 256;
+            const int e = ptid + i * (C::NPW * 64);
             const int v = e / C::Q4, c4 = e - v * C::Q4;
             const int hr = v / C::TXP, hc = v - hr * C::TXP;
             hrc[i] = (e < C::NLOAD) ? ((hr << 16) | hc) : -1;
@@ -452,13 +456,13 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         // finish the K-split tiles of a step: sum the partial tiles, BN scale/shift, ReLU, skip-add, store.  Two halves: epi_open at
         // the start of the tick works out where this wave's (tile, m-tile) units go and issues the skip-connection loads; epi_close
         // at the end of the tick (a stash and a fetch later) does the arithmetic, so the loads' latency is off the tick's critical path
-        constexpr int NEU = (KSPLIT > 1) ? (C::NTILE * C::MT_ALL + 3) / 4 : 1;
+        constexpr int NEU = (KSPLIT > 1) ? (C::NTILE * C::MT_ALL + C::NPW - 1) / C::NPW : 1;
         x3_f32x4 esc[NEU], esh[NEU], erv[NEU];
         long long eov[NEU];            // element offset of the unit's float4 in y / res; < 0 = nothing to store
         if constexpr (KSPLIT > 1) {
 #pragma unroll
             for (int i = 0; i < NEU; ++i) {
-                const int u = min(pw + 4 * i, C::NTILE * C::MT_ALL - 1);
+                const int u = min(pw + C::NPW * i, C::NTILE * C::MT_ALL - 1);
                 long long ov; int co0;
                 x3_out_coord<C, COUT, KIND>(dm, 0, 0, 0, 0, 0, u % C::MT_ALL, n, kk, ov, co0);      // co0 depends on the m-tile and the lane only
                 esc[i] = scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f};
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             if constexpr (KSPLIT > 1) {
 #pragma unroll
                 for (int i = 0; i < NEU; ++i) {
-                    const int u = pw + 4 * i;                       // (tile, m-tile) unit of this producer wave
+                    const int u = pw + C::NPW * i;                  // (tile, m-tile) unit of this producer wave
                     long long ov; int co0;
                     const bool ok = u < C::NTILE * C::MT_ALL && x3_out_coord<C, COUT, KIND>(dm, w.b, w.x0, w.y0, z, u / C::MT_ALL, u % C::MT_ALL, n, kk, ov, co0);
                     eov[i] = ok ? ov * COUT + co0 : -1;
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
 #pragma unroll
                 for (int i = 0; i < NEU; ++i) {
                     if (eov[i] < 0) continue;
-                    const x3_f32x4* pp = part + (pw + 4 * i) * KSPLIT * 64 + lane;
+                    const x3_f32x4* pp = part + (pw + C::NPW * i) * KSPLIT * 64 + lane;
                     x3_f32x4 v = pp[0];
 #pragma unroll
                     for (int k = 1; k < KSPLIT; ++k) v += pp[k * 64];
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 #define RCMVS_X3_LIST(X) X(8, 8, X3_S1) X(16, 8, X3_S1) X(32, 8, X3_S1) X(16, 16, X3_S1) X(8, 16, X3_S2) X(16, 32, X3_S2) X(16, 8, X3_T2) \
-    X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1)
+    X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1) X(32, 32, X3_S1) X(32, 16, X3_T2)
 
 bool conv3d_x3_supported(int Ci, int Co, int kind) {
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;

@@ -226,7 +226,7 @@ def test_conv3d_vs_oracle(hip, Ci, Co, stride):
     assert rel_err(y2.cpu().permute(0, 4, 1, 2, 3), ref2) < 2e-5
 
 
-@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 8), (32, 8), (16, 16)])
+@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 8), (32, 8), (16, 16), (32, 32)])
 @pytest.mark.parametrize("shape", [(2, 5, 11, 21), (1, 9, 37, 70), (1, 20, 8, 32)])
 def test_conv3d_x3_vs_fp64(hip, Ci, Co, shape):
     """The split-bf16 MFMA kernels (csrc/conv3d_x3.hip: three bf16 pieces per fp32 operand, six MFMAs per product, fp32
@@ -263,7 +263,7 @@ def test_conv3d_x3_vs_fp64(hip, Ci, Co, shape):
         assert float((yT - refT).abs().max()) < 3e-6 * float(refT.abs().max())
 
 
-@pytest.mark.parametrize("Ci,Co,kind", [(8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2")])
+@pytest.mark.parametrize("Ci,Co,kind", [(8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2"), (32, 16, "t2")])
 @pytest.mark.parametrize("shape", [(2, 5, 11, 21), (1, 9, 37, 70), (1, 16, 8, 32)])
 def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
     """Stride-2 and transposed stride-2 forms of the split-bf16 MFMA kernel against fp64 (odd sizes: the stride-2 output of an
@@ -334,7 +334,7 @@ def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
 
 
 @pytest.mark.parametrize("Ci,Co,kind", [(8, 8, "s1"), (16, 8, "s1"), (32, 8, "s1"), (16, 16, "s1"), (8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2"),
-                                        (8, 8, "p1"), (16, 16, "p1"), (32, 32, "p1")])
+                                        (32, 32, "s1"), (32, 16, "t2"), (8, 8, "p1"), (16, 16, "p1"), (32, 32, "p1")])
 def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
     """The split-bf16 kernel is persistent: one block walks several (batch, tile, z chunk) work items with the LDS ring running
     across item boundaries.  Whatever the block count (3: many items per block, round robin; 8 / 16: the XCD-contiguous order;
