@@ -13,6 +13,9 @@ The JSON line also carries
   roofline      the fused warp+variance kernel (K1): algorithmic bytes of its three per-scene
                 launches (137.6 + 194.0 + 125.8 MB) / their HIP-event durations
                 recorded on the launch stream inside the timed region, vs the 8 TB/s HBM peak;
+  roofline_conv the 3-D convolutions that run on the bf16 matrix cores at fp32 accuracy (csrc/conv3d_x3.hip): algorithmic flops
+                of every such launch of a scene / HIP-event durations from a separate untimed pass, vs the fp32 dense peak
+                (157 TF; the six bf16 MFMAs per product are priced against the bf16 peak as `matrix_pipe_frac`);
   cpu_baseline  the oracle's ATen op graph (= the reference's CPU path) timed on the host cores
                 of this box on a bounded sample, rank 0, N=1 only -- a reported baseline, plus
                 the depth-L1 parity of the HIP output against it on the same inputs.
@@ -56,6 +59,53 @@ def host_threads():
     except Exception:
         pass
     return max(1, min(n, 32))
+
+
+# layer shapes served by the split-bf16 matrix-core kernels (csrc/conv3d_x3.hip): (kind, Ci, Co); one-plane stride-1 volumes use
+# the planar form (9 taps)
+X3_LAYERS = {("s1", 8, 8), ("s1", 16, 8), ("s1", 32, 8), ("s1", 16, 16), ("s1", 32, 32), ("s2", 8, 16), ("s2", 16, 32), ("t2", 16, 8), ("t2", 32, 16)}
+FP32_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH: fp32 vector = fp32 MFMA dense peak
+BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak
+
+
+def conv_roofline(conv_events, nscenes):
+    """Second roofline object: the 3-D convolutions that run on the bf16 matrix cores at fp32 accuracy.  `achieved` counts the
+    layer's ALGORITHMIC flops (2 x taps x Ci x Co per output voxel / input cell: what an fp32 convolution does) against the
+    fp32 dense peak -- the precision class the results are in; `matrix_pipe_frac` prices the six bf16 MFMAs per product
+    (block-Toeplitz padding not counted) against the dense bf16 peak."""
+    if not conv_events or nscenes <= 0:
+        return None
+    flops = ms = 0.0
+    per_layer = {}
+    for e0, e1, (kind, B, D, H, W, Ci, Co) in conv_events:
+        if (kind, Ci, Co) not in X3_LAYERS:
+            continue
+        taps = 9 if (kind == "s1" and D == 1) else 27
+        if kind == "t2":
+            cells = B * D * H * W                                  # every input cell meets all 27 taps once over its 8 outputs
+        elif kind == "s2":
+            cells = B * ((D - 1) // 2 + 1) * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        else:
+            cells = B * D * H * W
+        f = 2.0 * taps * Ci * Co * cells
+        t = e0.elapsed_time(e1)
+        flops += f
+        ms += t
+        k = f"{kind} {Ci}->{Co} {D}x{H}x{W}" + (f" x{B}" if B > 1 else "")
+        a = per_layer.setdefault(k, [0.0, 0.0])
+        a[0] += f
+        a[1] += t
+    if ms <= 0:
+        return None
+    tf = flops / (ms * 1e-3) / 1e12
+    top = sorted(per_layer.items(), key=lambda kv: -kv[1][1])[:6]
+    return {"bound": "mfma", "kernel": "rcmvs::conv3d_x3_kernel family (split-bf16 3-D / planar convolutions, all launches of a scene)",
+            "achieved": round(tf, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4),
+            "peak_note": "fp32 dense peak: the results are fp32-accurate (exact 3-way bf16 operand split, 6 MFMAs per product)",
+            "matrix_pipe_frac": round(6.0 * tf / BF16_PEAK_TFLOPS, 4), "us_per_scene": round(ms * 1e3 / nscenes, 1),
+            "gflop_per_scene": round(flops / nscenes / 1e9, 2),
+            "largest_layers_us_tflops": {k: [round(v[1] * 1e3 / nscenes, 1), round(v[0] / (v[1] * 1e-3) / 1e12, 1)] for k, v in top},
+            "timing": "HIP events on the launch stream around every launch, separate untimed pass of 10 scenes"}
 
 
 def k1_algorithmic_bytes():
@@ -356,6 +406,15 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     events, ops.K1_EVENTS = ops.K1_EVENTS, None
+    # second, UNTIMED pass with HIP events around every 3-D convolution launch (80 event records per scene would perturb `value`)
+    conv_events = []
+    if rank == 0:
+        with torch.no_grad():
+            ops.CONV_EVENTS = conv_events
+            for i in range(min(10, args.steps)):
+                step(i)
+            torch.cuda.synchronize()
+            ops.CONV_EVENTS = None
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -387,6 +446,8 @@ def main():
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)]}
 
+    roofline_conv = conv_roofline(conv_events, min(10, args.steps))
+
     result = {
         "metric": "ref-scenes/sec (DTU 3-view 512x640, D=48/32/8)",
         "value": round(world * args.steps / elapsed, 3),
@@ -404,6 +465,7 @@ def main():
                                "D=(48,32,8), batch 1 per GPU, fp32, random-init seeded weights",
                    "views": V, "height": H, "width": W, "ndepths": list(NDEPTHS), "parallelism": f"scene-per-gpu x{world}"},
         "roofline": roofline,
+        "roofline_conv": roofline_conv,
     }
 
     # ---- CPU baseline (oracle, ATen op graph of the reference) + parity on the same inputs -----

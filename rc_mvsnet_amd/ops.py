@@ -14,6 +14,8 @@ from . import _lib
 # bench.py sets this to a list to have every K1 launch bracketed by HIP events recorded on the
 # launch stream (torch's current stream); None = no instrumentation.
 K1_EVENTS = None
+# same for the 3-D convolutions: list of (event0, event1, key) with key = (kind, B, D, H, W, Ci, Co), kind 's1' | 's2' | 't2'
+CONV_EVENTS = None
 
 
 def _stream():
@@ -201,14 +203,21 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
                     dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"conv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
+    ev = None
+    if CONV_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        CONV_EVENTS.append(ev + (("s1" if stride == 1 else "s2", B, D, H, W, Ci, Co),))
     if _CONV_IMPL:
         _lib.check(_lib.load().rcmvs_debug_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                                       _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
                                                       _CONV_IMPL, _stream()), "debug_conv3d_fwd")
-        return y
-    _lib.check(_lib.load().rcmvs_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
-                                            _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
-                                            _stream()), "conv3d_fwd")
+    else:
+        _lib.check(_lib.load().rcmvs_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                                _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
+                                                _stream()), "conv3d_fwd")
+    if ev is not None:
+        ev[1].record()
     return y
 
 
@@ -222,14 +231,21 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"deconv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)} "
                               "(volume sizes must be divisible by 8, as in the reference)")
+    ev = None
+    if CONV_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        CONV_EVENTS.append(ev + (("t2", B, D, H, W, Ci, Co),))
     if _CONV_IMPL:
         _lib.check(_lib.load().rcmvs_debug_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                                         _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
                                                         _CONV_IMPL, _stream()), "debug_deconv3d_fwd")
-        return y
-    _lib.check(_lib.load().rcmvs_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
-                                              _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
-                                              _stream()), "deconv3d_fwd")
+    else:
+        _lib.check(_lib.load().rcmvs_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                                  _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
+                                                  _stream()), "deconv3d_fwd")
+    if ev is not None:
+        ev[1].record()
     return y
 
 
