@@ -113,7 +113,12 @@ class FeatureNet(nn.Module):
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
             if self.num_stage >= 2:
                 plan["inner1"] = (ops.pack_conv2d_weight(self.inner1.weight), self.inner1.bias.detach().float().contiguous())
-                plan["out2"] = ops.pack_conv2d_weight(self.out2.weight)
+                if tuple(self.out2.weight.shape) == (16, 32, 3, 3):       # 32 -> 16 3x3: planar split-bf16 kernel, as the trunk's square layers
+                    w3 = self.out2.weight.detach().new_zeros(16, 32, 3, 3, 3)
+                    w3[:, :, 1] = self.out2.weight.detach()
+                    plan["out2"] = ("mfma3d", ops.pack_conv3d_weight(w3))
+                else:
+                    plan["out2"] = ops.pack_conv2d_weight(self.out2.weight)
             if self.num_stage == 3:
                 plan["inner2"] = (ops.pack_conv2d_weight(self.inner2.weight), self.inner2.bias.detach().float().contiguous())
                 plan["out3"] = ops.pack_conv2d_weight(self.out3.weight)
@@ -150,7 +155,10 @@ class FeatureNet(nn.Module):
         out = {"stage1": (lambda t=c2: ops.conv2d(t, p["out1"]))}
         if self.num_stage >= 2:
             intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
-            out["stage2"] = (lambda t=intra: ops.conv2d(t, p["out2"]))
+            if isinstance(p["out2"], tuple):
+                out["stage2"] = (lambda t=intra: ops.conv3d(t.unsqueeze(1), p["out2"][1]).squeeze(1))
+            else:
+                out["stage2"] = (lambda t=intra: ops.conv2d(t, p["out2"]))
         if self.num_stage == 3:
             if p.get("fuse_out3") and c0.shape[1] % 2 == 0 and c0.shape[2] % 2 == 0:
                 # the full-resolution 32-channel merge is never stored: 1x1 lateral + up-add + 3x3 output conv in one launch

@@ -139,6 +139,103 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
     }
 }
 
+// ---- prob conv (8 -> 1), plane-marching form ---------------------------------------------------------------------------
+// The tile kernel above reads every input voxel 27 times from LDS for the single output channel (54 ds_read_b128 per voxel) and
+// stages a 4 x 10 x 18 halo per 2 x 8 x 16 outputs (2.8x the tile).  Here a block owns an 8 x 32 pixel tile and MARCHES over z:
+// input plane z is staged once (10 x 34 halo, 1.33x) and read 9 times (18 ds_read_b128 per voxel); its 3x3 neighbourhood feeds the
+// three kd taps at once -- plane z contributes the kd = 0 term of out[z + 1], the kd = 1 term of out[z] and the kd = 2 term of
+// out[z - 1] -- into three rolling accumulators, and out[z - 1] is complete when plane z is done.  Planes are double buffered in
+// LDS (next plane prefetched into registers during the FMAs): one barrier per plane.  Weights are wave-uniform scalar loads;
+// channel pairs go through v_pk_fma_f32 as in the tile kernel.
+constexpr int PM_TH = 8, PM_TW = 32, PM_HH = PM_TH + 2, PM_HW = PM_TW + 2, PM_STRIDE = 12, PM_ZC = 8;
+constexpr int PM_PLANE = PM_HH * PM_HW * PM_STRIDE;          // floats per staged plane (16,320 B)
+constexpr int PM_NLD = (PM_HH * PM_HW * 2 + 255) / 256;      // float4 per thread per plane
+
+__global__ __launch_bounds__(256) void prob_conv_march_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, float* __restrict__ y, int D, int H, int W, int tiles_w, int tiles_h, int relu) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float plane[2][PM_PLANE];
+    const int b = blockIdx.z, zc = blockIdx.y;
+    const unsigned t2 = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = t2 % tiles_w, th = t2 / tiles_w;
+    const int h0 = th * PM_TH, w0 = tw * PM_TW, z0 = zc * PM_ZC;
+    const int z1 = min(D, z0 + PM_ZC);                          // outputs z0 .. z1-1, input planes z0-1 .. z1
+    const int lw = threadIdx.x % PM_TW, lh = threadIdx.x / PM_TW;
+    const float* xb = x + (long long)b * D * H * W * 8;
+    // this thread's share of a plane's halo: element e = (halo voxel, float4 half)
+    int goff[PM_NLD], loff[PM_NLD];
+#pragma unroll
+    for (int i = 0; i < PM_NLD; ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int v = e >> 1, c4 = e & 1;
+        const int hh = v / PM_HW, hw_ = v - hh * PM_HW;
+        const int ih = h0 + hh - 1, iw = w0 + hw_ - 1;
+        const bool ok = e < PM_HH * PM_HW * 2 && ih >= 0 && ih < H && iw >= 0 && iw < W;
+        goff[i] = ok ? (ih * W + iw) * 8 + c4 * 4 : -1;
+        loff[i] = (e < PM_HH * PM_HW * 2) ? v * PM_STRIDE + c4 * 4 : -1;
+    }
+    float4 pf[PM_NLD];
+    auto fetch = [&](int z) {
+        const bool zin = z >= 0 && z < D;
+        const float* xp = xb + (long long)z * H * W * 8;
+#pragma unroll
+        for (int i = 0; i < PM_NLD; ++i)
+            pf[i] = (zin && goff[i] >= 0) ? *reinterpret_cast<const float4*>(xp + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PM_NLD; ++i)
+            if (loff[i] >= 0) *reinterpret_cast<float4*>(&plane[buf][loff[i]]) = pf[i];
+    };
+    fetch(z0 - 1);
+    stash(0);
+    fetch(z0);
+    __syncthreads();
+    f2v acc_prev = (f2v){0.f, 0.f}, acc_cur = (f2v){0.f, 0.f};      // out[z-1] and out[z] while plane z is processed
+    const int oh = h0 + lh, ow = w0 + lw;
+    const bool live = oh < H && ow < W;
+    int buf = 0;
+    for (int z = z0 - 1; z <= z1; ++z) {
+        f2v acc_next = (f2v){0.f, 0.f};                             // out[z+1]
+        const float* tp0 = &plane[buf][(lh * PM_HW + lw) * PM_STRIDE];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* tp = tp0 + (kh * PM_HW + kw) * PM_STRIDE;
+                const float4 xa = *reinterpret_cast<const float4*>(tp), xc = *reinterpret_cast<const float4*>(tp + 4);
+                const f2v x01 = (f2v){xa.x, xa.y}, x23 = (f2v){xa.z, xa.w}, x45 = (f2v){xc.x, xc.y}, x67 = (f2v){xc.z, xc.w};
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float* wt = wp + ((kd * 3 + kh) * 3 + kw) * 8;
+                    f2v a = (kd == 0) ? acc_next : (kd == 1 ? acc_cur : acc_prev);
+                    a = __builtin_elementwise_fma(x01, (f2v){wt[0], wt[1]}, a);
+                    a = __builtin_elementwise_fma(x23, (f2v){wt[2], wt[3]}, a);
+                    a = __builtin_elementwise_fma(x45, (f2v){wt[4], wt[5]}, a);
+                    a = __builtin_elementwise_fma(x67, (f2v){wt[6], wt[7]}, a);
+                    if (kd == 0) acc_next = a; else if (kd == 1) acc_cur = a; else acc_prev = a;
+                }
+            }
+        const int zo = z - 1;                                       // complete now
+        if (live && zo >= z0 && zo < z1) {
+            float v = acc_prev.x + acc_prev.y;
+            if (scale) v = v * scale[0] + shift[0];
+            if (relu) v = fmaxf(v, 0.0f);
+            const long long ov = (((long long)b * D + zo) * H + oh) * W + ow;
+            if (res) v += res[ov];
+            y[ov] = v;
+        }
+        acc_prev = acc_cur; acc_cur = acc_next;
+        if (z < z1) {
+            stash(buf ^ 1);                                         // plane z+1 (fetched during the previous iteration)
+            if (z + 2 <= z1) fetch(z + 2);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 bool conv3d_lds_supported(int Ci, int Co, int stride) {
     return stride == 1 && ((Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32 || Ci == 44)) || (Co == 1 && Ci == 8) ||
                            (Co == 16 && Ci == 16));
@@ -179,7 +276,13 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
         else            hipLaunchKernelGGL((conv3d_lds_kernel<16, 16, 1, 8>), grid, block, lds, st, x, wp, scale, shift, res, y, D, H, W, tiles_w, tiles_h, relu);
         return launch_status("conv3d_lds(16x16)");
     }
-    if (Co == 1 && Ci == 8) {                                   // prob conv 8 -> 1 (logits, (B,D,H,W) since Co = 1)
+    if (Co == 1 && Ci == 8 && !(g_lds_cfg & 1)) {               // prob conv 8 -> 1 (logits, (B,D,H,W) since Co = 1): plane-marching kernel
+        const int tw_ = (W + PM_TW - 1) / PM_TW, th_ = (H + PM_TH - 1) / PM_TH;
+        hipLaunchKernelGGL(prob_conv_march_kernel, dim3(tw_ * th_, (D + PM_ZC - 1) / PM_ZC, B), dim3(256), 0, st, x, wp, scale, shift, res, y,
+                           D, H, W, tw_, th_, relu);
+        return launch_status("conv3d_lds(prob, marching)");
+    }
+    if (Co == 1 && Ci == 8) {                                   // the tile kernel form (bit 0 of lds_cfg: A/B and cross-check)
         dim3 block1(256);
         hipLaunchKernelGGL((conv3d_lds_kernel<8, 1, 1, 8>), grid, block1, (size_t)LH_VOX * 12 * sizeof(float), st, x, wp, scale, shift,
                            res, y, D, H, W, tiles_w, tiles_h, relu);

@@ -24,13 +24,21 @@
 //               input neighbourhood; A holds tap p - 2*nb + 1 per axis (zero where it falls outside 0..2).
 //   K step = 32 = (32 / Cin) tap positions x Cin channels; lane (n = l & 15, kk = l >> 4) supplies channels 8*kk.. of its position.
 //
-// Data flow.  512 threads = 4 consumer waves (MFMA only) + 4 producer waves; a block owns a TY x TX tile of the tile grid and
-// marches over z.  The input z-slices it needs (halo included, already split into the three bf16 piece planes) sit in an LDS
-// ring; while the consumers work on step z the producers split + store the slice(s) of step z+1 (fetched into registers one
-// step earlier with raw buffer loads, out of range -> 0 = the zero padding) and issue the loads of step z+2: one barrier per
-// step, every input voxel is read once per block (x halo) and split once instead of once per tap.
+// Data flow.  512 threads = NCW consumer waves (MFMA + ds_read only) + NPW producer waves (4 + 4; 6 + 2 for the layers whose weight
+// image exceeds 4 x 128 registers: 32 -> 32 and the transposed 32 -> 16).  A block owns a TY x TX tile of the tile grid and
+// marches over z.  The input z-slices it needs (halo included, already split into the three bf16 piece planes) sit in an LDS ring
+// of 2 NKD slices; during tick s the consumers work on step s while the producers (1) split + store the slice(s) step s+1 adds
+// (fetched into registers two ticks earlier with raw buffer loads, out of range -> 0 = the zero padding), (2) issue the loads of
+// step s+3 and (3) finish the K-split partial tiles of step s-1: one barrier per step, every input voxel is read once per block
+// (x halo) and split once instead of once per tap.  Blocks are persistent (one per CU): a block walks its (batch, xy tile, z chunk)
+// work items back to back with the ring running across the item boundary.
 // Weights: K (and M) are cut over the consumer waves until a wave's share fits ~100 registers; with a K cut the partial
 // 16 x 16 tiles go through LDS and the producers finish them (sum, BN scale/shift, ReLU, skip-add, store).
+// Kinds: stride 1, stride 2, transposed stride 2, and "planar" (kd = 1 taps only: every z-plane on its own -- what a 3x3x3 conv
+// of a one-plane volume reduces to; the 2-D FeatureNet layers run as such volumes).
+// What bounds it (measured): on gfx950 VALU work -- of another wave on the SIMD or interleaved in the same
+// wave -- does not overlap v_mfma_f32_16x16x32_bf16, so a step costs MFMA time + producer VALU time; the producers are therefore
+// kept to the bare split (22 VALU per float4) and table-driven addressing.
 #include "common.h"
 
 namespace rcmvs {
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 #define RCMVS_X3_LIST(X) X(8, 8, X3_S1) X(16, 8, X3_S1) X(32, 8, X3_S1) X(16, 16, X3_S1) X(8, 16, X3_S2) X(16, 32, X3_S2) X(16, 8, X3_T2) \
-    X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1) X(32, 32, X3_S1) X(32, 16, X3_T2)
+    X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1) X(32, 16, X3_P1) X(32, 32, X3_S1) X(32, 16, X3_T2)
 
 bool conv3d_x3_supported(int Ci, int Co, int kind) {
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;

@@ -299,7 +299,7 @@ def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
         assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
 
 
-@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 16), (32, 32)])
+@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 16), (32, 32), (32, 16)])
 @pytest.mark.parametrize("shape", [(3, 11, 21), (2, 37, 70), (1, 8, 32)])
 def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
     """A one-plane volume (the FeatureNet 3x3 layers run as 3-D convs with D = 1) goes to the planar form of the split-bf16
@@ -327,6 +327,8 @@ def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
     for i, r in enumerate((ref, ref2)):
         e_x3, e_32 = float((outs["x3"][i] - r).abs().max()), float((outs["fp32"][i] - r).abs().max())
         assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
+    if Ci != Co:
+        return
     wt = torch.randn(Ci, Co, 3, 3, 3, generator=g) / (Ci * 9) ** 0.5
     refT = torch.nn.functional.conv_transpose3d(x.double(), wt.double(), padding=1)
     yT = hip.conv3d(xcl, hip.pack_conv3d_weight(gpu(wt), transposed=2)).cpu().permute(0, 4, 1, 2, 3).double()
@@ -334,7 +336,7 @@ def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
 
 
 @pytest.mark.parametrize("Ci,Co,kind", [(8, 8, "s1"), (16, 8, "s1"), (32, 8, "s1"), (16, 16, "s1"), (8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2"),
-                                        (32, 32, "s1"), (32, 16, "t2"), (8, 8, "p1"), (16, 16, "p1"), (32, 32, "p1")])
+                                        (32, 32, "s1"), (32, 16, "t2"), (32, 16, "p1"), (8, 8, "p1"), (16, 16, "p1"), (32, 32, "p1")])
 def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
     """The split-bf16 kernel is persistent: one block walks several (batch, tile, z chunk) work items with the LDS ring running
     across item boundaries.  Whatever the block count (3: many items per block, round robin; 8 / 16: the XCD-contiguous order;
@@ -361,6 +363,34 @@ def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
         finally:
             hip.force_direct_conv(0)
         assert torch.equal(y, base), (blocks, float((y - base).abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 11, 13, 45), (1, 20, 9, 70), (1, 3, 8, 32), (1, 8, 24, 33)])
+def test_prob_conv_marching_kernel(hip, shape):
+    """The 8 -> 1 prob conv runs on the plane-marching kernel (one staged plane feeds the three kd taps through rolling
+    accumulators): against fp64, against the tile kernel it replaces, ragged tiles, z chunks (D > 8), batch 2, epilogue."""
+    g = torch.Generator().manual_seed(shape[1])
+    B, D, H, W = shape
+    x = torch.randn(B, 8, D, H, W, generator=g) * torch.exp(torch.randn(B, 8, D, H, W, generator=g))
+    w = torch.randn(1, 8, 3, 3, 3, generator=g) / 216 ** 0.5
+    scale, shift = 0.5 + torch.rand(1, generator=g), 0.1 * torch.randn(1, generator=g)
+    res = torch.randn(B, 1, D, H, W, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
+    ref2 = torch.relu(ref * scale.double() + shift.double()) + res.double()
+    wp = hip.pack_conv3d_weight(gpu(w))
+    xcl, rcl = gpu(x.permute(0, 2, 3, 4, 1)), gpu(res.permute(0, 2, 3, 4, 1))
+    outs = {}
+    for name, cfg in (("march", 0), ("tile", 2)):
+        try:
+            hip.force_direct_conv(cfg)
+            outs[name] = (hip.conv3d(xcl, wp).cpu().permute(0, 4, 1, 2, 3).double(),
+                          hip.conv3d(xcl, wp, gpu(scale), gpu(shift), rcl, relu=True).cpu().permute(0, 4, 1, 2, 3).double())
+        finally:
+            hip.force_direct_conv(0)
+    mag = float(ref.abs().max())
+    for i, r in enumerate((ref, ref2)):
+        e_m, e_t = float((outs["march"][i] - r).abs().max()), float((outs["tile"][i] - r).abs().max())
+        assert e_m <= 2.0 * e_t + 1e-7 * mag and e_m < 3e-6 * mag, (i, e_m, e_t, mag)
 
 
 @pytest.mark.parametrize("Ci", [8, 16, 32, 44])
