@@ -89,6 +89,11 @@ int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot
 int rcmvs_warp_variance_bwd(const float* feats, const float* rot, const float* trans, const float* planes,
                             const float* grad_var, const float* grad_noref, float* grad_feats,
                             int B, int V, int C, int D, int h, int w, void* stream);
+/* Test / ablation twin of rcmvs_warp_variance_bwd (no reference counterpart).  variant bit 0: everything but the atomic scatter (timing
+ * floor; the source-view gradients are NOT produced); bit 1: no run-length merging of consecutive planes' footprints. */
+int rcmvs_debug_warp_variance_bwd(const float* feats, const float* rot, const float* trans, const float* planes,
+                            const float* grad_var, const float* grad_noref, float* grad_feats,
+                            int B, int V, int C, int D, int h, int w, int variant, void* stream);
 
 /* ---- K2/K3: 3-D convolution family, channels-last, fused epilogue ----------------------- */
 /* weight packing (host-visible layout change, done once per weight update):

@@ -112,7 +112,7 @@ def warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first):
     return out
 
 
-def warp_variance_bwd(feats, rot, trans, planes, grad_var, grad_noref=None):
+def warp_variance_bwd(feats, rot, trans, planes, grad_var, grad_noref=None, variant=0):
     """d loss / d feats (B,V,h,w,C) from d loss / d var (and, optionally, d loss / d no-ref variance), both
     (B,D,h,w,C) channels-last."""
     B, V, h, w, C = feats.shape
@@ -120,6 +120,12 @@ def warp_variance_bwd(feats, rot, trans, planes, grad_var, grad_noref=None):
     if tuple(grad_var.shape) != (B, D, h, w, C) or (grad_noref is not None and grad_noref.shape != grad_var.shape):
         raise _lib.RcmvsError(f"warp_variance_bwd: gradient shape {tuple(grad_var.shape)} does not match (B,D,h,w,C)")
     gf = torch.zeros_like(feats)
+    if variant:          # ablation twin (bit 0: no scatter -- timing only; bit 1: no run-length merging)
+        _lib.check(_lib.load().rcmvs_debug_warp_variance_bwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                             _chk(planes, "planes"), _chk(grad_var, "grad_var"),
+                                                             _opt(grad_noref, "grad_noref"), _chk(gf, "grad_feats"),
+                                                             B, V, C, D, h, w, int(variant), _stream()), "debug_warp_variance_bwd")
+        return gf
     _lib.check(_lib.load().rcmvs_warp_variance_bwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
                                                    _chk(planes, "planes"), _chk(grad_var, "grad_var"),
                                                    _opt(grad_noref, "grad_noref"), _chk(gf, "grad_feats"),

@@ -206,7 +206,9 @@ inline int __lane_id() { return ::shim::me().lin % ::shim::WAVE; }
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
-#define __builtin_amdgcn_wave_barrier() ((void)0)
+// on the hardware a wave runs in lockstep and the builtin only pins the order of LDS accesses; on fibers it has to be a real
+// rendezvous of the wave's lanes (wave-private LDS exchanges rely on it)
+#define __builtin_amdgcn_wave_barrier() ((void)::shim::exchange(0))
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 #define __ldg(p) (*(p))
 #define __expf(x) expf(x)
