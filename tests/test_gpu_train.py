@@ -123,6 +123,25 @@ def test_prob_depth_head_backward():
     assert e_dx < 1e-4 and e_dw < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 11, 21), (1, 20, 9, 37), (1, 3, 17, 16), (1, 35, 8, 16)])
+def test_prob_conv_weight_gradient_marching_kernel(shape):
+    """Weight gradient of the 8 -> 1 prob conv on the plane-marching kernel (persistent blocks over (tile, z chunk) items, rolling
+    dy[z-1], dy[z], dy[z+1], butterfly reduction): against fp64 autograd on ragged tiles, several z chunks (D > 16), batch 2."""
+    import torch.nn.functional as F
+    from rc_mvsnet_amd import _lib, train_ops
+    _lib.load()
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D + W)
+    x = torch.randn(B, 8, D, H, W, generator=g)
+    dy = torch.randn(B, 1, D, H, W, generator=g)
+    w = torch.zeros(1, 8, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv3d(x.double(), w, padding=1) * dy.double()).sum().backward()
+    dw = train_ops.conv3d_wgrad(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV), 1).cpu()
+    ref = w.grad[0].permute(1, 2, 3, 0).reshape(27, 8, 1)             # (27, Ci, Co)
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
 def test_cascade_train_native_vs_delegated_gradients():
     """CascadeMVSNet in train mode: the HIP training path (WarpVarianceFn + ConvBnReluFn + ProbDepthHeadFn) and the
     reference's op graph with autograd (oracle/aten_graph.py, same device) produce the same outputs, parameter gradients
