@@ -117,8 +117,15 @@ __host__ __device__ inline void x3_kslot(int js, int kk, int& q, int& ci0) {
 // Cin = 32 a voxel is 64 B, lane (n, kk) reads 16 B at 64 n + 16 kk and lanes n, n + 4 (n + 12) of a group collide: measured 43 %
 // of the LDS cycles.  Flipping bit 1 of the 16-byte slot on every second group of four columns makes all four groups
 // conflict-free for each of the three tap columns (exhaustive check in DESIGN.md); other layouts read conflict-free as they are.
+// With Cin = 64 a voxel is 128 B and a lane group sees only four distinct 16-byte slots (4-way conflicts); the slot's low three bits
+// (channel half, kk) are XORed with a per-column-pair value found by exhaustive search over the lane groups, both channel halves and
+// the three tap columns: table[hc >> 1] = 0 1 2 4 5 6 2 6 0 (3 bits each, packed below), conflict-free for the 18 halo columns.
 template <class C, int CIN, int KIND>
-__host__ __device__ inline int x3_swz(int hc) { return (CIN == 32 && x3_unit(KIND)) ? ((hc >> 2) & 1) * 32 : 0; }
+__host__ __device__ inline int x3_swz(int hc) {
+    if (CIN == 32 && x3_unit(KIND)) return ((hc >> 2) & 1) * 32;
+    if (CIN == 64 && x3_unit(KIND)) return (int)((0xCB5888u >> (3 * (hc >> 1))) & 7u) * 16;
+    return 0;
+}
 
 // ---- weight image: [K step][piece][m-tile][lane][8 bf16], the A fragment of v_mfma_f32_16x16x32_bf16 (row = lane & 15,
 // k = 8 * (lane >> 4) + e), pieces split by truncation like the activations.
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 #define RCMVS_X3_LIST(X) X(8, 8, X3_S1) X(16, 8, X3_S1) X(32, 8, X3_S1) X(16, 16, X3_S1) X(8, 16, X3_S2) X(16, 32, X3_S2) X(16, 8, X3_T2) \
-    X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1) X(32, 16, X3_P1) X(32, 32, X3_S1) X(32, 16, X3_T2)
+    X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1) X(32, 16, X3_P1) X(64, 32, X3_P1) X(32, 32, X3_S1) X(32, 16, X3_T2)
 
 bool conv3d_x3_supported(int Ci, int Co, int kind) {
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;

@@ -299,7 +299,7 @@ def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
         assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
 
 
-@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 16), (32, 32), (32, 16)])
+@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 16), (32, 32), (32, 16), (64, 32)])
 @pytest.mark.parametrize("shape", [(3, 11, 21), (2, 37, 70), (1, 8, 32)])
 def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
     """A one-plane volume (the FeatureNet 3x3 layers run as 3-D convs with D = 1) goes to the planar form of the split-bf16
@@ -336,7 +336,7 @@ def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
 
 
 @pytest.mark.parametrize("Ci,Co,kind", [(8, 8, "s1"), (16, 8, "s1"), (32, 8, "s1"), (16, 16, "s1"), (8, 16, "s2"), (16, 32, "s2"), (16, 8, "t2"),
-                                        (32, 32, "s1"), (32, 16, "t2"), (32, 16, "p1"), (8, 8, "p1"), (16, 16, "p1"), (32, 32, "p1")])
+                                        (32, 32, "s1"), (32, 16, "t2"), (32, 16, "p1"), (64, 32, "p1"), (8, 8, "p1"), (16, 16, "p1"), (32, 32, "p1")])
 def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
     """The split-bf16 kernel is persistent: one block walks several (batch, tile, z chunk) work items with the LDS ring running
     across item boundaries.  Whatever the block count (3: many items per block, round robin; 8 / 16: the XCD-contiguous order;

@@ -94,7 +94,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
 
 int main(int argc, char** argv) {
     int bad = 0;
-    const int cases[12][3] = {{0, 32, 32}, {2, 32, 16}, {0, 8, 8}, {0, 16, 8}, {0, 32, 8}, {0, 16, 16}, {1, 8, 16}, {1, 16, 32}, {2, 16, 8}, {3, 8, 8}, {3, 16, 16}, {3, 32, 32}};
+    const int cases[13][3] = {{3, 64, 32}, {0, 32, 32}, {2, 32, 16}, {0, 8, 8}, {0, 16, 8}, {0, 32, 8}, {0, 16, 16}, {1, 8, 16}, {1, 16, 32}, {2, 16, 8}, {3, 8, 8}, {3, 16, 16}, {3, 32, 32}};
     for (auto& p : cases) {
         bad |= run_case(p[0], p[1], p[2], 8, 8, 32, true, 0);
         bad |= run_case(p[0], p[1], p[2], 11, 13, 45, true, 0);     // ragged: partial tiles in x and y, z not a multiple of the chunk
@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
     }
     if (argc > 1 && atoi(argv[1]) == 0) return bad;
     if (argc > 1 && atoi(argv[1]) == 4) {        // FeatureNet layers: 3 views as planes
-        run_case(3, 8, 8, 3, 512, 640, false, 20); run_case(3, 16, 16, 3, 256, 320, false, 20); run_case(3, 32, 32, 3, 128, 160, false, 20);
+        run_case(3, 8, 8, 3, 512, 640, false, 20); run_case(3, 16, 16, 3, 256, 320, false, 20); run_case(3, 32, 32, 3, 128, 160, false, 20); run_case(3, 64, 32, 3, 128, 160, false, 20);
         run_case(0, 32, 32, 12, 32, 40, false, 20); run_case(0, 32, 32, 8, 64, 80, false, 20); run_case(0, 32, 32, 2, 128, 160, false, 20);
         run_case(2, 32, 16, 6, 16, 20, false, 20); run_case(2, 32, 16, 4, 32, 40, false, 20); run_case(2, 32, 16, 1, 64, 80, false, 20);
         return 0;
