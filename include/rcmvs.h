@@ -115,6 +115,14 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
 
 /* y = epilogue(conv_transpose3d(x, w, k=3, stride=2, pad=1, output_pad=1)),
  * x (B,D,H,W,Ci) -> y (B,2D,2H,2W,Co).  Replaces Deconv3d.forward (models/modules.py:196-204). */
+/* A 5x5 stride-2 (pad 2) 2-D convolution + BN(eval) + ReLU (models/modules.py:53-59 with the FeatureNet arguments of :418-423) as a
+ * 3x3 stride-1 convolution of the space-to-depth view of its input, on the planar split-bf16 kernel, WITHOUT materialising that view:
+ * x (N,H,W,C) channels-last, H and W even; w_packed = rcmvs_pack_conv3d_weight of the (Co, 4C, 3,3,3) weight whose middle depth slice
+ * holds the re-indexed 5x5 taps (tap k = 2t + parity per axis, channel order (row parity, column parity, c)); y (N,H/2,W/2,Co).
+ * Supported (4C, Co): (32,16), (64,32). */
+int rcmvs_conv2d_s2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                         int N, int H, int W, int C, int Co, int relu, void* stream);
+
 int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                        const float* residual, float* y,
                        int B, int D, int H, int W, int Ci, int Co, int relu, void* stream);

@@ -28,6 +28,7 @@ SIGNATURES = {
     "rcmvs_hypothesis_planes": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_conv2d_s2d_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_resize_planes_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

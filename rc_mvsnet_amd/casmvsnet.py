@@ -103,9 +103,10 @@ class FeatureNet(nn.Module):
                     w3[:, :, 1] = w.detach()
                     plan[n] = ("mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
                     continue
-                if w.shape[0] == 32 and w.shape[1] == 16 and w.shape[2] == 5 and m.stride == 2 and os.environ.get("RCMVS_S2D", "1") != "0":
-                    # 16 -> 32 5x5 stride 2 (12 % VALU busy on the scalar-weight kernel): space-to-depth turns it into a 64 -> 32
-                    # 3x3 stride-1 layer (tap k = 2t + parity; the k = 5 taps are zero), which runs on the MFMA kernel
+                if tuple(w.shape) in ((32, 16, 5, 5), (16, 8, 5, 5)) and m.stride == 2 and os.environ.get("RCMVS_S2D", "1") != "0":
+                    # 5x5 stride 2 (12 % VALU busy on the scalar-weight kernel): space-to-depth turns it into a 4C -> Co 3x3
+                    # stride-1 layer (tap k = 2t + parity; the k = 5 taps are zero) for the planar split-bf16 matrix-core kernel,
+                    # which reads the space-to-depth view straight from the un-rearranged map (ops.conv2d_s2d)
                     w3 = self._w3(self._w5s2(w.detach())).contiguous()
                     plan[n] = ("s2d_mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
                     continue
@@ -144,7 +145,9 @@ class FeatureNet(nn.Module):
                     raise RcmvsError(f"FeatureNet: image height and width must be multiples of 4 (got a {t.shape[1]}x{t.shape[2]} map "
                                      "at the second stride-2 layer), as the reference's three-level pyramid requires")
                 _, w3, sc, sh = p[n]
-                return ops.conv3d(self._s2d(t).contiguous().unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)
+                if ops._CONV_IMPL:          # tests / A-B with the split-bf16 kernels switched off: the materialised view on the selected kernels
+                    return ops.conv3d(self._s2d(t).contiguous().unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)
+                return ops.conv2d_s2d(t, w3, sc, sh, relu=True)
             w, sc, sh, stride = p[n]
             return ops.conv2d(t, w, sc, sh, stride=stride, relu=True)
 

@@ -153,7 +153,7 @@ bool conv3d_x3_supported(int Ci, int Co, int kind);
 long long conv3d_x3_weight_floats(int Ci, int Co, int kind);
 int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, hipStream_t st);
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks);
+                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d = 0);
 
 // packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 images of
 // the four kinds (each present when the pair has that kernel)
@@ -235,6 +235,16 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
                      const float* residual, float* y,
                      int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream) {
     return conv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, stride, relu, stream, ConvImpl(0));
+}
+
+int rcmvs_conv2d_s2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                         int N, int H, int W, int C, int Co, int relu, void* stream) {
+    RCMVS_REQUIRE(x && w_packed && y, "conv2d_s2d_fwd: null pointer");
+    RCMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv2d_s2d_fwd: H and W must be even (got %d x %d)", H, W);
+    RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv2d_s2d_fwd: scale and shift go together");
+    RCMVS_REQUIRE(conv3d_x3_supported(4 * C, Co, X3_KIND_PLANAR), "conv2d_s2d_fwd: no planar split-bf16 kernel for %d -> %d channels", 4 * C, Co);
+    return conv3d_x3_launch(x, w_packed + x3_image_offset(4 * C, Co, X3_KIND_PLANAR), scale, shift, nullptr, y, N, 1, H / 2, W / 2, 4 * C, Co,
+                            X3_KIND_PLANAR, relu, as_stream(stream), 0, 1);
 }
 
 int rcmvs_debug_conv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,

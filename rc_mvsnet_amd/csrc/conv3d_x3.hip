@@ -195,6 +195,8 @@ struct X3Dims {
     int Dt;             // extent of the tile grid in z (= Do for the convolutions, D for the transposed convolution)
     int tiles_x, zchunk, relu;
     int B, ntiles, nchunks, nitems;   // work items = B x xy tiles x z chunks
+    int s2d;            // planar kind only: the input is physically (B, D, 2H, 2W, CIN / 4) and is read through a space-to-depth view
+                        // (channel (py, px, c) of voxel (y, x) = channel c of pixel (2y + py, 2x + px)): a 5x5 stride-2 layer as a 3x3 one
 };
 
 // output voxel + first channel of the float4 a lane holds for (tile tl, m-tile mtg, step z); false = outside the volume
@@ -424,7 +426,13 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             const int v = e / C::Q4, c4 = e - v * C::Q4;
             const int hr = v / C::TXP, hc = v - hr * C::TXP;
             hrc[i] = (e < C::NLOAD) ? ((hr << 16) | hc) : -1;
-            grel[i] = ((hr * dm.W + hc) * CIN + c4 * 4) * 4;
+            if (dm.s2d) {
+                constexpr int CP = CIN / 4, QP = CP / 4 > 0 ? CP / 4 : 1;      // physical channels, float4 per physical pixel
+                const int par = c4 / QP, cq = c4 - par * QP;
+                grel[i] = (((2 * hr + (par >> 1)) * (2 * dm.W) + 2 * hc + (par & 1)) * CP + cq * 4) * 4;
+            } else {
+                grel[i] = ((hr * dm.W + hc) * CIN + c4 * 4) * 4;
+            }
             loff[i] = (e < C::NLOAD) ? hr * C::ROWB + hc * C::VB + ((c4 * 8) ^ x3_swz<C, CIN, KIND>(hc)) : -1;
             goff[i] = OOB;
         }
@@ -436,7 +444,8 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             const X3Item& w = t.w;
             const int hy0 = x3_unit(KIND) ? w.y0 - 1 : (KIND == X3_S2 ? 2 * w.y0 - 1 : w.y0);
             const int hx0 = x3_unit(KIND) ? w.x0 - 1 : (KIND == X3_S2 ? 2 * w.x0 - 1 : w.x0);
-            const int base = (w.b * dm.D * dm.H + hy0) * dm.W * CIN * 4 + hx0 * CIN * 4;
+            const int base = dm.s2d ? ((w.b * dm.D * 2 * dm.H + 2 * hy0) * (2 * dm.W) + 2 * hx0) * CIN
+                                    : (w.b * dm.D * dm.H + hy0) * dm.W * CIN * 4 + hx0 * CIN * 4;
 #pragma unroll
             for (int i = 0; i < C::NPF; ++i) {
                 const int gy = hy0 + (hrc[i] >> 16), gx = hx0 + (hrc[i] & 0xffff);
@@ -595,7 +604,8 @@ int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int tra
 }
 
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks) {
+                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d) {
+    if (s2d && (kind != X3_P1 || Ci % 16 != 0)) return fail(-1, "conv3d_x3: the space-to-depth view needs the planar kind and Ci a multiple of 16");
     if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_x3: input tensor too large for 32-bit offsets");
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -606,7 +616,7 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     }
     const int n_blk = max_blocks > 0 ? max_blocks : n_cu;      // max_blocks: test / tuning hook (few blocks = many items per block)
     X3Dims dm;
-    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu;
+    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d;
     if (kind == X3_T2) { dm.Do = 2 * D; dm.Ho = 2 * H; dm.Wo = 2 * W; }
     else { const int s = kind == X3_S2 ? 2 : 1; dm.Do = (D - 1) / s + 1; dm.Ho = (H - 1) / s + 1; dm.Wo = (W - 1) / s + 1; }
     const int gh = kind == X3_T2 ? H : dm.Ho, gw = kind == X3_T2 ? W : dm.Wo;      // tile grid

@@ -255,6 +255,19 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     return y
 
 
+def conv2d_s2d(x, w_packed, scale=None, shift=None, relu=False):
+    """5x5 stride-2 conv as a 3x3 conv of the space-to-depth view of x (N,H,W,C), the view never materialised: -> (N,H/2,W/2,Co).
+    w_packed: pack_conv3d_weight of the (Co,4C,3,3,3) re-indexed weight."""
+    N, H, W, C = x.shape
+    Co = w_packed.co
+    if w_packed.ci != 4 * C:
+        raise _lib.RcmvsError(f"conv2d_s2d: input has {C} channels, the packed weight expects {w_packed.ci} = 4 x C")
+    y = torch.empty((N, H // 2, W // 2, Co), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_conv2d_s2d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                                _chk(y, "y"), N, H, W, C, Co, int(relu), _stream()), "conv2d_s2d_fwd")
+    return y
+
+
 # ------------------------------------------------------------------------------- 2-D feature pyramid
 def rgb_to_nhwc4(x):
     """(N,3,H,W) -> (N,H,W,4), zero 4th channel."""

@@ -399,6 +399,33 @@ def test_prob_conv_marching_kernel(hip, shape):
         assert e_m <= 2.0 * e_t + 1e-7 * mag and e_m < 3e-6 * mag, (i, e_m, e_t, mag)
 
 
+@pytest.mark.parametrize("C,Co", [(8, 16), (16, 32)])
+@pytest.mark.parametrize("shape", [(3, 22, 70), (1, 38, 36), (2, 8, 32)])
+def test_conv2d_s2d_is_the_5x5_stride2_layer(hip, C, Co, shape):
+    """rcmvs_conv2d_s2d_fwd: the FeatureNet 5x5 stride-2 layers as a 3x3 conv of the space-to-depth view of the input, read by the
+    planar split-bf16 kernel straight from the un-rearranged map.  Against nn.Conv2d(k = 5, stride 2, pad 2) in fp64, with the
+    folded-BN epilogue, and against the same kernel on the materialised view (bit-identical)."""
+    from rc_mvsnet_amd.casmvsnet import FeatureNet
+    from rc_mvsnet_amd._lib import RcmvsError
+    N, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, C, H, W, generator=g))
+    w5 = torch.randn(Co, C, 5, 5, generator=g) / (25 * C) ** 0.5
+    scale, shift = 0.5 + torch.rand(Co, generator=g), 0.1 * torch.randn(Co, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w5.double(), stride=2, padding=2) * scale.double().view(1, -1, 1, 1)
+                     + shift.double().view(1, -1, 1, 1))
+    wp = hip.pack_conv3d_weight(gpu(FeatureNet._w3(FeatureNet._w5s2(w5)).contiguous()))
+    xcl = gpu(x.permute(0, 2, 3, 1))
+    y = hip.conv2d_s2d(xcl, wp, gpu(scale), gpu(shift), relu=True)
+    assert tuple(y.shape) == (N, H // 2, W // 2, Co)
+    err = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max())
+    assert err < 3e-6 * float(ref.abs().max()), err
+    y2 = hip.conv3d(FeatureNet._s2d(xcl).contiguous().unsqueeze(1), wp, gpu(scale), gpu(shift), relu=True).squeeze(1)
+    assert torch.equal(y, y2)
+    with pytest.raises(RcmvsError):
+        hip.conv2d_s2d(xcl[:, :H - 1].contiguous(), wp)            # odd height
+
+
 @pytest.mark.parametrize("Ci", [8, 16, 32, 44])
 def test_conv3d_lds_halo_kernel(hip, Ci):
     """Cout = 8 stride-1 layers run on the LDS-staged halo kernel: against the oracle (ragged tiles: sizes
