@@ -607,13 +607,18 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
                      int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d) {
     if (s2d && (kind != X3_P1 || Ci % 16 != 0)) return fail(-1, "conv3d_x3: the space-to-depth view needs the planar kind and Ci a multiple of 16");
     if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_x3: input tensor too large for 32-bit offsets");
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
+    // per-device facts (a process may drive several GPUs, e.g. nn.DataParallel replicas): CU count, and whether the kernel's
+    // dynamic-LDS limit has been raised on that device.  Races are benign (the same values are written).
+    constexpr int MAXDEV = 64;
+    static int cu_of[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return fail(-1, "conv3d_x3: cannot query the device");
+    if (cu_of[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(-1, "conv3d_x3: cannot query the device");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(-1, "conv3d_x3: cannot query the device");
+        cu_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int n_cu = cu_of[dev];
     const int n_blk = max_blocks > 0 ? max_blocks : n_cu;      // max_blocks: test / tuning hook (few blocks = many items per block)
     X3Dims dm;
     dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d;
@@ -641,8 +646,8 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
         if (items >= 0x7fffffffLL) return fail(-1, "conv3d_x3: too many work items"); \
         dm.nitems = (int)items; \
         dim3 grid((unsigned)(dm.nitems < n_blk ? dm.nitems : n_blk)); \
-        static bool attr_set = false; \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSB); attr_set = true; } \
+        static bool attr_set[MAXDEV]; \
+        if (!attr_set[dev]) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSB); attr_set[dev] = true; } \
         hipLaunchKernelGGL((conv3d_x3_kernel<CI, CO, K>), grid, dim3(512), C::LDSB, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, res, y, dm); \
         return launch_status("conv3d_x3"); }
     RCMVS_X3_LIST(X3_CASE)
