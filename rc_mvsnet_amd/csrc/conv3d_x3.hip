@@ -122,7 +122,7 @@ __host__ __device__ inline void x3_kslot(int js, int kk, int& q, int& ci0) {
 // the three tap columns: table[hc >> 1] = 0 1 2 4 5 6 2 6 0 (3 bits each, packed below), conflict-free for the 18 halo columns.
 template <class C, int CIN, int KIND>
 __host__ __device__ inline int x3_swz(int hc) {
-    if (CIN == 32 && x3_unit(KIND)) return ((hc >> 2) & 1) * 32;
+    if (CIN == 32 && (x3_unit(KIND) || KIND == X3_T2)) return ((hc >> 2) & 1) * 32;       // transposed: same geometry (columns one voxel apart, tap columns 0..1)
     if (CIN == 64 && x3_unit(KIND)) return (int)((0xCB5888u >> (3 * (hc >> 1))) & 7u) * 16;
     return 0;
 }

@@ -74,7 +74,7 @@ FAST = {
 }
 SLOW = {
     GP: ["test_train_variant_volume_feature", "test_warp_variance_variants_agree", "test_feature_net_vs_oracle",
-         "test_cascade_batch_two_equals_two_singles"],
+         "test_cascade_batch_two_equals_two_singles", "test_conv3d_x3_vs_fp64", "test_conv3d_x3_strided_vs_fp64"],
     GR: ["test_neural_volume_vs_golden", "test_render_forward_vs_reference_golden"],
     GT: ["test_conv_bn_relu_block_forward_backward", "test_neural_volume_net_train_native_vs_delegated",
          "test_renderer_train_native_vs_delegated", "test_featurenet_train_native_vs_delegated",

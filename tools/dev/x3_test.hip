@@ -63,7 +63,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     CK(hipMemcpy(dres, res.data(), ny * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dy, 0xff, ny * 4));
     if (conv3d_x3_pack(dw, dimg, Co, Ci, kind, kind == 2 ? 1 : 0, 0)) return 1;
-    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks)) return 1;
+    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0)) return 1;
     CK(hipDeviceSynchronize());
     int bad = 0;
     if (check) {
@@ -80,9 +80,9 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     }
     if (reps > 0) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks);
+        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0);
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks);
+        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         double us = ms * 1e3 / reps, fl = 2.0 * (kind == 3 ? 9 : 27) * Ci * Co * (kind == 2 ? (double)D * H * W : (double)Do * Ho * Wo);
