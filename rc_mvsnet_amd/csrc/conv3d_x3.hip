@@ -276,7 +276,6 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     } else {
         it_first = bid; it_stride = nblk; it_limit = dm.nitems;
     }
-    const int blk_per_xcd = it_stride;
     X3Dims dmx = dm;
     dmx.nitems = it_limit;                      // the step iterators stop at the end of this block's range
     const bool relu = dm.relu != 0;
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                         }
                     }
             }
-            st.advance(dmx, blk_per_xcd);
+            st.advance(dmx, it_stride);
             s0 = (s0 + (st.first ? NKD : ZADV)) % NSLOT;      // a new item starts right behind the last plane of the previous one
             ++tick;
             __syncthreads();
