@@ -32,7 +32,13 @@ template <int CI, int CO, int STRIDE>
 struct WgradCfg {
     static constexpr int CQ = CI / 4;
     static constexpr int TPM = 16 / CQ;
-    static constexpr int NGRP = (27 + TPM - 1) / TPM;
+    // CO = 8 fills only half of the 16 MFMA columns.  The idle half takes dy shifted by ONE cell along w: with A = x at tap
+    // (kd, kh, kw), column 8 + co then accumulates sum x[cell + kw - 1] dy[cell + 1][co] = the gradient of tap (kd, kh, kw - 1).
+    // Rows therefore only enumerate kw = 1, 2 (18 "row taps" instead of 27): kw = 1 rows yield kw = 1 (left half) and kw = 0
+    // (right half), kw = 2 rows yield kw = 2 (their right half repeats kw = 1 and is dropped): 3/4 of the tile is useful.
+    static constexpr bool PAIR = (CO == 8 && STRIDE == 1);
+    static constexpr int NT = PAIR ? 18 : 27;                       // row taps
+    static constexpr int NGRP = (NT + TPM - 1) / TPM;
     static constexpr int NJ = CO >= 16 ? CO / 16 : 1;
     static constexpr int GMAX = 4;                                   // accumulator groups per wave (x 16 NJ registers each)
     static constexpr int G = (GMAX / NJ) < 1 ? 1 : ((GMAX / NJ) < NGRP ? (GMAX / NJ) : NGRP);
@@ -58,9 +64,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     int tdx[G];                              // packed (valid << 6) | (td << 4) | (th << 2) | tw of this lane's tap per group
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) {
-        const int tap = (g0 + gi) * TPM + tapsel;
-        const bool valid = (g0 + gi) < NGRP && tap < 27;
-        tdx[gi] = valid ? (64 | ((tap / 9) << 4) | (((tap / 3) % 3) << 2) | (tap % 3)) : 0;
+        const int rt = (g0 + gi) * TPM + tapsel;                  // row tap of this lane
+        const bool valid = (g0 + gi) < NGRP && rt < Cfg::NT;
+        const int td = Cfg::PAIR ? rt / 6 : rt / 9, th = Cfg::PAIR ? (rt / 2) % 3 : (rt / 3) % 3, tw = Cfg::PAIR ? 1 + (rt & 1) : rt % 3;
+        tdx[gi] = valid ? (64 | (td << 4) | (th << 2) | tw) : 0;
     }
     f32x4 acc[G][4][NJ];
 #pragma unroll
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
             const int t0 = (g0 + gi) * TPM, t1 = t0 + TPM - 1;
-            if (t1 < 9 || t0 >= 18) gdead |= 1u << gi;
+            if (Cfg::PAIR ? (t1 < 6 || t0 >= 12) : (t1 < 9 || t0 >= 18)) gdead |= 1u << gi;
         }
     }
     const int w_lo = PLANE ? blockIdx.z * wchunk : 0, w_hi = PLANE ? min(dm.Wo, w_lo + wchunk) : dm.Wo;   // few rows: the row is split across grid.z
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
         const int oh = row % dm.Ho;
         const int od = (row / dm.Ho) % dm.Do;
         const int b = row / (dm.Ho * dm.Do);
-        const float* dyrow = dy + ((((long long)b * dm.Do + od) * dm.Ho + oh) * dm.Wo) * CO + NJ * m;
+        const float* dyrow = dy + ((((long long)b * dm.Do + od) * dm.Ho + oh) * dm.Wo) * CO + (Cfg::PAIR ? (m & 7) : NJ * m);
         // per group: byte offset of (b, id, ih, iw = 0) for this lane's tap, or "row invalid"
         int rbase[G];
         unsigned rok = 0;                                       // bit gi: the tap's (d, h) row exists
@@ -120,7 +127,12 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
                 if (w_ok) t = *reinterpret_cast<const float2*>(dyrow + (long long)ow * CO);
                 bv[0] = t.x; bv[1] = t.y;
             } else {
-                bv[0] = (n_ok && w_ok) ? dyrow[(long long)ow * CO] : 0.0f;
+                if constexpr (Cfg::PAIR) {                          // columns 8..15: dy of the next cell along w (tap kw - 1)
+                    const int sh = m >> 3;
+                    bv[0] = (w_ok && ow + sh < dm.Wo) ? dyrow[(long long)(ow + sh) * CO] : 0.0f;
+                } else {
+                    bv[0] = (n_ok && w_ok) ? dyrow[(long long)ow * CO] : 0.0f;
+                }
             }
             const int iw0 = ow * STRIDE;                         // input column of tap tw = 1 (the -1 is folded into rbase)
             f32x4 av[G];
@@ -152,14 +164,20 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mrow = 4 * kq + r;
-            const int tap = (g0 + gi) * TPM + mrow / CQ;
-            if (tap >= 27) continue;
+            const int rt = (g0 + gi) * TPM + mrow / CQ;
+            if (rt >= Cfg::NT) continue;
             const int cq = mrow % CQ;
+            int tap = rt;                                            // weight-gradient tap of this lane's column
+            if constexpr (Cfg::PAIR) {
+                const int kw = 1 + (rt & 1), half = m >> 3;
+                tap = (rt / 6) * 9 + ((rt / 2) % 3) * 3 + (kw - half);
+                if (half && kw == 2) continue;                       // right half of a kw = 2 row repeats kw = 1
+            }
 #pragma unroll
             for (int ja = 0; ja < 4; ++ja)
 #pragma unroll
                 for (int jb = 0; jb < NJ; ++jb) {
-                    const int co = co0 + jb;
+                    const int co = Cfg::PAIR ? (m & 7) : co0 + jb;
                     if (co < CO) unsafeAtomicAdd(dw + ((long long)tap * ci_total + ci_off + cq * 4 + ja) * CO + co, acc[gi][ja][jb][r]);
                 }
         }

@@ -65,7 +65,7 @@ FAST = {
          "test_costreg_vs_golden", "test_conv2d_vs_torch_cpu", "test_depth_head_vs_oracle", "test_depth_head_golden",
          "test_fpn_out_fused_is_bit_identical"],
     GR: ["test_resize_planes", "test_gu_sampler_vs_oracle", "test_nerf_mlp_vs_oracle", "test_composite_vs_oracle"],
-    GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel"],
+    GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel", "test_conv3d_weight_gradient_cout8_paired_columns"],
     GL: ["test_unsup_loss_multi_stage_matches_reference", "test_inverse_warping_matches_reference", "test_aug_loss_and_sl1_match_reference",
          "test_unsup_loss_argument_checks"],
     GF: ["test_check_geometric_consistency_matches_reference", "test_filter_depth_matches_reference", "test_fuse_view_argument_checks",

@@ -142,6 +142,30 @@ def test_prob_conv_weight_gradient_marching_kernel(shape):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("Ci", [4, 8, 16, 32])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 21), (1, 1, 3, 200), (1, 4, 9, 37), (1, 1, 16, 70)])
+def test_conv3d_weight_gradient_cout8_paired_columns(Ci, shape):
+    """Weight gradient of the Cout = 8 stride-1 layers: the idle eight MFMA columns take dy shifted by one cell along w, which
+    yields tap kw - 1 from the rows of tap kw (18 row taps instead of 27).  Against fp64 autograd: ragged rows, batch 2, one-plane
+    volumes whose rows are split across blocks in w (the shifted cell of a chunk's last x cell belongs to the next chunk)."""
+    import torch.nn.functional as F
+    from rc_mvsnet_amd import _lib, train_ops
+    _lib.load()
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(Ci + W)
+    x = torch.randn(B, Ci, D, H, W, generator=g)
+    dy = torch.randn(B, 8, D, H, W, generator=g)
+    w = torch.zeros(8, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv3d(x.double(), w, padding=1) * dy.double()).sum().backward()
+    dw = train_ops.conv3d_wgrad(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV), 1).cpu()
+    ref = w.grad.permute(2, 3, 4, 1, 0).reshape(27, Ci, 8)               # (27, Ci, Co)
+    if D == 1:
+        ref = ref.clone(); ref[:9] = 0; ref[18:] = 0                     # one-plane volumes: the kernel skips the dead tap planes (padding only)
+        assert float(w.grad[:, :, 0].abs().max()) == 0.0 and float(w.grad[:, :, 2].abs().max()) == 0.0
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
 def test_cascade_train_native_vs_delegated_gradients():
     """CascadeMVSNet in train mode: the HIP training path (WarpVarianceFn + ConvBnReluFn + ProbDepthHeadFn) and the
     reference's op graph with autograd (oracle/aten_graph.py, same device) produce the same outputs, parameter gradients
