@@ -23,29 +23,85 @@ import torch
 import torch.distributed as dist
 
 
+# Test hook (tests/test_multiproc_cpu.py): gloo has no reduce_scatter_tensor, so on the CPU rig every exchange takes the plain
+# all_reduce branch and the two-step branch -- shard sizes, padding to the world size, the chained future of the DDP hook --
+# would never execute before the first RCCL run.  With COMPOSE_ON_GLOO = True the two-step branch runs on gloo as well, its
+# reduce-scatter composed from the collectives gloo does have (`_reduce_scatter` below).
+COMPOSE_ON_GLOO = False
+
+
 def _has_reduce_scatter(group):
-    return dist.get_backend(group) != "gloo"
+    return COMPOSE_ON_GLOO or dist.get_backend(group) != "gloo"
+
+
+class _Done:
+    """A completed piece of work with the Work.get_future() surface the DDP hook chains on."""
+
+    def __init__(self, value):
+        self._fut = torch.futures.Future()
+        self._fut.set_result(value)
+
+    def get_future(self):
+        return self._fut
+
+    def wait(self):
+        return True
+
+
+def _reduce_scatter(shard, flat, group, async_op=False):
+    """shard <- this rank's 1/W slice of the sum of `flat` over the group.  RCCL: reduce_scatter_tensor.  gloo (test rig only):
+    one reduce per slice towards the rank that owns it -- the same result and the same shard arithmetic."""
+    if dist.get_backend(group) != "gloo":
+        return dist.reduce_scatter_tensor(shard, flat, group=group, async_op=async_op)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = shard.numel()
+    for r in range(world):
+        piece = flat[r * n:(r + 1) * n].clone()
+        dist.reduce(piece, dst=dist.get_global_rank(group, r), group=group)
+        if r == rank:
+            shard.copy_(piece)
+    return _Done([shard]) if async_op else None
 
 
 def _direct_allreduce(flat, group):
-    """In-place sum of `flat` (numel divisible by the world size) over the group: reduce-scatter + all-gather."""
+    """In-place sum of `flat` (numel divisible by the world size) over the group: reduce-scatter + all-gather.  Which
+    algorithm RCCL runs underneath each of the two collectives (direct / ring / tree over the xGMI links) is RCCL's choice
+    (NCCL_ALGO / its tuner); nothing here controls it."""
     world = dist.get_world_size(group)
     if world == 1:
         return
     if not _has_reduce_scatter(group):
         dist.all_reduce(flat, group=group)
         return
+    if flat.numel() % world:
+        raise ValueError(f"_direct_allreduce: {flat.numel()} elements do not split over {world} ranks (pad the buffer)")
     shard = torch.empty(flat.numel() // world, dtype=flat.dtype, device=flat.device)
-    dist.reduce_scatter_tensor(shard, flat, group=group)
+    _reduce_scatter(shard, flat, group)
     dist.all_gather_into_tensor(flat, shard, group=group)
 
 
 class GradSync:
     """One flat gradient buffer for a list of modules + the one-message exchange over it (see the module docstring)."""
 
-    def __init__(self, modules, group=None):
+    def __init__(self, modules, group=None, broadcast=True):
         self.group = group or dist.group.WORLD
         self.world = dist.get_world_size(self.group)
+        if broadcast and self.world > 1:
+            # what DistributedDataParallel does at construction (train_rcmvsnet.py:565-578 relies on it): every replica starts
+            # from rank 0's parameters and buffers, as ONE flat message per dtype
+            src = dist.get_global_rank(self.group, 0)
+            with torch.no_grad():
+                by_dtype = {}
+                for m in modules:
+                    for t in list(m.parameters()) + list(m.buffers()):
+                        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+                for ts in by_dtype.values():
+                    flat = torch.cat([t.detach().reshape(-1) for t in ts])
+                    dist.broadcast(flat, src=src, group=self.group)
+                    off = 0
+                    for t in ts:
+                        t.copy_(flat[off:off + t.numel()].view_as(t))
+                        off += t.numel()
         self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("GradSync: no trainable parameters")
@@ -56,8 +112,10 @@ class GradSync:
         self.numel = n
         self.flat = torch.zeros((n + self.world - 1) // self.world * self.world, dtype=dt, device=dev)
         off = 0
+        self._offsets = []
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)       # backward accumulates into the message itself
+            self._offsets.append(off)
             off += p.numel()
 
     def zero(self):
@@ -65,17 +123,12 @@ class GradSync:
 
     def sync(self):
         """Average the gradients over the ranks, in place."""
-        for p, (a, b) in zip(self.params, self._spans()):
-            if p.grad is None or p.grad.data_ptr() != self.flat[a:b].data_ptr():
+        base, esz = self.flat.data_ptr(), self.flat.element_size()
+        for p, off in zip(self.params, self._offsets):          # pointer arithmetic only: no tensor slices per step
+            if p.grad is None or p.grad.data_ptr() != base + off * esz:
                 raise RuntimeError("GradSync: a parameter's .grad was replaced (use optimizer.zero_grad(set_to_none=False) or GradSync.zero())")
         self.flat.div_(self.world)
         _direct_allreduce(self.flat, self.group)
-
-    def _spans(self):
-        off = 0
-        for p in self.params:
-            yield off, off + p.numel()
-            off += p.numel()
 
 
 def flat_allreduce_hook(state, bucket):
@@ -84,12 +137,18 @@ def flat_allreduce_hook(state, bucket):
     world = dist.get_world_size(group)
     buf = bucket.buffer()
     buf.div_(world)
-    if _has_reduce_scatter(group) and buf.numel() % world == 0 and world > 1:
-        shard = torch.empty(buf.numel() // world, dtype=buf.dtype, device=buf.device)
-        fut = dist.reduce_scatter_tensor(shard, buf, group=group, async_op=True).get_future()
+    if _has_reduce_scatter(group) and world > 1:
+        # DDP's bucket size is whatever its parameters add up to: pad the message to a multiple of the world size
+        n = buf.numel()
+        padded = (n + world - 1) // world * world
+        msg = buf if padded == n else torch.cat([buf, buf.new_zeros(padded - n)])
+        shard = torch.empty(padded // world, dtype=buf.dtype, device=buf.device)
+        fut = _reduce_scatter(shard, msg, group, async_op=True).get_future()
 
         def gather(_):
-            dist.all_gather_into_tensor(buf, shard, group=group)
+            dist.all_gather_into_tensor(msg, shard, group=group)
+            if msg is not buf:
+                buf.copy_(msg[:n])
             return buf
 
         return fut.then(gather)

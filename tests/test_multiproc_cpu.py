@@ -47,44 +47,55 @@ def test_scene_sharding_world2():
         assert abs(len(gathered[0]) - len(gathered[1])) <= 1
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, compose=False):
     import torch.nn as nn
     from torch.nn.parallel import DistributedDataParallel as DDP
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import aten_graph
+    from rc_mvsnet_amd import parallel
     from rc_mvsnet_amd.parallel import GradSync, flat_allreduce_hook
     from rc_mvsnet_amd.casmvsnet import CostRegNet
+    parallel.COMPOSE_ON_GLOO = compose           # True: the reduce-scatter + all-gather branch (what runs on RCCL) on gloo
 
     class Graph(nn.Module):                      # the product module refuses CPU tensors: run its parameters through the oracle graph
         def __init__(self, net):
             super().__init__()
             self.net = net
+            self.gain = nn.Parameter(torch.ones(2))          # 292824 + 2 parameters: a multiple of neither 4 nor 3 (padding path)
 
         def forward(self, x):
-            return aten_graph.unet3d(self.net, x, self.net.prob)
+            return aten_graph.unet3d(self.net, x, self.net.prob) * self.gain.mean()
 
     torch.manual_seed(0)
     net = CostRegNet(8, 8)                       # a real sub-module of the path (3-D U-Net, BN included)
-    ref = CostRegNet(8, 8)
-    ref.load_state_dict(net.state_dict())
-    ddp = DDP(Graph(net))
+    torch.manual_seed(1000 + rank)               # the GradSync replica starts from DIFFERENT weights on every rank ...
+    ref = Graph(CostRegNet(8, 8))
+    gnet = Graph(net)
+    ddp = DDP(gnet)
     ddp.register_comm_hook(state=None, hook=flat_allreduce_hook)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(1, 8, 16, 16, 16, generator=g)
     ddp(x).square().mean().backward()
-    sync = GradSync([ref])                       # one flat buffer, .grad are views into it
+    sync = GradSync([ref])                       # one flat buffer, .grad are views into it; ... and is broadcast from rank 0
     assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in ref.parameters())
-    Graph(ref)(x).square().mean().backward()
+    assert sync.flat.numel() % world == 0 and sync.flat.numel() - sync.numel < world
+    first = [None] * world
+    dist.all_gather_object(first, float(sum(p.double().abs().sum() for p in ref.parameters()) + sum(b.double().abs().sum() for b in ref.buffers())))
+    assert all(v == first[0] for v in first), first          # identical replicas after construction
+    ref.load_state_dict(gnet.state_dict())
+    if world == 3:
+        assert sync.flat.numel() != sync.numel               # the padding path really runs
+    ref(x).square().mean().backward()
     local = [p.grad.clone() for p in ref.parameters()]
     sync.sync()                                  # must agree with the DDP hook
-    err = max(float((a.grad - b.grad).abs().max()) for a, b in zip(net.parameters(), ref.parameters()))
+    err = max(float((a.grad - b.grad).abs().max()) for a, b in zip(gnet.parameters(), ref.parameters()))
     # and with the plain average of the two ranks' local gradients
     gathered = [None] * world
     dist.all_gather_object(gathered, [t.numpy() for t in local])
     mean = [sum(torch.as_tensor(gathered[r][i]) for r in range(world)) / world for i in range(len(local))]
     err = max(err, max(float((p.grad - m).abs().max()) for p, m in zip(ref.parameters(), mean)))
-    gsum = float(sum(p.grad.abs().sum() for p in net.parameters()))
+    gsum = float(sum(p.grad.abs().sum() for p in gnet.parameters()))
     sync.zero()
     zeroed = all(float(p.grad.abs().max()) == 0.0 for p in ref.parameters())
     next(ref.parameters()).grad = torch.zeros_like(next(ref.parameters()))
@@ -97,23 +108,40 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_flat_allreduce_hook_world2():
-    """Gradient exchange over gloo, world size 2: the DDP comm hook and GradSync (one flat buffer for all parameters, .grad
-    views into it) both leave every rank with the average of the ranks' gradients; GradSync.zero() clears through the views
-    and a replaced .grad is detected."""
+def _run_ddp(world, compose):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q, compose)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(err < 1e-6 for _, err, _, _ in res), res
     assert all(ok for _, _, _, ok in res), res
-    assert abs(res[0][2] - res[1][2]) < 1e-4 * max(1.0, res[0][2])      # same averaged gradients on both ranks
+    assert all(abs(r[2] - res[0][2]) < 1e-4 * max(1.0, res[0][2]) for r in res)      # same averaged gradients on every rank
+
+
+def test_flat_allreduce_hook_world2():
+    """Gradient exchange over gloo, world size 2: the DDP comm hook and GradSync (one flat buffer for all parameters, .grad
+    views into it, replicas broadcast from rank 0 at construction) both leave every rank with the average of the ranks'
+    gradients; GradSync.zero() clears through the views and a replaced .grad is detected."""
+    _run_ddp(2, compose=False)
+
+
+def test_direct_allreduce_branch_world2():
+    """The branch RCCL takes -- reduce-scatter of the flat message into 1/W shards, all-gather of the reduced shards, and in the
+    DDP hook the all-gather chained on the reduce-scatter's future -- executed on gloo with a composed reduce-scatter
+    (parallel.COMPOSE_ON_GLOO): same averaged gradients as the plain all_reduce."""
+    _run_ddp(2, compose=True)
+
+
+def test_direct_allreduce_branch_world3_padding():
+    """World size 3: neither the flat GradSync buffer nor DDP's bucket is a multiple of the world size, so the padding of the
+    message and the un-padding after the all-gather execute."""
+    _run_ddp(3, compose=True)
 
 
 def _syncbn_worker(rank, world, port, q):

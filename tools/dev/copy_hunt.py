@@ -1,4 +1,6 @@
-import sys, os, traceback
+"""Hunt for stray device copies / ATen glue kernels in one CascadeMVSNet_eval.forward (GPU box): every aten op that launches a
+device kernel or a DtoD copy is listed with its input shapes and the package line that called it."""
+import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rc_mvsnet_amd import _lib, synthetic
@@ -13,10 +15,17 @@ with torch.no_grad():
     for _ in range(3): m(imgs, pm, dv)
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         m(imgs, pm, dv)
         torch.cuda.synchronize()
-    evs = [e for e in prof.events() if "emcpy" in e.name or "copy" in e.name.lower()]
-    for e in evs[:60]:
-        print(e.name, e.device_type, getattr(e, "cuda_time", None), e.input_shapes if hasattr(e, "input_shapes") else "")
-    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25))
+agg = collections.OrderedDict()
+for e in prof.events():
+    if not e.name.startswith("aten::"): continue
+    dt = getattr(e, "device_time_total", None) or getattr(e, "cuda_time_total", 0)
+    if not dt: continue
+    site = next((s for s in (e.stack or []) if "rc_mvsnet_amd" in s), "?")
+    key = (e.name, str(e.input_shapes)[:90], site.strip()[-80:])
+    a = agg.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += dt
+for (name, shapes, site), (n, dt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:50]:
+    print(f"{dt:8.1f} us x{n:3d} {name:28s} {shapes:90s} {site}")
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
