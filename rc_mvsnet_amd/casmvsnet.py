@@ -444,6 +444,7 @@ class _CascadeBase(nn.Module):
         feats_cl = None
         if features is None:
             feats_cl = self.feature.forward_cl(imgs.reshape(B * V, 3, H, W), lazy=True)
+            feats_cl = self._fpn_outputs_on_side_stream(feats_cl, imgs)
         outputs = {}
         depth = None
         for s in range(self.num_stage):
@@ -475,6 +476,37 @@ class _CascadeBase(nn.Module):
             outputs[key] = out
             outputs.update(out)
         return outputs
+
+    def _fpn_outputs_on_side_stream(self, thunks, imgs):
+        """The output convs of pyramid levels 2 and 3 (0.11 ms per scene, a third of FeatureNet) depend on the trunk only, not on
+        the cascade: enqueue them on a second HIP stream right after the trunk so that they run beside stage 1's cost
+        regularisation, whose deep U-Net levels (N/64 and N/512 voxels: 120-160 persistent blocks, latency-bound) leave most of the
+        256 CUs idle.  Each later stage waits on its level's event before its warp; stage 1's own output conv stays on the
+        launch stream (it is needed at once).  MEASURED (MI355X, round 3, profiles/r3_side_stream_ab.txt): 1.546 ms per scene
+        against 1.506 ms for the single-stream just-in-time order -- the two extra kernels contend with conv0 / K1 for the
+        CUs and the caches instead of filling idle ones -- so this is OFF unless RCMVS_SIDE_STREAM=1 (kept as the A/B switch)."""
+        if not imgs.is_cuda or os.environ.get("RCMVS_SIDE_STREAM", "0") != "1" or len(thunks) < 2:
+            return thunks
+        main = torch.cuda.current_stream(imgs.device)
+        side = getattr(self, "_side", None)
+        if side is None or side.device != imgs.device:
+            side = self._side = torch.cuda.Stream(device=imgs.device)
+        trunk_done = torch.cuda.Event()
+        trunk_done.record(main)
+        out = {"stage1": thunks["stage1"]}
+        with torch.cuda.stream(side):
+            side.wait_event(trunk_done)
+            for key in [k for k in thunks if k != "stage1"]:
+                fk = thunks[key]()
+                done = torch.cuda.Event()
+                done.record(side)
+                fk.record_stream(main)            # allocated on the side stream's pool, consumed on the launch stream
+
+                def take(fk=fk, done=done, keep=thunks):      # `keep`: the trunk maps the side-stream kernels read stay allocated
+                    torch.cuda.current_stream(fk.device).wait_event(done)      # until every level has been handed over
+                    return fk
+                out[key] = take
+        return out
 
     # ---------------------------------------------------------------- native training path
     def _forward_train_hip(self, imgs, proj_matrices, depth_values):

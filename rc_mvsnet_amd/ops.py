@@ -85,7 +85,7 @@ def warp_variance(feats, rot, trans, planes, ndepth, variant=0):
     B, V, h, w, C = feats.shape
     var = torch.empty((B, ndepth, h, w, C), device=feats.device, dtype=torch.float32)
     ev = None
-    if K1_EVENTS is not None:
+    if K1_EVENTS is not None and not variant:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     if variant:
@@ -170,10 +170,12 @@ class WarpVarianceFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------- K2/K3
 class PackedWeight:
     """Device blob produced by rcmvs_pack_conv3d_weight plus its channel counts."""
-    __slots__ = ("blob", "ci", "co", "k")
+    __slots__ = ("blob", "ci", "co", "k", "transposed")
 
-    def __init__(self, blob, ci, co):
-        self.blob, self.ci, self.co = blob, ci, co
+    def __init__(self, blob, ci, co, transposed=0):
+        # transposed: the pack mode (0 conv weight, 1 ConvTranspose3d weight, 2 flipped adjoint of a stride-1 conv).  The blob holds
+        # the matrix-core images of the matching kernels only (rcmvs_pack_conv3d_weight), so conv3d / deconv3d check it
+        self.blob, self.ci, self.co, self.transposed = blob, ci, co, int(transposed)
 
 
 _CONV_IMPL = 0      # test / A-B hook (force_direct_conv): kernel selection handed to the rcmvs_debug_* conv entry points
@@ -196,7 +198,7 @@ def pack_conv3d_weight(w, transposed=False):
     blob = torch.empty((n,), device=w.device, dtype=torch.float32)
     _lib.check(_lib.load().rcmvs_pack_conv3d_weight(_chk(w, "w"), _chk(blob, "packed"), Co, Ci, int(transposed), _stream()),
                "pack_conv3d_weight")
-    return PackedWeight(blob, Ci, Co)
+    return PackedWeight(blob, Ci, Co, int(transposed))
 
 
 def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False):
@@ -205,6 +207,8 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
     Co = w_packed.co
     if w_packed.ci != Ci:
         raise _lib.RcmvsError(f"conv3d: input has {Ci} channels, weight expects {w_packed.ci}")
+    if w_packed.transposed == 1:
+        raise _lib.RcmvsError("conv3d: the weight was packed as a ConvTranspose3d weight (transposed=1); its blob holds no conv images")
     y = torch.empty((B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1, Co), device=x.device,
                     dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
@@ -213,7 +217,6 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
     if CONV_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-        CONV_EVENTS.append(ev + (("s1" if stride == 1 else "s2", B, D, H, W, Ci, Co),))
     if _CONV_IMPL:
         _lib.check(_lib.load().rcmvs_debug_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                                       _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
@@ -224,6 +227,7 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
                                                 _stream()), "conv3d_fwd")
     if ev is not None:
         ev[1].record()
+        CONV_EVENTS.append(ev + (("s1" if stride == 1 else "s2", B, D, H, W, Ci, Co),))      # only complete pairs are listed
     return y
 
 
@@ -233,6 +237,8 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     Co = w_packed.co
     if w_packed.ci != Ci:
         raise _lib.RcmvsError(f"deconv3d: input has {Ci} channels, weight expects {w_packed.ci}")
+    if w_packed.transposed != 1:
+        raise _lib.RcmvsError("deconv3d: the weight was not packed with transposed=True; its blob holds no transposed-conv image")
     y = torch.empty((B, 2 * D, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"deconv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)} "
@@ -241,7 +247,6 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     if CONV_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-        CONV_EVENTS.append(ev + (("t2", B, D, H, W, Ci, Co),))
     if _CONV_IMPL:
         _lib.check(_lib.load().rcmvs_debug_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                                         _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
@@ -252,6 +257,7 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
                                                   _stream()), "deconv3d_fwd")
     if ev is not None:
         ev[1].record()
+        CONV_EVENTS.append(ev + (("t2", B, D, H, W, Ci, Co),))
     return y
 
 
@@ -320,17 +326,23 @@ def fpn_out_fused(lat, up, w_inner_packed, b_inner, w_out_packed):
 
 
 # ------------------------------------------------------------------------------- K4
-def depth_head(x8, w_prob_packed, planes, want_prob=False):
-    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)]."""
+def depth_head(x8, w_prob_packed, planes, want_prob=False, variant=0):
+    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)].  variant 1: the two-launch form of
+    rcmvs_debug_depth_head_fwd (tests / A-B)."""
     B, D, h, w, C = x8.shape
     if C != 8:
         raise _lib.RcmvsError("depth_head: the prob conv takes 8 channels")
     depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
-    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32)     # logit scratch -> probabilities
-    _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
-                                                _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
-                                                _stream()), "depth_head_fwd")
+    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32) if (want_prob or variant) else None
+    if variant:
+        _lib.check(_lib.load().rcmvs_debug_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
+                                                          _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
+                                                          int(variant), _stream()), "debug_depth_head_fwd")
+    else:
+        _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
+                                                    _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
+                                                    _stream()), "depth_head_fwd")
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 

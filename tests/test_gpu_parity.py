@@ -165,6 +165,9 @@ def test_warp_variance_variants_agree(hip):
         print(f"K1 C={C} D={D} V={V}: production vs reference-order bit-identical {exact:.6f}; FMA build max rel {err1:.2e}")
         assert torch.equal(v0, vref)
         assert err1 < 2e-6
+        if V == 3:       # experimental schedules of the production arithmetic (two source views): same bits
+            for var in (4, 5, 6):
+                assert torch.equal(hip.warp_variance(feats, rot, trans, planes, D, variant=var), vref), var
     with pytest.raises(Exception):
         hip.warp_variance(feats, rot, trans, planes, D, variant=9)
 
@@ -555,6 +558,23 @@ def test_depth_head_vs_oracle(hip, D, h, w):
     fidx = od.depth_regression(p_ref, torch.arange(D, dtype=torch.float32))
     safe = (fidx - fidx.round()).abs() > 1e-3
     assert float((conf.cpu() - conf_ref).abs()[safe].max()) < 1e-4
+
+
+@pytest.mark.parametrize("D,h,w", [(8, 12, 40), (48, 7, 70), (32, 9, 130), (20, 5, 33), (64, 6, 34), (5, 3, 9)])
+def test_depth_head_fused_equals_two_launch_form(hip, D, h, w):
+    """The single-launch head (logits of a pixel tile kept in LDS for all D planes, softmax in the same block) against the
+    two-launch form it replaced (plane-marching prob conv -> logit volume -> in-place softmax kernel): bit-identical depth,
+    confidence and probabilities for every z-split (D <= 16 / 32 / 64), ragged chunks and ragged tiles; without `prob`
+    requested nothing else changes."""
+    g = torch.Generator().manual_seed(D + h)
+    x = gpu(torch.randn(2, D, h, w, 8, generator=g))
+    wp = hip.pack_conv3d_weight(gpu(torch.randn(1, 8, 3, 3, 3, generator=g) * 0.5))
+    planes = gpu(torch.stack((425.0 + 50 * torch.rand(2, h, w, generator=g), 1.0 + 5 * torch.rand(2, h, w, generator=g)), dim=-1))
+    d1, c1, p1 = hip.depth_head(x, wp, planes, want_prob=True, variant=1)
+    d0, c0, p0 = hip.depth_head(x, wp, planes, want_prob=True)
+    assert torch.equal(p0, p1) and torch.equal(d0, d1) and torch.equal(c0, c1)
+    d2, c2 = hip.depth_head(x, wp, planes)
+    assert torch.equal(d2, d1) and torch.equal(c2, c1)
 
 
 def test_depth_head_golden(hip):
