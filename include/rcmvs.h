@@ -139,6 +139,27 @@ int rcmvs_debug_deconv3d_fwd(const float* x, const float* w_packed, const float*
                              const float* residual, float* y,
                              int B, int D, int H, int W, int Ci, int Co, int relu, int impl, void* stream);
 
+/* Activation bounds (round 3).  A bound is a device vector of RCMVS_ABSMAX_FLOATS floats: 64 slots, 16 floats apart, the bound is the
+ * maximum of the slots (the kernels that maintain one issue ONE atomic max per block into slot block & 63: same-address atomics
+ * serialise).  The caller zero-fills it.  rcmvs_absmax_fwd computes the bound of a tensor nobody maintained one for: max|x| over n
+ * floats, or its square (square != 0: the bound of a variance from the bound of its samples, models/casmvsnet.py:288). */
+#define RCMVS_ABSMAX_FLOATS 1024
+int rcmvs_absmax_fwd(const float* x, long long n, int square, float* amax, void* stream);
+/* The same two layers with activation bounds.  x_absmax: bound of max|x| in the format above (NULL = none known); where the channel
+ * pair has the kernel, the convolution then runs on the fp16 matrix cores with TWO fp16 pieces per fp32 operand after an exact
+ * power-of-two pre-scale derived from the bound (|x - (h + l) / s| <= 2^-22 |x| down to 2^-17 of the bound, 2^-39 of the bound below
+ * that; three MFMAs per product instead of the six of the exact three-piece bf16 split; csrc/conv3d_x3.hip).  y_absmax (NULL = not
+ * wanted): bound vector that receives max|y| -- the caller zero-fills it and hands it to the next layer as its
+ * x_absmax; only the split-operand matrix-core kernels maintain it (error for channel pairs without one).  impl: the kernel
+ * selector of rcmvs_debug_conv3d_fwd (0 = production).  A bound that is too small by a factor 2^k costs k bits of fp16 range at the
+ * top (overflow to inf beyond 2^1), one that is too large only raises the absolute floor: pass a true upper bound. */
+int rcmvs_conv3d_scaled_fwd(const float* x, const float* x_absmax, const float* w_packed, const float* scale, const float* shift,
+                            const float* residual, float* y, float* y_absmax,
+                            int B, int D, int H, int W, int Ci, int Co, int stride, int relu, int impl, void* stream);
+int rcmvs_deconv3d_scaled_fwd(const float* x, const float* x_absmax, const float* w_packed, const float* scale, const float* shift,
+                              const float* residual, float* y, float* y_absmax,
+                              int B, int D, int H, int W, int Ci, int Co, int relu, int impl, void* stream);
+
 /* ---- training: the 3-D blocks with BATCH statistics, forward and backward ---------------- */
 /* Conv3d / Deconv3d in train mode = conv -> BatchNorm3d(batch stats) -> ReLU (models/modules.py:149-157,
  * 196-204).  The convolution is rcmvs_conv3d_fwd / rcmvs_deconv3d_fwd with a NULL epilogue; autograd's

@@ -326,20 +326,36 @@ class CostRegNet(nn.Module):
             self._plan, self._plan_key = plan, key
         return self._plan
 
-    def features_cl(self, x):
-        """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8)."""
+    def features_cl(self, x, x_absmax=None):
+        """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8).
+        x_absmax: bound of max|x| (ops.absmax format; the cascade derives it from the feature maps).  With it the layers run on the
+        fp16-pair form of the matrix-core kernels (half the matrix-pipe work of the exact bf16 triple): every layer hands the
+        bound of its output to its consumer through a zero-filled scratch vector (one small fill per call).  Without it: the
+        three-piece form, as in round 2."""
         B, D, h, w, _ = x.shape
         if D % 8 or h % 8 or w % 8:
             raise RcmvsError(f"CostRegNet: volume {D}x{h}x{w} must be divisible by 8 in every axis "
                              "(three stride-2 levels with skip connections, models/modules.py:492-499)")
         p = self.hip_plan()
-        conv0 = ops.conv3d(x, *p["conv0"], relu=True)
-        conv2 = ops.conv3d(ops.conv3d(conv0, *p["conv1"], stride=2, relu=True), *p["conv2"], relu=True)
-        conv4 = ops.conv3d(ops.conv3d(conv2, *p["conv3"], stride=2, relu=True), *p["conv4"], relu=True)
-        t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)
+        if x_absmax is None or os.environ.get("RCMVS_FP16_PAIR", "1") == "0":
+            conv0 = ops.conv3d(x, *p["conv0"], relu=True)
+            conv2 = ops.conv3d(ops.conv3d(conv0, *p["conv1"], stride=2, relu=True), *p["conv2"], relu=True)
+            conv4 = ops.conv3d(ops.conv3d(conv2, *p["conv3"], stride=2, relu=True), *p["conv4"], relu=True)
+            t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)
+            t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True)
+            t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True)
+            return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True)
+        m = torch.zeros(5, ops.ABSMAX_FLOATS, device=x.device, dtype=torch.float32)          # bounds of conv0, 1, 2, 3, 9
+        b = [m[i] for i in range(5)]
+        conv0 = ops.conv3d(x, *p["conv0"], relu=True, x_absmax=x_absmax, y_absmax=b[0])
+        conv1 = ops.conv3d(conv0, *p["conv1"], stride=2, relu=True, x_absmax=b[0], y_absmax=b[1])
+        conv2 = ops.conv3d(conv1, *p["conv2"], relu=True, x_absmax=b[1], y_absmax=b[2])
+        conv3 = ops.conv3d(conv2, *p["conv3"], stride=2, relu=True, x_absmax=b[2], y_absmax=b[3])
+        conv4 = ops.conv3d(conv3, *p["conv4"], relu=True, x_absmax=b[3])
+        t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)          # fp32-MFMA deep levels: no bounds kept
         t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True)
-        t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True)
-        return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True)
+        t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True, y_absmax=b[4])                             # three-piece form (no bound of conv7's output)
+        return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True, x_absmax=b[4])
 
     def features_cl_train(self, x):
         """Train-mode twin of ``features_cl`` (batch-statistics BatchNorm, autograd through the HIP kernels:
@@ -465,7 +481,9 @@ class _CascadeBase(nn.Module):
             planes = ops.hypothesis_planes(depth, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
             var = ops.warp_variance(f_cl, rot, trans, planes, D)
             cr = self._cr(s)
-            x8 = cr.features_cl(var)
+            # var = E[f^2] - E[f]^2 <= max f^2: the bound of the variance volume from the feature maps (no pass over the volume)
+            vmax = ops.absmax(f_cl, square=True) if os.environ.get("RCMVS_FP16_PAIR", "1") != "0" else None
+            x8 = cr.features_cl(var, vmax)
             depth, conf = ops.depth_head(x8, cr.hip_plan()["prob"], planes)
             out = {"depth": depth, "photometric_confidence": conf}
             if self.TRAIN_VARIANT:

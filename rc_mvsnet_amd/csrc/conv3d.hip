@@ -153,14 +153,26 @@ bool conv3d_x3_supported(int Ci, int Co, int kind);
 long long conv3d_x3_weight_floats(int Ci, int Co, int kind);
 int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, hipStream_t st);
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d = 0);
+                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d = 0,
+                     const float* xmax = nullptr, float* ymax = nullptr);
+// the two-piece fp16 form of the same kernels (conv3d_x3.hip, NP = 2): needs a bound of max|x| (xmax of conv3d_x3_launch)
+bool conv3d_x3h_supported(int Ci, int Co, int kind);
+long long conv3d_x3h_weight_floats(int Ci, int Co, int kind);
+int conv3d_x3h_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, const float* wsc, hipStream_t st);
+int conv3d_x3_wscale(const float* w, int n, float* out, hipStream_t st);
 
 // packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 images of
-// the four kinds (each present when the pair has that kernel)
+// the four kinds (each present when the pair has that kernel), then the fp16-pair images of the four kinds, then 4 floats
+// {weight scale, 1 / scale, -, -} (what conv3d_x3_wscale computed for the pack kernels)
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
 static inline long long x3_image_offset(int Ci, int Co, int kind) {
     long long off = direct_weight_floats(Ci, Co) + (conv3d_mfma_supported(Ci, Co, 0) ? mfma_weight_floats_host(Ci, Co) : 0);
     for (int k = 0; k < kind; ++k) off += conv3d_x3_weight_floats(Ci, Co, k);
+    return off;
+}
+static inline long long x3h_image_offset(int Ci, int Co, int kind) {
+    long long off = x3_image_offset(Ci, Co, X3_NKINDS);
+    for (int k = 0; k < kind; ++k) off += conv3d_x3h_weight_floats(Ci, Co, k);
     return off;
 }
 
@@ -184,8 +196,8 @@ long long rcmvs_packed_weight_floats(int Co, int Ci) {
     if (Co <= 0 || Ci <= 0) return -1;
     long long n = direct_weight_floats(Ci, Co);
     if (conv3d_mfma_supported(Ci, Co, 0)) n += mfma_weight_floats_host(Ci, Co);
-    for (int k = 0; k < X3_NKINDS; ++k) n += conv3d_x3_weight_floats(Ci, Co, k);
-    return n;
+    for (int k = 0; k < X3_NKINDS; ++k) n += conv3d_x3_weight_floats(Ci, Co, k) + conv3d_x3h_weight_floats(Ci, Co, k);
+    return n + 4;
 }
 
 int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream) {
@@ -203,12 +215,23 @@ int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int 
         rc = conv3d_x3_pack(w, packed + x3_image_offset(Ci, Co, k), Co, Ci, k, transposed, as_stream(stream));
         if (rc) return rc;
     }
+    float* wsc = packed + x3h_image_offset(Ci, Co, X3_NKINDS);
+    bool scaled = false;
+    for (int k = 0; k < X3_NKINDS; ++k) {
+        if (!conv3d_x3h_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
+        if (!scaled) { rc = conv3d_x3_wscale(w, n, wsc, as_stream(stream)); if (rc) return rc; scaled = true; }
+        rc = conv3d_x3h_pack(w, packed + x3h_image_offset(Ci, Co, k), Co, Ci, k, transposed, wsc, as_stream(stream));
+        if (rc) return rc;
+    }
     return 0;
 }
 
+// xmax / ymax (the `scaled` entry points): device scalars; xmax = a bound of max|x| (selects the fp16-pair matrix-core form where the
+// channel pair has one), ymax = receives max|y| (only the split-operand matrix-core kernels maintain it: an error elsewhere)
 static int conv3d_dispatch(const float* x, const float* w_packed, const float* scale, const float* shift,
                            const float* residual, float* y,
-                           int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream, const ConvImpl& im) {
+                           int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream, const ConvImpl& im,
+                           const float* xmax = nullptr, float* ymax = nullptr) {
     RCMVS_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad sizes");
     RCMVS_REQUIRE(stride == 1 || stride == 2, "conv3d_fwd: stride must be 1 or 2");
@@ -217,9 +240,12 @@ static int conv3d_dispatch(const float* x, const float* w_packed, const float* s
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
     if (stride == 1 && D == 1 && conv3d_x3_supported(Ci, Co, X3_KIND_PLANAR) && !im.direct && !im.no_x3)      // one plane: the kd = 0, 2 taps only see padding
-        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, X3_KIND_PLANAR), scale, shift, residual, y, B, D, H, W, Ci, Co, X3_KIND_PLANAR, relu, st, im.x3_blocks);
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, X3_KIND_PLANAR), scale, shift, residual, y, B, D, H, W, Ci, Co, X3_KIND_PLANAR, relu, st, im.x3_blocks, 0, nullptr, ymax);
+    if (xmax && conv3d_x3h_supported(Ci, Co, mode) && !im.direct && !im.no_x3)
+        return conv3d_x3_launch(x, w_packed + x3h_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks, 0, xmax, ymax);
     if (conv3d_x3_supported(Ci, Co, mode) && !im.direct && !im.no_x3)
-        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks);
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks, 0, nullptr, ymax);
+    RCMVS_REQUIRE(!ymax, "conv3d_scaled_fwd: no split-operand kernel for Ci=%d Co=%d stride=%d, the output bound cannot be maintained", Ci, Co, stride);
     if (im.prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !im.direct)
         return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
     if (conv3d_mfma_supported(Ci, Co, mode) && !im.direct)
@@ -235,6 +261,12 @@ int rcmvs_conv3d_fwd(const float* x, const float* w_packed, const float* scale, 
                      const float* residual, float* y,
                      int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream) {
     return conv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, stride, relu, stream, ConvImpl(0));
+}
+
+int rcmvs_conv3d_scaled_fwd(const float* x, const float* x_absmax, const float* w_packed, const float* scale, const float* shift,
+                            const float* residual, float* y, float* y_absmax,
+                            int B, int D, int H, int W, int Ci, int Co, int stride, int relu, int impl, void* stream) {
+    return conv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, stride, relu, stream, ConvImpl(impl), x_absmax, y_absmax);
 }
 
 int rcmvs_conv2d_s2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
@@ -255,20 +287,31 @@ int rcmvs_debug_conv3d_fwd(const float* x, const float* w_packed, const float* s
 
 static int deconv3d_dispatch(const float* x, const float* w_packed, const float* scale, const float* shift,
                              const float* residual, float* y,
-                             int B, int D, int H, int W, int Ci, int Co, int relu, void* stream, const ConvImpl& im) {
+                             int B, int D, int H, int W, int Ci, int Co, int relu, void* stream, const ConvImpl& im,
+                             const float* xmax = nullptr, float* ymax = nullptr) {
     RCMVS_REQUIRE(x && w_packed && y, "deconv3d_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
     RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
     ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
+    if (xmax && conv3d_x3h_supported(Ci, Co, CONV_T2) && !im.direct && !im.no_x3)
+        return conv3d_x3_launch(x, w_packed + x3h_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
+                                as_stream(stream), im.x3_blocks, 0, xmax, ymax);
     if (conv3d_x3_supported(Ci, Co, CONV_T2) && !im.direct && !im.no_x3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
-                                as_stream(stream), im.x3_blocks);
+                                as_stream(stream), im.x3_blocks, 0, nullptr, ymax);
+    RCMVS_REQUIRE(!ymax, "deconv3d_scaled_fwd: no split-operand kernel for Ci=%d Co=%d, the output bound cannot be maintained", Ci, Co);
     if (deconv3d_lds_supported(Ci, Co) && !im.direct)
         return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
     if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !im.direct)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
                                   CONV_T2, relu, as_stream(stream));
     return direct_dispatch<CONV_T2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, as_stream(stream));
+}
+
+int rcmvs_deconv3d_scaled_fwd(const float* x, const float* x_absmax, const float* w_packed, const float* scale, const float* shift,
+                              const float* residual, float* y, float* y_absmax,
+                              int B, int D, int H, int W, int Ci, int Co, int relu, int impl, void* stream) {
+    return deconv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, stream, ConvImpl(impl), x_absmax, y_absmax);
 }
 
 int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,

@@ -36,12 +36,32 @@
 // 16 x 16 tiles go through LDS and the producers finish them (sum, BN scale/shift, ReLU, skip-add, store).
 // Kinds: stride 1, stride 2, transposed stride 2, and "planar" (kd = 1 taps only: every z-plane on its own -- what a 3x3x3 conv
 // of a one-plane volume reduces to; the 2-D FeatureNet layers run as such volumes).
+// Second arithmetic (round 3, NP = 2): TWO fp16 pieces per operand after an exact power-of-two pre-scale, THREE MFMAs per product.
+//   The caller hands over an upper bound of max|x| (a device scalar that the producing kernel's epilogue maintained with one
+//   atomic max per wave: `ymax` below); s = 2^e puts that bound into [2^14, 2^15).  xs = s x (exact), h = fp16(xs) and
+//   l = fp16(xs - h), both round-to-nearest-even: |xs - h - l| <= 2^-22 |xs| while l is a normal fp16 number, i.e. for
+//   |x| >= 2^-17 max|x|, and <= 2^-25 in scaled units (2^-39 max|x|) below that.  Weights are split the same way at pack time with
+//   their own scale.  Product = xh wh + (xh wl + xl wh) on v_mfma_f32_16x16x32_f16 (the products are exact, 11 x 11 bits; the
+//   dropped xl wl is <= 2^-22 |x||w|), two magnitude classes in separate fp32 accumulators, un-scaled by the exact factor
+//   2^-(e_x + e_w) folded into the BatchNorm scale of the epilogue.  Half the matrix-pipe work of the three-piece form, a 12-
+//   instead of 22-instruction split per float4, two thirds of the LDS ring.  Accuracy against fp64: tests/test_gpu_parity.py::
+//   test_conv3d_x3h_*.  The three-piece bf16 form (NP = 3: exact split, no scale, no bound needed) remains for callers without
+//   a bound (training data gradients, stand-alone calls).
 // What bounds it (measured): on gfx950 VALU work -- of another wave on the SIMD or interleaved in the same
 // wave -- does not overlap v_mfma_f32_16x16x32_bf16, so a step costs MFMA time + producer VALU time; the producers are therefore
 // kept to the bare split (22 VALU per float4) and table-driven addressing.
 #include "common.h"
 
+#ifndef X3_ABLATION
+#define X3_ABLATION 0       // tools/dev/x3_test.hip builds with 1: the phase-ablation switches of X3Dims::dbg (timing experiments only)
+#endif
+
 namespace rcmvs {
+
+#if X3_ABLATION
+int x3_ablation_mask = 0;   // bit 0: no MFMAs, 1: no split / ring stores, 2: no input loads, 3: no output stores, 4: no B-fragment reads
+#endif
+#define X3_DBG(BIT) (X3_ABLATION && ((dm.dbg >> (BIT)) & 1))
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
@@ -55,8 +75,9 @@ enum { X3_S1 = 0, X3_S2 = 1, X3_T2 = 2, X3_P1 = 3, X3_KINDS = 4 };
 __host__ __device__ constexpr bool x3_unit(int kind) { return kind == X3_S1 || kind == X3_P1; }       // stride-1 geometry in the plane
 enum { X3_XT = 0, X3_YT = 1, X3_PL = 2 };        // how an n-tile maps to voxels (see above)
 
-template <int CIN, int COUT, int KIND>
+template <int CIN, int COUT, int KIND, int NP = 3>
 struct X3 {
+    static constexpr int NPIECE = NP;                                    // 3 = bf16 pieces (exact split), 2 = scaled fp16 pieces
     static constexpr int MAP = (x3_unit(KIND) && COUT == 8) ? (CIN == 8 ? X3_XT : X3_YT) : X3_PL;
     static constexpr int MROWS = (KIND == X3_T2) ? 8 * COUT : (COUT == 8 ? 16 : COUT);
     static constexpr int MT_ALL = MROWS / 16;                            // 16-row tiles of A
@@ -69,10 +90,10 @@ struct X3 {
     static constexpr int PPKD = QR * QC;
     static constexpr int SPK = ((PPKD + PPS - 1) / PPS) * HALVES;       // K steps per plane (a step never straddles planes)
     static constexpr int KSTEPS = NKD * SPK;
-    static constexpr int WREG = KSTEPS * MT_ALL * 12;                    // registers the whole weight image would take
+    static constexpr int WREG = KSTEPS * MT_ALL * 4 * NP;                // registers the whole weight image would take
     // wave roles: 4 consumer + 4 producer waves; layers whose weight image exceeds 4 x 128 registers take 6 consumer waves (K cut
     // three ways, M two ways) and 2 producer waves -- their volumes are small and the producers have little to do
-    static constexpr int NCW = (WREG > 512) ? 6 : 4;
+    static constexpr int NCW = (KSTEPS * MT_ALL * 12 > 512) ? 6 : 4;     // (decided on the three-piece image: both forms share the tile geometry)
     static constexpr int NPW = 8 - NCW;
     static constexpr int MSPLIT = (MT_ALL >= 2 && WREG > 128) ? 2 : 1;
     static constexpr int KSPLIT = (NCW == 6) ? 3 : ((WREG / MSPLIT > 256) ? 4 / MSPLIT : ((WREG / MSPLIT > 128) ? 2 : 1));
@@ -86,7 +107,7 @@ struct X3 {
     static constexpr int TXP = x3_unit(KIND) ? TX + 2 : (KIND == X3_S2 ? 2 * TX + 1 : TX + 1);
     static constexpr int ROWB = TXP * VB;                                // bytes per halo row
     static constexpr int PLB = TYP * ROWB;                               // bytes per piece plane
-    static constexpr int SLB = 3 * PLB;                                  // bytes per z-slice (h, m, l planes)
+    static constexpr int SLB = NP * PLB;                                 // bytes per z-slice (h, m, l planes / h, l planes)
     static constexpr int ZADV = (KIND == X3_S2) ? 2 : 1;                 // input slices consumed per step
     static constexpr int NSLOT = 2 * NKD;                                // ring: the planes being read + the ones being written (up to NKD when the next item starts)
     static constexpr int NTX = (MAP == X3_XT) ? TX / 32 : TX / 16;       // n-tiles along x
@@ -94,6 +115,16 @@ struct X3 {
     static constexpr int NG = NCW / (KSPLIT * MSPLIT);                     // consumer waves that own different n-tiles
     static constexpr int NTW = NTILE / NG;                               // n-tiles per consumer wave
     static constexpr int TP = (MT <= 2 && NTW % 2 == 0) ? 2 : 1;         // n-tiles in flight (independent accumulators)
+    // B-fragment prefetch distance in K steps.  A consumer wave is alone on its SIMD, so the ~300 cycles between a ds_read_b128 and
+    // its data (four waves' bursts queue in the LDS) must be covered by the MFMAs of the K steps in between: 6 (4, 2) MFMAs of 17
+    // cycles per n-tile and m-tile and K step.  One step ahead (round 2) left every K step waiting on the LDS -- which is why
+    // halving the MFMA count (NP = 2) changed nothing (profiles/r3_x3_prefetch_distance.txt).  Bounded by the register budget.
+    static constexpr int MFMA_PER_KSTEP = TP * MT * (NP == 3 ? 6 : 3);
+    static constexpr int PD_WANT = (MFMA_PER_KSTEP >= 20) ? 1 : ((MFMA_PER_KSTEP >= 10) ? 2 : ((MFMA_PER_KSTEP >= 6) ? 3 : 4));
+    static constexpr int REG_FIXED = ((KSTEPS + KSPLIT - 1) / KSPLIT) * NP * MT * 4 + TP * MT * NP * 4 + 28;      // weights + accumulators + the rest
+    static constexpr int PD_FIT = (244 - REG_FIXED) / (TP * NP * 4) - 1;
+    static constexpr int PD_CAP = PD_WANT < PD_FIT ? PD_WANT : PD_FIT;
+    static constexpr int PD = PD_CAP < 1 ? 1 : (PD_CAP > (KSTEPS + KSPLIT - 1) / KSPLIT - 1 && (KSTEPS + KSPLIT - 1) / KSPLIT > 1 ? (KSTEPS + KSPLIT - 1) / KSPLIT - 1 : PD_CAP);
     static constexpr int Q4 = CIN / 4;                                   // float4 per voxel
     static constexpr int NLOAD = TYP * TXP * Q4;                         // float4 per z-slice
     static constexpr int NPF = (NLOAD + NPW * 64 - 1) / (NPW * 64);                      // float4 per producer thread per z-slice
@@ -131,9 +162,11 @@ __host__ __device__ inline int x3_swz(int hc) {
 // k = 8 * (lane >> 4) + e), pieces split by truncation like the activations.
 // transposed: 0 = Conv3d weight (Co,Ci,27); 1 = ConvTranspose3d weight (Ci,Co,27) (X3_T2 only); 2 = (Ci,Co,27) with flipped
 // taps = the adjoint of a stride-1 conv (training data gradient).
-template <int CIN, int COUT, int KIND>
-__global__ void x3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, int transposed) {
-    using C = X3<CIN, COUT, KIND>;
+// NP = 2: image = a 16-byte header {s_w, 1 / s_w, 0, 0} (s_w = the power of two that puts max|w| into [2^14, 2^15), read from
+// `wsc`, which x3_wscale_kernel filled) followed by the fp16 pieces of s_w * w in the same fragment order.
+template <int CIN, int COUT, int KIND, int NP>
+__global__ void x3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, int transposed, const float* __restrict__ wsc) {
+    using C = X3<CIN, COUT, KIND, NP>;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= C::KSTEPS * C::MT_ALL * 64 * 8) return;
     const int e = t & 7, lane = (t >> 3) & 63, mt = (t >> 9) % C::MT_ALL, j = (t >> 9) / C::MT_ALL;
@@ -159,15 +192,50 @@ __global__ void x3_pack_kernel(const float* __restrict__ w, unsigned short* __re
             v = transposed ? w[((long long)ci * COUT + co) * 27 + (transposed == 2 ? 26 - tap : tap)] : w[((long long)co * CIN + ci) * 27 + tap];
         }
     }
-    const unsigned hb = __float_as_uint(v) & 0xffff0000u;
-    const float r1 = v - __uint_as_float(hb);
-    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mb);
-    const unsigned lb = __float_as_uint(r2) & 0xffff0000u;
-    const long long base = (((long long)j * 3) * C::MT_ALL + mt) * 512 + lane * 8 + e;     // piece stride = MT_ALL * 512 shorts
-    img[base] = (unsigned short)(hb >> 16);
-    img[base + (long long)C::MT_ALL * 512] = (unsigned short)(mb >> 16);
-    img[base + 2LL * C::MT_ALL * 512] = (unsigned short)(lb >> 16);
+    if constexpr (NP == 3) {
+        const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+        const float r1 = v - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mb);
+        const unsigned lb = __float_as_uint(r2) & 0xffff0000u;
+        const long long base = (((long long)j * 3) * C::MT_ALL + mt) * 512 + lane * 8 + e;     // piece stride = MT_ALL * 512 shorts
+        img[base] = (unsigned short)(hb >> 16);
+        img[base + (long long)C::MT_ALL * 512] = (unsigned short)(mb >> 16);
+        img[base + 2LL * C::MT_ALL * 512] = (unsigned short)(lb >> 16);
+    } else {
+        const float sw = wsc[0];
+        if (t == 0) { float* hdr = reinterpret_cast<float*>(img); hdr[0] = sw; hdr[1] = wsc[1]; hdr[2] = 0.0f; hdr[3] = 0.0f; }
+        const float vs = v * sw;                                       // exact (power of two)
+        const _Float16 h = (_Float16)vs;                               // round to nearest even
+        const _Float16 l = (_Float16)(vs - (float)h);
+        const long long base = 8 + (((long long)j * 2) * C::MT_ALL + mt) * 512 + lane * 8 + e;
+        img[base] = __builtin_bit_cast(unsigned short, h);
+        img[base + (long long)C::MT_ALL * 512] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
+// power-of-two scale of a tensor bound: s = 2^e with s * m in [2^14, 2^15); 1 for m = 0, denormal or non-finite bounds.
+// The same function serves the weights (pack time) and the activations (every launch, from the caller's bound).
+__device__ __forceinline__ float x3_pow2_scale(float m, float& inv) {
+    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    int e = (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    inv = __uint_as_float((unsigned)(127 - e) << 23);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+
+// one block: out[0] = scale of max|w| over n weights, out[1] = its inverse
+__global__ void x3_wscale_kernel(const float* __restrict__ w, int n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { float inv; out[0] = x3_pow2_scale(red[0], inv); out[1] = inv; }
 }
 
 // four fp32 -> the three bf16 piece quadruples (two dwords each).  18 VALU operations: the packing v_perm_b32 takes the high
@@ -189,12 +257,34 @@ __device__ __forceinline__ void x3_split4(x3_f32x4 v, x3_u32x2& h, x3_u32x2& m, 
     l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
 }
 
+// four fp32 (already multiplied by the power-of-two scale) -> the two fp16 piece quadruples: h = rne(xs), l = rne(xs - h).
+// 2 v_cvt_pk_f16_f32 + 4 v_cvt_f32_f16 + 2 v_pk_add_f32 + 2 v_cvt_pk_f16_f32 (+ the 2 v_pk_mul_f32 of the scale at the call site)
+typedef _Float16 x3_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void x3_split4h(x3_f32x4 xs, x3_u32x2& h, x3_u32x2& l) {
+    const x3_f16x4 hh = __builtin_convertvector(xs, x3_f16x4);
+    const x3_f32x4 r = xs - __builtin_convertvector(hh, x3_f32x4);                  // exact
+    const x3_f16x4 ll = __builtin_convertvector(r, x3_f16x4);
+    h = __builtin_bit_cast(x3_u32x2, hh);
+    l = __builtin_bit_cast(x3_u32x2, ll);
+}
+
+template <int NP>
+__device__ __forceinline__ x3_f32x4 x3_mfma(x3_u32x4 a, x3_u32x4 b, x3_f32x4 c) {
+    if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, a), __builtin_bit_cast(x3_bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8, a), __builtin_bit_cast(x3_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float x3_absmax4(float m, x3_f32x4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 struct X3Dims {
     int D, H, W;        // input volume
     int Do, Ho, Wo;     // output volume
     int Dt;             // extent of the tile grid in z (= Do for the convolutions, D for the transposed convolution)
     int tiles_x, zchunk, relu;
     int B, ntiles, nchunks, nitems;   // work items = B x xy tiles x z chunks
+    int itemcap, stepcap;   // capacities of the block's schedule tables in LDS (items / steps per block, rounded up)
+    int dbg;            // phase-ablation mask (0 in the library; X3_ABLATION builds only)
     int s2d;            // planar kind only: the input is physically (B, D, 2H, 2W, CIN / 4) and is read through a space-to-depth view
                         // (channel (py, px, c) of voxel (y, x) = channel c of pixel (2y + py, 2x + px)): a 5x5 stride-2 layer as a 3x3 one
 };
@@ -232,34 +322,38 @@ __device__ __forceinline__ X3Item x3_item(const X3Dims& dm, int it) {
     w.ze = min(dm.Dt, w.zb + dm.zchunk);
     return w;
 }
-// a step of the block's schedule: item + z inside it; advance() moves to the next step (next item after the last z)
-template <class C>
-struct X3Step {
-    int it, z;
-    bool live, first;
-    X3Item w;
-    __device__ __forceinline__ void start(const X3Dims& dm, int it0) {
-        it = it0; live = it < dm.nitems; first = true;
-        if (live) { w = x3_item<C>(dm, it); z = w.zb; }
-    }
-    __device__ __forceinline__ void advance(const X3Dims& dm, int stride) {
-        if (!live) return;
-        first = false;
-        if (++z >= w.ze) {
-            it += stride; live = it < dm.nitems; first = true;
-            if (live) { w = x3_item<C>(dm, it); z = w.zb; }
-        }
-    }
+// The block's schedule lives in two LDS tables, built once by all threads (round 3: the tick loops used to advance four copies of
+// an item iterator with its integer divisions and branches -- ~500 mostly scalar instructions per tick in the producer waves,
+// which is what bounded every layer: profiles/r3_x3_phase_ablation.txt):
+//   itab[k] = {b, x0, y0, zb | ze << 16}     item k of this block (global item it_first + k it_stride)
+//   tab[s]  = k << 16 | first << 15 | z      step s: item, first step of its item?, z of the tile grid
+// A tick reads the descriptors of the steps it touches (s - 1: epilogue, s: compute, s + 1: ring stores, s + 3: loads).
+struct X3Sched {
+    const int4* itab;
+    const int* tab;
+    int nsteps;
+    __device__ __forceinline__ int desc(int s) const { return (s >= 0 && s < nsteps) ? __builtin_amdgcn_readfirstlane(tab[s]) : -1; }
 };
+__device__ __forceinline__ int x3_desc_item(int d) { return d >> 16; }
+__device__ __forceinline__ bool x3_desc_first(int d) { return (d >> 15) & 1; }
+__device__ __forceinline__ int x3_desc_z(int d) { return d & 0x7fff; }
 
-template <int CIN, int COUT, int KIND>
+// xmax (NP = 2 only): bound of max|x| -- 64 slots, 16 floats apart, the bound is their maximum (the scale of the activation split is
+// derived from it); ymax (optional, both forms): the same structure for max|y| over the stored outputs, maintained with ONE atomic
+// max per block into slot (block & 63) (same-address atomics serialise at ~90 per microsecond: one per wave into one word cost
+// 6-20 us per launch) -- the next layer's xmax.  The caller zero-fills it; |y| as an IEEE bit pattern orders like an unsigned integer.
+template <int CIN, int COUT, int KIND, int NP>
 __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     const float* __restrict__ x, const x3_u32x4* __restrict__ wimg, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, X3Dims dm) {
-    using C = X3<CIN, COUT, KIND>;
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, X3Dims dm,
+    const float* __restrict__ xmax, float* __restrict__ ymax) {
+    using C = X3<CIN, COUT, KIND, NP>;
     constexpr int MT = C::MT, KSW = C::KSW, KSPLIT = C::KSPLIT, TP = C::TP, NSLOT = C::NSLOT, NKD = C::NKD, ZADV = C::ZADV;
     extern __shared__ __attribute__((aligned(16))) x3_byte smem[];
     x3_byte* const partbase = smem + NSLOT * C::SLB;
+    int4* const itab_w = reinterpret_cast<int4*>(partbase + 2 * C::PARTB);
+    int* const tab_w = reinterpret_cast<int*>(itab_w + dm.itemcap);
+    float* const redmax = reinterpret_cast<float*>(tab_w + dm.stepcap);        // 8 floats: the waves' output maxima
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave >= C::NCW;
@@ -276,15 +370,48 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     } else {
         it_first = bid; it_stride = nblk; it_limit = dm.nitems;
     }
-    X3Dims dmx = dm;
-    dmx.nitems = it_limit;                      // the step iterators stop at the end of this block's range
     const bool relu = dm.relu != 0;
     if (it_first >= it_limit) return;            // (more blocks than items in this XCD's range)
+    // ---- schedule tables
+    const int nloc = (it_limit - it_first + it_stride - 1) / it_stride;
+    for (int k = tid; k < nloc; k += 512) {
+        const X3Item w = x3_item<C>(dm, it_first + k * it_stride);
+        itab_w[k] = make_int4(w.b, w.x0, w.y0, w.zb | (w.ze << 16));
+    }
+    __syncthreads();
+    X3Sched sch;
+    sch.itab = itab_w; sch.tab = tab_w;
+    {
+        int total = 0, mine = tid;      // this thread fills steps tid, tid + 512, ...
+        for (int k = 0; k < nloc; ++k) {
+            const int zz = itab_w[k].w, zb = zz & 0xffff, len = (zz >> 16) - zb;
+            while (mine < total + len) {           // step `mine` belongs to item k
+                tab_w[mine] = (k << 16) | ((mine == total) ? (1 << 15) : 0) | (zb + (mine - total));
+                mine += 512;
+            }
+            total += len;
+        }
+        sch.nsteps = total;
+    }
+    __syncthreads();
+    const int nsteps = sch.nsteps;
+    // NP = 2: activation scale from the caller's bound, weight scale from the image header; `unscale` = 2^-(e_x + e_w) is exact
+    float xs_scale = 1.0f, unscale = 1.0f;
+    if constexpr (NP == 2) {
+        float bound = xmax[lane * 16];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) bound = fmaxf(bound, __shfl_xor(bound, m));
+        float xinv;
+        xs_scale = x3_pow2_scale(bound, xinv);
+        unscale = xinv * reinterpret_cast<const float*>(wimg)[1];
+        wimg += 1;                                // skip the 16-byte header
+    }
+    float vmax = 0.0f;                            // max |stored output| seen by this thread (ymax)
 
     if (!producer) {
         // =============================== consumer: register-stationary weights of this wave's (K, M) slice
         const int ks = wave % KSPLIT, ms = (wave / KSPLIT) % C::MSPLIT, grp = wave / (KSPLIT * C::MSPLIT);
-        x3_bf16x8 wr[KSW][3][MT];
+        x3_u32x4 wr[KSW][NP][MT];          // raw fragment bits (bf16 or fp16 pieces)
         int kdj[KSW];      // input plane of K step j (wave-uniform)
         int boff[KSW];     // this lane's byte offset of the B fragment inside a z-slice, tile origin excluded
 #pragma unroll
@@ -293,12 +420,12 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             const bool live = jg < C::KSTEPS;
             const int jc = live ? jg : 0;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    x3_u32x4 v = wimg[((jc * 3 + p) * C::MT_ALL + ms * MT + mt) * 64 + lane];
+                    x3_u32x4 v = wimg[((jc * NP + p) * C::MT_ALL + ms * MT + mt) * 64 + lane];
                     if (!live) v = (x3_u32x4){0u, 0u, 0u, 0u};
-                    wr[j][p][mt] = __builtin_bit_cast(x3_bf16x8, v);
+                    wr[j][p][mt] = v;
                 }
             kdj[j] = jc / C::SPK;
             int q, ci0;
@@ -313,18 +440,24 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             for (int mt = 0; mt < MT; ++mt) {
                 long long ov; int co0;
                 x3_out_coord<C, COUT, KIND>(dm, 0, 0, 0, 0, 0, ms * MT + mt, n, kk, ov, co0);
-                sc[mt] = scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f};
+                sc[mt] = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
                 sh[mt] = shift ? *reinterpret_cast<const x3_f32x4*>(shift + co0) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        X3Step<C> st;
-        st.start(dmx, it_first);
+        // tile offsets inside a slice and tile ids of this wave: step-invariant
+        int toffv[C::NTW], tlv[C::NTW];
+#pragma unroll
+        for (int i = 0; i < C::NTW; ++i) {
+            tlv[i] = grp + C::NG * i;
+            toffv[i] = (tlv[i] / C::NTX) * C::RS * C::ROWB + (tlv[i] % C::NTX) * 16 * C::CS * C::VB;
+        }
         __syncthreads();          // the planes of the first step are in the ring
         int s0 = 0;               // ring slot of the first input plane of the current step
-        int tick = 0;
 #pragma unroll 1
-        while (st.live) {
-            const int z = st.z, x0 = st.w.x0, y0 = st.w.y0, b = st.w.b;
+        for (int s = 0; s < nsteps; ++s) {
+            const int d = sch.desc(s);
+            const int4 itm = sch.itab[x3_desc_item(d)];
+            const int z = x3_desc_z(d), x0 = itm.y, y0 = itm.z, b = itm.x;
             int slotoff[NKD];
 #pragma unroll
             for (int k = 0; k < NKD; ++k) slotoff[k] = ((s0 + k) % NSLOT) * C::SLB;
@@ -332,10 +465,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             for (int tp = 0; tp < C::NTW / TP; ++tp) {
                 int toff[TP], tl[TP];
 #pragma unroll
-                for (int t = 0; t < TP; ++t) {
-                    tl[t] = grp + C::NG * (TP * tp + t);
-                    toff[t] = (tl[t] / C::NTX) * C::RS * C::ROWB + (tl[t] % C::NTX) * 16 * C::CS * C::VB;
-                }
+                for (int t = 0; t < TP; ++t) { tl[t] = tlv[TP * tp + t]; toff[t] = toffv[TP * tp + t]; }
                 // skip-connection values of the tiles this wave finishes itself: loaded before the MFMA phase
                 x3_f32x4 rv[TP][MT];
                 long long ovv[TP][MT];
@@ -351,40 +481,49 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                             rv[t][mt] = (res && okv[t][mt]) ? *reinterpret_cast<const x3_f32x4*>(res + ovv[t][mt]) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                 }
-                x3_f32x4 acc[TP][MT][3];
+                x3_f32x4 acc[TP][MT][NP];          // one accumulator per magnitude class
 #pragma unroll
                 for (int t = 0; t < TP; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) acc[t][mt][a] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int a = 0; a < NP; ++a) acc[t][mt][a] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
                 // software pipeline: the B fragments of K step j+1 are read while the MFMAs of step j run; the MFMA order keeps
                 // >= 3 independent instructions between two uses of one accumulator
-                x3_bf16x8 bq[2][TP][3];
-                {
-                    const int a0 = boff[0] + slotoff[kdj[0]];
+                constexpr int PD = C::PD;
+                x3_u32x4 bq[PD + 1][TP][NP];
+#pragma unroll
+                for (int jj = 0; jj < PD; ++jj) {
+                    if (jj >= KSW) break;
+                    const int a0 = boff[jj] + slotoff[kdj[jj]];
 #pragma unroll
                     for (int t = 0; t < TP; ++t)
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) bq[0][t][p] = *reinterpret_cast<const x3_bf16x8*>(smem + a0 + toff[t] + p * C::PLB);
+                        for (int p = 0; p < NP; ++p) bq[jj][t][p] = *reinterpret_cast<const x3_u32x4*>(smem + a0 + toff[t] + p * C::PLB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < KSW; ++j) {
-                    const int cur = j & 1, nxt = cur ^ 1;
-                    const bool pre = j + 1 < KSW;
-                    const int na = pre ? boff[j + 1] + slotoff[kdj[j + 1]] : 0;
-                    // six slots: one B-fragment read of K step j+1, then the MFMAs of one product class of step j; the fences pin
+                    const int cur = j % (PD + 1), nxt = (j + PD) % (PD + 1);
+                    const bool pre = j + PD < KSW;
+                    const int na = pre ? boff[j + PD < KSW ? j + PD : 0] + slotoff[kdj[j + PD < KSW ? j + PD : 0]] : 0;
+                    // slots: B-fragment reads of K step j+PD, then the MFMAs of one product class of step j; the fences pin
                     // this order (left alone, the scheduler sinks every read to just before its first use and exposes the LDS latency)
 #define X3_MF(ACC, WP, BP) _Pragma("unroll") for (int t = 0; t < TP; ++t) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) \
-        acc[t][mt][ACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][WP][mt], bq[cur][t][BP], acc[t][mt][ACC], 0, 0, 0)
-#define X3_LD(I) if (pre && (I) < TP * 3) bq[nxt][((I) / 3) % TP][(I) % 3] = *reinterpret_cast<const x3_bf16x8*>(smem + na + toff[((I) / 3) % TP] + ((I) % 3) * C::PLB)
-                    X3_LD(0); X3_MF(2, 0, 2); __builtin_amdgcn_sched_barrier(0);
-                    X3_LD(1); X3_MF(1, 0, 1); __builtin_amdgcn_sched_barrier(0);
-                    X3_LD(2); X3_MF(0, 0, 0); __builtin_amdgcn_sched_barrier(0);
-                    X3_LD(3); X3_MF(2, 1, 1); __builtin_amdgcn_sched_barrier(0);
-                    X3_LD(4); X3_MF(1, 1, 0); __builtin_amdgcn_sched_barrier(0);
-                    X3_LD(5); X3_MF(2, 2, 0); __builtin_amdgcn_sched_barrier(0);
+        if (!X3_DBG(0)) acc[t][mt][ACC] = x3_mfma<NP>(wr[j][WP][mt], bq[cur][t][BP], acc[t][mt][ACC])
+#define X3_LD(I) if (pre && (I) < TP * NP && !X3_DBG(4)) bq[nxt][((I) / NP) % TP][(I) % NP] = *reinterpret_cast<const x3_u32x4*>(smem + na + toff[((I) / NP) % TP] + ((I) % NP) * C::PLB)
+                    if constexpr (NP == 3) {
+                        X3_LD(0); X3_MF(2, 0, 2); __builtin_amdgcn_sched_barrier(0);
+                        X3_LD(1); X3_MF(1, 0, 1); __builtin_amdgcn_sched_barrier(0);
+                        X3_LD(2); X3_MF(0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+                        X3_LD(3); X3_MF(2, 1, 1); __builtin_amdgcn_sched_barrier(0);
+                        X3_LD(4); X3_MF(1, 1, 0); __builtin_amdgcn_sched_barrier(0);
+                        X3_LD(5); X3_MF(2, 2, 0); __builtin_amdgcn_sched_barrier(0);
+                    } else {          // three slots: wh xl, wh xh, wl xh; the (up to) four fragment reads of K step j+1 spread over them
+                        X3_LD(0); X3_LD(1); X3_MF(1, 0, 1); __builtin_amdgcn_sched_barrier(0);
+                        X3_LD(2); X3_MF(0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+                        X3_LD(3); X3_MF(1, 1, 0); __builtin_amdgcn_sched_barrier(0);
+                    }
 #undef X3_MF
 #undef X3_LD
                 }
@@ -392,22 +531,24 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                 for (int t = 0; t < TP; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        x3_f32x4 v = acc[t][mt][0] + (acc[t][mt][1] + acc[t][mt][2]);
+                        x3_f32x4 v;
+                        if constexpr (NP == 3) v = acc[t][mt][0] + (acc[t][mt][1] + acc[t][mt][2]);
+                        else v = acc[t][mt][0] + acc[t][mt][1];
                         if constexpr (KSPLIT > 1) {
                             // hand the partial tile to the producers: [tile][m-tile][K slice][lane]
-                            x3_f32x4* part = reinterpret_cast<x3_f32x4*>(partbase + (tick & 1) * C::PARTB);
+                            x3_f32x4* part = reinterpret_cast<x3_f32x4*>(partbase + (s & 1) * C::PARTB);
                             part[((tl[t] * C::MT_ALL + ms * MT + mt) * KSPLIT + ks) * 64 + lane] = v;
                         } else if (okv[t][mt]) {
                             v = v * sc[mt] + sh[mt];
                             if (relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
                             v += rv[t][mt];
-                            *reinterpret_cast<x3_f32x4*>(y + ovv[t][mt]) = v;
+                            if (!X3_DBG(3)) *reinterpret_cast<x3_f32x4*>(y + ovv[t][mt]) = v;
+                            vmax = x3_absmax4(vmax, v);
                         }
                     }
             }
-            st.advance(dmx, it_stride);
-            s0 = (s0 + (st.first ? NKD : ZADV)) % NSLOT;      // a new item starts right behind the last plane of the previous one
-            ++tick;
+            const int dn = sch.desc(s + 1);
+            s0 = (s0 + ((dn >= 0 && x3_desc_first(dn)) ? NKD : ZADV)) % NSLOT;      // a new item starts right behind the last plane of the previous one
             __syncthreads();
         }
     } else {
@@ -437,14 +578,15 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         }
         const int zstride = dm.H * dm.W * CIN * 4;
         int goff_item = -1;
-        auto set_item = [&](const X3Step<C>& t) {
-            if (t.it == goff_item) return;
-            goff_item = t.it;
-            const X3Item& w = t.w;
-            const int hy0 = x3_unit(KIND) ? w.y0 - 1 : (KIND == X3_S2 ? 2 * w.y0 - 1 : w.y0);
-            const int hx0 = x3_unit(KIND) ? w.x0 - 1 : (KIND == X3_S2 ? 2 * w.x0 - 1 : w.x0);
-            const int base = dm.s2d ? ((w.b * dm.D * 2 * dm.H + 2 * hy0) * (2 * dm.W) + 2 * hx0) * CIN
-                                    : (w.b * dm.D * dm.H + hy0) * dm.W * CIN * 4 + hx0 * CIN * 4;
+        auto set_item = [&](int k) {
+            if (k == goff_item) return;
+            goff_item = k;
+            const int4 w = sch.itab[k];
+            const int wb = w.x, wx0 = w.y, wy0 = w.z;
+            const int hy0 = x3_unit(KIND) ? wy0 - 1 : (KIND == X3_S2 ? 2 * wy0 - 1 : wy0);
+            const int hx0 = x3_unit(KIND) ? wx0 - 1 : (KIND == X3_S2 ? 2 * wx0 - 1 : wx0);
+            const int base = dm.s2d ? ((wb * dm.D * 2 * dm.H + 2 * hy0) * (2 * dm.W) + 2 * hx0) * CIN
+                                    : (wb * dm.D * dm.H + hy0) * dm.W * CIN * 4 + hx0 * CIN * 4;
 #pragma unroll
             for (int i = 0; i < C::NPF; ++i) {
                 const int gy = hy0 + (hrc[i] >> 16), gx = hx0 + (hrc[i] & 0xffff);
@@ -452,57 +594,82 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                 goff[i] = ok ? base + grel[i] : OOB;
             }
         };
-        // fetch input plane zi of the current fetch item's halo tile: one add per float4 (an OOB entry stays out of range: the sum
-        // of two offsets below 2^31 does not wrap, and the buffer bounds check compares unsigned)
+        // fetch input plane zi of the current fetch item's halo tile: the plane offset rides in the scalar offset of the buffer load
+        // (an OOB entry stays out of range whatever is added: the sum of two offsets below 2^31 does not wrap, and the bounds check
+        // compares unsigned); a plane outside the volume is a wave-uniform case: zeros without loads
         auto fetch = [&](x3_f32x4 (&pf)[C::NPF], int zi) {
-            const bool zin = zi >= 0 && zi < dm.D;
-            const int zoff = zi * zstride;
+            if (zi >= 0 && zi < dm.D && !X3_DBG(2)) {
+                const int zoff = zi * zstride;
 #pragma unroll
-            for (int i = 0; i < C::NPF; ++i)
-                pf[i] = __builtin_bit_cast(x3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, zin ? goff[i] + zoff : OOB, 0, 0));
+                for (int i = 0; i < C::NPF; ++i)
+                    pf[i] = __builtin_bit_cast(x3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], zoff, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < C::NPF; ++i) pf[i] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         };
         auto stash = [&](const x3_f32x4 (&pf)[C::NPF], int slot) {
             x3_byte* sb = smem + slot * C::SLB;
 #pragma unroll
             for (int i = 0; i < C::NPF; ++i) {
-                if (loff[i] < 0) continue;
-                x3_u32x2 h, m, l;
-                x3_split4(pf[i], h, m, l);
-                *reinterpret_cast<x3_u32x2*>(sb + loff[i]) = h;
-                *reinterpret_cast<x3_u32x2*>(sb + C::PLB + loff[i]) = m;
-                *reinterpret_cast<x3_u32x2*>(sb + 2 * C::PLB + loff[i]) = l;
+                if (loff[i] < 0 || X3_DBG(1)) continue;
+                if constexpr (NP == 3) {
+                    x3_u32x2 h, m, l;
+                    x3_split4(pf[i], h, m, l);
+                    *reinterpret_cast<x3_u32x2*>(sb + loff[i]) = h;
+                    *reinterpret_cast<x3_u32x2*>(sb + C::PLB + loff[i]) = m;
+                    *reinterpret_cast<x3_u32x2*>(sb + 2 * C::PLB + loff[i]) = l;
+                } else {
+                    x3_u32x2 h, l;
+                    x3_split4h(pf[i] * xs_scale, h, l);
+                    *reinterpret_cast<x3_u32x2*>(sb + loff[i]) = h;
+                    *reinterpret_cast<x3_u32x2*>(sb + C::PLB + loff[i]) = l;
+                }
             }
         };
-        auto zin0 = [&](int z) { return (KIND == X3_S1) ? z - 1 : (KIND == X3_S2 ? 2 * z - 1 : z); };      // (planar: the plane itself)   // first input plane of step z
-        // the planes a step adds to the ring: all NKD on the first step of an item, the last ZADV afterwards
-        auto new_planes = [&](const X3Step<C>& t, int& first_plane) { first_plane = t.first ? zin0(t.z) : zin0(t.z) + NKD - ZADV; return t.first ? NKD : ZADV; };
+        auto zin0 = [&](int z) { return (KIND == X3_S1) ? z - 1 : (KIND == X3_S2 ? 2 * z - 1 : z); };      // first input plane of step z (planar: the plane itself)
         // finish the K-split tiles of a step: sum the partial tiles, BN scale/shift, ReLU, skip-add, store.  Two halves: epi_open at
         // the start of the tick works out where this wave's (tile, m-tile) units go and issues the skip-connection loads; epi_close
-        // at the end of the tick (a stash and a fetch later) does the arithmetic, so the loads' latency is off the tick's critical path
+        // at the end of the tick (a stash and a fetch later) does the arithmetic, so the loads' latency is off the tick's critical path.
+        // Inside an item the output offsets just advance by one z step of the tile grid; they are recomputed when the item changes.
         constexpr int NEU = (KSPLIT > 1) ? (C::NTILE * C::MT_ALL + C::NPW - 1) / C::NPW : 1;
         x3_f32x4 esc[NEU], esh[NEU], erv[NEU];
         long long eov[NEU];            // element offset of the unit's float4 in y / res; < 0 = nothing to store
+        int epi_item = -1;
+        const long long ostep = (long long)(KIND == X3_T2 ? 2 : 1) * dm.Ho * dm.Wo * COUT;
         if constexpr (KSPLIT > 1) {
 #pragma unroll
             for (int i = 0; i < NEU; ++i) {
                 const int u = min(pw + C::NPW * i, C::NTILE * C::MT_ALL - 1);
                 long long ov; int co0;
                 x3_out_coord<C, COUT, KIND>(dm, 0, 0, 0, 0, 0, u % C::MT_ALL, n, kk, ov, co0);      // co0 depends on the m-tile and the lane only
-                esc[i] = scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f};
+                esc[i] = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
                 esh[i] = shift ? *reinterpret_cast<const x3_f32x4*>(shift + co0) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
                 eov[i] = -1;
             }
         }
-        auto epi_open = [&](const X3Item& w, int z) {
+        auto epi_open = [&](int d) {
             if constexpr (KSPLIT > 1) {
+                if (d < 0) return;
+                const int k = x3_desc_item(d);
+                if (k == epi_item) {
 #pragma unroll
-                for (int i = 0; i < NEU; ++i) {
-                    const int u = pw + C::NPW * i;                  // (tile, m-tile) unit of this producer wave
-                    long long ov; int co0;
-                    const bool ok = u < C::NTILE * C::MT_ALL && x3_out_coord<C, COUT, KIND>(dm, w.b, w.x0, w.y0, z, u / C::MT_ALL, u % C::MT_ALL, n, kk, ov, co0);
-                    eov[i] = ok ? ov * COUT + co0 : -1;
-                    erv[i] = (res && ok) ? *reinterpret_cast<const x3_f32x4*>(res + eov[i]) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < NEU; ++i) if (eov[i] >= 0) eov[i] += ostep;
+                } else {
+                    epi_item = k;
+                    const int4 w = sch.itab[k];
+                    const int z = x3_desc_z(d);
+#pragma unroll
+                    for (int i = 0; i < NEU; ++i) {
+                        const int u = pw + C::NPW * i;                  // (tile, m-tile) unit of this producer wave
+                        long long ov; int co0;
+                        const bool ok = u < C::NTILE * C::MT_ALL && x3_out_coord<C, COUT, KIND>(dm, w.x, w.y, w.z, z, u / C::MT_ALL, u % C::MT_ALL, n, kk, ov, co0);
+                        eov[i] = ok ? ov * COUT + co0 : -1;
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < NEU; ++i)
+                    erv[i] = (res && eov[i] >= 0) ? *reinterpret_cast<const x3_f32x4*>(res + eov[i]) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
             }
         };
         auto epi_close = [&](int buf) {
@@ -518,69 +685,84 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                     v = v * esc[i] + esh[i];
                     if (relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
                     v += erv[i];
-                    *reinterpret_cast<x3_f32x4*>(y + eov[i]) = v;
+                    if (!X3_DBG(3)) *reinterpret_cast<x3_f32x4*>(y + eov[i]) = v;
+                    vmax = x3_absmax4(vmax, v);
                 }
             }
         };
         // schedule: during tick s the consumers compute step s while the producers (1) store into the ring the planes step s+1
         // adds, (2) issue the loads of the planes step s+3 adds -- two ticks of flight time, a load that misses to HBM under
         // load takes longer than one tick -- and (3) finish step s-1.  Register queue: buffer (t & 1) holds step t's planes from
-        // tick t-3 until they are stored in tick t-1.
-        X3Step<C> s_cur, s_n1, s_n2, s_n3;
+        // tick t-3 until they are stored in tick t-1.  The planes a step adds to the ring: all NKD on the first step of an item,
+        // the last ZADV afterwards.
         x3_f32x4 pfq[2][NKD][C::NPF];
         int wslot = 0;
-        auto fetch_step = [&](const X3Step<C>& t, x3_f32x4 (&q)[NKD][C::NPF]) {
-            if (!t.live) return;
-            int p;
-            const int c = new_planes(t, p);
-            set_item(t);
+        auto fetch_step = [&](int d, x3_f32x4 (&q)[NKD][C::NPF]) {
+            if (d < 0) return;
+            set_item(x3_desc_item(d));
+            const bool first = x3_desc_first(d);
+            const int p = first ? zin0(x3_desc_z(d)) : zin0(x3_desc_z(d)) + NKD - ZADV;
 #pragma unroll
-            for (int k = 0; k < NKD; ++k) if (k < c) fetch(q[k], p + k);
+            for (int k = 0; k < NKD; ++k) if (k < ZADV || first) fetch(q[k], p + k);
         };
-        auto stash_step = [&](const X3Step<C>& t, const x3_f32x4 (&q)[NKD][C::NPF]) {
-            if (!t.live) return;
-            int p;
-            const int c = new_planes(t, p);
+        auto stash_step = [&](int d, const x3_f32x4 (&q)[NKD][C::NPF]) {
+            if (d < 0) return;
+            const bool first = x3_desc_first(d);
 #pragma unroll
-            for (int k = 0; k < NKD; ++k) if (k < c) stash(q[k], (wslot + k) % NSLOT);
-            wslot = (wslot + c) % NSLOT;
+            for (int k = 0; k < NKD; ++k) if (k < ZADV || first) stash(q[k], (wslot + k) % NSLOT);
+            wslot = (wslot + (first ? NKD : ZADV)) % NSLOT;
         };
-        s_cur.start(dmx, it_first);
-        s_n1 = s_cur; s_n1.advance(dmx, it_stride);
-        s_n2 = s_n1; s_n2.advance(dmx, it_stride);
         // prologue: the planes of step 0 straight into the ring; steps 1 and 2 into the register queue
-        fetch_step(s_cur, pfq[0]);
-        fetch_step(s_n1, pfq[1]);
-        stash_step(s_cur, pfq[0]);
-        fetch_step(s_n2, pfq[0]);
+        fetch_step(sch.desc(0), pfq[0]);
+        fetch_step(sch.desc(1), pfq[1]);
+        stash_step(sch.desc(0), pfq[0]);
+        fetch_step(sch.desc(2), pfq[0]);
         __syncthreads();
-        int tick = 0;
-        X3Item done_w = s_cur.w;
-        int done_z = -1;
 #pragma unroll 1
-        while (s_cur.live) {
-            // step (tick + 1) sits in buffer ((tick + 1) & 1); that buffer then takes step (tick + 3)
-            s_n3 = s_n2; s_n3.advance(dmx, it_stride);
-            if (done_z >= 0) epi_open(done_w, done_z);
-            if (tick & 1) { stash_step(s_n1, pfq[0]); fetch_step(s_n3, pfq[0]); }
-            else          { stash_step(s_n1, pfq[1]); fetch_step(s_n3, pfq[1]); }
-            if (done_z >= 0) epi_close((tick + 1) & 1);
-            done_w = s_cur.w; done_z = s_cur.z;
-            s_cur = s_n1; s_n1 = s_n2; s_n2 = s_n3;
-            ++tick;
+        for (int s = 0; s < nsteps; ++s) {
+            // step (s + 1) sits in buffer ((s + 1) & 1); that buffer then takes step (s + 3)
+            const int d1 = sch.desc(s + 1), d3 = sch.desc(s + 3);
+            if (s > 0) epi_open(sch.desc(s - 1));
+            if (s & 1) { stash_step(d1, pfq[0]); fetch_step(d3, pfq[0]); }
+            else       { stash_step(d1, pfq[1]); fetch_step(d3, pfq[1]); }
+            if (s > 0) epi_close((s + 1) & 1);
             __syncthreads();
         }
-        if (done_z >= 0) { epi_open(done_w, done_z); epi_close((tick + 1) & 1); }
+        epi_open(sch.desc(nsteps - 1));
+        epi_close((nsteps + 1) & 1);
+    }
+    // ---- bound of the output: one atomic max per block
+    if (ymax) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+        if (lane == 0) redmax[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = redmax[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, redmax[i]);
+            atomicMax(reinterpret_cast<unsigned int*>(ymax) + (blockIdx.x & 63) * 16, __float_as_uint(m));
+        }
     }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 #define RCMVS_X3_LIST(X) X(8, 8, X3_S1) X(16, 8, X3_S1) X(32, 8, X3_S1) X(16, 16, X3_S1) X(8, 16, X3_S2) X(16, 32, X3_S2) X(16, 8, X3_T2) \
     X(8, 8, X3_P1) X(16, 16, X3_P1) X(32, 32, X3_P1) X(32, 16, X3_P1) X(64, 32, X3_P1) X(32, 32, X3_S1) X(32, 16, X3_T2)
+// the two-piece fp16 form: the 3-D kinds (the CostRegNet layers, whose producers maintain the activation bound)
+#define RCMVS_X3H_LIST(X) X(8, 8, X3_S1) X(16, 8, X3_S1) X(32, 8, X3_S1) X(16, 16, X3_S1) X(8, 16, X3_S2) X(16, 32, X3_S2) X(16, 8, X3_T2) \
+    X(32, 32, X3_S1) X(32, 16, X3_T2)
 
 bool conv3d_x3_supported(int Ci, int Co, int kind) {
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;
     RCMVS_X3_LIST(X3_CASE)
+#undef X3_CASE
+    return false;
+}
+
+bool conv3d_x3h_supported(int Ci, int Co, int kind) {
+#define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;
+    RCMVS_X3H_LIST(X3_CASE)
 #undef X3_CASE
     return false;
 }
@@ -592,18 +774,85 @@ long long conv3d_x3_weight_floats(int Ci, int Co, int kind) {      // size of on
     return 0;
 }
 
+long long conv3d_x3h_weight_floats(int Ci, int Co, int kind) {     // header (4 floats) + the fp16 pairs
+#define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return 4 + (long long)X3<CI, CO, K, 2>::KSTEPS * 2 * X3<CI, CO, K, 2>::MT_ALL * 64 * 8 / 2;
+    RCMVS_X3H_LIST(X3_CASE)
+#undef X3_CASE
+    return 0;
+}
+
 int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, hipStream_t st) {
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) { \
         const int nthr = X3<CI, CO, K>::KSTEPS * X3<CI, CO, K>::MT_ALL * 64 * 8; \
-        hipLaunchKernelGGL((x3_pack_kernel<CI, CO, K>), dim3((nthr + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(img), transposed); \
+        hipLaunchKernelGGL((x3_pack_kernel<CI, CO, K, 3>), dim3((nthr + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(img), transposed, (const float*)nullptr); \
         return launch_status("conv3d_x3_pack"); }
     RCMVS_X3_LIST(X3_CASE)
 #undef X3_CASE
     return fail(-1, "conv3d_x3_pack: unsupported Ci=%d Co=%d kind=%d", Ci, Co, kind);
 }
 
+// wsc: two device floats {scale, 1 / scale} of the weight tensor (conv3d_x3_wscale)
+int conv3d_x3h_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, const float* wsc, hipStream_t st) {
+#define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) { \
+        const int nthr = X3<CI, CO, K, 2>::KSTEPS * X3<CI, CO, K, 2>::MT_ALL * 64 * 8; \
+        hipLaunchKernelGGL((x3_pack_kernel<CI, CO, K, 2>), dim3((nthr + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(img), transposed, wsc); \
+        return launch_status("conv3d_x3h_pack"); }
+    RCMVS_X3H_LIST(X3_CASE)
+#undef X3_CASE
+    return fail(-1, "conv3d_x3h_pack: unsupported Ci=%d Co=%d kind=%d", Ci, Co, kind);
+}
+
+int conv3d_x3_wscale(const float* w, int n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(x3_wscale_kernel, dim3(1), dim3(256), 0, st, w, n, out);
+    return launch_status("conv3d_x3_wscale");
+}
+
+template <int CI, int CO, int K, int NP>
+static int x3_launch_t(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
+                       X3Dims dm, int gh, int gw, int n_blk, int dev, const float* xmax, float* ymax, hipStream_t st) {
+    using C = X3<CI, CO, K, NP>;
+    const int tiles_x = (gw + C::TX - 1) / C::TX, tiles_y = (gh + C::TY - 1) / C::TY;
+    dm.tiles_x = tiles_x; dm.ntiles = tiles_x * tiles_y;
+    // one persistent block per CU walks its share of the (batch, tile, z chunk) items: pick the chunk length that minimises the
+    // longest block (items per block x (steps per item + ~1.5 steps for the extra planes an item start loads))
+    long long best = -1; int zchunk = dm.Dt;
+    for (int zc = dm.Dt; zc >= (C::NKD > 1 ? 2 : 1); --zc) {
+        const int nch = (dm.Dt + zc - 1) / zc;
+        if (nch > 1 && (dm.Dt + nch - 1) / nch != zc) continue;            // only balanced splits
+        const long long items = (long long)dm.B * dm.ntiles * nch;
+        const long long per_blk = (items + n_blk - 1) / n_blk;
+        const long long cost = per_blk * (2 * zc + (C::NKD > 1 ? 3 : 0));
+        if (best < 0 || cost < best) { best = cost; zchunk = zc; }
+    }
+    dm.zchunk = zchunk; dm.nchunks = (dm.Dt + zchunk - 1) / zchunk;
+    const long long items = (long long)dm.B * dm.ntiles * dm.nchunks;
+    if (items >= 0x7fffffffLL) return fail(-1, "conv3d_x3: too many work items");
+    dm.nitems = (int)items;
+    // schedule tables of a block (LDS, behind the ring and the partial tiles): items per block (an XCD's share is split over
+    // grid / 8 blocks: + 1 for the remainders), steps per block; more blocks than CUs when the tables would not fit
+    int grid_n = dm.nitems < n_blk ? dm.nitems : n_blk;
+    size_t lds = 0;
+    for (;;) {
+        const long long per_blk = (items + grid_n - 1) / grid_n + 2;
+        dm.itemcap = (int)((per_blk + 3) & ~3LL);
+        dm.stepcap = (int)(((long long)dm.itemcap * dm.zchunk + 3) & ~3LL);
+        lds = (size_t)C::LDSB + (size_t)dm.itemcap * 16 + (size_t)dm.stepcap * 4 + 64;
+        if (lds <= 160 * 1024 || grid_n >= dm.nitems) break;
+        grid_n = grid_n * 2 < dm.nitems ? grid_n * 2 : dm.nitems;
+    }
+    if (lds > 160 * 1024) return fail(-1, "conv3d_x3: the schedule of a block does not fit the LDS (%zu bytes)", lds);
+    if (dm.zchunk >= 32768 || dm.itemcap >= 32768) return fail(-1, "conv3d_x3: schedule descriptor fields overflow");
+    dim3 grid((unsigned)grid_n);
+    static bool attr_set[64];
+    if (!attr_set[dev]) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[dev] = true; }
+    hipLaunchKernelGGL((conv3d_x3_kernel<CI, CO, K, NP>), grid, dim3(512), lds, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, res, y, dm, xmax, ymax);
+    return launch_status("conv3d_x3");
+}
+
+// xmax != nullptr selects the two-piece fp16 form (wimg must then be the x3h image of the pair); ymax is optional in both forms
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d) {
+                     int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d,
+                     const float* xmax, float* ymax) {
     if (s2d && (kind != X3_P1 || Ci % 16 != 0)) return fail(-1, "conv3d_x3: the space-to-depth view needs the planar kind and Ci a multiple of 16");
     if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_x3: input tensor too large for 32-bit offsets");
     // per-device facts (a process may drive several GPUs, e.g. nn.DataParallel replicas): CU count, and whether the kernel's
@@ -620,35 +869,22 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     const int n_cu = cu_of[dev];
     const int n_blk = max_blocks > 0 ? max_blocks : n_cu;      // max_blocks: test / tuning hook (few blocks = many items per block)
     X3Dims dm;
-    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d;
+    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d; dm.dbg = 0;
+#if X3_ABLATION
+    dm.dbg = x3_ablation_mask;
+#endif
     if (kind == X3_T2) { dm.Do = 2 * D; dm.Ho = 2 * H; dm.Wo = 2 * W; }
     else { const int s = kind == X3_S2 ? 2 : 1; dm.Do = (D - 1) / s + 1; dm.Ho = (H - 1) / s + 1; dm.Wo = (W - 1) / s + 1; }
     const int gh = kind == X3_T2 ? H : dm.Ho, gw = kind == X3_T2 ? W : dm.Wo;      // tile grid
     dm.Dt = kind == X3_T2 ? D : dm.Do;
-#define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) { \
-        using C = X3<CI, CO, K>; \
-        const int tiles_x = (gw + C::TX - 1) / C::TX, tiles_y = (gh + C::TY - 1) / C::TY; \
-        dm.tiles_x = tiles_x; dm.ntiles = tiles_x * tiles_y; \
-        /* one persistent block per CU walks its share of the (batch, tile, z chunk) items: pick the chunk length that minimises the \
-           longest block (items per block x (steps per item + ~1.5 steps for the extra planes an item start loads)) */ \
-        long long best = -1; int zchunk = dm.Dt; \
-        for (int zc = dm.Dt; zc >= (C::NKD > 1 ? 2 : 1); --zc) { \
-            const int nch = (dm.Dt + zc - 1) / zc; \
-            if (nch > 1 && (dm.Dt + nch - 1) / nch != zc) continue;            /* only balanced splits */ \
-            const long long items = (long long)B * dm.ntiles * nch; \
-            const long long per_blk = (items + n_blk - 1) / n_blk; \
-            const long long cost = per_blk * (2 * zc + (C::NKD > 1 ? 3 : 0)); \
-            if (best < 0 || cost < best) { best = cost; zchunk = zc; } \
-        } \
-        dm.zchunk = zchunk; dm.nchunks = (dm.Dt + zchunk - 1) / zchunk; \
-        const long long items = (long long)B * dm.ntiles * dm.nchunks; \
-        if (items >= 0x7fffffffLL) return fail(-1, "conv3d_x3: too many work items"); \
-        dm.nitems = (int)items; \
-        dim3 grid((unsigned)(dm.nitems < n_blk ? dm.nitems : n_blk)); \
-        static bool attr_set[MAXDEV]; \
-        if (!attr_set[dev]) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDSB); attr_set[dev] = true; } \
-        hipLaunchKernelGGL((conv3d_x3_kernel<CI, CO, K>), grid, dim3(512), C::LDSB, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, res, y, dm); \
-        return launch_status("conv3d_x3"); }
+    dm.tiles_x = dm.zchunk = dm.ntiles = dm.nchunks = dm.nitems = dm.itemcap = dm.stepcap = 0;
+    if (xmax) {
+#define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return x3_launch_t<CI, CO, K, 2>(x, wimg, scale, shift, res, y, dm, gh, gw, n_blk, dev, xmax, ymax, st);
+        RCMVS_X3H_LIST(X3_CASE)
+#undef X3_CASE
+        return fail(-1, "conv3d_x3 (fp16 pair form): unsupported Ci=%d Co=%d kind=%d", Ci, Co, kind);
+    }
+#define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return x3_launch_t<CI, CO, K, 3>(x, wimg, scale, shift, res, y, dm, gh, gw, n_blk, dev, xmax, ymax, st);
     RCMVS_X3_LIST(X3_CASE)
 #undef X3_CASE
     return fail(-1, "conv3d_x3: unsupported Ci=%d Co=%d kind=%d", Ci, Co, kind);

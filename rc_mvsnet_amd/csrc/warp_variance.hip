@@ -195,16 +195,14 @@ struct K1Fetch {
     v4f w[NV];
 };
 
-// WL = true: the weights are not carried with the taps (8 registers per view and set) but re-read from the LDS record when the
-// set is blended -- the experimental variants 4 / 5 (deeper prefetch within the same register budget)
-template <int NV, int DKB, int PIX, bool WL = false>
+template <int NV, int DKB, int PIX>
 __device__ __forceinline__ void k1_issue(K1Fetch<NV>& f, const v4i* lds_o, const v4f* lds_w, __amdgpu_buffer_rsrc_t rsrc,
                                          int k, int p, int q4b, int v0 = 0) {
 #pragma unroll
     for (int va = 0; va < NV; ++va) {
         const int idx = ((v0 + va) * DKB + k) * PIX + p;
         const v4i o = lds_o[idx];
-        if (!WL) f.w[va] = lds_w[idx];
+        f.w[va] = lds_w[idx];
         f.t[va][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
         f.t[va][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
         f.t[va][2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
@@ -224,8 +222,8 @@ __device__ __forceinline__ void k1_store_variance(v4f a, v4f a2, float fV, float
     __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dst));
 }
 
-template <int C, int DKB, bool FAST, int NVT, int NG = (NVT == 0 ? 1 : (NVT > 4 ? 3 : NVT)), int PF = 1, bool WL = false, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void warp_variance_tp_kernel(
+template <int C, int DKB, bool FAST, int NVT, int NG = (NVT == 0 ? 1 : (NVT > 4 ? 3 : NVT))>
+__global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
 #pragma clang fp contract(off)
@@ -307,22 +305,19 @@ __global__ __launch_bounds__(256, MINW) void warp_variance_tp_kernel(
             // Views are accumulated in ascending order whatever the grouping, so the result is bit-identical.
             constexpr int NGRP = NVT / NG, NS = DKB * NGRP;
             static_assert(NVT % NG == 0, "view groups must divide the view count");
-            // PF = sets in flight ahead of the one being blended (1 = production: double buffer; 2 = experimental variants)
-            K1Fetch<NG> f[PF + 1];
-#pragma unroll
-            for (int i = 0; i < PF; ++i)
-                if (i < NS) k1_issue<NG, DKB, PIX, WL>(f[i], lds_o, lds_w, rsrc, i / NGRP, p, q4b, (i % NGRP) * NG);
+            K1Fetch<NG> f0, f1;
+            k1_issue<NG, DKB, PIX>(f0, lds_o, lds_w, rsrc, 0, p, q4b, 0);
             v4f a = ref, a2 = ref * ref;
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 const int k = st / NGRP, gi = st % NGRP;
-                K1Fetch<NG>& cur = f[st % (PF + 1)];
-                if (st + PF < NS) k1_issue<NG, DKB, PIX, WL>(f[(st + PF) % (PF + 1)], lds_o, lds_w, rsrc, (st + PF) / NGRP, p, q4b, ((st + PF) % NGRP) * NG);
+                K1Fetch<NG>& cur = (st & 1) ? f1 : f0;
+                K1Fetch<NG>& nxt = (st & 1) ? f0 : f1;
+                if (st + 1 < NS) k1_issue<NG, DKB, PIX>(nxt, lds_o, lds_w, rsrc, (st + 1) / NGRP, p, q4b, ((st + 1) % NGRP) * NG);
                 if (gi == 0) { a = ref; a2 = ref * ref; }
 #pragma unroll
                 for (int va = 0; va < NG; ++va) {
-                    const v4f wt = WL ? lds_w[((gi * NG + va) * DKB + k) * PIX + p] : cur.w[va];
-                    v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], wt);
+                    v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], cur.w[va]);
                     a = a + val;
                     if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
                 }
@@ -353,6 +348,10 @@ __global__ __launch_bounds__(256, MINW) void warp_variance_tp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 3 (profiles/r3_k1_schedule_variants.txt, bit-identical forms of the kernel above, two source views): bilinear weights re-read
+// from the LDS record at blend time instead of carried with the taps (133-136 instead of 153-156 VGPRs) 155.6 us per scene; the same
+// with two tap sets prefetched 181.2; the same capped at 128 VGPRs for four waves per SIMD (28-36 bytes of scratch) 173.2; against
+// 139.2 for the kernel above in the same process.  Fewer registers / deeper prefetch do not help: code removed.
 // What is NOT here any more (measured on the MI355X in round 2, profiles/r2_k1_pipelined_variants_timed.txt): the
 // LDS-window variants of this kernel -- block-staged windows (78 / 102 / 84 us per stage), the persistent double-buffered
 // form with buffer_load ... lds (137 / 164 / 116 us; 75 / 86 / 69 us with a 72-texel budget), its static-LDS-set form
@@ -439,19 +438,16 @@ using namespace rcmvs;
 extern "C" {
 
 // variant: 0 = production (exact arithmetic), 1 = production with FMA-contracted blend, 2 = reference-order kernel (one full
-// coordinate chain per lane, compiler IEEE division: what variant 0 is held bit-identical to), 3 = store-only ablation,
-// 4 / 5 / 6 = experimental forms of variant 0 for two source views (weights re-read from LDS at blend time; 5: two sets
-// prefetched; 6: as 4 with the register allocation capped for four waves per SIMD)
+// coordinate chain per lane, compiler IEEE division: what variant 0 is held bit-identical to), 3 = store-only ablation
 static int k1_launch(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
                      int B, int V, int C, int D, int h, int w, int variant, hipStream_t st) {
     RCMVS_REQUIRE(feats && rot && trans && planes && var, "warp_variance_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
     RCMVS_REQUIRE((long long)h * w * C < (1LL << 31), "warp_variance_fwd: feature map too large for 32-bit offsets");
-    RCMVS_REQUIRE(variant >= 0 && variant <= 6, "warp_variance_fwd: unknown variant %d", variant);
-    if (variant >= 4 && V != 3) variant = 0;
+    RCMVS_REQUIRE(variant >= 0 && variant <= 3, "warp_variance_fwd: unknown variant %d", variant);
     RCMVS_REQUIRE(C == 8 || C == 16 || C == 32, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
-    if (variant <= 1 || variant >= 4) {
+    if (variant <= 1) {
         const bool fastm = variant == 1;
         const int LPP = C / 4, PIX = 256 / LPP;
         const int nsrc = V - 1;
@@ -470,18 +466,6 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
 #define RCMVS_K1TP_N(CC, DD, FF) do { if (nvt == 2) RCMVS_K1TP(CC, DD, FF, 2); else if (nvt == 4) RCMVS_K1TP(CC, DD, FF, 4); else RCMVS_K1TP(CC, DD, FF, 0); } while (0)
 #define RCMVS_K1TP_F(CC, DD) do { if (fastm) RCMVS_K1TP_N(CC, DD, true); else RCMVS_K1TP_N(CC, DD, false); } while (0)
 #define RCMVS_K1TP_6(CC, DD) do { if (fastm) RCMVS_K1TP(CC, DD, true, 6); else RCMVS_K1TP(CC, DD, false, 6); } while (0)
-        if (variant >= 4) {
-#define RCMVS_K1TP_X(CC, DD) do { if (variant == 4) hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, false, 2, 2, 1, true>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC); \
-                                  else if (variant == 6) hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, false, 2, 2, 1, true, 4>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC); \
-                                  else hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, false, 2, 2, 2, true>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC); } while (0)
-            switch (C) {
-                case 8:  RCMVS_K1TP_X(8, 4); break;
-                case 16: RCMVS_K1TP_X(16, 8); break;
-                default: RCMVS_K1TP_X(32, 8); break;
-            }
-#undef RCMVS_K1TP_X
-            return launch_status("warp_variance_fwd");
-        }
         if (nvt == 6) {
             switch (C) {
                 case 8:  RCMVS_K1TP_6(8, 2); break;

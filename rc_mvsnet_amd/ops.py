@@ -79,6 +79,17 @@ def hypothesis_planes(prev_depth, depth_values, full_hw, scale, ndepth, ratio):
 
 
 # ------------------------------------------------------------------------------- K1
+ABSMAX_FLOATS = 1024      # RCMVS_ABSMAX_FLOATS of include/rcmvs.h: a bound is 64 slots, 16 floats apart
+
+
+def absmax(x, square=False, out=None):
+    """Bound of max|x| (or its square) in the slot format conv3d(x_absmax=) takes: a (1024,) float vector whose maximum is the bound."""
+    if out is None:
+        out = torch.zeros(ABSMAX_FLOATS, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_absmax_fwd(_chk(x, "x"), x.numel(), int(bool(square)), _chk(out, "absmax"), _stream()), "absmax_fwd")
+    return out
+
+
 def warp_variance(feats, rot, trans, planes, ndepth, variant=0):
     """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C).  variant != 0: the test / profiling code variants of
     rcmvs_debug_warp_variance_fwd (1 FMA blend, 2 reference-order kernel, 3 store-only)."""
@@ -201,8 +212,10 @@ def pack_conv3d_weight(w, transposed=False):
     return PackedWeight(blob, Ci, Co, int(transposed))
 
 
-def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False):
-    """x (B,D,H,W,Ci) -> (B,Do,Ho,Wo,Co) with fused [relu](v*scale+shift) + residual."""
+def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False, x_absmax=None, y_absmax=None):
+    """x (B,D,H,W,Ci) -> (B,Do,Ho,Wo,Co) with fused [relu](v*scale+shift) + residual.
+    x_absmax / y_absmax ((1024,) bound vectors, ops.absmax / rcmvs_conv3d_scaled_fwd): a bound of max|x| selects the fp16-pair
+    matrix-core form where the channel pair has one; y_absmax (zero-filled by the caller) receives max|y| for the next layer."""
     B, D, H, W, Ci = x.shape
     Co = w_packed.co
     if w_packed.ci != Ci:
@@ -217,7 +230,11 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
     if CONV_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    if _CONV_IMPL:
+    if x_absmax is not None or y_absmax is not None:
+        _lib.check(_lib.load().rcmvs_conv3d_scaled_fwd(_chk(x, "x"), _opt(x_absmax, "x_absmax"), _chk(w_packed.blob, "w"), _opt(scale, "scale"),
+                                                       _opt(shift, "shift"), _opt(residual, "residual"), _chk(y, "y"), _opt(y_absmax, "y_absmax"),
+                                                       B, D, H, W, Ci, Co, stride, int(relu), _CONV_IMPL, _stream()), "conv3d_scaled_fwd")
+    elif _CONV_IMPL:
         _lib.check(_lib.load().rcmvs_debug_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                                       _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
                                                       _CONV_IMPL, _stream()), "debug_conv3d_fwd")
@@ -231,8 +248,8 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
     return y
 
 
-def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
-    """x (B,D,H,W,Ci) -> (B,2D,2H,2W,Co)."""
+def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False, x_absmax=None, y_absmax=None):
+    """x (B,D,H,W,Ci) -> (B,2D,2H,2W,Co).  x_absmax / y_absmax: as in conv3d (rcmvs_deconv3d_scaled_fwd)."""
     B, D, H, W, Ci = x.shape
     Co = w_packed.co
     if w_packed.ci != Ci:
@@ -247,7 +264,11 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False):
     if CONV_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    if _CONV_IMPL:
+    if x_absmax is not None or y_absmax is not None:
+        _lib.check(_lib.load().rcmvs_deconv3d_scaled_fwd(_chk(x, "x"), _opt(x_absmax, "x_absmax"), _chk(w_packed.blob, "w"), _opt(scale, "scale"),
+                                                         _opt(shift, "shift"), _opt(residual, "residual"), _chk(y, "y"), _opt(y_absmax, "y_absmax"),
+                                                         B, D, H, W, Ci, Co, int(relu), _CONV_IMPL, _stream()), "deconv3d_scaled_fwd")
+    elif _CONV_IMPL:
         _lib.check(_lib.load().rcmvs_debug_deconv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                                         _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, int(relu),
                                                         _CONV_IMPL, _stream()), "debug_deconv3d_fwd")
@@ -327,14 +348,14 @@ def fpn_out_fused(lat, up, w_inner_packed, b_inner, w_out_packed):
 
 # ------------------------------------------------------------------------------- K4
 def depth_head(x8, w_prob_packed, planes, want_prob=False, variant=0):
-    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)].  variant 1: the two-launch form of
-    rcmvs_debug_depth_head_fwd (tests / A-B)."""
+    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)].  variant: rcmvs_debug_depth_head_fwd's selector
+    (tests / A-B; 1 two-launch form, 2 fused single launch, 3 strip-mined single launch)."""
     B, D, h, w, C = x8.shape
     if C != 8:
         raise _lib.RcmvsError("depth_head: the prob conv takes 8 channels")
     depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
-    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32) if (want_prob or variant) else None
+    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32) if (want_prob or variant < 2) else None
     if variant:
         _lib.check(_lib.load().rcmvs_debug_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
                                                           _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,

@@ -47,6 +47,8 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 inline float2 make_float2(float a, float b) { return {a, b}; }
 inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+struct int4 { int x, y, z, w; } __attribute__((aligned(16)));
+inline int4 make_int4(int a, int b, int c, int d) { return {a, b, c, d}; }
 
 template <class T> inline T min(T a, T b) { return b < a ? b : a; }
 template <class T> inline T max(T a, T b) { return a < b ? b : a; }
@@ -267,6 +269,30 @@ inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16_emu(emu_v8bf a, emu_v8bf 
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16_emu((a), (b), (c), (x), (y), (z))
+// v_mfma_f32_16x16x32_f16: the same fragment layout with fp16 elements (products of two fp16 are exact in fp32)
+typedef _Float16 emu_v8h __attribute__((ext_vector_type(8)));
+inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x32_f16_emu(emu_v8h a, emu_v8h b, emu_v4f c, int, int, int) {
+    struct H8 { _Float16 h[8]; } ha, hb;
+    std::memcpy(ha.h, &a, 16);
+    std::memcpy(hb.h, &b, 16);
+    const auto wa = ::shim::exchange(ha);
+    const int j = wa.lane % 16, g = wa.lane / 16;
+    H8 xa[4][4];
+    for (int r = 0; r < 4; ++r)
+        for (int kq = 0; kq < 4; ++kq) xa[r][kq] = ::shim::lane_value(wa, 4 * g + r + 16 * kq, H8{});
+    const auto wb = ::shim::exchange(hb);
+    emu_v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        float s = 0.0f;
+        for (int kq = 0; kq < 4; ++kq) {
+            const H8 y = ::shim::lane_value(wb, j + 16 * kq, H8{});
+            for (int e = 0; e < 8; ++e) s += (float)xa[r][kq].h[e] * (float)y.h[e];
+        }
+        d[r] = c[r] + s;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16_emu((a), (b), (c), (x), (y), (z))
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte value {s0 (bytes 4..7), s1 (bytes 0..3)} (selectors 0..7 only)
 inline unsigned __builtin_amdgcn_perm_emu(unsigned s0, unsigned s1, unsigned sel) {
     const unsigned long long v = ((unsigned long long)s0 << 32) | s1;

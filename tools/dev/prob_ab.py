@@ -12,7 +12,7 @@ for D, H, W in ((48, 128, 160), (32, 256, 320), (8, 512, 640)):
     # volumes of all three stages alternate, as in the pipeline, so that nothing is served from a warm Infinity Cache
     xs = [torch.randn(1, D, H, W, 8, device=dev) for _ in range(4)]
     planes = torch.stack((425.0 + 50 * torch.rand(1, H, W, device=dev), 1.0 + 5 * torch.rand(1, H, W, device=dev)), dim=-1).contiguous()
-    for name, var in (("fused", 0), ("two-launch", 1)):
+    for name, var in (("strip", 3), ("fused", 2), ("two-launch", 1)):
         for i in range(4): ops.depth_head(xs[i], w, planes, variant=var)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -1,5 +1,6 @@
 // Standalone developer harness for csrc/conv3d_x3.hip (GPU box, no torch): accuracy against an fp64 CPU convolution on small
 // volumes, then HIP-event timings at the config-2 layer shapes.   hipcc --offload-arch=gfx950 -O3 tools/dev/x3_test.hip -o x3_test
+// -DX3_ABLATION=1 adds the phase-ablation switches (X3_DBG=<mask>; the switches themselves slow the MFMA loop: compare within that build only)
 #include "../../rc_mvsnet_amd/csrc/conv3d_x3.hip"
 #include <vector>
 #include <random>
@@ -54,16 +55,21 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     for (auto& v : sc) v = 0.5f + fabsf(nd(rng));
     for (auto& v : sh) v = 0.1f * nd(rng);
     for (auto& v : res) v = nd(rng);
-    float *dx, *dw, *dimg, *dsc, *dsh, *dres, *dy;
-    long long imgf = conv3d_x3_weight_floats(Ci, Co, kind);
+    float *dx, *dw, *dimg, *dsc, *dsh, *dres, *dy, *dmax;
+    const bool pair = getenv("X3_NP") && atoi(getenv("X3_NP")) == 2 && conv3d_x3h_supported(Ci, Co, kind);     // the fp16-pair form
+    long long imgf = pair ? conv3d_x3h_weight_floats(Ci, Co, kind) : conv3d_x3_weight_floats(Ci, Co, kind);
+    CK(hipMalloc(&dmax, 4096 + 64));                 // bound vector (64 slots, 16 floats apart) + the weight-scale scratch
+    { float m = 0.f; for (auto v : x) m = fmaxf(m, fabsf(v)); std::vector<float> h(1024 + 16, 0.f); h[0] = m; CK(hipMemcpy(dmax, h.data(), 4096 + 64, hipMemcpyHostToDevice)); }
+    const float* xmx = pair ? dmax : nullptr;
     CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dimg, imgf * 4)); CK(hipMalloc(&dsc, Co * 4)); CK(hipMalloc(&dsh, Co * 4));
     CK(hipMalloc(&dres, ny * 4)); CK(hipMalloc(&dy, ny * 4));
     CK(hipMemcpy(dx, x.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), nw * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dsc, sc.data(), Co * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dsh, sh.data(), Co * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dres, res.data(), ny * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dy, 0xff, ny * 4));
-    if (conv3d_x3_pack(dw, dimg, Co, Ci, kind, kind == 2 ? 1 : 0, 0)) return 1;
-    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0)) return 1;
+    if (pair) { if (conv3d_x3_wscale(dw, (int)nw, dmax + 1024, 0) || conv3d_x3h_pack(dw, dimg, Co, Ci, kind, kind == 2 ? 1 : 0, dmax + 1024, 0)) return 1; }
+    else if (conv3d_x3_pack(dw, dimg, Co, Ci, kind, kind == 2 ? 1 : 0, 0)) return 1;
+    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr)) return 1;
     CK(hipDeviceSynchronize());
     int bad = 0;
     if (check) {
@@ -80,15 +86,21 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     }
     if (reps > 0) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0);
+#if X3_ABLATION
+        x3_ablation_mask = getenv("X3_DBG") ? atoi(getenv("X3_DBG")) : 0;
+#endif
+        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr);
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0);
+        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr);
+#if X3_ABLATION
+        x3_ablation_mask = 0;
+#endif
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         double us = ms * 1e3 / reps, fl = 2.0 * (kind == 3 ? 9 : 27) * Ci * Co * (kind == 2 ? (double)D * H * W : (double)Do * Ho * Wo);
-        printf("time  kind=%d Ci=%d Co=%d %dx%dx%d: %8.1f us  %6.1f TF (fp32-equivalent)\n", kind, Ci, Co, D, H, W, us, fl / us / 1e6);
+        printf("time  kind=%d Ci=%d Co=%d %dx%dx%d %s: %8.1f us  %6.1f TF (fp32-equivalent)\n", kind, Ci, Co, D, H, W, pair ? "fp16 pair  " : "bf16 triple", us, fl / us / 1e6);
     }
-    hipFree(dx); hipFree(dw); hipFree(dimg); hipFree(dsc); hipFree(dsh); hipFree(dres); hipFree(dy);
+    hipFree(dmax); hipFree(dx); hipFree(dw); hipFree(dimg); hipFree(dsc); hipFree(dsh); hipFree(dres); hipFree(dy);
     return bad;
 }
 
@@ -96,6 +108,7 @@ int main(int argc, char** argv) {
     int bad = 0;
     const int cases[13][3] = {{3, 64, 32}, {0, 32, 32}, {2, 32, 16}, {0, 8, 8}, {0, 16, 8}, {0, 32, 8}, {0, 16, 16}, {1, 8, 16}, {1, 16, 32}, {2, 16, 8}, {3, 8, 8}, {3, 16, 16}, {3, 32, 32}};
     for (auto& p : cases) {
+        if (getenv("X3_NOCHECK")) break;
         bad |= run_case(p[0], p[1], p[2], 8, 8, 32, true, 0);
         bad |= run_case(p[0], p[1], p[2], 11, 13, 45, true, 0);     // ragged: partial tiles in x and y, z not a multiple of the chunk
         bad |= run_case(p[0], p[1], p[2], 3, 20, 70, true, 0);

@@ -9,8 +9,7 @@ from rc_mvsnet_amd import _lib, ops, synthetic
 lib = _lib.load()
 dev = "cuda:0"
 V, H, W = int(os.environ.get('K1_V', '3')), 512, 640
-names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 4: "weights from LDS", 5: "weights from LDS, 2 sets ahead",
-         6: "weights from LDS, 4 waves/SIMD", 100: "torch zero_ (memset)"}
+names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 100: "torch zero_ (memset)"}
 variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 100]
 dv = synthetic.depth_values(1).to(dev)
 tot = {}
