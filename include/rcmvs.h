@@ -222,16 +222,10 @@ int rcmvs_fpn_out_fused(const float* lat, const float* up, const float* w_inner,
 /* replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression and the
  * confidence gather of DepthNet_eval.forward (models/casmvsnet.py:293-309).
  *   x (B,D,h,w,8) channels-last, w_prob packed [27][8][1];  depth, conf (B,h,w);
- *   prob (B,D,h,w): optional (NULL = not wanted) -- receives the probabilities (training: rcmvs_depth_head_bwd reads them).
- * One launch: a block keeps the logits of its pixel tile in LDS for all D planes (D <= 64) and runs the softmax on them. */
+ *   prob (B,D,h,w): required -- receives the logits, then the probabilities in place. */
 int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
                          float* depth, float* conf, float* prob,
                          int B, int D, int h, int w, void* stream);
-/* Test / A-B twin: variant 0 = rcmvs_depth_head_fwd, 1 = the two-launch form (prob conv writing logits into `prob`, which is
- * then required, + an in-place softmax kernel) that the fused kernel is held bit-identical to. */
-int rcmvs_debug_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
-                               float* depth, float* conf, float* prob,
-                               int B, int D, int h, int w, int variant, void* stream);
 
 /* ---- rendering-consistency branch --------------------------------------------------------- */
 /* F.interpolate(size=[Do,h,w], trilinear, align_corners=True) along the plane axis only

@@ -330,14 +330,14 @@ class CostRegNet(nn.Module):
         """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8).
         x_absmax: bound of max|x| (ops.absmax format; the cascade derives it from the feature maps).  With it the layers run on the
         fp16-pair form of the matrix-core kernels (half the matrix-pipe work of the exact bf16 triple): every layer hands the
-        bound of its output to its consumer through a zero-filled scratch vector (one small fill per call).  Without it: the
-        three-piece form, as in round 2."""
+        bound of its output to its consumer through a zero-filled scratch vector (one small fill per call).  Without it (the
+        default): the exact three-piece bf16 form."""
         B, D, h, w, _ = x.shape
         if D % 8 or h % 8 or w % 8:
             raise RcmvsError(f"CostRegNet: volume {D}x{h}x{w} must be divisible by 8 in every axis "
                              "(three stride-2 levels with skip connections, models/modules.py:492-499)")
         p = self.hip_plan()
-        if x_absmax is None or os.environ.get("RCMVS_FP16_PAIR", "1") == "0":
+        if x_absmax is None:
             conv0 = ops.conv3d(x, *p["conv0"], relu=True)
             conv2 = ops.conv3d(ops.conv3d(conv0, *p["conv1"], stride=2, relu=True), *p["conv2"], relu=True)
             conv4 = ops.conv3d(ops.conv3d(conv2, *p["conv3"], stride=2, relu=True), *p["conv4"], relu=True)
@@ -481,8 +481,11 @@ class _CascadeBase(nn.Module):
             planes = ops.hypothesis_planes(depth, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
             var = ops.warp_variance(f_cl, rot, trans, planes, D)
             cr = self._cr(s)
-            # var = E[f^2] - E[f]^2 <= max f^2: the bound of the variance volume from the feature maps (no pass over the volume)
-            vmax = ops.absmax(f_cl, square=True) if os.environ.get("RCMVS_FP16_PAIR", "1") != "0" else None
+            # RCMVS_FP16_PAIR=1: the cost regularisation on the two-piece fp16 form of the matrix-core kernels (half the MFMAs of the exact
+            # bf16 triple).  It needs a bound of max|var|: var = E[f^2] - E[f]^2 <= max f^2, from the feature maps, no pass over the
+            # volume.  Measured (profiles/r3_x3_times_final.txt): faster kernels stand-alone (conv0 118 against 144 us), but in the
+            # pipeline both forms sit behind the producer waves (1.502 against 1.475 ms per scene with the bound kernels): off by default.
+            vmax = ops.absmax(f_cl, square=True) if os.environ.get("RCMVS_FP16_PAIR", "0") == "1" else None
             x8 = cr.features_cl(var, vmax)
             depth, conf = ops.depth_head(x8, cr.hip_plan()["prob"], planes)
             out = {"depth": depth, "photometric_confidence": conf}

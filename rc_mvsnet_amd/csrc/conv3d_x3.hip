@@ -60,8 +60,12 @@ namespace rcmvs {
 
 #if X3_ABLATION
 int x3_ablation_mask = 0;   // bit 0: no MFMAs, 1: no split / ring stores, 2: no input loads, 3: no output stores, 4: no B-fragment reads
+long long* x3_trace_buf = nullptr;      // device buffer [64 ticks][8 stamps] of s_memtime values of block 0 (consumer wave 0: 0-2, producer wave NCW: 4-7)
+#define X3_STAMP(SLOT) do { if (dm.trace && blockIdx.x == 0 && lane == 0 && s < 64) dm.trace[s * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define X3_STAMP(SLOT) do { } while (0)
 #endif
-#define X3_DBG(BIT) (X3_ABLATION && ((dm.dbg >> (BIT)) & 1))
+#define X3_DBG(BIT) (X3_ABLATION == 1 && ((dm.dbg >> (BIT)) & 1))       // (X3_ABLATION == 2: time stamps only, no switches)
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
@@ -119,6 +123,11 @@ struct X3 {
     // its data (four waves' bursts queue in the LDS) must be covered by the MFMAs of the K steps in between: 6 (4, 2) MFMAs of 17
     // cycles per n-tile and m-tile and K step.  One step ahead (round 2) left every K step waiting on the LDS -- which is why
     // halving the MFMA count (NP = 2) changed nothing (profiles/r3_x3_prefetch_distance.txt).  Bounded by the register budget.
+    // who finishes the K-split tiles (sum of the partial tiles, BN, ReLU, skip-add, store): with three pieces the consumers' MFMA
+    // phase is the longer half of a tick and the producers have the slack; with two pieces it is the other way round
+    // (profiles/r3_x3_tick_trace.txt)
+    static constexpr bool EPI_CONSUMER = (NP == 2);
+    static constexpr int NEW = EPI_CONSUMER ? NCW : NPW;                 // waves the (tile, m-tile) units are dealt to
     static constexpr int MFMA_PER_KSTEP = TP * MT * (NP == 3 ? 6 : 3);
     static constexpr int PD_WANT = (MFMA_PER_KSTEP >= 20) ? 1 : ((MFMA_PER_KSTEP >= 10) ? 2 : ((MFMA_PER_KSTEP >= 6) ? 3 : 4));
     static constexpr int REG_FIXED = ((KSTEPS + KSPLIT - 1) / KSPLIT) * NP * MT * 4 + TP * MT * NP * 4 + 28;      // weights + accumulators + the rest
@@ -285,6 +294,7 @@ struct X3Dims {
     int B, ntiles, nchunks, nitems;   // work items = B x xy tiles x z chunks
     int itemcap, stepcap;   // capacities of the block's schedule tables in LDS (items / steps per block, rounded up)
     int dbg;            // phase-ablation mask (0 in the library; X3_ABLATION builds only)
+    long long* trace;   // s_memtime stamps of block 0 (nullptr in the library; X3_ABLATION builds only)
     int s2d;            // planar kind only: the input is physically (B, D, 2H, 2W, CIN / 4) and is read through a space-to-depth view
                         // (channel (py, px, c) of voxel (y, x) = channel c of pixel (2y + py, 2x + px)): a 5x5 stride-2 layer as a 3x3 one
 };
@@ -408,6 +418,79 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     }
     float vmax = 0.0f;                            // max |stored output| seen by this thread (ymax)
 
+    constexpr int OOB = 0x7ffffff0;
+    const int ew = max(C::EPI_CONSUMER ? wave : wave - C::NCW, 0);       // index among the waves that finish tiles (the others never call epi_*)
+    // Finishing the K-split tiles of a step (sum of the partial tiles, BN scale/shift, ReLU, skip-add, store) falls to the waves with
+    // the slack in a tick (C::EPI_CONSUMER): the producers in the three-piece form (as in round 2); the consumers in the two-piece
+    // form, whose MFMA phase is half as long -- a consumer then waits at the tick barrier for the producers anyway, whose ring stores
+    // cannot overlap the MFMAs of the wave they share a SIMD with (profiles/r3_x3_tick_trace.txt).  epi_open works out where this wave's (tile, m-tile) units go and issues the skip-connection
+    // loads, epi_close does the arithmetic.  Inside an item the output offsets just advance by one z step of the tile grid; they are
+    // recomputed when the item changes.  Output and skip tensor go through buffer descriptors with 32-bit byte offsets (host-checked
+    // < 2^31): a unit outside the volume, a missing skip tensor and a step that does not exist are out-of-range offsets.
+    constexpr int NEU = (KSPLIT > 1) ? (C::NTILE * C::MT_ALL + C::NEW - 1) / C::NEW : 1;
+    x3_f32x4 esc[NEU], esh[NEU], erv[NEU];
+    int eob[NEU];                  // byte offset of the unit's float4 in y / res; OOB = nothing to store
+    int epi_item = -1;
+    const int ostep = (KIND == X3_T2 ? 2 : 1) * dm.Ho * dm.Wo * COUT * 4;
+    const int ybytes = (int)((long long)dm.B * dm.Do * dm.Ho * dm.Wo * COUT * 4);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, (short)0, ybytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res ? res : y), (short)0, res ? ybytes : 0, 0x00020000);
+    if constexpr (KSPLIT > 1) {
+#pragma unroll
+        for (int i = 0; i < NEU; ++i) {
+            const int u = min(ew + C::NEW * i, C::NTILE * C::MT_ALL - 1);
+            long long ov; int co0;
+            x3_out_coord<C, COUT, KIND>(dm, 0, 0, 0, 0, 0, u % C::MT_ALL, n, kk, ov, co0);      // co0 depends on the m-tile and the lane only
+            esc[i] = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
+            esh[i] = shift ? *reinterpret_cast<const x3_f32x4*>(shift + co0) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
+            eob[i] = OOB;
+        }
+    }
+    auto epi_open = [&](int d) {
+        if constexpr (KSPLIT > 1) {
+            if (d >= 0) {
+                const int k = x3_desc_item(d);
+                if (k == epi_item) {
+#pragma unroll
+                    for (int i = 0; i < NEU; ++i) if (eob[i] != OOB) eob[i] += ostep;
+                } else {
+                    epi_item = k;
+                    const int4 w = sch.itab[k];
+                    const int z = x3_desc_z(d);
+#pragma unroll
+                    for (int i = 0; i < NEU; ++i) {
+                        const int u = ew + C::NEW * i;                  // (tile, m-tile) unit of this wave
+                        long long ov; int co0;
+                        const bool ok = u < C::NTILE * C::MT_ALL && x3_out_coord<C, COUT, KIND>(dm, w.x, w.y, w.z, z, u / C::MT_ALL, u % C::MT_ALL, n, kk, ov, co0);
+                        eob[i] = ok ? (int)((ov * COUT + co0) * 4) : OOB;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NEU; ++i) eob[i] = OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < NEU; ++i)          // (no skip tensor: a zero-length descriptor, every lane out of range)
+                erv[i] = __builtin_bit_cast(x3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, eob[i], 0, 0));
+        }
+    };
+    auto epi_close = [&](int buf) {
+        if constexpr (KSPLIT > 1) {
+            const x3_f32x4* part = reinterpret_cast<const x3_f32x4*>(partbase + buf * C::PARTB);
+#pragma unroll
+            for (int i = 0; i < NEU; ++i) {
+                const x3_f32x4* pp = part + min(ew + C::NEW * i, C::NTILE * C::MT_ALL - 1) * KSPLIT * 64 + lane;
+                x3_f32x4 v = pp[0];
+#pragma unroll
+                for (int k = 1; k < KSPLIT; ++k) v += pp[k * 64];
+                v = v * esc[i] + esh[i];
+                if (relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
+                v += erv[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(x3_u32x4, v), yrs, X3_DBG(3) ? OOB : eob[i], 0, 0);
+                if (eob[i] != OOB) vmax = x3_absmax4(vmax, v);
+            }
+        }
+    };
     if (!producer) {
         // =============================== consumer: register-stationary weights of this wave's (K, M) slice
         const int ks = wave % KSPLIT, ms = (wave / KSPLIT) % C::MSPLIT, grp = wave / (KSPLIT * C::MSPLIT);
@@ -455,7 +538,9 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         int s0 = 0;               // ring slot of the first input plane of the current step
 #pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
+            if (wave == 0) X3_STAMP(0);
             const int d = sch.desc(s);
+            if constexpr (KSPLIT > 1 && C::EPI_CONSUMER) { if (s > 0) epi_close((s + 1) & 1); }      // finish step s - 1 (its partial tiles were complete at the barrier, its skip loads in flight since before it)
             const int4 itm = sch.itab[x3_desc_item(d)];
             const int z = x3_desc_z(d), x0 = itm.y, y0 = itm.z, b = itm.x;
             int slotoff[NKD];
@@ -527,6 +612,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
 #undef X3_MF
 #undef X3_LD
                 }
+                if (wave == 0 && tp == C::NTW / TP - 1) X3_STAMP(1);
 #pragma unroll
                 for (int t = 0; t < TP; ++t)
 #pragma unroll
@@ -549,12 +635,14 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             }
             const int dn = sch.desc(s + 1);
             s0 = (s0 + ((dn >= 0 && x3_desc_first(dn)) ? NKD : ZADV)) % NSLOT;      // a new item starts right behind the last plane of the previous one
+            if constexpr (KSPLIT > 1 && C::EPI_CONSUMER) epi_open(d);       // where step s goes + its skip-connection loads: consumed after the barrier
+            if (wave == 0) X3_STAMP(2);
             __syncthreads();
         }
+        if constexpr (KSPLIT > 1 && C::EPI_CONSUMER) epi_close((nsteps + 1) & 1);
     } else {
         // =============================== producer
         const int pw = wave - C::NCW, ptid = tid - C::NCW * 64;
-        constexpr int OOB = 0x7ffffff0;
         const long long vol = (long long)dm.B * dm.D * dm.H * dm.W * CIN * 4;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)vol, 0x00020000);
         // which float4 of a halo slice this thread moves: halo row / column and offsets (item-invariant), and -- recomputed when the
@@ -594,19 +682,20 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                 goff[i] = ok ? base + grel[i] : OOB;
             }
         };
-        // fetch input plane zi of the current fetch item's halo tile: the plane offset rides in the scalar offset of the buffer load
-        // (an OOB entry stays out of range whatever is added: the sum of two offsets below 2^31 does not wrap, and the bounds check
-        // compares unsigned); a plane outside the volume is a wave-uniform case: zeros without loads
-        auto fetch = [&](x3_f32x4 (&pf)[C::NPF], int zi) {
-            if (zi >= 0 && zi < dm.D && !X3_DBG(2)) {
-                const int zoff = zi * zstride;
+        // A tick of a producer wave issues a FIXED number of vector-memory operations, whatever the step needs: NKD planes of loads
+        // (the planes a step does not add, steps that do not exist, lanes outside the volume = out-of-range buffer offsets: the load
+        // returns 0 without touching memory), and the tick loop is unrolled by two so that the register queue alternates statically.
+        // Only then can the compiler's s_waitcnt bookkeeping -- vmcnt counts in issue order -- wait for the two-tick-old planes with
+        // a partial count; with data-dependent counts it fell back to vmcnt(0) in front of every use, i.e. it waited for the loads
+        // issued a few hundred cycles earlier (profiles/r3_x3_tick_trace.txt: producer 4400 of a 4600-cycle tick).  (Loading only
+        // the ZADV planes every step adds and fetching the leading planes of an item synchronously was measured too: better on the
+        // long conv0 items, worse on the short items of the deep levels, 1.503 against 1.474 ms per scene.)
+        auto fetch = [&](x3_f32x4 (&pf)[C::NPF], int zi, bool want) {
+            const bool zin = want && zi >= 0 && zi < dm.D && !X3_DBG(2);
+            const int zoff = zin ? zi * zstride : 0;
 #pragma unroll
-                for (int i = 0; i < C::NPF; ++i)
-                    pf[i] = __builtin_bit_cast(x3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], zoff, 0));
-            } else {
-#pragma unroll
-                for (int i = 0; i < C::NPF; ++i) pf[i] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 0; i < C::NPF; ++i)
+                pf[i] = __builtin_bit_cast(x3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, zin ? goff[i] : OOB, zoff, 0));
         };
         auto stash = [&](const x3_f32x4 (&pf)[C::NPF], int slot) {
             x3_byte* sb = smem + slot * C::SLB;
@@ -628,68 +717,6 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             }
         };
         auto zin0 = [&](int z) { return (KIND == X3_S1) ? z - 1 : (KIND == X3_S2 ? 2 * z - 1 : z); };      // first input plane of step z (planar: the plane itself)
-        // finish the K-split tiles of a step: sum the partial tiles, BN scale/shift, ReLU, skip-add, store.  Two halves: epi_open at
-        // the start of the tick works out where this wave's (tile, m-tile) units go and issues the skip-connection loads; epi_close
-        // at the end of the tick (a stash and a fetch later) does the arithmetic, so the loads' latency is off the tick's critical path.
-        // Inside an item the output offsets just advance by one z step of the tile grid; they are recomputed when the item changes.
-        constexpr int NEU = (KSPLIT > 1) ? (C::NTILE * C::MT_ALL + C::NPW - 1) / C::NPW : 1;
-        x3_f32x4 esc[NEU], esh[NEU], erv[NEU];
-        long long eov[NEU];            // element offset of the unit's float4 in y / res; < 0 = nothing to store
-        int epi_item = -1;
-        const long long ostep = (long long)(KIND == X3_T2 ? 2 : 1) * dm.Ho * dm.Wo * COUT;
-        if constexpr (KSPLIT > 1) {
-#pragma unroll
-            for (int i = 0; i < NEU; ++i) {
-                const int u = min(pw + C::NPW * i, C::NTILE * C::MT_ALL - 1);
-                long long ov; int co0;
-                x3_out_coord<C, COUT, KIND>(dm, 0, 0, 0, 0, 0, u % C::MT_ALL, n, kk, ov, co0);      // co0 depends on the m-tile and the lane only
-                esc[i] = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
-                esh[i] = shift ? *reinterpret_cast<const x3_f32x4*>(shift + co0) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
-                eov[i] = -1;
-            }
-        }
-        auto epi_open = [&](int d) {
-            if constexpr (KSPLIT > 1) {
-                if (d < 0) return;
-                const int k = x3_desc_item(d);
-                if (k == epi_item) {
-#pragma unroll
-                    for (int i = 0; i < NEU; ++i) if (eov[i] >= 0) eov[i] += ostep;
-                } else {
-                    epi_item = k;
-                    const int4 w = sch.itab[k];
-                    const int z = x3_desc_z(d);
-#pragma unroll
-                    for (int i = 0; i < NEU; ++i) {
-                        const int u = pw + C::NPW * i;                  // (tile, m-tile) unit of this producer wave
-                        long long ov; int co0;
-                        const bool ok = u < C::NTILE * C::MT_ALL && x3_out_coord<C, COUT, KIND>(dm, w.x, w.y, w.z, z, u / C::MT_ALL, u % C::MT_ALL, n, kk, ov, co0);
-                        eov[i] = ok ? ov * COUT + co0 : -1;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NEU; ++i)
-                    erv[i] = (res && eov[i] >= 0) ? *reinterpret_cast<const x3_f32x4*>(res + eov[i]) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        auto epi_close = [&](int buf) {
-            if constexpr (KSPLIT > 1) {
-                const x3_f32x4* part = reinterpret_cast<const x3_f32x4*>(partbase + buf * C::PARTB);
-#pragma unroll
-                for (int i = 0; i < NEU; ++i) {
-                    if (eov[i] < 0) continue;
-                    const x3_f32x4* pp = part + (pw + C::NPW * i) * KSPLIT * 64 + lane;
-                    x3_f32x4 v = pp[0];
-#pragma unroll
-                    for (int k = 1; k < KSPLIT; ++k) v += pp[k * 64];
-                    v = v * esc[i] + esh[i];
-                    if (relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
-                    v += erv[i];
-                    if (!X3_DBG(3)) *reinterpret_cast<x3_f32x4*>(y + eov[i]) = v;
-                    vmax = x3_absmax4(vmax, v);
-                }
-            }
-        };
         // schedule: during tick s the consumers compute step s while the producers (1) store into the ring the planes step s+1
         // adds, (2) issue the loads of the planes step s+3 adds -- two ticks of flight time, a load that misses to HBM under
         // load takes longer than one tick -- and (3) finish step s-1.  Register queue: buffer (t & 1) holds step t's planes from
@@ -698,12 +725,15 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         x3_f32x4 pfq[2][NKD][C::NPF];
         int wslot = 0;
         auto fetch_step = [&](int d, x3_f32x4 (&q)[NKD][C::NPF]) {
-            if (d < 0) return;
-            set_item(x3_desc_item(d));
-            const bool first = x3_desc_first(d);
-            const int p = first ? zin0(x3_desc_z(d)) : zin0(x3_desc_z(d)) + NKD - ZADV;
+            bool first = false;
+            int p = 0;
+            if (d >= 0) {
+                set_item(x3_desc_item(d));
+                first = x3_desc_first(d);
+                p = first ? zin0(x3_desc_z(d)) : zin0(x3_desc_z(d)) + NKD - ZADV;
+            }
 #pragma unroll
-            for (int k = 0; k < NKD; ++k) if (k < ZADV || first) fetch(q[k], p + k);
+            for (int k = 0; k < NKD; ++k) fetch(q[k], p + k, d >= 0 && (k < ZADV || first));
         };
         auto stash_step = [&](int d, const x3_f32x4 (&q)[NKD][C::NPF]) {
             if (d < 0) return;
@@ -712,6 +742,19 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             for (int k = 0; k < NKD; ++k) if (k < ZADV || first) stash(q[k], (wslot + k) % NSLOT);
             wslot = (wslot + (first ? NKD : ZADV)) % NSLOT;
         };
+        // one tick: step (s + 1) sits in buffer qa = pfq[(s + 1) & 1]; that buffer then takes step (s + 3)
+        auto tick = [&](int s, x3_f32x4 (&qa)[NKD][C::NPF]) {
+            if (pw == 0) X3_STAMP(4);
+            const int d1 = sch.desc(s + 1), d3 = sch.desc(s + 3);
+            if constexpr (KSPLIT > 1 && !C::EPI_CONSUMER) epi_open(sch.desc(s - 1));      // step s - 1: where it goes + its skip loads
+            stash_step(d1, qa);
+            if (pw == 0) X3_STAMP(5);
+            fetch_step(d3, qa);
+            if (pw == 0) X3_STAMP(6);
+            if constexpr (KSPLIT > 1 && !C::EPI_CONSUMER) epi_close((s + 1) & 1);
+            if (pw == 0) X3_STAMP(7);
+            __syncthreads();
+        };
         // prologue: the planes of step 0 straight into the ring; steps 1 and 2 into the register queue
         fetch_step(sch.desc(0), pfq[0]);
         fetch_step(sch.desc(1), pfq[1]);
@@ -719,17 +762,11 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         fetch_step(sch.desc(2), pfq[0]);
         __syncthreads();
 #pragma unroll 1
-        for (int s = 0; s < nsteps; ++s) {
-            // step (s + 1) sits in buffer ((s + 1) & 1); that buffer then takes step (s + 3)
-            const int d1 = sch.desc(s + 1), d3 = sch.desc(s + 3);
-            if (s > 0) epi_open(sch.desc(s - 1));
-            if (s & 1) { stash_step(d1, pfq[0]); fetch_step(d3, pfq[0]); }
-            else       { stash_step(d1, pfq[1]); fetch_step(d3, pfq[1]); }
-            if (s > 0) epi_close((s + 1) & 1);
-            __syncthreads();
+        for (int s = 0; s < nsteps; s += 2) {
+            tick(s, pfq[1]);
+            if (s + 1 < nsteps) tick(s + 1, pfq[0]);
         }
-        epi_open(sch.desc(nsteps - 1));
-        epi_close((nsteps + 1) & 1);
+        if constexpr (KSPLIT > 1 && !C::EPI_CONSUMER) { epi_open(sch.desc(nsteps - 1)); epi_close((nsteps + 1) & 1); }
     }
     // ---- bound of the output: one atomic max per block
     if (ymax) {
@@ -855,6 +892,10 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
                      const float* xmax, float* ymax) {
     if (s2d && (kind != X3_P1 || Ci % 16 != 0)) return fail(-1, "conv3d_x3: the space-to-depth view needs the planar kind and Ci a multiple of 16");
     if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_x3: input tensor too large for 32-bit offsets");
+    {
+        const long long so = kind == X3_T2 ? 8 : (kind == X3_S2 ? 1 : 1);        // output voxels per input voxel (upper bound)
+        if ((long long)B * D * H * W * so * Co * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_x3: output tensor too large for 32-bit offsets");
+    }
     // per-device facts (a process may drive several GPUs, e.g. nn.DataParallel replicas): CU count, and whether the kernel's
     // dynamic-LDS limit has been raised on that device.  Races are benign (the same values are written).
     constexpr int MAXDEV = 64;
@@ -869,9 +910,10 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     const int n_cu = cu_of[dev];
     const int n_blk = max_blocks > 0 ? max_blocks : n_cu;      // max_blocks: test / tuning hook (few blocks = many items per block)
     X3Dims dm;
-    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d; dm.dbg = 0;
+    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d; dm.dbg = 0; dm.trace = nullptr;
 #if X3_ABLATION
     dm.dbg = x3_ablation_mask;
+    dm.trace = x3_trace_buf;
 #endif
     if (kind == X3_T2) { dm.Do = 2 * D; dm.Ho = 2 * H; dm.Wo = 2 * W; }
     else { const int s = kind == X3_S2 ? 2 : 1; dm.Do = (D - 1) / s + 1; dm.Ho = (H - 1) / s + 1; dm.Wo = (W - 1) / s + 1; }

@@ -347,23 +347,17 @@ def fpn_out_fused(lat, up, w_inner_packed, b_inner, w_out_packed):
 
 
 # ------------------------------------------------------------------------------- K4
-def depth_head(x8, w_prob_packed, planes, want_prob=False, variant=0):
-    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)].  variant: rcmvs_debug_depth_head_fwd's selector
-    (tests / A-B; 1 two-launch form, 2 fused single launch, 3 strip-mined single launch)."""
+def depth_head(x8, w_prob_packed, planes, want_prob=False):
+    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)]."""
     B, D, h, w, C = x8.shape
     if C != 8:
         raise _lib.RcmvsError("depth_head: the prob conv takes 8 channels")
     depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
-    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32) if (want_prob or variant < 2) else None
-    if variant:
-        _lib.check(_lib.load().rcmvs_debug_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
-                                                          _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
-                                                          int(variant), _stream()), "debug_depth_head_fwd")
-    else:
-        _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
-                                                    _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
-                                                    _stream()), "depth_head_fwd")
+    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32)     # logit scratch -> probabilities
+    _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
+                                                _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
+                                                _stream()), "depth_head_fwd")
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 

@@ -327,6 +327,12 @@ inline emu_v2u __builtin_amdgcn_raw_buffer_load_b64_emu(__amdgpu_buffer_rsrc_t r
     return v;
 }
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b128_emu((r), (v), (s), (a))
+// raw buffer stores drop out-of-range lanes
+inline void __builtin_amdgcn_raw_buffer_store_b128_emu(emu_v4u v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    const unsigned off = (unsigned)voffset + (unsigned)soffset;
+    if (off < r.num_records && off + 16u <= r.num_records) std::memcpy(const_cast<char*>(r.base) + off, &v, 16);
+}
+#define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, a) __builtin_amdgcn_raw_buffer_store_b128_emu((d), (r), (v), (s), (a))
 #define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b64_emu((r), (v), (s), (a))
 
 // buffer_load ... lds (direct-to-LDS DMA): lane i of the wave writes `size` bytes at ldsptr + i * size.  Emulated synchronously,

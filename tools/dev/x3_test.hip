@@ -84,6 +84,26 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
         printf("check kind=%d Ci=%d Co=%d %dx%dx%d: max|y|=%.3f  max err x3 = %.3e (at %zu)  max err fp32 fma chain = %.3e\n", kind, Ci, Co, D, H, W, mag, eg, worst, e32);
         if (!(eg <= 4 * e32 + 1e-6 * mag)) { bad = 1; printf("   MISMATCH: gpu %.6f ref %.6f\n", yg[worst], yr[worst]); }
     }
+#if X3_ABLATION
+    if (reps > 0 && getenv("X3_TRACE")) {      // s_memtime stamps of block 0 (ticks 8..55): where a tick's time goes
+        long long* dtr; CK(hipMalloc(&dtr, 64 * 8 * 8)); CK(hipMemset(dtr, 0, 64 * 8 * 8));
+        x3_trace_buf = dtr;
+        conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr);
+        CK(hipDeviceSynchronize());
+        x3_trace_buf = nullptr;
+        std::vector<long long> tr(64 * 8); CK(hipMemcpy(tr.data(), dtr, 64 * 8 * 8, hipMemcpyDeviceToHost)); hipFree(dtr);
+        double acc[8] = {0}; int cnt = 0;
+        for (int s = 8; s < 56; ++s) {
+            if (!tr[(s + 1) * 8] || !tr[s * 8 + 7]) continue;
+            const long long t0 = tr[s * 8];
+            acc[0] += tr[s * 8 + 1] - t0; acc[1] += tr[s * 8 + 2] - t0; acc[2] += tr[(s + 1) * 8] - t0;            // consumer: MFMA phase end, before barrier, next tick start
+            acc[4] += tr[s * 8 + 5] - tr[s * 8 + 4]; acc[5] += tr[s * 8 + 6] - tr[s * 8 + 4]; acc[6] += tr[s * 8 + 7] - tr[s * 8 + 4];
+            acc[7] += tr[s * 8 + 4] - t0; ++cnt;
+        }
+        if (cnt) printf("trace kind=%d Ci=%d Co=%d (memtime ticks, 100 MHz?; mean over %d ticks): consumer MFMA-end %.0f, pre-barrier %.0f, tick %.0f | producer start-skew %.0f, stash-done %.0f, fetch-done %.0f, epilogue-done %.0f\n",
+                        kind, Ci, Co, cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[7] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt);
+    }
+#endif
     if (reps > 0) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 #if X3_ABLATION
