@@ -312,8 +312,8 @@ def bench_train_step(args, rank, world, dev):
                 "note": "4 fp32 atomics per (tap, channel quad): atomic-rate bound, not bandwidth bound"}
     result = {"metric": "training iterations/sec (DTU-shaped 4 views 512x640, D=48/32/8, rendering branch 1024 rays x 128 samples)",
               "value": round(world * args.steps / elapsed, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-              "data": "synthetic",
+              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "timed_region_s": round(elapsed, 4), "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: train_rcmvsnet.py iteration (2 x CascadeMVSNet.forward, "
                                      "Rendering_Consistency_Net.forward, UnsupLoss + AugLoss + render losses, backward, Adam), batch 1 per GPU",
                          "views": Vt, "height": H, "width": W, "ndepths": list(NDEPTHS), "rays": 1024, "samples": 128,
@@ -361,6 +361,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl")          # RCCL; used only for the barrier / max-time reduction
+        assert dist.get_world_size() == world
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with torch.distributed.run --nproc-per-node N"
 
     from rc_mvsnet_amd import _lib, ops, synthetic
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
@@ -403,6 +405,7 @@ def main():
         for i in range(args.steps):
             out = step(i)
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0                      # this rank's K steps (reported per rank; `value` uses the max after the barrier)
         barrier()
         elapsed = time.perf_counter() - t0
     events, ops.K1_EVENTS = ops.K1_EVENTS, None
@@ -416,7 +419,12 @@ def main():
             torch.cuda.synchronize()
             ops.CONV_EVENTS = None
 
+    rank_rates = None
     if world > 1:
+        mine = torch.tensor([own], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                        # every rank's own time: per-rank scenes/s (min / max) in the line
+        rank_rates = [args.steps / float(t.item()) for t in every]
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -435,13 +443,13 @@ def main():
     achieved = sum(bytes_stage) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     traffic = None                      # HBM bytes per scene from the committed PMC profile (FETCH_SIZE x2 + WRITE_SIZE)
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_k1_traffic.json")))["bytes_per_scene"]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_k1_traffic.json")))["bytes_per_scene"]
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": "rcmvs::warp_variance_tp_kernel (K1, 3 launches per scene)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_note": "bytes per scene (sum of the 3 launches), rocprofv3 PMC passes of profiles/r1_k1_traffic.json",
+                "traffic_note": "bytes per scene (sum of the 3 launches), rocprofv3 PMC passes of profiles/r3_k1_traffic.json (re-measured in round 3)",
                 "algorithmic_bytes_per_scene": sum(bytes_stage),
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)]}
@@ -456,6 +464,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "timed_region_s": round(elapsed, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -467,6 +476,8 @@ def main():
         "roofline": roofline,
         "roofline_conv": roofline_conv,
     }
+    if rank_rates:
+        result["per_rank_scenes_per_s"] = {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2), "ranks": world}
 
     # ---- CPU baseline (oracle, ATen op graph of the reference) + parity on the same inputs -----
     if world == 1 and not args.no_cpu_baseline:

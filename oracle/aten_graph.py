@@ -76,16 +76,23 @@ def plane_sweep_warp(src, src_proj, ref_proj, samples):
     hypothesis plane.  src (B,C,h,w), samples (B,D,h,w) -> (B,C,D,h,w).  Coordinates carry no gradient (:313)."""
     B, C, h, w = src.shape
     D = samples.shape[1]
+    grid = plane_sweep_grid(src_proj, ref_proj, samples, h, w)
+    out = F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    return out.reshape(B, C, D, h, w)
+
+
+def plane_sweep_grid(src_proj, ref_proj, samples, h, w):
+    """The normalised sampling grid of homo_warping (models/modules.py:313-331), (B, D*h, w, 2), in the dtype of its inputs."""
+    B, D = samples.shape[:2]
+    dt, dev = samples.dtype, samples.device
     with torch.no_grad():
         rel = src_proj @ torch.inverse(ref_proj)
-        ys, xs = torch.meshgrid(torch.arange(h, dtype=src.dtype, device=src.device), torch.arange(w, dtype=src.dtype, device=src.device), indexing="ij")
-        pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, dtype=src.dtype, device=src.device)))     # (3, hw)
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=dt, device=dev), torch.arange(w, dtype=dt, device=dev), indexing="ij")
+        pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, dtype=dt, device=dev)))                   # (3, hw)
         ray = rel[:, :3, :3] @ pix                                                                                    # (B,3,hw)
         pts = ray.unsqueeze(2) * samples.reshape(B, 1, D, h * w) + rel[:, :3, 3].reshape(B, 3, 1, 1)
         uv = pts[:, :2] / pts[:, 2:3]
-        grid = torch.stack((uv[:, 0] / ((w - 1) / 2) - 1, uv[:, 1] / ((h - 1) / 2) - 1), dim=-1).reshape(B, D * h, w, 2)
-    out = F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
-    return out.reshape(B, C, D, h, w)
+        return torch.stack((uv[:, 0] / ((w - 1) / 2) - 1, uv[:, 1] / ((h - 1) / 2) - 1), dim=-1).reshape(B, D * h, w, 2)
 
 
 def stage_samples(prev_depth, depth_values, ndepth, ratio, full_hw, stage_hw):

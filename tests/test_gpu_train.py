@@ -294,34 +294,38 @@ def test_renderer_train_native_vs_delegated():
 
 
 def test_hip_training_path_vs_reference_gradients():
-    """The HIP training path against gradients produced by the REFERENCE's own autograd (tests/golden/train_grads.npz,
-    make_golden.py --only-train-grads): K1 scatter, conv data / weight gradients, batch-statistics BatchNorm forward and
-    backward with running statistics, prob conv + softmax + soft-argmin backward.  FeatureNet gradients come through the
-    K1 backward, so they check it end to end.
+    """The HIP training path against gradients produced by the REFERENCE's own autograd on the well-conditioned fixture
+    (tests/golden/train_grads_cond.npz, make_golden.py --only-train-grads: prob.weight x1, 128x160, D = 16/16/8): K1 scatter, conv
+    data / weight gradients, batch-statistics BatchNorm forward and backward with running statistics, prob conv + softmax +
+    soft-argmin backward.  FeatureNet gradients come through the K1 backward, so they check it end to end.
 
-    Tolerances: the loss and the running statistics are tight.  The gradients of this seeded random network are
-    ill-conditioned -- adding 1e-6 relative noise to the input images changes the REFERENCE's own CPU gradients by up to
-    13 % (ReLU masks and batch statistics over the 6-voxel deepest level flip; tools/train_grad_diag.py) --
-    and the MIOpen FeatureNet forward differs from the CPU one at that level, so two GPU runs land on either side.  The
-    kernels themselves are held to 1e-6 against float64 autograd by the block tests above; here the bound is the
-    median and the worst per-tensor error."""
+    Bounds (round 3).  What the error of this comparison is made of was bisected (profiles/r3_grad_outlier_bisect.txt): against the
+    fp64 graph the HIP path is at 9e-6 at the gradient of the variance volume EXCEPT in one 3x3x3 neighbourhood -- ONE ReLU of
+    cost_regularization.0.conv0 (327,680 output voxels) whose pre-activation sits within a rounding error of zero takes the other
+    branch.  One element of N changes a gradient that sums N comparable terms by ~1 / sqrt(N) = 1.7e-3: measured 2.0e-3 at
+    conv0's own weight gradient, 6e-4 at the variance gradient, 1.3e-3 at the FeatureNet BatchNorm parameters (everything at or
+    upstream of that ReLU); the reference's fp32 graph on the CPU has its own such element in FeatureNet (9e-4 at
+    feature.conv2.2.bn.bias against fp64).  So: every tensor DOWNSTREAM of conv0's ReLU (the rest of the 3-D U-Net, the prob conv)
+    within 1e-4; the tensors at or upstream of it within 3e-3 (two single-element events), median over all 5e-4.  The older,
+    ill-conditioned fixture (train_grads.npz: 64x96, D = 8, prob.weight x2, 6 voxels per channel at the deepest level) stays as the
+    CPU pin of the restated graph only."""
     from conftest import load_golden
     from rc_mvsnet_amd import _lib, synthetic
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet
     _lib.load()
     warnings.simplefilter("ignore")
     dev = DEV
-    g = load_golden("train_grads")
-    m = CascadeMVSNet(ndepths=[8, 8, 8], depth_interals_ratio=[4, 2, 1])
-    m.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=2.0), strict=True)
+    g = load_golden("train_grads_cond")
+    m = CascadeMVSNet(ndepths=[16, 16, 8], depth_interals_ratio=[4, 2, 1])
+    m.load_state_dict(synthetic.cascade_state_dict(0, prob_gain=1.0), strict=True)
     m = m.to(dev).train()
-    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 64, 96, 0)
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 128, 160, 0)
     outputs, noref = m(imgs.to(dev), {k: v.to(dev) for k, v in pm.items()}, dv.to(dev))
     loss = ((outputs["stage1"]["depth"] - 600.0) ** 2).mean() / 1e4 + 1e-2 * (noref ** 2).mean()
     loss.backward()
     print(f"loss {float(loss):.6f} vs reference {float(g['loss']):.6f}")
-    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
-    assert float((outputs["stage1"]["depth"].cpu() - g["depth1"]).abs().max()) < 2e-2
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert float((outputs["stage1"]["depth"].cpu() - g["depth1"]).abs().max()) < 1e-2
     params = dict(m.named_parameters())
     errs = {}
     for k in g.keys():
@@ -330,8 +334,11 @@ def test_hip_training_path_vs_reference_gradients():
     vals = sorted(errs.values())
     worst = max(errs, key=errs.get)
     print(f"gradient mismatch vs reference autograd: median {vals[len(vals) // 2]:.2e}, worst {errs[worst]:.2e} at {worst}")
-    assert vals[len(vals) // 2] < 5e-2 and errs[worst] < 2e-1
-    assert errs["cost_regularization.0.prob.weight"] < 1e-3                                  # downstream of every unstable mask
+    print("   " + ", ".join(f"{k.replace('cost_regularization.0.', 'cr0.')} {v:.1e}" for k, v in errs.items()))
+    assert vals[len(vals) // 2] < 5e-4 and errs[worst] < 3e-3, errs
+    for k, v in errs.items():                                                                # downstream of conv0's ReLU
+        if k.startswith("cost_regularization.0.") and not k.startswith("cost_regularization.0.conv0."):
+            assert v < 1e-4, (k, v)
     bufs = dict(m.named_buffers())
     assert float((bufs["cost_regularization.0.conv0.bn.running_mean"].cpu() - torch.as_tensor(g["running_mean_conv0"])).abs().max()) < 1e-5
     assert _rel(bufs["cost_regularization.0.conv0.bn.running_var"].cpu(), torch.as_tensor(g["running_var_conv0"])) < 1e-4
@@ -570,5 +577,7 @@ def test_cascade_train_gradients_conditioned_network(grad_method):
     ev, sv = sorted(errs.values()), sorted(sens.values())
     print(f"conditioned network ({grad_method}): loss {l1:.6f} vs fp64 {l64:.6f}; gradient error vs fp64 (Frobenius) median {ev[len(ev) // 2]:.2e}, "
           f"worst {errs[worst]:.2e} at {worst}; fp64 gradient change under 1e-6 input perturbations (max of 3 draws): median {sv[len(sv) // 2]:.2e}, worst {sv[-1]:.2e}")
-    assert errs[worst] <= 2.0 * sv[-1], (worst, errs[worst], sv[-1])
-    assert ev[len(ev) // 2] <= max(1e-4, sv[len(sv) // 2]), (ev[len(ev) // 2], sv[len(sv) // 2])
+    # absolute bounds (round 3; the sensitivities above are printed for the record): what the worst case consists of is known --
+    # single ReLU pre-activations within one rounding error of zero, profiles/r3_grad_outlier_bisect.txt
+    assert errs[worst] <= 2e-3, (worst, errs[worst], sv[-1])
+    assert ev[len(ev) // 2] <= (1e-4 if grad_method == "detach" else 1e-3), (ev[len(ev) // 2], sv[len(sv) // 2])
