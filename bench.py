@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--steps", type=int, default=600, help="timed steps (default: ~1 s of cascade forwards)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the short config-3 training-iteration timing appended to the default line")
     ap.add_argument("--cpu-scenes", type=int, default=5, help="scenes timed on the CPU baseline after 2 warm-ups (bounded sample, BASELINE.md section 3)")
     args = ap.parse_args()
 
@@ -524,6 +525,28 @@ def main():
         d1 = (hip1["depth"].cpu() - ref1["depth"]).abs()
         result["parity"]["smooth_head"] = {"depth_l1_over_range": float(d1.mean()) / rng, "depth_max_abs_mm": float(d1.max()),
                                            "frac_pixels_over_0.1mm": float((d1 > 0.1).float().mean())}
+    # ---- BASELINE configs[2] next to the headline: a short timing of the training iteration (full size), so that the driver's
+    # default run carries a number for it too (`--workload train_step` is the full line with its own roofline / CPU baseline)
+    if world == 1 and not args.no_train_step:
+        try:
+            from rc_mvsnet_amd import train_step as ts
+            del model, scenes
+            torch.cuda.empty_cache()
+            tm, tn, topt = ts.build(dev, seed=0)
+            ti, tp, td, tb = ts.synthetic_sample(dev, H=H, W=W, V=4, seed=0)
+            for _ in range(2):
+                ts.train_step(tm, tn, topt, ti, tp, td, tb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                last = ts.train_step(tm, tn, topt, ti, tp, td, tb)
+            torch.cuda.synchronize()
+            t_it = (time.perf_counter() - t0) / 5
+            result["train_step"] = {"ms_per_iteration": round(t_it * 1e3, 2), "iterations": 5, "warmup": 2, "loss": round(last["loss"], 5),
+                                    "config": "BASELINE configs[2]: train_rcmvsnet.py iteration, 4 views 512x640, D=48/32/8, rendering branch "
+                                              "1024 rays x 128 samples, reference losses, backward, Adam; batch 1, fp32, synthetic"}
+        except Exception as e:                               # the headline number must not depend on this appendix
+            result["train_step"] = {"error": repr(e)[:200]}
     print(json.dumps(result))
 
 

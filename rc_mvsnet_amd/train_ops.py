@@ -346,7 +346,11 @@ class NerfMlpFn(torch.autograd.Function):
         N, S = ctx.dims
         M = N * S
         graw = graw.contiguous().float()
-        gws = torch.empty((lib.rcmvs_nerf_bwd_workspace_floats(M),), device=raw.device, dtype=torch.float32)
+        key = (M, raw.device)              # backward scratch (415 MB at 1024 x 128 points): one buffer per (size, device), reused every step
+        gws = _NERF_BWD_SCRATCH.get(key)
+        if gws is None:
+            _NERF_BWD_SCRATCH.clear()
+            gws = _NERF_BWD_SCRATCH[key] = torch.empty((lib.rcmvs_nerf_bwd_workspace_floats(M),), device=raw.device, dtype=torch.float32)
         dfeat = torch.empty_like(feat)
         grads = [torch.empty_like(p) for p in ps]
         warr = (ctypes.c_void_p * 22)(*[_chk(t, "nerf weight").value for t in ps])
@@ -354,6 +358,9 @@ class NerfMlpFn(torch.autograd.Function):
         _lib.check(lib.rcmvs_nerf_mlp_bwd(warr, _chk(feat, "feat"), feat.shape[1], _chk(tws, "workspace"), _chk(raw, "raw"), _chk(graw, "grad_raw"),
                                           _chk(gws, "scratch"), _chk(dfeat, "grad_feat"), garr, N, S, _stream()), "nerf_mlp_bwd")
         return (None, dfeat, None, None, *grads)
+
+
+_NERF_BWD_SCRATCH = {}
 
 
 def nerf_mlp_train(net, ndc, feat, dirs, w2c_ref):

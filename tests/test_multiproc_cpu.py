@@ -164,8 +164,20 @@ def _syncbn_worker(rank, world, port, q):
     x = x_all[rank:rank + 1].clone().requires_grad_(True)
     z = train_ops.conv_bn_train(blk.conv, blk.bn, x, relu=True)
     (z * G_all[rank:rank + 1]).sum().backward()
-    q.put((rank, z.detach().numpy(), x.grad.numpy(), blk.conv.weight.grad.numpy(), blk.bn.weight.grad.numpy(),
-           blk.bn.running_mean.numpy().copy(), blk.bn.running_var.numpy().copy()))
+    local = (blk.conv.weight.grad.numpy().copy(), blk.bn.weight.grad.numpy().copy())
+    # ... and one data-parallel optimizer step on top (config 4: SyncBatchNorm + GradSync + Adam): the gradients of the two ranks are
+    # averaged through the flat buffer (copied in: they were produced before the buffer existed), every rank takes the same step
+    from rc_mvsnet_amd.parallel import GradSync
+    grads = [p.grad.clone() for p in blk.parameters()]
+    sync = GradSync([blk])
+    for p, gcopy in zip(blk.parameters(), grads):
+        p.grad.copy_(gcopy)
+    opt = torch.optim.Adam(blk.parameters(), lr=1e-3)
+    sync.sync()
+    opt.step()
+    q.put((rank, z.detach().numpy(), x.grad.numpy(), local[0], local[1],
+           blk.bn.running_mean.numpy().copy(), blk.bn.running_var.numpy().copy(),
+           blk.conv.weight.detach().numpy().copy(), blk.bn.weight.detach().numpy().copy(), blk.bn.bias.detach().numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -196,9 +208,22 @@ def test_sync_batchnorm_statistics_world2():
     z = torch.relu(blk.bn(blk.conv(x)))
     (z * G_all.double().permute(0, 4, 1, 2, 3)).sum().backward()
     rel = lambda a, b: float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
-    for rank, zr, gx, gw, gg, rm, rv in res:
+    for rank, zr, gx, gw, gg, rm, rv, *_ in res:
         assert rel(zr[0], z[rank].detach().permute(1, 2, 3, 0).numpy()) < 1e-5
         assert rel(gx[0], x.grad[rank].permute(1, 2, 3, 0).numpy()) < 1e-4
         assert rel(rm, blk.bn.running_mean.numpy()) < 1e-5 and rel(rv, blk.bn.running_var.numpy()) < 1e-4
     assert rel(res[0][3] + res[1][3], blk.conv.weight.grad.numpy()) < 1e-4
     assert rel(res[0][4] + res[1][4], blk.bn.weight.grad.numpy()) < 1e-4
+    # the data-parallel step: both ranks hold the same updated weights, equal to ONE single-process Adam step on the two-sample
+    # batch with the averaged gradient (what DistributedDataParallel + SyncBatchNorm compute in train_rcmvsnet.py:524-525,565-578)
+    w0 = {n: p.detach().clone() for n, p in blk.named_parameters()}
+    for p in blk.parameters():
+        p.grad = p.grad / 2                                  # mean over the two ranks of the per-rank (per-sample) losses
+    torch.optim.Adam(blk.parameters(), lr=1e-3).step()
+    for a, b in zip(res[0][7:], res[1][7:]):
+        assert np.array_equal(a, b)                           # identical replicas after the step
+    got = dict(zip(("conv.weight", "bn.weight", "bn.bias"), res[0][7:]))
+    for n, p in blk.named_parameters():
+        step_ref = (p.detach() - w0[n]).numpy()
+        step_got = got[n] - w0[n].numpy()
+        assert np.abs(step_got - step_ref).max() <= 3e-7, (n, np.abs(step_got - step_ref).max())      # fp32 weights of magnitude ~1 vs the fp64 step
