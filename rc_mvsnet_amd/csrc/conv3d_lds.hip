@@ -147,20 +147,23 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
 // out[z - 1] -- into three rolling accumulators, and out[z - 1] is complete when plane z is done.  Planes are double buffered in
 // LDS (next plane prefetched into registers during the FMAs): one barrier per plane.  Weights are wave-uniform scalar loads;
 // channel pairs go through v_pk_fma_f32 as in the tile kernel.
-constexpr int PM_TH = 8, PM_TW = 32, PM_HH = PM_TH + 2, PM_HW = PM_TW + 2, PM_STRIDE = 12, PM_ZC = 8;
+constexpr int PM_TH = 8, PM_TW = 32, PM_HH = PM_TH + 2, PM_HW = PM_TW + 2, PM_STRIDE = 12;
 constexpr int PM_PLANE = PM_HH * PM_HW * PM_STRIDE;          // floats per staged plane (16,320 B)
 constexpr int PM_NLD = (PM_HH * PM_HW * 2 + 255) / 256;      // float4 per thread per plane
 
-__global__ __launch_bounds__(256) void prob_conv_march_kernel(
+// Occupancy: 32.6 KB of LDS per block = five blocks per CU, and the register budget is held to five waves per SIMD to match
+// (round 3: at 107 VGPRs four blocks were resident, and the 1280 blocks of the two large stages ran as 1024 + 256 -- two rounds
+// for 1.25 rounds of work).  The z chunk is chosen per launch (prob_zchunk below) so that the grid fills those 1280 slots once.
+__global__ __launch_bounds__(256, 5) void prob_conv_march_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ res, float* __restrict__ y, int D, int H, int W, int tiles_w, int tiles_h, int relu) {
+    const float* __restrict__ res, float* __restrict__ y, int D, int H, int W, int tiles_w, int tiles_h, int relu, int zchunk) {
     typedef float f2v __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) float plane[2][PM_PLANE];
     const int b = blockIdx.z, zc = blockIdx.y;
     const unsigned t2 = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = t2 % tiles_w, th = t2 / tiles_w;
-    const int h0 = th * PM_TH, w0 = tw * PM_TW, z0 = zc * PM_ZC;
-    const int z1 = min(D, z0 + PM_ZC);                          // outputs z0 .. z1-1, input planes z0-1 .. z1
+    const int h0 = th * PM_TH, w0 = tw * PM_TW, z0 = zc * zchunk;
+    const int z1 = min(D, z0 + zchunk);                          // outputs z0 .. z1-1, input planes z0-1 .. z1
     const int lw = threadIdx.x % PM_TW, lh = threadIdx.x / PM_TW;
     const float* xb = x + (long long)b * D * H * W * 8;
     // this thread's share of a plane's halo: element e = (halo voxel, float4 half)
@@ -199,24 +202,63 @@ __global__ __launch_bounds__(256) void prob_conv_march_kernel(
     for (int z = z0 - 1; z <= z1; ++z) {
         f2v acc_next = (f2v){0.f, 0.f};                             // out[z+1]
         const float* tp0 = &plane[buf][(lh * PM_HW + lw) * PM_STRIDE];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        // One halo row at a time, as ONE block of hand-placed instructions: the row's 72 weights -- taps (kd, kh, 0..2) x 8
+        // channels, 24 consecutive floats per kd -- are fetched with six scalar loads into s[16:87] (scalar cache), then the
+        // 36 v_pk_fma_f32 of the row take them as their scalar operand.  Left to the optimiser (plain wp[...] indexing, rounds
+        // 1-2) all 216 loop-invariant weights are hoisted out of the plane loop, the SGPR file overflows, 164 of them are parked
+        // in VGPR lanes and every plane pays ~160 v_readlane_b32 next to its 108 v_pk_fma_f32: the kernel ran at 41 % of its
+        // VALU floor (profiles/r3_prob_conv.txt); fencing the loads (asm loads, sched_barrier) only moved the spills.
+        // Scalar loads return out of order: one s_waitcnt lgkmcnt(0) per row -- the fragment reads of the NEXT row are issued in
+        // front of it, so LDS and scalar-cache latency overlap -- and five waves per SIMD cover the rest.
+        f2v xr[2][3][4];
+        auto read_row = [&](int kh, f2v (&q)[3][4]) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const float* tp = tp0 + (kh * PM_HW + kw) * PM_STRIDE;
                 const float4 xa = *reinterpret_cast<const float4*>(tp), xc = *reinterpret_cast<const float4*>(tp + 4);
-                const f2v x01 = (f2v){xa.x, xa.y}, x23 = (f2v){xa.z, xa.w}, x45 = (f2v){xc.x, xc.y}, x67 = (f2v){xc.z, xc.w};
-#pragma unroll
-                for (int kd = 0; kd < 3; ++kd) {
-                    const float* wt = wp + ((kd * 3 + kh) * 3 + kw) * 8;
-                    f2v a = (kd == 0) ? acc_next : (kd == 1 ? acc_cur : acc_prev);
-                    a = __builtin_elementwise_fma(x01, (f2v){wt[0], wt[1]}, a);
-                    a = __builtin_elementwise_fma(x23, (f2v){wt[2], wt[3]}, a);
-                    a = __builtin_elementwise_fma(x45, (f2v){wt[4], wt[5]}, a);
-                    a = __builtin_elementwise_fma(x67, (f2v){wt[6], wt[7]}, a);
-                    if (kd == 0) acc_next = a; else if (kd == 1) acc_cur = a; else acc_prev = a;
-                }
+                q[kw][0] = (f2v){xa.x, xa.y}; q[kw][1] = (f2v){xa.z, xa.w}; q[kw][2] = (f2v){xc.x, xc.y}; q[kw][3] = (f2v){xc.z, xc.w};
             }
+        };
+        read_row(0, xr[0]);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            if (kh < 2) read_row(kh + 1, xr[(kh + 1) & 1]);
+            f2v (&xq)[3][4] = xr[kh & 1];
+#if defined(__AMDGCN__)
+            asm volatile("s_load_dwordx16 s[16:31], %[wp], 0x0\n\ts_load_dwordx8 s[32:39], %[wp], 0x40\n\t"
+                         "s_load_dwordx16 s[40:55], %[wp], 0x120\n\ts_load_dwordx8 s[56:63], %[wp], 0x160\n\t"
+                         "s_load_dwordx16 s[64:79], %[wp], 0x240\n\ts_load_dwordx8 s[80:87], %[wp], 0x280\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_pk_fma_f32 %[a0], %[x00], s[16:17], %[a0]\n\tv_pk_fma_f32 %[a1], %[x00], s[40:41], %[a1]\n\tv_pk_fma_f32 %[a2], %[x00], s[64:65], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x01], s[18:19], %[a0]\n\tv_pk_fma_f32 %[a1], %[x01], s[42:43], %[a1]\n\tv_pk_fma_f32 %[a2], %[x01], s[66:67], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x02], s[20:21], %[a0]\n\tv_pk_fma_f32 %[a1], %[x02], s[44:45], %[a1]\n\tv_pk_fma_f32 %[a2], %[x02], s[68:69], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x03], s[22:23], %[a0]\n\tv_pk_fma_f32 %[a1], %[x03], s[46:47], %[a1]\n\tv_pk_fma_f32 %[a2], %[x03], s[70:71], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x10], s[24:25], %[a0]\n\tv_pk_fma_f32 %[a1], %[x10], s[48:49], %[a1]\n\tv_pk_fma_f32 %[a2], %[x10], s[72:73], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x11], s[26:27], %[a0]\n\tv_pk_fma_f32 %[a1], %[x11], s[50:51], %[a1]\n\tv_pk_fma_f32 %[a2], %[x11], s[74:75], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x12], s[28:29], %[a0]\n\tv_pk_fma_f32 %[a1], %[x12], s[52:53], %[a1]\n\tv_pk_fma_f32 %[a2], %[x12], s[76:77], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x13], s[30:31], %[a0]\n\tv_pk_fma_f32 %[a1], %[x13], s[54:55], %[a1]\n\tv_pk_fma_f32 %[a2], %[x13], s[78:79], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x20], s[32:33], %[a0]\n\tv_pk_fma_f32 %[a1], %[x20], s[56:57], %[a1]\n\tv_pk_fma_f32 %[a2], %[x20], s[80:81], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x21], s[34:35], %[a0]\n\tv_pk_fma_f32 %[a1], %[x21], s[58:59], %[a1]\n\tv_pk_fma_f32 %[a2], %[x21], s[82:83], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x22], s[36:37], %[a0]\n\tv_pk_fma_f32 %[a1], %[x22], s[60:61], %[a1]\n\tv_pk_fma_f32 %[a2], %[x22], s[84:85], %[a2]\n\t"
+                         "v_pk_fma_f32 %[a0], %[x23], s[38:39], %[a0]\n\tv_pk_fma_f32 %[a1], %[x23], s[62:63], %[a1]\n\tv_pk_fma_f32 %[a2], %[x23], s[86:87], %[a2]\n\t"
+                         : [a0] "+v"(acc_next), [a1] "+v"(acc_cur), [a2] "+v"(acc_prev)
+                         : [wp] "s"(wp + kh * 24),
+                           [x00] "v"(xq[0][0]), [x01] "v"(xq[0][1]), [x02] "v"(xq[0][2]), [x03] "v"(xq[0][3]),
+                           [x10] "v"(xq[1][0]), [x11] "v"(xq[1][1]), [x12] "v"(xq[1][2]), [x13] "v"(xq[1][3]),
+                           [x20] "v"(xq[2][0]), [x21] "v"(xq[2][1]), [x22] "v"(xq[2][2]), [x23] "v"(xq[2][3])
+                         : "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
+#else       // host pass of hipcc / the CPU emulation of the tests (tests/emu): the same 36 fused multiply-adds in the same order
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const float* wt = wp + kh * 24 + kw * 8 + 2 * pr;
+                    acc_next = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[0], wt[1]}, acc_next);
+                    acc_cur = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[72], wt[73]}, acc_cur);
+                    acc_prev = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[144], wt[145]}, acc_prev);
+                }
+#endif
+        }
         const int zo = z - 1;                                       // complete now
         if (live && zo >= z0 && zo < z1) {
             float v = acc_prev.x + acc_prev.y;
@@ -234,6 +276,24 @@ __global__ __launch_bounds__(256) void prob_conv_march_kernel(
         __syncthreads();
         buf ^= 1;
     }
+}
+
+// z chunk of the marching prob conv: a block of chunk length c stages c + 2 planes for c output planes; the grid runs in
+// ceil(blocks / slots) rounds (slots = CUs x 5 resident blocks).  Minimise rounds x (c + 2), ties to the longer chunk.
+static int prob_zchunk(int tiles, int D) {
+    static int slots = 0;
+    if (!slots) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * 5;
+    }
+    long long best = -1; int zc = D < 8 ? D : 8;
+    for (int c = D < 16 ? D : 16; c >= 2; --c) {
+        const long long blocks = (long long)tiles * ((D + c - 1) / c);
+        const long long cost = ((blocks + slots - 1) / slots) * (c + 2);
+        if (best < 0 || cost < best) { best = cost; zc = c; }
+    }
+    return zc;
 }
 
 bool conv3d_lds_supported(int Ci, int Co, int stride) {
@@ -278,8 +338,10 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
     }
     if (Co == 1 && Ci == 8 && !(g_lds_cfg & 1)) {               // prob conv 8 -> 1 (logits, (B,D,H,W) since Co = 1): plane-marching kernel
         const int tw_ = (W + PM_TW - 1) / PM_TW, th_ = (H + PM_TH - 1) / PM_TH;
-        hipLaunchKernelGGL(prob_conv_march_kernel, dim3(tw_ * th_, (D + PM_ZC - 1) / PM_ZC, B), dim3(256), 0, st, x, wp, scale, shift, res, y,
-                           D, H, W, tw_, th_, relu);
+        const int zc_force = (g_lds_cfg >> 8) & 0xff;           // test / tuning override of the z chunk
+        const int zc = zc_force ? (zc_force < D ? zc_force : D) : prob_zchunk(B * tw_ * th_, D);
+        hipLaunchKernelGGL(prob_conv_march_kernel, dim3(tw_ * th_, (D + zc - 1) / zc, B), dim3(256), 0, st, x, wp, scale, shift, res, y,
+                           D, H, W, tw_, th_, relu, zc);
         return launch_status("conv3d_lds(prob, marching)");
     }
     if (Co == 1 && Ci == 8) {                                   // the tile kernel form (bit 0 of lds_cfg: A/B and cross-check)

@@ -254,6 +254,10 @@ __global__ void x3_wscale_kernel(const float* __restrict__ w, int n, float* __re
 typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x3_split4(x3_f32x4 v, x3_u32x2& h, x3_u32x2& m, x3_u32x2& l) {
     const x3_u32x4 vb = __builtin_bit_cast(x3_u32x4, v);
+#ifdef X3_FAKE_SPLIT       // timing experiment only (tools/dev): no split arithmetic, WRONG results -- the ceiling of a pre-split activation format
+    h.x = vb[0]; h.y = vb[1]; m.x = vb[2]; m.y = vb[3]; l.x = vb[0]; l.y = vb[2];
+    return;
+#endif
     const x3_u32x4 hb = vb & 0xffff0000u;
     const x3_f32x4 r1 = v - __builtin_bit_cast(x3_f32x4, hb);                       // exact
     const x3_u32x4 r1b = __builtin_bit_cast(x3_u32x4, r1);

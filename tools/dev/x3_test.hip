@@ -100,7 +100,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
             acc[4] += tr[s * 8 + 5] - tr[s * 8 + 4]; acc[5] += tr[s * 8 + 6] - tr[s * 8 + 4]; acc[6] += tr[s * 8 + 7] - tr[s * 8 + 4];
             acc[7] += tr[s * 8 + 4] - t0; ++cnt;
         }
-        if (cnt) printf("trace kind=%d Ci=%d Co=%d (memtime ticks, 100 MHz?; mean over %d ticks): consumer MFMA-end %.0f, pre-barrier %.0f, tick %.0f | producer start-skew %.0f, stash-done %.0f, fetch-done %.0f, epilogue-done %.0f\n",
+        if (cnt) printf("trace kind=%d Ci=%d Co=%d (s_memtime units; mean over %d ticks): consumer MFMA-end %.0f, pre-barrier %.0f, tick %.0f | producer start-skew %.0f, stash-done %.0f, fetch-done %.0f, epilogue-done %.0f\n",
                         kind, Ci, Co, cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[7] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt);
     }
 #endif
