@@ -95,12 +95,42 @@ struct X3 {
     static constexpr int SPK = ((PPKD + PPS - 1) / PPS) * HALVES;       // K steps per plane (a step never straddles planes)
     static constexpr int KSTEPS = NKD * SPK;
     static constexpr int WREG = KSTEPS * MT_ALL * 4 * NP;                // registers the whole weight image would take
+    // Transposed kind: output parity class (pd, ph, pw) only reaches the input cells nb <= p per axis (tap p - 2 nb + 1 must be 0..2), so
+    // whole 16 x 32 weight fragments are zero: bit (j * MT_ALL + mt) of LIVEMASK = fragment (K step j, m-tile mt) holds a tap.
+    // Computed with the pack kernel's own index arithmetic.
+    static constexpr bool frag_live(int j, int mt) {
+        if (KIND != X3_T2) return true;
+        const int kd = j / SPK, js = j % SPK;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = mt * 16 + (lane & 15), kk = lane >> 4;
+            const int q = (HALVES == 1) ? js * PPS + kk / (4 / PPS) : js / HALVES;
+            if (q >= PPKD) continue;
+            const int r = q / QC, c = q % QC, p = m / COUT;
+            const int td = ((p >> 2) & 1) - 2 * kd + 1, th = ((p >> 1) & 1) - 2 * r + 1, tw = (p & 1) - 2 * c + 1;
+            if (td >= 0 && td < 3 && th >= 0 && th < 3 && tw >= 0 && tw < 3) return true;
+        }
+        return false;
+    }
+    static constexpr unsigned long long live_mask() {
+        unsigned long long m = 0;
+        for (int j = 0; j < KSTEPS; ++j)
+            for (int mt = 0; mt < MT_ALL; ++mt)
+                if (KSTEPS * MT_ALL > 64 || frag_live(j, mt)) m |= 1ULL << ((j * MT_ALL + mt) & 63);
+        return m;
+    }
+    static constexpr int popcount64(unsigned long long v) { int n = 0; for (; v; v &= v - 1) ++n; return n; }
+    static constexpr unsigned long long LIVEMASK = live_mask();
+    static constexpr int NLIVE = (KSTEPS * MT_ALL > 64) ? KSTEPS * MT_ALL : popcount64(LIVEMASK);
+    // the zero fragments are skipped (no registers, no MFMAs) where the live ones fit ONE wave's budget: every consumer wave then
+    // holds the same compile-time pattern (a K / M cut would make the pattern depend on the wave: branches around the MFMAs)
+    static constexpr bool SKIP = (KIND == X3_T2) && NLIVE < KSTEPS * MT_ALL && NLIVE * 4 * NP <= 128;
+    static constexpr bool live(int j, int mt) { return !SKIP || ((LIVEMASK >> (j * MT_ALL + mt)) & 1ULL); }
     // wave roles: 4 consumer + 4 producer waves; layers whose weight image exceeds 4 x 128 registers take 6 consumer waves (K cut
     // three ways, M two ways) and 2 producer waves -- their volumes are small and the producers have little to do
     static constexpr int NCW = (KSTEPS * MT_ALL * 12 > 512) ? 6 : 4;     // (decided on the three-piece image: both forms share the tile geometry)
     static constexpr int NPW = 8 - NCW;
-    static constexpr int MSPLIT = (MT_ALL >= 2 && WREG > 128) ? 2 : 1;
-    static constexpr int KSPLIT = (NCW == 6) ? 3 : ((WREG / MSPLIT > 256) ? 4 / MSPLIT : ((WREG / MSPLIT > 128) ? 2 : 1));
+    static constexpr int MSPLIT = (MT_ALL >= 2 && WREG > 128 && !SKIP) ? 2 : 1;
+    static constexpr int KSPLIT = SKIP ? 1 : ((NCW == 6) ? 3 : ((WREG / MSPLIT > 256) ? 4 / MSPLIT : ((WREG / MSPLIT > 128) ? 2 : 1)));
     static constexpr int MT = MT_ALL / MSPLIT;                           // m-tiles per consumer wave
     static constexpr int KSW = (KSTEPS + KSPLIT - 1) / KSPLIT;          // K steps per consumer wave
     static constexpr int TX = ((x3_unit(KIND) && CIN >= 32) || (KIND == X3_S2 && CIN >= 16) || NCW == 6) ? 16 : 32;
@@ -128,9 +158,9 @@ struct X3 {
     // (profiles/r3_x3_tick_trace.txt)
     static constexpr bool EPI_CONSUMER = (NP == 2);
     static constexpr int NEW = EPI_CONSUMER ? NCW : NPW;                 // waves the (tile, m-tile) units are dealt to
-    static constexpr int MFMA_PER_KSTEP = TP * MT * (NP == 3 ? 6 : 3);
+    static constexpr int MFMA_PER_KSTEP = (SKIP ? (TP * NLIVE + KSTEPS - 1) / KSTEPS : TP * MT) * (NP == 3 ? 6 : 3);      // (average over the K steps when fragments are skipped)
     static constexpr int PD_WANT = (MFMA_PER_KSTEP >= 20) ? 1 : ((MFMA_PER_KSTEP >= 10) ? 2 : ((MFMA_PER_KSTEP >= 6) ? 3 : 4));
-    static constexpr int REG_FIXED = ((KSTEPS + KSPLIT - 1) / KSPLIT) * NP * MT * 4 + TP * MT * NP * 4 + 28;      // weights + accumulators + the rest
+    static constexpr int REG_FIXED = (SKIP ? NLIVE * NP * 4 : ((KSTEPS + KSPLIT - 1) / KSPLIT) * NP * MT * 4) + TP * MT * NP * 4 + 28;      // weights + accumulators + the rest
     static constexpr int PD_FIT = (244 - REG_FIXED) / (TP * NP * 4) - 1;
     static constexpr int PD_CAP = PD_WANT < PD_FIT ? PD_WANT : PD_FIT;
     static constexpr int PD = PD_CAP < 1 ? 1 : (PD_CAP > (KSTEPS + KSPLIT - 1) / KSPLIT - 1 && (KSTEPS + KSPLIT - 1) / KSPLIT > 1 ? (KSTEPS + KSPLIT - 1) / KSPLIT - 1 : PD_CAP);
@@ -139,7 +169,7 @@ struct X3 {
     static constexpr int NPF = (NLOAD + NPW * 64 - 1) / (NPW * 64);                      // float4 per producer thread per z-slice
     static constexpr int PARTB = (KSPLIT > 1) ? NTILE * MT_ALL * KSPLIT * 1024 : 0;   // one buffer of partial output tiles
     static constexpr int LDSB = NSLOT * SLB + 2 * PARTB;
-    static_assert(NCW % (KSPLIT * MSPLIT) == 0 && WREG / (KSPLIT * MSPLIT) <= 128, "weight slice per wave");
+    static_assert(NCW % (KSPLIT * MSPLIT) == 0 && (SKIP ? NLIVE * 4 * NP : WREG / (KSPLIT * MSPLIT)) <= 128, "weight slice per wave");
     static_assert(NTILE % NG == 0 && NTW % TP == 0, "tiles per wave");
     static_assert(MAP != X3_XT || PPS == 4, "XT packs the four kw' positions of 8 channels into one K step");
     static_assert(LDSB <= 160 * 1024, "LDS budget");
@@ -491,7 +521,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                 if (relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
                 v += erv[i];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(x3_u32x4, v), yrs, X3_DBG(3) ? OOB : eob[i], 0, 0);
-                if (eob[i] != OOB) vmax = x3_absmax4(vmax, v);
+                if (ymax && eob[i] != OOB) vmax = x3_absmax4(vmax, v);
             }
         }
     };
@@ -510,7 +540,8 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    x3_u32x4 v = wimg[((jc * NP + p) * C::MT_ALL + ms * MT + mt) * 64 + lane];
+                    x3_u32x4 v = (x3_u32x4){0u, 0u, 0u, 0u};
+                    if (C::live(C::SKIP ? j : 0, C::SKIP ? mt : 0)) v = wimg[((jc * NP + p) * C::MT_ALL + ms * MT + mt) * 64 + lane];      // (SKIP: one K / M slice, j and mt are the global indices)
                     if (!live) v = (x3_u32x4){0u, 0u, 0u, 0u};
                     wr[j][p][mt] = v;
                 }
@@ -521,10 +552,13 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             const int hc = q % C::QC + n * C::CS;      // halo column of this lane's voxel (tile column offsets are multiples of 16: same swizzle)
             boff[j] = (q / C::QC) * C::ROWB + hc * C::VB + ((ci0 * 2) ^ x3_swz<C, CIN, KIND>(hc));
         }
-        x3_f32x4 sc[MT], sh[MT];      // epilogue constants (used when this wave finishes its own tiles: KSPLIT == 1)
+        // epilogue constants (used when this wave finishes its own tiles: KSPLIT == 1).  Transposed kind: an m-tile is 16 / COUT parity
+        // classes, every tile sees the same channels
+        constexpr int SCN = (KIND == X3_T2 && 16 % COUT == 0) ? 1 : MT;
+        x3_f32x4 sc[SCN], sh[SCN];
         if constexpr (KSPLIT == 1) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < SCN; ++mt) {
                 long long ov; int co0;
                 x3_out_coord<C, COUT, KIND>(dm, 0, 0, 0, 0, 0, ms * MT + mt, n, kk, ov, co0);
                 sc[mt] = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
@@ -538,6 +572,11 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             tlv[i] = grp + C::NG * i;
             toffv[i] = (tlv[i] / C::NTX) * C::RS * C::ROWB + (tlv[i] % C::NTX) * 16 * C::CS * C::VB;
         }
+        // KSPLIT == 1: this wave stores its own tiles.  Byte offset of the lane's float4 per (n-tile, m-tile) in y / the skip tensor
+        // (OOB outside the volume): worked out on the first step of an item, advanced by one z step of the tile grid afterwards
+        // (round 2 recomputed the 64-bit voxel index for every tile of every step: ~50 VALU per float4 -- on the transposed layer, 8 float4
+        // per lane and step, the epilogue was a quarter of the tick: profiles/r3_x3_tick_trace.txt)
+        int cob[KSPLIT == 1 ? C::NTW : 1][MT];
         __syncthreads();          // the planes of the first step are in the ring
         int s0 = 0;               // ring slot of the first input plane of the current step
 #pragma unroll 1
@@ -550,6 +589,23 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             int slotoff[NKD];
 #pragma unroll
             for (int k = 0; k < NKD; ++k) slotoff[k] = ((s0 + k) % NSLOT) * C::SLB;
+            if constexpr (KSPLIT == 1) {
+                if (x3_desc_first(d)) {
+#pragma unroll
+                    for (int i = 0; i < C::NTW; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            long long ov; int co0;
+                            const bool ok = x3_out_coord<C, COUT, KIND>(dm, b, x0, y0, z, tlv[i], ms * MT + mt, n, kk, ov, co0);
+                            cob[i][mt] = ok ? (int)((ov * COUT + co0) * 4) : OOB;
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < C::NTW; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) if (cob[i][mt] != OOB) cob[i][mt] += ostep;
+                }
+            }
 #pragma unroll
             for (int tp = 0; tp < C::NTW / TP; ++tp) {
                 int toff[TP], tl[TP];
@@ -557,18 +613,12 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                 for (int t = 0; t < TP; ++t) { tl[t] = tlv[TP * tp + t]; toff[t] = toffv[TP * tp + t]; }
                 // skip-connection values of the tiles this wave finishes itself: loaded before the MFMA phase
                 x3_f32x4 rv[TP][MT];
-                long long ovv[TP][MT];
-                bool okv[TP][MT];
                 if constexpr (KSPLIT == 1) {
 #pragma unroll
                     for (int t = 0; t < TP; ++t)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            int co0;
-                            okv[t][mt] = x3_out_coord<C, COUT, KIND>(dm, b, x0, y0, z, tl[t], ms * MT + mt, n, kk, ovv[t][mt], co0);
-                            ovv[t][mt] = ovv[t][mt] * COUT + co0;
-                            rv[t][mt] = (res && okv[t][mt]) ? *reinterpret_cast<const x3_f32x4*>(res + ovv[t][mt]) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
-                        }
+                        for (int mt = 0; mt < MT; ++mt)          // (no skip tensor: a zero-length descriptor, zeros)
+                            rv[t][mt] = __builtin_bit_cast(x3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, cob[TP * tp + t][mt], 0, 0));
                 }
                 x3_f32x4 acc[TP][MT][NP];          // one accumulator per magnitude class
 #pragma unroll
@@ -599,7 +649,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                     // slots: B-fragment reads of K step j+PD, then the MFMAs of one product class of step j; the fences pin
                     // this order (left alone, the scheduler sinks every read to just before its first use and exposes the LDS latency)
 #define X3_MF(ACC, WP, BP) _Pragma("unroll") for (int t = 0; t < TP; ++t) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) \
-        if (!X3_DBG(0)) acc[t][mt][ACC] = x3_mfma<NP>(wr[j][WP][mt], bq[cur][t][BP], acc[t][mt][ACC])
+        if (!X3_DBG(0) && C::live(C::SKIP ? j : 0, C::SKIP ? mt : 0)) acc[t][mt][ACC] = x3_mfma<NP>(wr[j][WP][mt], bq[cur][t][BP], acc[t][mt][ACC])
 #define X3_LD(I) if (pre && (I) < TP * NP && !X3_DBG(4)) bq[nxt][((I) / NP) % TP][(I) % NP] = *reinterpret_cast<const x3_u32x4*>(smem + na + toff[((I) / NP) % TP] + ((I) % NP) * C::PLB)
                     if constexpr (NP == 3) {
                         X3_LD(0); X3_MF(2, 0, 2); __builtin_amdgcn_sched_barrier(0);
@@ -628,12 +678,13 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
                             // hand the partial tile to the producers: [tile][m-tile][K slice][lane]
                             x3_f32x4* part = reinterpret_cast<x3_f32x4*>(partbase + (s & 1) * C::PARTB);
                             part[((tl[t] * C::MT_ALL + ms * MT + mt) * KSPLIT + ks) * 64 + lane] = v;
-                        } else if (okv[t][mt]) {
-                            v = v * sc[mt] + sh[mt];
+                        } else {
+                            v = v * sc[mt % SCN] + sh[mt % SCN];
                             if (relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
                             v += rv[t][mt];
-                            if (!X3_DBG(3)) *reinterpret_cast<x3_f32x4*>(y + ovv[t][mt]) = v;
-                            vmax = x3_absmax4(vmax, v);
+                            const int ob = cob[TP * tp + t][mt];
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(x3_u32x4, v), yrs, X3_DBG(3) ? OOB : ob, 0, 0);
+                            if (ymax && ob != OOB) vmax = x3_absmax4(vmax, v);
                         }
                     }
             }
