@@ -40,11 +40,16 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
     const float* xb = x + (long long)n * H * W * CI;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
 
-    float acc[PPT][CO];
+    // output channel PAIRS per v_pk_fma_f32: acc2[co / 2] += splat(x) * (w[co], w[co + 1]) -- the splat is an operand selector of the
+    // packed instruction, the weight pair two neighbouring SGPRs: half the VALU instructions of the scalar form, the same arithmetic
+    // per accumulator (round 3; fpn_fused.hip likewise)
+    static_assert(CO % 2 == 0, "output channels are accumulated in pairs");
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v acc2[PPT][CO / 2];
 #pragma unroll
     for (int p = 0; p < PPT; ++p)
 #pragma unroll
-        for (int c = 0; c < CO; ++c) acc[p][c] = 0.0f;
+        for (int c = 0; c < CO / 2; ++c) acc2[p][c] = (f2v){0.0f, 0.0f};
 
     for (int c0 = 0; c0 < CI; c0 += C2_CK) {
         const int ck = (CI - c0 < C2_CK) ? (CI - c0) : C2_CK;       // multiple of 4
@@ -78,21 +83,29 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                                for (int co = 0; co < CO; ++co) {
-                                    const float wv = wt[(c4 * 4 + j) * CO + co];
+                                for (int co = 0; co < CO; co += 2) {
+                                    if constexpr (K > 1) {
+                                        const f2v wv = (f2v){wt[(c4 * 4 + j) * CO + co], wt[(c4 * 4 + j) * CO + co + 1]};
 #pragma unroll
-                                    for (int p = 0; p < PPT; ++p) acc[p][co] = fmaf(xv[p][j], wv, acc[p][co]);
+                                        for (int p = 0; p < PPT; ++p) acc2[p][co / 2] = __builtin_elementwise_fma((f2v){xv[p][j], xv[p][j]}, wv, acc2[p][co / 2]);
+                                    } else {      // 1x1 layers: the packed form makes the optimiser hoist every weight of the layer (233 SGPRs spilled to VGPR lanes)
+                                        const float w0 = wt[(c4 * 4 + j) * CO + co], w1 = wt[(c4 * 4 + j) * CO + co + 1];
+#pragma unroll
+                                        for (int p = 0; p < PPT; ++p) {
+                                            acc2[p][co / 2].x = fmaf(xv[p][j], w0, acc2[p][co / 2].x);
+                                            acc2[p][co / 2].y = fmaf(xv[p][j], w1, acc2[p][co / 2].y);
+                                        }
+                                    }
                                 }
                             }
                         } else {
                             // one pixel, wide Cout: four input channels per accumulator back to back (measured faster
                             // for the 32 -> 32 / 32 -> 16 3x3 layers: 69 vs 118 us)
 #pragma unroll
-                            for (int co = 0; co < CO; ++co) {
-                                acc[0][co] = fmaf(xv[0].x, wt[(c4 * 4 + 0) * CO + co], acc[0][co]);
-                                acc[0][co] = fmaf(xv[0].y, wt[(c4 * 4 + 1) * CO + co], acc[0][co]);
-                                acc[0][co] = fmaf(xv[0].z, wt[(c4 * 4 + 2) * CO + co], acc[0][co]);
-                                acc[0][co] = fmaf(xv[0].w, wt[(c4 * 4 + 3) * CO + co], acc[0][co]);
+                            for (int co = 0; co < CO; co += 2) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc2[0][co / 2] = __builtin_elementwise_fma((f2v){xv[0][j], xv[0][j]}, (f2v){wt[(c4 * 4 + j) * CO + co], wt[(c4 * 4 + j) * CO + co + 1]}, acc2[0][co / 2]);
                             }
                         }
                     }
@@ -100,6 +113,11 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
             }
         }
     }
+    float acc[PPT][CO];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p)
+#pragma unroll
+        for (int c = 0; c < CO / 2; ++c) { acc[p][2 * c] = acc2[p][c].x; acc[p][2 * c + 1] = acc2[p][c].y; }
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
         const int oy = oy0 + ly + p * TH;

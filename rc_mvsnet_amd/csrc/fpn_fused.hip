@@ -43,9 +43,12 @@ __global__ __launch_bounds__(256) void fpn_out_fused_kernel(
         *reinterpret_cast<f4v*>(lat_s + v * ST + c4 * 4) = val;
     }
 
-    float acc[CO];
+    // output channel PAIRS per v_pk_fma_f32: acc2[co / 2] += splat(x) * (w[co], w[co + 1]) -- the splat is an operand selector of the
+    // packed instruction, the weight pair two neighbouring SGPRs: half the VALU instructions of the scalar form, same arithmetic
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v acc2[CO / 2];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+    for (int c = 0; c < CO / 2; ++c) acc2[c] = (f2v){0.0f, 0.0f};
 
     for (int c0 = 0; c0 < CM; c0 += CK) {
         __syncthreads();                                                // lat_s / w_s ready (first pass); tile free (later passes)
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256) void fpn_out_fused_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv[j], wt[(c4 * 4 + j) * CO + co], acc[co]);
+                        for (int co = 0; co < CO; co += 2)
+                            acc2[co / 2] = __builtin_elementwise_fma((f2v){xv[j], xv[j]}, (f2v){wt[(c4 * 4 + j) * CO + co], wt[(c4 * 4 + j) * CO + co + 1]}, acc2[co / 2]);
                 }
             }
         }
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void fpn_out_fused_kernel(
     if (oy < H && ox < W) {
         float* yp = y + (((long long)n * H + oy) * W + ox) * CO;
 #pragma unroll
-        for (int co = 0; co < CO; co += 4) *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+        for (int co = 0; co < CO; co += 4) *reinterpret_cast<float4*>(yp + co) = make_float4(acc2[co / 2].x, acc2[co / 2].y, acc2[co / 2 + 1].x, acc2[co / 2 + 1].y);
     }
 }
 
