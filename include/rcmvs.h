@@ -104,6 +104,14 @@ int rcmvs_debug_warp_variance_bwd(const float* feats, const float* rot, const fl
  * fragment-ordered image [27][Ci/(4*VEC)][Co/16][64 lanes][VEC] those kernels read. */
 long long rcmvs_packed_weight_floats(int Co, int Ci);   /* size of `packed` in floats ([27][Ci][Co] + MFMA image) */
 int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream);
+/* Selective form (no reference counterpart: the reference's weights are consumed in place by cuDNN).  A blob holds several images of
+ * the same weight, one per kernel family (bit 0: direct / LDS-halo layout, bit 1: fp32 matrix-core fragments, 4 << k: split-bf16 image
+ * of kind k = 0 stride 1, 1 stride 2, 2 transposed, 3 planar; 256 << k: fp16-pair image of kind k).  rcmvs_conv3d_images tells which ONE
+ * rcmvs_conv3d_fwd (transposed = 0; planar = the volume is one plane deep) / rcmvs_deconv3d_fwd (transposed = 1) reads for a layer;
+ * rcmvs_pack_conv3d_weight_sel writes only the images in `images` (training re-packs every weight every step for one call each).
+ * Calling a forward entry on a blob whose image was not written is undefined: the Python host keeps the mask next to the blob and checks. */
+int rcmvs_conv3d_images(int Co, int Ci, int stride, int transposed, int planar);
+int rcmvs_pack_conv3d_weight_sel(const float* w, float* packed, int Co, int Ci, int transposed, int images, void* stream);
 
 /* y = epilogue(conv3d(x, w, k=3, pad=1, stride)),  x (B,D,H,W,Ci) -> y (B,Do,Ho,Wo,Co),
  * Do = (D-1)/stride+1 ...;   epilogue(v) = [relu](v*scale[co] + shift[co]) + residual
@@ -166,20 +174,22 @@ int rcmvs_deconv3d_scaled_fwd(const float* x, const float* x_absmax, const float
  * backward of the block is rcmvs_bn_bwd_* + the data gradient (the same forward kernels on re-packed
  * weights: dgrad(conv s1) = conv with flipped, transposed weights; dgrad(conv s2) = deconv; dgrad(deconv) =
  * conv s2) + rcmvs_conv3d_wgrad.  All tensors channels-last, rows = B*D*H*W.
- *   rcmvs_bn_stats:          sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2     (fp64, caller zero-fills;
- *                            these 2C doubles are what a SyncBatchNorm all-reduce exchanges)
+ *   rcmvs_bn_stats:          sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2, sums[2C] += rows     (fp64; these 2C + 1
+ *                            doubles are what a SyncBatchNorm all-reduce exchanges).  The buffer starts at zero ONCE: the
+ *                            finalize calls below clear what they consumed, so one buffer per layer serves every step.
  *   rcmvs_scale_shift_relu:  y = [relu](x*scale[c] + shift[c]) + residual   (scale/shift/residual may be NULL)
  *   rcmvs_bn_bwd_reduce:     sums[0..C) += sum g, sums[C..2C) += sum g*xhat,  g = dz*[y*scale+shift > 0] (relu) or dz
  *   rcmvs_bn_bwd_apply:      dy = scale * (g - coef[c] - xhat*coef[C+c]),  coef = {dbeta/N, dgamma/N},
  *                            xhat = (y-mean)*invstd, scale = gamma*invstd */
 int rcmvs_bn_stats(const float* x, double* sums, long long rows, int C, void* stream);
-/* sums (2C, fp64) + *count -> batch mean / biased var / invstd, scale = gamma*invstd, shift = beta - mean*scale, and
- * (when given) the momentum update of running_mean / running_var (unbiased), exactly nn.BatchNorm's bookkeeping. */
-int rcmvs_bn_finalize(const double* sums, const double* count, const float* gamma, const float* beta, float eps, float momentum,
+/* sums (2C + 1, fp64: consumed and cleared) -> batch mean / biased var / invstd, scale = gamma*invstd, shift = beta - mean*scale, and
+ * (when given) the momentum update of running_mean / running_var (unbiased), exactly nn.BatchNorm's bookkeeping; *count receives the
+ * row count (sums[2C]) for the backward pass. */
+int rcmvs_bn_finalize(double* sums, double* count, const float* gamma, const float* beta, float eps, float momentum,
                       float* mean, float* var, float* invstd, float* scale, float* shift,
                       float* running_mean, float* running_var, int C, void* stream);
-/* local sums -> dgamma, dbeta of this replica; total (all-reduced) sums / *count -> coef for rcmvs_bn_bwd_apply */
-int rcmvs_bn_bwd_finalize(const double* local_sums, const double* total_sums, const double* count, float* dgamma, float* dbeta,
+/* local sums (2C: consumed and cleared) -> dgamma, dbeta of this replica; total (all-reduced) sums / *count -> coef for rcmvs_bn_bwd_apply */
+int rcmvs_bn_bwd_finalize(double* local_sums, const double* total_sums, const double* count, float* dgamma, float* dbeta,
                           float* coef, int C, void* stream);
 int rcmvs_scale_shift_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                            long long rows, int C, int relu, void* stream);

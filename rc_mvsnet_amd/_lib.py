@@ -58,6 +58,8 @@ SIGNATURES = {
     "rcmvs_warp_noref_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_packed_weight_floats": [_i, _i],
     "rcmvs_pack_conv3d_weight": [_p, _p, _i, _i, _i, _p],
+    "rcmvs_pack_conv3d_weight_sel": [_p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_conv3d_images": [_i, _i, _i, _i, _i],
     "rcmvs_debug_conv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_deconv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_conv3d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

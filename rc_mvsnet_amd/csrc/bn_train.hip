@@ -53,6 +53,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(const float* __restr
         acc[1] += v * v;
     }
     block_reduce_to_global<2>(acc, q, nq, sums, C);
+    if (blockIdx.x == 0 && threadIdx.x == 0) unsafeAtomicAdd(sums + 2 * C, (double)rows);      // the row count travels with the sums (SyncBatchNorm all-reduces 2C + 1 doubles)
 }
 
 __global__ __launch_bounds__(BN_BLOCK) void scale_shift_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -117,16 +118,22 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const float* __r
 // fp64 sums -> everything the block needs, in one launch (replaces a dozen 32-element tensor ops):
 // batch mean / biased variance / invstd, the folded scale = gamma*invstd and shift = beta - mean*scale, and the
 // running-statistics update of nn.BatchNorm (running_var takes the unbiased variance).
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ count,
+// The sums are CONSUMED: one block reads them, then clears all 2C + 1 doubles, so the caller can keep ONE accumulation buffer per
+// BatchNorm module alive across steps instead of zero-filling a fresh one per call (round 3: ~250 fp64 fill launches per training
+// iteration); the row count is handed on in *count_out for the backward pass.
+__global__ void bn_finalize_kernel(double* __restrict__ sums, double* __restrict__ count_out,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
                                    float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double n = *count;
-    const double m = sums[c] / n;
-    double v = sums[C + c] / n - m * m;
+    const double n = sums[2 * C];
+    __syncthreads();
+    if (threadIdx.x == 0) { count_out[0] = n; sums[2 * C] = 0.0; }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double s1 = sums[c], s2 = sums[C + c];
+    sums[c] = 0.0; sums[C + c] = 0.0;
+    const double m = s1 / n;
+    double v = s2 / n - m * m;
     v = v < 0.0 ? 0.0 : v;
     const float is = (float)(1.0 / sqrt(v + (double)eps));
     const float mf = (float)m;
@@ -138,19 +145,23 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const double
         running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
         running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(v * (n / (n - 1.0)));
     }
+    }
 }
 
 // backward: this replica's parameter gradients from its own sums, the normalisation coefficients from the totals
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ local, const double* __restrict__ total,
+// (the local sums are consumed -- cleared -- like the forward ones; `total` may be the same buffer)
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ local, const double* __restrict__ total,
                                        const double* __restrict__ count, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
     const double n = *count;
-    dbeta[c] = (float)local[c];
-    dgamma[c] = (float)local[C + c];
-    coef[c] = (float)(total[c] / n);
-    coef[C + c] = (float)(total[C + c] / n);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double t0 = total[c], t1 = total[C + c], l0 = local[c], l1 = local[C + c];
+        local[c] = 0.0; local[C + c] = 0.0;
+        dbeta[c] = (float)l0;
+        dgamma[c] = (float)l1;
+        coef[c] = (float)(t0 / n);
+        coef[C + c] = (float)(t1 / n);
+    }
 }
 
 static inline unsigned grid_for(long long work_items) {
@@ -171,20 +182,20 @@ int rcmvs_bn_stats(const float* x, double* sums, long long rows, int C, void* st
     return launch_status("bn_stats");
 }
 
-int rcmvs_bn_finalize(const double* sums, const double* count, const float* gamma, const float* beta, float eps, float momentum,
+int rcmvs_bn_finalize(double* sums, double* count, const float* gamma, const float* beta, float eps, float momentum,
                       float* mean, float* var, float* invstd, float* scale, float* shift,
                       float* running_mean, float* running_var, int C, void* stream) {
     RCMVS_REQUIRE(sums && count && gamma && beta && mean && var && invstd && scale && shift && C > 0, "bn_finalize: bad arguments");
     RCMVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean and running_var go together");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), sums, count, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), sums, count, gamma, beta, eps, momentum,
                        mean, var, invstd, scale, shift, running_mean, running_var, C);
     return launch_status("bn_finalize");
 }
 
-int rcmvs_bn_bwd_finalize(const double* local_sums, const double* total_sums, const double* count, float* dgamma, float* dbeta,
+int rcmvs_bn_bwd_finalize(double* local_sums, const double* total_sums, const double* count, float* dgamma, float* dbeta,
                           float* coef, int C, void* stream) {
     RCMVS_REQUIRE(local_sums && total_sums && count && dgamma && dbeta && coef && C > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), local_sums, total_sums, count,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), local_sums, total_sums, count,
                        dgamma, dbeta, coef, C);
     return launch_status("bn_bwd_finalize");
 }

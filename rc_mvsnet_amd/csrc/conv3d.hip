@@ -201,30 +201,77 @@ long long rcmvs_packed_weight_floats(int Co, int Ci) {
     return n + 4;
 }
 
-int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream) {
+// Which kernel family a forward call lands on (shared by the dispatchers and by the selective weight pack below, so the two cannot
+// disagree).  planar = stride-1 conv of a one-plane volume; scaled = the caller supplied an activation bound.
+enum ConvSel { SEL_X3_PLANAR, SEL_X3H, SEL_X3, SEL_LDS, SEL_MFMA, SEL_DIRECT };
+static ConvSel conv_select(int Ci, int Co, int mode, bool planar, bool scaled, const ConvImpl& im) {
+    const bool x3 = !im.direct && !im.no_x3;
+    if (mode == CONV_T2) {
+        if (scaled && x3 && conv3d_x3h_supported(Ci, Co, CONV_T2)) return SEL_X3H;
+        if (x3 && conv3d_x3_supported(Ci, Co, CONV_T2)) return SEL_X3;
+        if (deconv3d_lds_supported(Ci, Co) && !im.direct) return SEL_LDS;
+        if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !im.direct) return SEL_MFMA;
+        return SEL_DIRECT;
+    }
+    const int stride = mode == CONV_S1 ? 1 : 2;
+    if (planar && x3 && conv3d_x3_supported(Ci, Co, X3_KIND_PLANAR)) return SEL_X3_PLANAR;      // one plane: the kd = 0, 2 taps only see padding
+    if (scaled && x3 && conv3d_x3h_supported(Ci, Co, mode)) return SEL_X3H;
+    if (x3 && conv3d_x3_supported(Ci, Co, mode)) return SEL_X3;
+    if (im.prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !im.direct) return SEL_LDS;
+    if (conv3d_mfma_supported(Ci, Co, mode) && !im.direct) return SEL_MFMA;
+    if (conv3d_lds_supported(Ci, Co, stride) && !im.direct) return SEL_LDS;
+    return SEL_DIRECT;
+}
+
+// Images of a packed-weight blob as a bit mask: 1 = direct / LDS-halo layout, 2 = fp32-MFMA fragments, 4 << k = split-bf16 image of
+// kind k, 256 << k = fp16-pair image of kind k.
+enum { IMG_DIRECT = 1, IMG_MFMA = 2, IMG_X3 = 4, IMG_X3H = 256, IMG_ALL = 0x7fffffff };
+
+int rcmvs_conv3d_images(int Co, int Ci, int stride, int transposed, int planar) {
+    // the image the PRODUCTION dispatch (rcmvs_conv3d_fwd / rcmvs_deconv3d_fwd, no activation bound) reads for this layer
+    const int mode = transposed ? CONV_T2 : (stride == 1 ? CONV_S1 : CONV_S2);
+    switch (conv_select(Ci, Co, mode, !transposed && stride == 1 && planar, false, ConvImpl(0))) {
+        case SEL_X3_PLANAR: return IMG_X3 << X3_KIND_PLANAR;
+        case SEL_X3: return IMG_X3 << mode;
+        case SEL_X3H: return IMG_X3H << mode;
+        case SEL_MFMA: return IMG_MFMA;
+        default: return IMG_DIRECT;
+    }
+}
+
+// images: mask of the images to write (IMG_ALL = every image this channel pair has).  Training re-packs ~200 weights per iteration
+// for one forward kernel each: the full blob costs up to 8 launches per weight, the selected image one (round 3).
+int rcmvs_pack_conv3d_weight_sel(const float* w, float* packed, int Co, int Ci, int transposed, int images, void* stream) {
     RCMVS_REQUIRE(w && packed && Co > 0 && Ci > 0, "pack_conv3d_weight: bad arguments");
     int n = 27 * Ci * Co;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, packed, Co, Ci, transposed);
-    int rc = launch_status("pack_conv3d_weight");
-    if (rc) return rc;
-    if (conv3d_mfma_supported(Ci, Co, 0)) {
+    int rc = 0;
+    if (images & IMG_DIRECT) {
+        hipLaunchKernelGGL(pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, packed, Co, Ci, transposed);
+        rc = launch_status("pack_conv3d_weight");
+        if (rc) return rc;
+    }
+    if ((images & IMG_MFMA) && conv3d_mfma_supported(Ci, Co, 0)) {
         rc = pack_weight_mfma_launch(w, packed + direct_weight_floats(Ci, Co), Co, Ci, transposed, as_stream(stream));
         if (rc) return rc;
     }
     for (int k = 0; k < X3_NKINDS; ++k) {         // a ConvTranspose3d weight (transposed == 1) feeds the transposed kernel only, and vice versa
-        if (!conv3d_x3_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
+        if (!(images & (IMG_X3 << k)) || !conv3d_x3_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
         rc = conv3d_x3_pack(w, packed + x3_image_offset(Ci, Co, k), Co, Ci, k, transposed, as_stream(stream));
         if (rc) return rc;
     }
     float* wsc = packed + x3h_image_offset(Ci, Co, X3_NKINDS);
     bool scaled = false;
     for (int k = 0; k < X3_NKINDS; ++k) {
-        if (!conv3d_x3h_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
+        if (!(images & (IMG_X3H << k)) || !conv3d_x3h_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
         if (!scaled) { rc = conv3d_x3_wscale(w, n, wsc, as_stream(stream)); if (rc) return rc; scaled = true; }
         rc = conv3d_x3h_pack(w, packed + x3h_image_offset(Ci, Co, k), Co, Ci, k, transposed, wsc, as_stream(stream));
         if (rc) return rc;
     }
     return 0;
+}
+
+int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int transposed, void* stream) {
+    return rcmvs_pack_conv3d_weight_sel(w, packed, Co, Ci, transposed, IMG_ALL, stream);
 }
 
 // xmax / ymax (the `scaled` entry points): device scalars; xmax = a bound of max|x| (selects the fp16-pair matrix-core form where the
@@ -240,20 +287,19 @@ static int conv3d_dispatch(const float* x, const float* w_packed, const float* s
     ConvDims dm{B, D, H, W, (D - 1) / stride + 1, (H - 1) / stride + 1, (W - 1) / stride + 1};
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
-    if (stride == 1 && D == 1 && conv3d_x3_supported(Ci, Co, X3_KIND_PLANAR) && !im.direct && !im.no_x3)      // one plane: the kd = 0, 2 taps only see padding
+    const ConvSel sel = conv_select(Ci, Co, mode, stride == 1 && D == 1, xmax != nullptr, im);
+    if (sel == SEL_X3_PLANAR)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, X3_KIND_PLANAR), scale, shift, residual, y, B, D, H, W, Ci, Co, X3_KIND_PLANAR, relu, st, im.x3_blocks, 0, nullptr, ymax);
-    if (xmax && conv3d_x3h_supported(Ci, Co, mode) && !im.direct && !im.no_x3)
+    if (sel == SEL_X3H)
         return conv3d_x3_launch(x, w_packed + x3h_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks, 0, xmax, ymax);
-    if (conv3d_x3_supported(Ci, Co, mode) && !im.direct && !im.no_x3)
+    if (sel == SEL_X3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks, 0, nullptr, ymax);
     RCMVS_REQUIRE(!ymax, "conv3d_scaled_fwd: no split-operand kernel for Ci=%d Co=%d stride=%d, the output bound cannot be maintained", Ci, Co, stride);
-    if (im.prefer_lds && conv3d_lds_supported(Ci, Co, stride) && !im.direct)
+    if (sel == SEL_LDS)
         return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
-    if (conv3d_mfma_supported(Ci, Co, mode) && !im.direct)
+    if (sel == SEL_MFMA)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
                                   mode, relu, st);
-    if (conv3d_lds_supported(Ci, Co, stride) && !im.direct)
-        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
     if (stride == 1) return direct_dispatch<CONV_S1>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
     return direct_dispatch<CONV_S2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
 }
@@ -294,16 +340,17 @@ static int deconv3d_dispatch(const float* x, const float* w_packed, const float*
     RCMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "deconv3d_fwd: bad sizes");
     RCMVS_REQUIRE((scale == nullptr) == (shift == nullptr), "deconv3d_fwd: scale and shift go together");
     ConvDims dm{B, D, H, W, 2 * D, 2 * H, 2 * W};
-    if (xmax && conv3d_x3h_supported(Ci, Co, CONV_T2) && !im.direct && !im.no_x3)
+    const ConvSel sel = conv_select(Ci, Co, CONV_T2, false, xmax != nullptr, im);
+    if (sel == SEL_X3H)
         return conv3d_x3_launch(x, w_packed + x3h_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
                                 as_stream(stream), im.x3_blocks, 0, xmax, ymax);
-    if (conv3d_x3_supported(Ci, Co, CONV_T2) && !im.direct && !im.no_x3)
+    if (sel == SEL_X3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
                                 as_stream(stream), im.x3_blocks, 0, nullptr, ymax);
     RCMVS_REQUIRE(!ymax, "deconv3d_scaled_fwd: no split-operand kernel for Ci=%d Co=%d, the output bound cannot be maintained", Ci, Co);
-    if (deconv3d_lds_supported(Ci, Co) && !im.direct)
+    if (sel == SEL_LDS)
         return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
-    if (conv3d_mfma_supported(Ci, Co, CONV_T2) && !im.direct)
+    if (sel == SEL_MFMA)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
                                   CONV_T2, relu, as_stream(stream));
     return direct_dispatch<CONV_T2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, as_stream(stream));

@@ -179,14 +179,18 @@ class WarpVarianceFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------- K2/K3
+IMG_ALL = 0x7fffffff
+
+
 class PackedWeight:
     """Device blob produced by rcmvs_pack_conv3d_weight plus its channel counts."""
-    __slots__ = ("blob", "ci", "co", "k", "transposed")
+    __slots__ = ("blob", "ci", "co", "k", "transposed", "images")
 
-    def __init__(self, blob, ci, co, transposed=0):
+    def __init__(self, blob, ci, co, transposed=0, images=IMG_ALL):
         # transposed: the pack mode (0 conv weight, 1 ConvTranspose3d weight, 2 flipped adjoint of a stride-1 conv).  The blob holds
-        # the matrix-core images of the matching kernels only (rcmvs_pack_conv3d_weight), so conv3d / deconv3d check it
-        self.blob, self.ci, self.co, self.transposed = blob, ci, co, int(transposed)
+        # the matrix-core images of the matching kernels only (rcmvs_pack_conv3d_weight), so conv3d / deconv3d check it.
+        # images: which images were written (rcmvs_pack_conv3d_weight_sel; IMG_ALL = every image the channel pair has)
+        self.blob, self.ci, self.co, self.transposed, self.images = blob, ci, co, int(transposed), int(images)
 
 
 _CONV_IMPL = 0      # test / A-B hook (force_direct_conv): kernel selection handed to the rcmvs_debug_* conv entry points
@@ -200,16 +204,34 @@ def force_direct_conv(on):
     _CONV_IMPL = int(on)
 
 
-def pack_conv3d_weight(w, transposed=False):
+def conv3d_images(ci, co, stride=1, transposed=False, planar=False):
+    """Mask of the blob image the production dispatch reads for this layer (rcmvs_conv3d_images)."""
+    return int(_lib.load().rcmvs_conv3d_images(co, ci, int(stride), int(bool(transposed)), int(bool(planar))))
+
+
+def pack_conv3d_weight(w, transposed=False, use=None):
     """conv (Co,Ci,3,3,3) / deconv (Ci,Co,3,3,3) -> PackedWeight (direct [27][Ci][Co] + MFMA image).
-    transposed=2: the adjoint of a stride-1 conv whose weight is (Ci,Co,3,3,3) (taps flipped as well)."""
+    transposed=2: the adjoint of a stride-1 conv whose weight is (Ci,Co,3,3,3) (taps flipped as well).
+    use=(stride, planar): write only the image the production dispatch reads for a call with that stride on a volume that
+    is (planar=True) / is not one plane deep -- training re-packs every weight every step for exactly one call; inference plans keep
+    the full blob (use=None).  Ignored while a test hook selects other kernels (force_direct_conv)."""
     w = w.detach().contiguous().float()
     Ci, Co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     n = _lib.load().rcmvs_packed_weight_floats(Co, Ci)
     blob = torch.empty((n,), device=w.device, dtype=torch.float32)
-    _lib.check(_lib.load().rcmvs_pack_conv3d_weight(_chk(w, "w"), _chk(blob, "packed"), Co, Ci, int(transposed), _stream()),
+    images = IMG_ALL
+    if use is not None and not _CONV_IMPL:
+        images = conv3d_images(Ci, Co, stride=use[0], transposed=(int(transposed) == 1), planar=use[1])
+    _lib.check(_lib.load().rcmvs_pack_conv3d_weight_sel(_chk(w, "w"), _chk(blob, "packed"), Co, Ci, int(transposed), images, _stream()),
                "pack_conv3d_weight")
-    return PackedWeight(blob, Ci, Co, int(transposed))
+    return PackedWeight(blob, Ci, Co, int(transposed), images)
+
+
+def _check_image(w_packed, ci, co, stride, transposed, planar, scaled, who):
+    if w_packed.images == IMG_ALL:
+        return
+    if _CONV_IMPL or scaled or not (w_packed.images & conv3d_images(ci, co, stride, transposed, planar)):
+        raise _lib.RcmvsError(f"{who}: the weight was packed for another call (pack_conv3d_weight(use=...)): the image this call reads was not written")
 
 
 def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False, x_absmax=None, y_absmax=None):
@@ -222,6 +244,7 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
         raise _lib.RcmvsError(f"conv3d: input has {Ci} channels, weight expects {w_packed.ci}")
     if w_packed.transposed == 1:
         raise _lib.RcmvsError("conv3d: the weight was packed as a ConvTranspose3d weight (transposed=1); its blob holds no conv images")
+    _check_image(w_packed, Ci, Co, stride, False, D == 1, x_absmax is not None, "conv3d")
     y = torch.empty((B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1, Co), device=x.device,
                     dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
@@ -256,6 +279,7 @@ def deconv3d(x, w_packed, scale=None, shift=None, residual=None, relu=False, x_a
         raise _lib.RcmvsError(f"deconv3d: input has {Ci} channels, weight expects {w_packed.ci}")
     if w_packed.transposed != 1:
         raise _lib.RcmvsError("deconv3d: the weight was not packed with transposed=True; its blob holds no transposed-conv image")
+    _check_image(w_packed, Ci, Co, 2, True, False, x_absmax is not None, "deconv3d")
     y = torch.empty((B, 2 * D, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
         raise _lib.RcmvsError(f"deconv3d: residual {tuple(residual.shape)} != output {tuple(y.shape)} "

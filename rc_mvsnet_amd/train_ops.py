@@ -90,25 +90,57 @@ def _pad_in_channels(w, cx):
     return torch.cat((w, w.new_zeros(w.shape[0], cx - w.shape[1], 3, 3, 3)), dim=1)
 
 
-def _conv_raw(x, w, transposed, stride):
-    """The block's convolution with an identity epilogue (weights re-packed: they change every step)."""
+# Packed images of PARAMETERS, reused while the parameter is unchanged: an iteration runs two cascade passes (standard and augmented
+# views) over the same weights, forward and backward.  Keyed by the parameter object (kept alive by the entry, so its id cannot be
+# recycled) and its autograd version counter, which every in-place optimizer update bumps.  Derived weight tensors (FeatureNet's
+# embedded 2-D kernels, channel-padded copies) are new tensors every call and are packed every call.
+# (An update through `.data` does not bump the counter: call clear_pack_cache() after such a write.)
+_PACK_CACHE = {}
+
+
+def clear_pack_cache():
+    _PACK_CACHE.clear()
+
+
+def _param_of(w):
+    return w if isinstance(w, torch.nn.Parameter) else None
+
+
+def _packed(w, transposed, stride, planar, param=None):
+    """PackedWeight of `w` holding the one image a production call (stride, planar) reads."""
+    if param is None or ops._CONV_IMPL:
+        return ops.pack_conv3d_weight(w, transposed=transposed, use=(stride, planar))
+    key = (int(transposed), int(stride), bool(planar))
+    ent = _PACK_CACHE.get(id(param))
+    if ent is None or ent[0] is not param or ent[1] != param._version:
+        ent = _PACK_CACHE[id(param)] = (param, param._version, {})
+    pk = ent[2].get(key)
+    if pk is None:
+        pk = ent[2][key] = ops.pack_conv3d_weight(w, transposed=transposed, use=(stride, planar))
+    return pk
+
+
+def _conv_raw(x, w, transposed, stride, param=None):
+    """The block's convolution with an identity epilogue (weights re-packed when they change: every step)."""
     if transposed:
-        return ops.deconv3d(x, ops.pack_conv3d_weight(w, transposed=True))
-    return ops.conv3d(x, ops.pack_conv3d_weight(_pad_in_channels(w, x.shape[-1]), transposed=False), stride=stride)
+        return ops.deconv3d(x, _packed(w, True, 2, False, param))
+    wp = _pad_in_channels(w, x.shape[-1])
+    return ops.conv3d(x, _packed(wp, False, stride, stride == 1 and x.shape[1] == 1, param if wp.shape == w.shape else None), stride=stride)
 
 
-def _conv_dgrad(dy, w, transposed, stride, cx):
+def _conv_dgrad(dy, w, transposed, stride, cx, param=None):
     """d loss / d x of the block's convolution, on the forward kernels with re-packed weights (cx = channels of x)."""
     w = w.detach()
     if transposed:                                   # adjoint of ConvTranspose3d(stride 2) = Conv3d(stride 2), same weight tensor
-        return ops.conv3d(dy, ops.pack_conv3d_weight(w, transposed=False), stride=2)
+        return ops.conv3d(dy, _packed(w, False, 2, False, param), stride=2)
     if stride == 2:                                  # adjoint of Conv3d(stride 2) = ConvTranspose3d(stride 2, output_padding 1)
-        return ops.deconv3d(dy, ops.pack_conv3d_weight(w, transposed=True))
+        return ops.deconv3d(dy, _packed(w, True, 2, False, param))
     # adjoint of Conv3d(stride 1, pad 1) = Conv3d with flipped taps and swapped channel roles: pack mode 2 does both
     co = w.shape[1]                                  # output channels of the adjoint = input channels of the layer
     if co not in (1, 8) and co % 16:                 # e.g. 41 input channels: the MFMA kernels want a multiple of 16 outputs
         w = _pad_in_channels(w, (co + 15) // 16 * 16)
-    dx = ops.conv3d(dy, ops.pack_conv3d_weight(w, transposed=2), stride=1)
+        param = None
+    dx = ops.conv3d(dy, _packed(w, 2, 1, dy.shape[1] == 1, param), stride=1)
     if dx.shape[-1] != cx:                           # back to the (padded) channel count of x; padding channels get zero
         dx = dx[..., :cx].contiguous() if dx.shape[-1] > cx else torch.nn.functional.pad(dx, (0, cx - dx.shape[-1]))
     return dx
@@ -119,6 +151,19 @@ def _conv_wgrad(x, dy, w_shape, transposed, stride):
         return conv3d_wgrad(dy, x, 2).permute(2, 1, 0).reshape(w_shape)
     dw = conv3d_wgrad(x, dy, stride)                 # (27, Cx, Co), Cx >= Ci when the input carries padding channels
     return dw[:, :w_shape[1]].permute(2, 1, 0).reshape(w_shape)
+
+
+def _bn_scratch(cfg, which, S, n, device):
+    """The layer's fp64 accumulation buffer (S segments x n doubles), created zero once and kept on the BatchNorm module: the
+    finalize kernels clear what they consume (rcmvs.h), so no call fills it again.  Calls of one module are stream-ordered."""
+    store = cfg.get("scratch")
+    if store is None:
+        return torch.zeros((S, n), device=device, dtype=torch.float64)
+    key = (which, S, n, str(device))
+    buf = store.get(key)
+    if buf is None:
+        buf = store[key] = torch.zeros((S, n), device=device, dtype=torch.float64)
+    return buf
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -133,12 +178,12 @@ class ConvBnReluFn(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta, residual, running_mean, running_var, cfg):
         x = x.contiguous()
         lib = _lib.load()
-        y = _conv_raw(x, w.detach(), cfg["transposed"], cfg["stride"])
+        y = _conv_raw(x, w.detach(), cfg["transposed"], cfg["stride"], _param_of(w))
         C = y.shape[-1]
         S = int(cfg.get("segments", 1))
         nb = y.shape[0] // S
-        pack = torch.zeros((S, 2 * C + 1), device=x.device, dtype=torch.float64)   # per segment [sum | sum of squares | count]
-        pack[:, -1] = float(nb * (y.numel() // (C * y.shape[0])))
+        pack = _bn_scratch(cfg, "fwd", S, 2 * C + 1, x.device)                   # per segment [sum | sum of squares | rows]: zero between uses
+        cnt = torch.empty((S,), device=x.device, dtype=torch.float64)           # rows behind the statistics (all ranks), for the backward pass
         stats = torch.empty((S, 5, C), device=x.device, dtype=torch.float32)     # mean, var, invstd, scale, shift
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         res = None if residual is None else residual.contiguous()
@@ -150,26 +195,26 @@ class ConvBnReluFn(torch.autograd.Function):
             if cfg.get("group") is not None:
                 dist.all_reduce(pack[sgm], group=cfg["group"])
             st = stats[sgm]
-            _lib.check(lib.rcmvs_bn_finalize(ptr(pack[sgm]), ptr(pack[sgm, 2 * C:]), _chk(g32, "gamma"), _chk(b32, "beta"),
+            _lib.check(lib.rcmvs_bn_finalize(ptr(pack[sgm]), ptr(cnt[sgm:]), _chk(g32, "gamma"), _chk(b32, "beta"),
                                              float(cfg["eps"]), float(cfg.get("momentum", 0.0)), ptr(st[0]), ptr(st[1]), ptr(st[2]),
                                              ptr(st[3]), ptr(st[4]), _opt(running_mean, "running_mean"),
                                              _opt(running_var, "running_var"), C, _stream()), "bn_finalize")
             scale_shift_relu(ys, st[3], st[4], None if res is None else res[sgm * nb:(sgm + 1) * nb], cfg["relu"],
                              out=z[sgm * nb:(sgm + 1) * nb])
-        ctx.save_for_backward(x, w, y, stats, pack)
+        ctx.save_for_backward(x, w, y, stats, cnt)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, w, y, stats, pack = ctx.saved_tensors
+        x, w, y, stats, cnt = ctx.saved_tensors
         cfg = ctx.cfg
         C = y.shape[-1]
         S = int(cfg.get("segments", 1))
         nb = y.shape[0] // S
         dz = dz.contiguous()
-        sums = torch.zeros((S, 2 * C), device=y.device, dtype=torch.float64)
+        sums = _bn_scratch(cfg, "bwd", S, 2 * C, y.device)                         # zero between uses (bn_bwd_finalize clears it)
         out = torch.empty((S, 4, C), device=y.device, dtype=torch.float32)        # per segment: dgamma, dbeta, coef (2C)
         dy = torch.empty_like(y)
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -181,11 +226,11 @@ class ConvBnReluFn(torch.autograd.Function):
             if cfg.get("group") is not None:
                 tot = sums[sgm].clone()
                 dist.all_reduce(tot, group=cfg["group"])
-            _lib.check(_lib.load().rcmvs_bn_bwd_finalize(ptr(sums[sgm]), ptr(tot), ptr(pack[sgm, 2 * C:]), ptr(out[sgm, 0]),
+            _lib.check(_lib.load().rcmvs_bn_bwd_finalize(ptr(sums[sgm]), ptr(tot), ptr(cnt[sgm:]), ptr(out[sgm, 0]),
                                                          ptr(out[sgm, 1]), ptr(out[sgm, 2]), C, _stream()), "bn_bwd_finalize")
             bn_bwd_apply(y[sl], dz[sl], scale, shift, mean, invstd, out[sgm, 2:].reshape(-1), cfg["relu"], out=dy[sl])
         dgamma, dbeta = (out[0, 0], out[0, 1]) if S == 1 else (out[:, 0].sum(0), out[:, 1].sum(0))
-        dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"], x.shape[-1]) if ctx.needs_input_grad[0] else None
+        dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"], x.shape[-1], _param_of(w)) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad(x, dy, w.shape, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[1] else None
         return dx, dw, dgamma, dbeta, (dz if ctx.has_res else None), None, None, None
 
@@ -215,8 +260,11 @@ def conv_bn_train_w(weight, bn, x, relu, residual=None, transposed=False, stride
         # momentum=None means a cumulative average; that needs the step count on the host (one sync) -- the reference
         # always sets a momentum (modules.py:146, bn_momentum=0.1), so this branch is cold
         mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    scratch = bn.__dict__.get("_rcmvs_scratch")
+    if scratch is None:
+        scratch = bn.__dict__["_rcmvs_scratch"] = {}
     cfg = {"transposed": transposed, "stride": stride, "relu": bool(relu), "eps": bn.eps, "momentum": mom, "group": group,
-           "segments": segments}
+           "segments": segments, "scratch": scratch}
     return ConvBnReluFn.apply(x, weight, bn.weight, bn.bias, residual, bn.running_mean if track else None,
                               bn.running_var if track else None, cfg)
 
@@ -230,7 +278,8 @@ class ConvPlainFn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        pk = ops.pack_conv3d_weight(_pad_in_channels(w.detach(), x.shape[-1]))
+        wp = _pad_in_channels(w.detach(), x.shape[-1])
+        pk = _packed(wp, False, 1, x.shape[1] == 1, _param_of(w) if wp.shape == w.shape else None)
         if bias is None:
             return ops.conv3d(x, pk)
         b32 = bias.detach().float().contiguous()
@@ -240,7 +289,7 @@ class ConvPlainFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = _conv_dgrad(dy, w, False, 1, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        dx = _conv_dgrad(dy, w, False, 1, x.shape[-1], _param_of(w)) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad(x, dy, w.shape, False, 1) if ctx.needs_input_grad[1] else None
         db = dy.sum(dim=(0, 1, 2, 3)) if ctx.has_bias else None
         return dx, dw, db
