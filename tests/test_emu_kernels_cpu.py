@@ -99,7 +99,7 @@ def test_results_do_not_depend_on_the_thread_schedule(emu):
     model = CascadeMVSNet_eval(ndepths=[8, 8, 8], depth_interals_ratio=[4, 2, 1])
     model.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
     model.eval()
-    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 32, 64, 0)
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 32, 32, 0)
     g = torch.Generator().manual_seed(5)
     feats = torch.randn(1, 3, 12, 20, 16, generator=g)
     rot, trans = ops.compose_homography(synthetic.proj_matrices(1, 3, 48, 80)["stage1"])
