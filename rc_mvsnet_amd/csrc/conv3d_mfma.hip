@@ -63,6 +63,8 @@ __global__ void pack_weight_mfma_kernel(const float* __restrict__ w, float* __re
 // their accumulators through LDS.  The deep U-Net levels have only a few hundred tiles (6x16x20 cells = 120 n-tiles): one
 // wave per tile leaves most SIMDs empty and every wave walks a 27-tap dependent chain of load -> MFMA; splitting the taps
 // gives 4x the waves and a 4x shorter chain (measured: the 64->64 level 49 -> 19 us, the stride-2 32->64 level 27 -> 13 us).
+// (Round 3: nine waves of three taps, and a four-way split of the transposed form's parity classes, were measured: 64->64 14.6 -> 16.9 us,
+// 32->64 11.4 -> 14.3, 64->32 transposed 14.8 -> 14.2 -- the tap chain is no longer what these launches wait for.)
 template <int CIN, int COUT, int MODE, int NT, int KS = 1>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wm, const float* __restrict__ scale,
