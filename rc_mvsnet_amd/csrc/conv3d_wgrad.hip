@@ -18,6 +18,7 @@
 // which the atomic units coalesce -- writing nn.Conv3d's (CO, CI, 27) layout directly made the flush 2-3x slower
 // (summation order is not deterministic).
 #include "common.h"
+#include <cstdlib>
 
 namespace rcmvs {
 
@@ -155,6 +156,36 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
                 }
             }
         }
+    }
+    // The block's four waves hold the same accumulator set (they walked different rows): sum them through LDS so that ONE wave
+    // flushes.  The flush is what the kernel waits for -- every flushing wave adds its whole set to the same [27][CI][CO] words
+    // (round 3, profiles/r3_wgrad_flush.txt: 32 -> 8 at 48x128x160 with 1024 blocks x 4 flushing waves 718 us, 256 blocks 370 us, for the
+    // same arithmetic) -- so the number of flushes, not of rows, sets the duration.
+    {
+        constexpr int NACC = G * 4 * NJ;
+        __shared__ f32x4 red[NACC * 64];
+#pragma unroll 1
+        for (int src = 1; src < 4; ++src) {
+            if (wave == src) {
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                        for (int jb = 0; jb < NJ; ++jb) red[((gi * 4 + ja) * NJ + jb) * 64 + lane] = acc[gi][ja][jb];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                        for (int jb = 0; jb < NJ; ++jb) acc[gi][ja][jb] += red[((gi * 4 + ja) * NJ + jb) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wave != 0) return;
     }
     // flush: D[mrow][n], lane holds rows 4*kq + r of column n = lane & 15
     const int co0 = NJ * m;
@@ -387,7 +418,8 @@ static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradD
     using Cfg = WgradCfg<CI, CO, STRIDE>;
     const int rows = dm.B * dm.Do * dm.Ho;
     int gx = (rows + 3) / 4;
-    if (gx > 1024) gx = 1024;
+    static const int gx_cap = [] { const char* e = getenv("RCMVS_WGRAD_GX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();      // (developer sweep hook)
+    if (gx > gx_cap) gx = gx_cap;
     if (dm.D == 1 && STRIDE == 1) {
         // few rows (one-plane volumes): split each row into chunks of >= 64 cells until there are ~512 waves (more waves cost
         // more than they gain: every wave ends with an atomic flush of its whole accumulator set)
