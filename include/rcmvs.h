@@ -193,6 +193,18 @@ int rcmvs_bn_bwd_finalize(double* local_sums, const double* total_sums, const do
                           float* coef, int C, void* stream);
 int rcmvs_scale_shift_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                            long long rows, int C, int relu, void* stream);
+/* Fused forms, one launch instead of two (what the training path calls):
+ *   rcmvs_bn_norm_fwd = rcmvs_bn_finalize + rcmvs_scale_shift_relu: y = [relu](x*scale + shift) + residual with scale / shift derived from
+ *     `sums` (2C + 1 doubles, NOT modified); stats (5 x C floats) receives mean | biased var | invstd | scale | shift, *count the row
+ *     count; running statistics updated when given.
+ *   rcmvs_bn_norm_bwd = rcmvs_bn_bwd_finalize + rcmvs_bn_bwd_apply, with `stats` as written by the forward form.
+ * Neither can clear the sums it reads (other blocks are still reading them): the caller alternates between TWO accumulation buffers
+ * per layer and passes the one the PREVIOUS call of that layer consumed as `clear` (2C + 1 / 2C doubles, zeroed on return). */
+int rcmvs_bn_norm_fwd(const float* x, const double* sums, double* clear, const float* gamma, const float* beta, float eps, float momentum,
+                      float* stats, double* count, float* running_mean, float* running_var, const float* residual, float* y,
+                      long long rows, int C, int relu, void* stream);
+int rcmvs_bn_norm_bwd(const float* y, const float* dz, const float* stats, const double* local_sums, const double* total_sums,
+                      const double* count, double* clear, float* dgamma, float* dbeta, float* dy, long long rows, int C, int relu, void* stream);
 int rcmvs_bn_bwd_reduce(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,
                         const float* invstd, double* sums, long long rows, int C, int relu, void* stream);
 int rcmvs_bn_bwd_apply(const float* y, const float* dz, const float* scale, const float* shift, const float* mean,

@@ -50,6 +50,8 @@ SIGNATURES = {
     "rcmvs_bn_finalize": [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "rcmvs_bn_bwd_finalize": [_p, _p, _p, _p, _p, _p, _i, _p],
     "rcmvs_scale_shift_relu": [_p, _p, _p, _p, _p, _ll, _i, _i, _p],
+    "rcmvs_bn_norm_fwd": [_p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
+    "rcmvs_bn_norm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
     "rcmvs_bn_bwd_reduce": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
     "rcmvs_bn_bwd_apply": [_p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
     "rcmvs_conv3d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

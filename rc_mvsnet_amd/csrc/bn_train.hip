@@ -164,6 +164,81 @@ __global__ void bn_bwd_finalize_kernel(double* __restrict__ local, const double*
     }
 }
 
+// ---- fused forms (round 3): finalize + apply in ONE launch, forward and backward.  A training iteration has 134 BatchNorm layers x
+// two passes; the two one-block finalize launches per layer were 268 launches of 3 us that the host -- which issues ~2400 launches per
+// iteration and is what the GPU waits for since the weight-gradient flush was fixed -- can do without.  Every thread derives the
+// folded scale / shift (backward: the two coefficients) of its own channel quad from the fp64 sums (a few dozen flops, the same
+// expressions as the finalize kernels: bit-identical statistics); block 0 also writes the statistics the backward pass needs, the
+// running-statistics update and the parameter gradients.  The sums cannot be cleared here (other blocks are still reading them):
+// the caller alternates between TWO accumulation buffers per layer and this kernel clears the one the previous call consumed.
+__global__ __launch_bounds__(BN_BLOCK) void bn_norm_fwd_kernel(const float* __restrict__ x, const double* __restrict__ sums, double* __restrict__ clear,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                              float* __restrict__ stats, double* __restrict__ count_out,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              const float* __restrict__ res, float* __restrict__ y, long long n4, int C, int relu) {
+    const int nq = C / 4;
+    const double n = sums[2 * C];
+    const int q = threadIdx.x % nq;                        // (gridDim.x * BN_BLOCK) % nq == 0: a thread keeps its channel quad
+    v4f sc, sh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = q * 4 + k;
+        const double m = sums[c] / n;
+        double v = sums[C + c] / n - m * m;
+        v = v < 0.0 ? 0.0 : v;
+        const float is = (float)(1.0 / sqrt(v + (double)eps));
+        const float mf = (float)m;
+        const float s = gamma[c] * is;
+        sc[k] = s;
+        sh[k] = beta[c] - mf * s;
+        if (blockIdx.x == 0 && (int)threadIdx.x < nq) {    // one thread per channel quad records the layer's statistics
+            stats[c] = mf; stats[C + c] = (float)v; stats[2 * C + c] = is; stats[3 * C + c] = s; stats[4 * C + c] = sh[k];
+            if (running_mean) {
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(v * (n / (n - 1.0)));
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) count_out[0] = n;
+        for (int c = threadIdx.x; c < 2 * C + 1; c += BN_BLOCK) clear[c] = 0.0;
+    }
+    for (long long i = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; i < n4; i += (long long)gridDim.x * BN_BLOCK) {
+        v4f v = reinterpret_cast<const v4f*>(x)[i] * sc + sh;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (res) v += reinterpret_cast<const v4f*>(res)[i];
+        reinterpret_cast<v4f*>(y)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(BN_BLOCK) void bn_norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dz,
+                                                              const float* __restrict__ stats, const double* __restrict__ local,
+                                                              const double* __restrict__ total, const double* __restrict__ count, double* __restrict__ clear,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dy,
+                                                              long long n4, int C, int relu) {
+    const int nq = C / 4;
+    const double n = *count;
+    const int q = threadIdx.x % nq;
+    const v4f mu = reinterpret_cast<const v4f*>(stats)[q], is = reinterpret_cast<const v4f*>(stats + 2 * C)[q];
+    const v4f sc = reinterpret_cast<const v4f*>(stats + 3 * C)[q], sh = reinterpret_cast<const v4f*>(stats + 4 * C)[q];
+    v4f a, b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = q * 4 + k;
+        a[k] = (float)(total[c] / n);
+        b[k] = (float)(total[C + c] / n);
+        if (blockIdx.x == 0 && (int)threadIdx.x < nq) { dbeta[c] = (float)local[c]; dgamma[c] = (float)local[C + c]; }
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < 2 * C; c += BN_BLOCK) clear[c] = 0.0;
+    for (long long i = (long long)blockIdx.x * BN_BLOCK + threadIdx.x; i < n4; i += (long long)gridDim.x * BN_BLOCK) {
+        const v4f v = reinterpret_cast<const v4f*>(y)[i];
+        v4f g = reinterpret_cast<const v4f*>(dz)[i];
+        if (relu) g = relu_mask(g, v * sc + sh);
+        reinterpret_cast<v4f*>(dy)[i] = sc * (g - a - ((v - mu) * is) * b);
+    }
+}
+
 static inline unsigned grid_for(long long work_items) {
     long long g = cdiv(work_items, (long long)BN_BLOCK);
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -227,6 +302,30 @@ int rcmvs_bn_bwd_apply(const float* y, const float* dz, const float* scale, cons
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4 / 4)), dim3(BN_BLOCK), 0, as_stream(stream),
                        y, dz, scale, shift, mean, invstd, coef, dy, n4, C, relu);
     return launch_status("bn_bwd_apply");
+}
+
+int rcmvs_bn_norm_fwd(const float* x, const double* sums, double* clear, const float* gamma, const float* beta, float eps, float momentum,
+                      float* stats, double* count, float* running_mean, float* running_var, const float* residual, float* y,
+                      long long rows, int C, int relu, void* stream) {
+    RCMVS_REQUIRE(x && sums && clear && gamma && beta && stats && count && y && rows > 0, "bn_norm_fwd: bad arguments");
+    RCMVS_REQUIRE(sums != clear, "bn_norm_fwd: the buffer to clear must be the OTHER accumulation buffer of the layer");
+    RCMVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_norm_fwd: running_mean and running_var go together");
+    RCMVS_REQUIRE(C >= 4 && C % 4 == 0 && BN_BLOCK % (C / 4) == 0, "bn_norm_fwd: C=%d must be 4, 8, 16, 32, 64 ...", C);
+    const long long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_norm_fwd_kernel, dim3(grid_for(n4 / 4)), dim3(BN_BLOCK), 0, as_stream(stream), x, sums, clear, gamma, beta, eps, momentum,
+                       stats, count, running_mean, running_var, residual, y, n4, C, relu);
+    return launch_status("bn_norm_fwd");
+}
+
+int rcmvs_bn_norm_bwd(const float* y, const float* dz, const float* stats, const double* local_sums, const double* total_sums,
+                      const double* count, double* clear, float* dgamma, float* dbeta, float* dy, long long rows, int C, int relu, void* stream) {
+    RCMVS_REQUIRE(y && dz && stats && local_sums && total_sums && count && clear && dgamma && dbeta && dy && rows > 0, "bn_norm_bwd: bad arguments");
+    RCMVS_REQUIRE(local_sums != clear && total_sums != clear, "bn_norm_bwd: the buffer to clear must be the OTHER accumulation buffer of the layer");
+    RCMVS_REQUIRE(C >= 4 && C % 4 == 0 && BN_BLOCK % (C / 4) == 0, "bn_norm_bwd: C=%d unsupported", C);
+    const long long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_norm_bwd_kernel, dim3(grid_for(n4 / 4)), dim3(BN_BLOCK), 0, as_stream(stream), y, dz, stats, local_sums, total_sums, count,
+                       clear, dgamma, dbeta, dy, n4, C, relu);
+    return launch_status("bn_norm_bwd");
 }
 
 }  // extern "C"

@@ -154,16 +154,20 @@ def _conv_wgrad(x, dy, w_shape, transposed, stride):
 
 
 def _bn_scratch(cfg, which, S, n, device):
-    """The layer's fp64 accumulation buffer (S segments x n doubles), created zero once and kept on the BatchNorm module: the
-    finalize kernels clear what they consume (rcmvs.h), so no call fills it again.  Calls of one module are stream-ordered."""
+    """-> (cur, other): the layer's two fp64 accumulation buffers (S segments x n doubles each), created zero once and kept on the
+    BatchNorm module.  A call accumulates into `cur` and hands `other` -- the buffer the previous call of this layer consumed -- to
+    the fused normalisation kernel, which clears it (rcmvs_bn_norm_fwd / _bwd): no call fills a buffer again.  Calls of one
+    module are stream-ordered."""
     store = cfg.get("scratch")
     if store is None:
-        return torch.zeros((S, n), device=device, dtype=torch.float64)
+        z = torch.zeros((2, S, n), device=device, dtype=torch.float64)
+        return z[0], z[1]
     key = (which, S, n, str(device))
-    buf = store.get(key)
-    if buf is None:
-        buf = store[key] = torch.zeros((S, n), device=device, dtype=torch.float64)
-    return buf
+    ent = store.get(key)
+    if ent is None:
+        ent = store[key] = [torch.zeros((2, S, n), device=device, dtype=torch.float64), 0]
+    ent[1] ^= 1
+    return ent[0][ent[1]], ent[0][ent[1] ^ 1]
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -182,7 +186,7 @@ class ConvBnReluFn(torch.autograd.Function):
         C = y.shape[-1]
         S = int(cfg.get("segments", 1))
         nb = y.shape[0] // S
-        pack = _bn_scratch(cfg, "fwd", S, 2 * C + 1, x.device)                   # per segment [sum | sum of squares | rows]: zero between uses
+        pack, spent = _bn_scratch(cfg, "fwd", S, 2 * C + 1, x.device)            # per segment [sum | sum of squares | rows]; `spent`: the previous call's
         cnt = torch.empty((S,), device=x.device, dtype=torch.float64)           # rows behind the statistics (all ranks), for the backward pass
         stats = torch.empty((S, 5, C), device=x.device, dtype=torch.float32)     # mean, var, invstd, scale, shift
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
@@ -194,13 +198,12 @@ class ConvBnReluFn(torch.autograd.Function):
             bn_stats(ys, pack[sgm])
             if cfg.get("group") is not None:
                 dist.all_reduce(pack[sgm], group=cfg["group"])
-            st = stats[sgm]
-            _lib.check(lib.rcmvs_bn_finalize(ptr(pack[sgm]), ptr(cnt[sgm:]), _chk(g32, "gamma"), _chk(b32, "beta"),
-                                             float(cfg["eps"]), float(cfg.get("momentum", 0.0)), ptr(st[0]), ptr(st[1]), ptr(st[2]),
-                                             ptr(st[3]), ptr(st[4]), _opt(running_mean, "running_mean"),
-                                             _opt(running_var, "running_var"), C, _stream()), "bn_finalize")
-            scale_shift_relu(ys, st[3], st[4], None if res is None else res[sgm * nb:(sgm + 1) * nb], cfg["relu"],
-                             out=z[sgm * nb:(sgm + 1) * nb])
+            rs = None if res is None else res[sgm * nb:(sgm + 1) * nb]
+            zs = z[sgm * nb:(sgm + 1) * nb]
+            _lib.check(lib.rcmvs_bn_norm_fwd(_chk(ys, "y"), ptr(pack[sgm]), ptr(spent[sgm]), _chk(g32, "gamma"), _chk(b32, "beta"),
+                                             float(cfg["eps"]), float(cfg.get("momentum", 0.0)), ptr(stats[sgm]), ptr(cnt[sgm:]),
+                                             _opt(running_mean, "running_mean"), _opt(running_var, "running_var"), _opt(rs, "residual"),
+                                             _chk(zs, "z"), ys.numel() // C, C, int(bool(cfg["relu"])), _stream()), "bn_norm_fwd")
         ctx.save_for_backward(x, w, y, stats, cnt)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
@@ -214,8 +217,8 @@ class ConvBnReluFn(torch.autograd.Function):
         S = int(cfg.get("segments", 1))
         nb = y.shape[0] // S
         dz = dz.contiguous()
-        sums = _bn_scratch(cfg, "bwd", S, 2 * C, y.device)                         # zero between uses (bn_bwd_finalize clears it)
-        out = torch.empty((S, 4, C), device=y.device, dtype=torch.float32)        # per segment: dgamma, dbeta, coef (2C)
+        sums, spent = _bn_scratch(cfg, "bwd", S, 2 * C, y.device)
+        out = torch.empty((S, 2, C), device=y.device, dtype=torch.float32)        # per segment: dgamma, dbeta
         dy = torch.empty_like(y)
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
         for sgm in range(S):
@@ -226,9 +229,9 @@ class ConvBnReluFn(torch.autograd.Function):
             if cfg.get("group") is not None:
                 tot = sums[sgm].clone()
                 dist.all_reduce(tot, group=cfg["group"])
-            _lib.check(_lib.load().rcmvs_bn_bwd_finalize(ptr(sums[sgm]), ptr(tot), ptr(cnt[sgm:]), ptr(out[sgm, 0]),
-                                                         ptr(out[sgm, 1]), ptr(out[sgm, 2]), C, _stream()), "bn_bwd_finalize")
-            bn_bwd_apply(y[sl], dz[sl], scale, shift, mean, invstd, out[sgm, 2:].reshape(-1), cfg["relu"], out=dy[sl])
+            _lib.check(_lib.load().rcmvs_bn_norm_bwd(_chk(y[sl], "y"), _chk(dz[sl], "dz"), ptr(stats[sgm]), ptr(sums[sgm]), ptr(tot), ptr(cnt[sgm:]),
+                                                     ptr(spent[sgm]), ptr(out[sgm, 0]), ptr(out[sgm, 1]), _chk(dy[sl], "dy"), y[sl].numel() // C, C,
+                                                     int(bool(cfg["relu"])), _stream()), "bn_norm_bwd")
         dgamma, dbeta = (out[0, 0], out[0, 1]) if S == 1 else (out[:, 0].sum(0), out[:, 1].sum(0))
         dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"], x.shape[-1], _param_of(w)) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad(x, dy, w.shape, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[1] else None
