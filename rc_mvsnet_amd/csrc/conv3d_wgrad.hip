@@ -48,8 +48,9 @@ struct WgradCfg {
 
 // PLANE = the volume has a single plane (2-D layers run as D = 1): dead tap planes are skipped (kept out of the 3-D
 // instantiation, whose schedule the extra branches would disturb: 64->64 1.4 -> 3.8 ms when they were unconditional).
+constexpr int WG_WAVES = 8;       // row-walking waves per block: they are summed through LDS before the flush (fewer, larger flushes)
 template <int CI, int CO, int STRIDE, bool PLANE>
-__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(WG_WAVES * 64) void conv3d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dw, WgradDims dm, int rows,
                                                            int ldx, int ci_off, int ci_total, int wchunk) {
     using Cfg = WgradCfg<CI, CO, STRIDE>;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     constexpr int OOB = 0x7ffffff0;
     const int lane_off = (ci_off + cig * 4) * 4;
     const int cell_bytes = ldx * 4;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * WG_WAVES + wave; row < rows; row += gridDim.x * WG_WAVES) {
         const int oh = row % dm.Ho;
         const int od = (row / dm.Ho) % dm.Do;
         const int b = row / (dm.Ho * dm.Do);
@@ -157,15 +158,15 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
             }
         }
     }
-    // The block's four waves hold the same accumulator set (they walked different rows): sum them through LDS so that ONE wave
+    // The block's eight waves hold the same accumulator set (they walked different rows): sum them through LDS so that ONE wave
     // flushes.  The flush is what the kernel waits for -- every flushing wave adds its whole set to the same [27][CI][CO] words
     // (round 3, profiles/r3_wgrad_flush.txt: 32 -> 8 at 48x128x160 with 1024 blocks x 4 flushing waves 718 us, 256 blocks 370 us, for the
-    // same arithmetic) -- so the number of flushes, not of rows, sets the duration.
+    // same arithmetic) -- so the number of flushes, not of rows, sets the duration.  Four waves per block summed: 385 us; eight: 295 us; sixteen: 320 us.
     {
         constexpr int NACC = G * 4 * NJ;
         __shared__ f32x4 red[NACC * 64];
 #pragma unroll 1
-        for (int src = 1; src < 4; ++src) {
+        for (int src = 1; src < WG_WAVES; ++src) {
             if (wave == src) {
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi)
@@ -417,19 +418,19 @@ template <int CI, int CO, int STRIDE>
 static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradDims& dm, int ldx, int ci_off, int ci_total, hipStream_t st) {
     using Cfg = WgradCfg<CI, CO, STRIDE>;
     const int rows = dm.B * dm.Do * dm.Ho;
-    int gx = (rows + 3) / 4;
+    int gx = (rows + WG_WAVES - 1) / WG_WAVES;
     static const int gx_cap = [] { const char* e = getenv("RCMVS_WGRAD_GX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();      // (developer sweep hook)
     if (gx > gx_cap) gx = gx_cap;
     if (dm.D == 1 && STRIDE == 1) {
         // few rows (one-plane volumes): split each row into chunks of >= 64 cells until there are ~512 waves (more waves cost
         // more than they gain: every wave ends with an atomic flush of its whole accumulator set)
         int wchunks = 1;
-        while (gx * 4 * wchunks < 512 && dm.Wo / (wchunks * 2) >= 64) wchunks *= 2;
+        while (gx * WG_WAVES * wchunks < 512 && dm.Wo / (wchunks * 2) >= 64) wchunks *= 2;
         const int wchunk = ((dm.Wo + wchunks - 1) / wchunks + 3) / 4 * 4;
-        hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE, true>), dim3(gx, Cfg::SPLITS, (dm.Wo + wchunk - 1) / wchunk), dim3(256), 0, st,
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE, true>), dim3(gx, Cfg::SPLITS, (dm.Wo + wchunk - 1) / wchunk), dim3(WG_WAVES * 64), 0, st,
                            x, dy, dw, dm, rows, ldx, ci_off, ci_total, wchunk);
     } else {
-        hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE, false>), dim3(gx, Cfg::SPLITS), dim3(256), 0, st, x, dy, dw, dm, rows, ldx,
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, CO, STRIDE, false>), dim3(gx, Cfg::SPLITS), dim3(WG_WAVES * 64), 0, st, x, dy, dw, dm, rows, ldx,
                            ci_off, ci_total, dm.Wo);
     }
     return launch_status("conv3d_wgrad");
