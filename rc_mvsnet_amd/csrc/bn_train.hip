@@ -14,6 +14,7 @@
 // statistics of a million-voxel volume accurate to fp32 round-off.  The fp64 sums are what a
 // SyncBatchNorm all-reduce exchanges (train_rcmvsnet.py:525), so the multi-GPU path needs no extra kernel.
 #include "common.h"
+#include <cstdlib>
 
 namespace rcmvs {
 
@@ -47,7 +48,16 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_kernel(const float* __restr
     const int q = threadIdx.x % nq;
     const long long rpb = BN_BLOCK / nq;                   // rows per block iteration
     v4f acc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
-    for (long long r = (long long)blockIdx.x * rpb + threadIdx.x / nq; r < rows; r += (long long)gridDim.x * rpb) {
+    const long long stride = (long long)gridDim.x * rpb;
+    long long r = (long long)blockIdx.x * rpb + threadIdx.x / nq;
+    for (; r + 3 * stride < rows; r += 4 * stride) {           // four independent loads in flight per lane
+        v4f v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const v4f*>(x + (r + k * stride) * C + q * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[0] += v[k]; acc[1] += v[k] * v[k]; }
+    }
+    for (; r < rows; r += stride) {
         const v4f v = *reinterpret_cast<const v4f*>(x + r * C + q * 4);
         acc[0] += v;
         acc[1] += v * v;
@@ -86,7 +96,23 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_reduce_kernel(const float* __
     const v4f sc = reinterpret_cast<const v4f*>(scale)[q], sh = reinterpret_cast<const v4f*>(shift)[q];
     const v4f mu = reinterpret_cast<const v4f*>(mean)[q], is = reinterpret_cast<const v4f*>(invstd)[q];
     v4f acc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
-    for (long long r = (long long)blockIdx.x * rpb + threadIdx.x / nq; r < rows; r += (long long)gridDim.x * rpb) {
+    const long long stride = (long long)gridDim.x * rpb;
+    long long r = (long long)blockIdx.x * rpb + threadIdx.x / nq;
+    for (; r + stride < rows; r += 2 * stride) {               // two rows (four loads) in flight per lane
+        v4f v[2], g[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            v[k] = *reinterpret_cast<const v4f*>(y + (r + k * stride) * C + q * 4);
+            g[k] = *reinterpret_cast<const v4f*>(dz + (r + k * stride) * C + q * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (relu) g[k] = relu_mask(g[k], v[k] * sc + sh);
+            acc[0] += g[k];
+            acc[1] += g[k] * ((v[k] - mu) * is);
+        }
+    }
+    for (; r < rows; r += stride) {
         const v4f v = *reinterpret_cast<const v4f*>(y + r * C + q * 4);
         v4f g = *reinterpret_cast<const v4f*>(dz + r * C + q * 4);
         if (relu) g = relu_mask(g, v * sc + sh);
@@ -243,6 +269,13 @@ static inline unsigned grid_for(long long work_items) {
     long long g = cdiv(work_items, (long long)BN_BLOCK);
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
+// the two reductions end with one fp64 atomic per channel and BLOCK on the same 2C words: same-address atomics serialise (~90 per
+// microsecond), so their grid is capped lower than the element-wise kernels' (developer hook RCMVS_BN_RED_GRID for the sweep)
+static inline unsigned grid_for_reduce(long long work_items) {
+    static const long long cap = [] { const char* e = getenv("RCMVS_BN_RED_GRID"); const int v = e ? atoi(e) : 0; return (long long)(v > 0 ? v : 256); }();      // (sweep: profiles/r3_bn_reduce_grid.txt)
+    long long g = cdiv(work_items, (long long)BN_BLOCK);
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
 
 }  // namespace rcmvs
 
@@ -253,7 +286,7 @@ extern "C" {
 int rcmvs_bn_stats(const float* x, double* sums, long long rows, int C, void* stream) {
     RCMVS_REQUIRE(x && sums && rows > 0, "bn_stats: bad arguments");
     RCMVS_REQUIRE(C >= 4 && C % 4 == 0 && BN_BLOCK % (C / 4) == 0, "bn_stats: C=%d must be 4, 8, 16, 32, 64 ...", C);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows * (C / 4) / 8)), dim3(BN_BLOCK), 0, as_stream(stream), x, sums, rows, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for_reduce(rows * (C / 4) / 8)), dim3(BN_BLOCK), 0, as_stream(stream), x, sums, rows, C);
     return launch_status("bn_stats");
 }
 
@@ -289,7 +322,7 @@ int rcmvs_bn_bwd_reduce(const float* y, const float* dz, const float* scale, con
                         const float* invstd, double* sums, long long rows, int C, int relu, void* stream) {
     RCMVS_REQUIRE(y && dz && scale && shift && mean && invstd && sums && rows > 0, "bn_bwd_reduce: bad arguments");
     RCMVS_REQUIRE(C >= 4 && C % 4 == 0 && BN_BLOCK % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows * (C / 4) / 8)), dim3(BN_BLOCK), 0, as_stream(stream),
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for_reduce(rows * (C / 4) / 8)), dim3(BN_BLOCK), 0, as_stream(stream),
                        y, dz, scale, shift, mean, invstd, sums, rows, C, relu);
     return launch_status("bn_bwd_reduce");
 }
