@@ -215,6 +215,10 @@ int rcmvs_bn_bwd_apply(const float* y, const float* dz, const float* scale, cons
  *   input, stride 2: dw[27][Cout][Cin] -> permute to (Cin,Cout,27). */
 int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D, int H, int W, int Ci, int Co, int stride,
                        void* stream);
+/* packed gradient [27][P][Q] (as rcmvs_conv3d_wgrad accumulates it) -> out (Q, Pk, 27) = nn.Conv3d's weight layout (Co, Ci, 27) /
+ * nn.ConvTranspose3d's (Cin, Cout, 27) with the roles swapped; rows p >= Pk (padding channels) are dropped; `packed` is ZEROED, ready to
+ * accumulate the next gradient of that shape (what autograd does with a permute + reshape copy, plus the zero fill before). */
+int rcmvs_wgrad_finish(float* packed, float* out, int P, int Q, int Pk, void* stream);
 /* data gradient of the 1-output-channel prob conv (modules.py:489): dy (B,D,H,W), w (1,Ci,3,3,3) as stored, dx (B,D,H,W,Ci) */
 int rcmvs_conv3d_dgrad_c1(const float* dy, const float* w, float* dx, int B, int D, int H, int W, int Ci, void* stream);
 /* softmax + soft-argmin backward (casmvsnet.py:299-300): grad_logits = prob * (d_k - depth) * grad_depth */

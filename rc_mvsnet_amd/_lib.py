@@ -55,6 +55,7 @@ SIGNATURES = {
     "rcmvs_bn_bwd_reduce": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
     "rcmvs_bn_bwd_apply": [_p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p],
     "rcmvs_conv3d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_wgrad_finish": [_p, _p, _i, _i, _i, _p],
     "rcmvs_conv3d_dgrad_c1": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rcmvs_depth_head_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_warp_noref_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

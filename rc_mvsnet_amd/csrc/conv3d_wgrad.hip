@@ -410,6 +410,18 @@ __global__ __launch_bounds__(256) void conv3d_dgrad_c1_kernel(const float* __res
         *reinterpret_cast<f32x4*>(dx + i * CI + c) = (f32x4){acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
 }
 
+// packed accumulation layout [27][P][Q] -> the parameter's layout (Q, Pk, 27), Pk <= P (padding channels dropped), and the packed
+// buffer is cleared for its next use: one launch instead of a zero fill before and a permute copy after every weight gradient.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ packed, float* __restrict__ out, int P, int Q, int Pk) {
+    const int n = 27 * P * Q;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const int q = e % Q, p = (e / Q) % P, t = e / (Q * P);
+        const float v = packed[e];
+        packed[e] = 0.0f;
+        if (p < Pk) out[((long long)q * Pk + p) * 27 + t] = v;
+    }
+}
+
 }  // namespace rcmvs
 
 using namespace rcmvs;
@@ -437,6 +449,13 @@ static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradD
 }
 
 extern "C" {
+
+int rcmvs_wgrad_finish(float* packed, float* out, int P, int Q, int Pk, void* stream) {
+    RCMVS_REQUIRE(packed && out && P > 0 && Q > 0 && Pk > 0 && Pk <= P, "wgrad_finish: bad arguments");
+    const int n = 27 * P * Q;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((n + 255) / 256 > 512 ? 512 : (n + 255) / 256), dim3(256), 0, as_stream(stream), packed, out, P, Q, Pk);
+    return launch_status("wgrad_finish");
+}
 
 int rcmvs_conv3d_wgrad(const float* x, const float* dy, float* dw, int B, int D, int H, int W, int Ci, int Co, int stride,
                        void* stream) {

@@ -51,17 +51,35 @@ def bn_bwd_apply(y, dz, scale, shift, mean, invstd, coef, relu, out=None):
     return dy
 
 
-def conv3d_wgrad(x, dy, stride):
-    """x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) -> packed weight gradient (27,Ci,Co)."""
+def conv3d_wgrad(x, dy, stride, out=None):
+    """x (B,D,H,W,Ci), dy (B,Do,Ho,Wo,Co) -> packed weight gradient (27,Ci,Co); `out`: a ZERO (27,Ci,Co) buffer to accumulate into."""
     B, D, H, W, Ci = x.shape
     Co = dy.shape[-1]
     exp = (B, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1)
     if tuple(dy.shape[:4]) != exp:
         raise _lib.RcmvsError(f"conv3d_wgrad: dy {tuple(dy.shape)} does not match x {tuple(x.shape)} at stride {stride}")
-    dw = torch.zeros((27, Ci, Co), device=x.device, dtype=torch.float32)
+    dw = torch.zeros((27, Ci, Co), device=x.device, dtype=torch.float32) if out is None else out
     _lib.check(_lib.load().rcmvs_conv3d_wgrad(_chk(x, "x"), _chk(dy, "dy"), _chk(dw, "dw"), B, D, H, W, Ci, Co, stride, _stream()),
                "conv3d_wgrad")
     return dw
+
+
+# packed-gradient accumulation buffers by shape: zero when created, re-zeroed by rcmvs_wgrad_finish after every use (stream-ordered)
+_WGRAD_SCRATCH = {}
+
+
+def _wgrad_to_param_layout(big, small, stride, w_shape):
+    """Weight gradient in the parameter's layout (w_shape = (Q, Pk, 3, 3, 3)): accumulate [27][P][Q] into the persistent zero buffer
+    of that shape, then one launch that permutes it out and clears the buffer (no zero fill, no permute copy)."""
+    P, Q = big.shape[-1], small.shape[-1]
+    key = (P, Q, str(big.device))
+    buf = _WGRAD_SCRATCH.get(key)
+    if buf is None:
+        buf = _WGRAD_SCRATCH[key] = torch.zeros((27, P, Q), device=big.device, dtype=torch.float32)
+    conv3d_wgrad(big, small, stride, out=buf)
+    out = torch.empty(tuple(w_shape), device=big.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_wgrad_finish(_chk(buf, "packed"), _chk(out, "dw"), P, Q, int(w_shape[1]), _stream()), "wgrad_finish")
+    return out
 
 
 def conv3d_dgrad_c1(dy, w):
@@ -148,9 +166,8 @@ def _conv_dgrad(dy, w, transposed, stride, cx, param=None):
 
 def _conv_wgrad(x, dy, w_shape, transposed, stride):
     if transposed:                                   # roles swap: the large tensor (dy) is strided over -> (27, Cout_T, Cin_T)
-        return conv3d_wgrad(dy, x, 2).permute(2, 1, 0).reshape(w_shape)
-    dw = conv3d_wgrad(x, dy, stride)                 # (27, Cx, Co), Cx >= Ci when the input carries padding channels
-    return dw[:, :w_shape[1]].permute(2, 1, 0).reshape(w_shape)
+        return _wgrad_to_param_layout(dy, x, 2, w_shape)
+    return _wgrad_to_param_layout(x, dy, stride, w_shape)       # (27, Cx, Co), Cx >= Ci when the input carries padding channels
 
 
 def _bn_scratch(cfg, which, S, n, device):
