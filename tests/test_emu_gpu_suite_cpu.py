@@ -61,11 +61,13 @@ def reuse(module, name, slow=False):
 FAST = {
     GP: ["test_layout_roundtrip", "test_compose_homography", "test_hypothesis_planes_vs_golden", "test_hypothesis_planes_stage1_exact",
          "test_warp_variance_vs_oracle", "test_warp_variance_golden_fixture", "test_warp_variance_backward_vs_oracle_autograd",
-         "test_conv3d_vs_oracle", "test_conv3d_x3_item_schedule_is_bit_exact", "test_conv3d_x3_planar_vs_fp64", "test_conv3d_x3h_vs_fp64", "test_prob_conv_marching_kernel", "test_conv2d_s2d_is_the_5x5_stride2_layer", "test_conv3d_lds_halo_kernel", "test_deconv3d_vs_oracle", "test_conv3d_golden_and_linearity",
+         "test_conv3d_vs_oracle", "test_conv3d_x3_item_schedule_is_bit_exact", "test_conv3d_x3_planar_vs_fp64", "test_conv3d_x3h_vs_fp64", "test_prob_conv_marching_kernel", "test_prob_conv_z_chunk_does_not_change_the_result", "test_conv2d_s2d_is_the_5x5_stride2_layer", "test_conv3d_lds_halo_kernel", "test_deconv3d_vs_oracle", "test_conv3d_golden_and_linearity",
          "test_costreg_vs_golden", "test_conv2d_vs_torch_cpu", "test_depth_head_vs_oracle", "test_depth_head_golden",
          "test_fpn_out_fused_is_bit_identical"],
     GR: ["test_resize_planes", "test_gu_sampler_vs_oracle", "test_nerf_mlp_vs_oracle", "test_composite_vs_oracle"],
-    GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel", "test_conv3d_weight_gradient_cout8_paired_columns"],
+    GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel", "test_conv3d_weight_gradient_cout8_paired_columns",
+         "test_selective_weight_pack_matches_full_blob_and_is_checked", "test_packed_weight_reuse_follows_the_parameter_version",
+         "test_fused_batchnorm_forms_equal_the_two_launch_forms", "test_weight_gradient_finish_permutes_and_clears"],
     GL: ["test_unsup_loss_multi_stage_matches_reference", "test_inverse_warping_matches_reference", "test_aug_loss_and_sl1_match_reference",
          "test_unsup_loss_argument_checks"],
     GF: ["test_check_geometric_consistency_matches_reference", "test_filter_depth_matches_reference", "test_fuse_view_argument_checks",

@@ -429,6 +429,22 @@ def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
         assert torch.equal(y, base), (blocks, float((y - base).abs().max()))
 
 
+def test_prob_conv_z_chunk_does_not_change_the_result(hip):
+    """The marching prob conv picks its z chunk per launch (grid fill); a block stages chunk + 2 planes, every output voxel still sums
+    the same three planes in the same order: any chunk length (debug selector bits 16-23) must give bit-identical logits."""
+    g = torch.Generator().manual_seed(21)
+    x = gpu(torch.randn(1, 13, 20, 40, 8, generator=g))
+    w = hip.pack_conv3d_weight(gpu(torch.randn(1, 8, 3, 3, 3, generator=g) / 15))
+    base = hip.conv3d(x, w).cpu()
+    for zc in (2, 3, 5, 13, 16):
+        try:
+            hip.force_direct_conv(zc << 16)
+            y = hip.conv3d(x, w).cpu()
+        finally:
+            hip.force_direct_conv(0)
+        assert torch.equal(y, base), zc
+
+
 @pytest.mark.parametrize("shape", [(2, 11, 13, 45), (1, 20, 9, 70), (1, 3, 8, 32), (1, 8, 24, 33)])
 def test_prob_conv_marching_kernel(hip, shape):
     """The 8 -> 1 prob conv runs on the plane-marching kernel (one staged plane feeds the three kd taps through rolling

@@ -581,3 +581,115 @@ def test_cascade_train_gradients_conditioned_network(grad_method):
     # single ReLU pre-activations within one rounding error of zero, profiles/r3_grad_outlier_bisect.txt
     assert errs[worst] <= 2e-3, (worst, errs[worst], sv[-1])
     assert ev[len(ev) // 2] <= (1e-4 if grad_method == "detach" else 1e-3), (ev[len(ev) // 2], sv[len(sv) // 2])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: the bookkeeping around the training kernels (selective weight pack, pack reuse, fused BatchNorm forms, gradient finish)
+# ------------------------------------------------------------------------------------------------
+def test_selective_weight_pack_matches_full_blob_and_is_checked():
+    """rcmvs_pack_conv3d_weight_sel writes only the image the production dispatch reads for a call; the result of that call equals
+    the one on the full blob bit for bit, and a call that would read an image that was not written is refused on the host."""
+    from rc_mvsnet_amd import ops, _lib
+    _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for (ci, co, stride, shape) in ((16, 8, 1, (1, 4, 9, 35)), (8, 16, 2, (1, 4, 10, 34)), (32, 32, 1, (2, 1, 12, 20)), (64, 64, 1, (1, 2, 6, 10))):
+        x = torch.randn(*shape, ci, generator=g).to(DEV)
+        w = (torch.randn(co, ci, 3, 3, 3, generator=g) / (ci * 27) ** 0.5).to(DEV)
+        planar = stride == 1 and shape[1] == 1
+        full, one = ops.pack_conv3d_weight(w), ops.pack_conv3d_weight(w, use=(stride, planar))
+        assert one.images != ops.IMG_ALL and bin(one.images).count("1") == 1
+        assert torch.equal(ops.conv3d(x, full, stride=stride), ops.conv3d(x, one, stride=stride))
+        other = ops.pack_conv3d_weight(w, use=(stride, not planar)) if stride == 1 else None
+        if other is not None and other.images != one.images:
+            with pytest.raises(_lib.RcmvsError):
+                ops.conv3d(x, other, stride=stride)
+    wt = (torch.randn(16, 8, 3, 3, 3, generator=g) / 20).to(DEV)
+    x = torch.randn(1, 3, 6, 18, 16, generator=g).to(DEV)
+    assert torch.equal(ops.deconv3d(x, ops.pack_conv3d_weight(wt, transposed=True)), ops.deconv3d(x, ops.pack_conv3d_weight(wt, transposed=True, use=(2, False))))
+
+
+def test_packed_weight_reuse_follows_the_parameter_version():
+    """train_ops reuses a parameter's packed image while the parameter is unchanged and re-packs after an in-place update."""
+    from rc_mvsnet_amd import train_ops, _lib
+    _lib.load()
+    train_ops.clear_pack_cache()
+    g = torch.Generator().manual_seed(4)
+    w = torch.nn.Parameter((torch.randn(8, 16, 3, 3, 3, generator=g) / 20).to(DEV))
+    x = torch.randn(1, 4, 9, 20, 16, generator=g).to(DEV)
+    a = train_ops._packed(w.detach(), False, 1, False, w)
+    assert train_ops._packed(w.detach(), False, 1, False, w) is a                      # same version: the cached blob
+    assert train_ops._packed(w.detach(), 2, 1, False, w) is not a                      # another pack mode: its own entry
+    y0 = train_ops._conv_raw(x, w.detach(), False, 1, w)
+    with torch.no_grad():
+        w.mul_(2.0)                                                                   # what an optimizer step does: bumps the version
+    b = train_ops._packed(w.detach(), False, 1, False, w)
+    assert b is not a
+    y1 = train_ops._conv_raw(x, w.detach(), False, 1, w)
+    assert float((y1 - 2.0 * y0).abs().max()) <= 1e-5 * float(y1.abs().max())
+    train_ops.clear_pack_cache()
+
+
+@pytest.mark.parametrize("C,rows,relu", [(8, 1000, True), (32, 77, False), (64, 513, True)])
+def test_fused_batchnorm_forms_equal_the_two_launch_forms(C, rows, relu):
+    """rcmvs_bn_norm_fwd / _bwd = finalize + apply in one launch: bit-identical statistics, outputs and gradients; the accumulation
+    buffer handed over as `clear` comes back zero and the one that was read is left intact."""
+    import ctypes
+    from rc_mvsnet_amd import train_ops, _lib
+    lib = _lib.load()
+    from rc_mvsnet_amd.ops import _stream
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    g = torch.Generator().manual_seed(C + rows)
+    y = (torch.randn(rows, C, generator=g) * 3 + 1).to(DEV)
+    res = torch.randn(rows, C, generator=g).to(DEV)
+    dz = torch.randn(rows, C, generator=g).to(DEV)
+    gamma, beta = (0.5 + torch.rand(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    f64 = lambda n: torch.zeros(n, device=DEV, dtype=torch.float64)
+    # ---- two-launch reference
+    s_a = f64(2 * C + 1); train_ops.bn_stats(y, s_a)
+    keep = s_a.clone()
+    cnt_a = f64(1); st_a = torch.empty(5, C, device=DEV)
+    rm_a, rv_a = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    _lib.check(lib.rcmvs_bn_finalize(ptr(s_a), ptr(cnt_a), ptr(gamma), ptr(beta), 1e-5, 0.1, ptr(st_a[0]), ptr(st_a[1]), ptr(st_a[2]), ptr(st_a[3]),
+                                     ptr(st_a[4]), ptr(rm_a), ptr(rv_a), C, _stream()), "bn_finalize")
+    assert float(s_a.abs().max()) == 0.0 and float(cnt_a[0]) == rows                   # consumed and cleared, the row count handed on
+    z_a = train_ops.scale_shift_relu(y, st_a[3], st_a[4], res, relu)
+    # ---- fused
+    s_b = keep.clone(); dirty = torch.full((2 * C + 1,), 7.0, device=DEV, dtype=torch.float64)
+    cnt_b = f64(1); st_b = torch.empty(5, C, device=DEV); z_b = torch.empty_like(y)
+    rm_b, rv_b = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    _lib.check(lib.rcmvs_bn_norm_fwd(ptr(y), ptr(s_b), ptr(dirty), ptr(gamma), ptr(beta), 1e-5, 0.1, ptr(st_b), ptr(cnt_b), ptr(rm_b), ptr(rv_b),
+                                     ptr(res), ptr(z_b), rows, C, int(relu), _stream()), "bn_norm_fwd")
+    assert torch.equal(st_a, st_b) and torch.equal(z_a, z_b) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    assert float(dirty.abs().max()) == 0.0 and torch.equal(s_b, keep) and float(cnt_b[0]) == rows
+    # ---- backward
+    l_a = f64(2 * C); train_ops.bn_bwd_reduce(y, dz, st_a[3], st_a[4], st_a[0], st_a[2], l_a, relu)
+    keep = l_a.clone()
+    out_a = torch.empty(4, C, device=DEV)
+    _lib.check(lib.rcmvs_bn_bwd_finalize(ptr(l_a), ptr(keep), ptr(cnt_a), ptr(out_a[0]), ptr(out_a[1]), ptr(out_a[2]), C, _stream()), "bn_bwd_finalize")
+    dy_a = train_ops.bn_bwd_apply(y, dz, st_a[3], st_a[4], st_a[0], st_a[2], out_a[2:].reshape(-1), relu)
+    l_b = keep.clone(); dirty = torch.full((2 * C,), 7.0, device=DEV, dtype=torch.float64)
+    out_b = torch.empty(2, C, device=DEV); dy_b = torch.empty_like(y)
+    _lib.check(lib.rcmvs_bn_norm_bwd(ptr(y), ptr(dz), ptr(st_b), ptr(l_b), ptr(l_b), ptr(cnt_b), ptr(dirty), ptr(out_b[0]), ptr(out_b[1]), ptr(dy_b),
+                                     rows, C, int(relu), _stream()), "bn_norm_bwd")
+    assert torch.equal(out_a[:2], out_b) and torch.equal(dy_a, dy_b) and float(dirty.abs().max()) == 0.0 and torch.equal(l_b, keep)
+
+
+def test_weight_gradient_finish_permutes_and_clears():
+    """rcmvs_wgrad_finish: packed [27][P][Q] -> (Q, Pk, 27) with the padding rows dropped, packed buffer zero afterwards; the layer-level
+    path (persistent accumulation buffer) gives the same gradient twice in a row."""
+    from rc_mvsnet_amd import train_ops, _lib
+    from rc_mvsnet_amd.ops import _chk, _stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    P, Q, Pk = 12, 8, 9
+    packed = torch.randn(27, P, Q, generator=g).to(DEV)
+    want = packed[:, :Pk].permute(2, 1, 0).contiguous()
+    out = torch.empty(Q, Pk, 27, device=DEV)
+    _lib.check(lib.rcmvs_wgrad_finish(_chk(packed, "packed"), _chk(out, "out"), P, Q, Pk, _stream()), "wgrad_finish")
+    assert torch.equal(out, want) and float(packed.abs().max()) == 0.0
+    x = torch.randn(1, 3, 7, 22, 16, generator=g).to(DEV)
+    dy = torch.randn(1, 3, 7, 22, 8, generator=g).to(DEV)
+    ref = train_ops.conv3d_wgrad(x, dy, 1).permute(2, 1, 0).reshape(8, 16, 3, 3, 3)
+    for _ in range(2):                                                                  # second call: the buffer the first one cleared
+        got = train_ops._conv_wgrad(x, dy, (8, 16, 3, 3, 3), False, 1)
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())          # (atomic summation order differs between launches)
