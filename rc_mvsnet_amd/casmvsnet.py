@@ -20,6 +20,8 @@ Execution:
 """
 import os
 
+FP16_PAIR_DEFAULT = True       # inference CostRegNet on the fp16-pair matrix-core form unless RCMVS_FP16_PAIR=0 (the exact bf16 triple)
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -328,10 +330,10 @@ class CostRegNet(nn.Module):
 
     def features_cl(self, x, x_absmax=None):
         """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8).
-        x_absmax: bound of max|x| (ops.absmax format; the cascade derives it from the feature maps).  With it the layers run on the
-        fp16-pair form of the matrix-core kernels (half the matrix-pipe work of the exact bf16 triple): every layer hands the
-        bound of its output to its consumer through a zero-filled scratch vector (one small fill per call).  Without it (the
-        default): the exact three-piece bf16 form."""
+        x_absmax: None = the exact three-piece bf16 form of the matrix-core kernels; or a (7, ops.ABSMAX_FLOATS) tensor whose row 0
+        is a bound of max|x| (ops.absmax format; the cascade derives it from the feature maps) and whose rows 1-6 are ZERO: the
+        layers then run on the fp16-pair form (half the matrix-pipe work) and every layer leaves the bound of its output in the
+        next row for its consumer (one atomic max per block, inside the kernel)."""
         B, D, h, w, _ = x.shape
         if D % 8 or h % 8 or w % 8:
             raise RcmvsError(f"CostRegNet: volume {D}x{h}x{w} must be divisible by 8 in every axis "
@@ -345,16 +347,16 @@ class CostRegNet(nn.Module):
             t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True)
             t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True)
             return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True)
-        m = torch.zeros(5, ops.ABSMAX_FLOATS, device=x.device, dtype=torch.float32)          # bounds of conv0, 1, 2, 3, 9
-        b = [m[i] for i in range(5)]
+        b = [x_absmax[i] for i in range(1, 7)]                    # bounds of conv0, 1, 2, 3, 9, 7 (zero on entry: the caller's one fill per scene)
+        x_absmax = x_absmax[0]
         conv0 = ops.conv3d(x, *p["conv0"], relu=True, x_absmax=x_absmax, y_absmax=b[0])
         conv1 = ops.conv3d(conv0, *p["conv1"], stride=2, relu=True, x_absmax=b[0], y_absmax=b[1])
         conv2 = ops.conv3d(conv1, *p["conv2"], relu=True, x_absmax=b[1], y_absmax=b[2])
         conv3 = ops.conv3d(conv2, *p["conv3"], stride=2, relu=True, x_absmax=b[2], y_absmax=b[3])
         conv4 = ops.conv3d(conv3, *p["conv4"], relu=True, x_absmax=b[3])
         t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)          # fp32-MFMA deep levels: no bounds kept
-        t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True)
-        t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True, y_absmax=b[4])                             # three-piece form (no bound of conv7's output)
+        t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True, y_absmax=b[5])                             # (the fp32 kernel keeps the bound too)
+        t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True, x_absmax=b[5], y_absmax=b[4])
         return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True, x_absmax=b[4])
 
     def features_cl_train(self, x):
@@ -463,6 +465,16 @@ class _CascadeBase(nn.Module):
             feats_cl = self._fpn_outputs_on_side_stream(feats_cl, imgs)
         outputs = {}
         depth = None
+        bounds = None
+        pair = FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
+        if pair and B == 1:          # (the bounds are per launch: with B > 1 a sample's rounding would depend on its batch mates -> exact form)
+            # activation bounds of the fp16-pair kernels: one persistent (stage, 7, 1024) buffer per model, ONE fill per scene
+            # (row 0 of a stage: bound of the variance volume; rows 1-6: written by the layers).  Not re-entrant across streams.
+            bounds = getattr(self, "_pair_bounds", None)
+            if bounds is None or bounds.device != imgs.device:
+                bounds = self._pair_bounds = torch.zeros(self.num_stage, 7, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
+            else:
+                bounds.zero_()
         for s in range(self.num_stage):
             key = "stage{}".format(s + 1)
             scale = int(self.stage_infos[key]["scale"])
@@ -481,11 +493,13 @@ class _CascadeBase(nn.Module):
             planes = ops.hypothesis_planes(depth, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
             var = ops.warp_variance(f_cl, rot, trans, planes, D)
             cr = self._cr(s)
-            # RCMVS_FP16_PAIR=1: the cost regularisation on the two-piece fp16 form of the matrix-core kernels (half the MFMAs of the exact
-            # bf16 triple).  It needs a bound of max|var|: var = E[f^2] - E[f]^2 <= max f^2, from the feature maps, no pass over the
-            # volume.  Measured (profiles/r3_x3_times_final.txt): faster kernels stand-alone (conv0 118 against 144 us), but in the
-            # pipeline both forms sit behind the producer waves (1.502 against 1.475 ms per scene with the bound kernels): off by default.
-            vmax = ops.absmax(f_cl, square=True) if os.environ.get("RCMVS_FP16_PAIR", "0") == "1" else None
+            # The cost regularisation runs on the two-piece fp16 form of the matrix-core kernels (half the MFMAs of the exact bf16
+            # triple; RCMVS_FP16_PAIR=0 selects the exact form).  It needs a bound of max|var|: var = E[f^2] - E[f]^2 <= max f^2, from
+            # the feature maps, no pass over the volume; the layers keep the bounds of their outputs themselves.
+            vmax = None
+            if bounds is not None:
+                vmax = bounds[s]
+                ops.absmax(f_cl, square=True, out=vmax[0])
             x8 = cr.features_cl(var, vmax)
             depth, conf = ops.depth_head(x8, cr.hip_plan()["prob"], planes)
             out = {"depth": depth, "photometric_confidence": conf}

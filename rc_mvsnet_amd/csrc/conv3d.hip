@@ -131,7 +131,7 @@ static int direct_dispatch(const float* x, const float* wp, const float* scale, 
 
 // conv3d_mfma.hip
 int conv3d_mfma_launch(const float* x, const float* wm, const float* scale, const float* shift, const float* res,
-                       float* y, int B, int D, int H, int W, int Ci, int Co, int mode, int relu, hipStream_t st);
+                       float* y, int B, int D, int H, int W, int Ci, int Co, int mode, int relu, hipStream_t st, float* ymax = nullptr);
 bool conv3d_mfma_supported(int Ci, int Co, int mode);
 int pack_weight_mfma_launch(const float* w, float* packed, int Co, int Ci, int transposed, hipStream_t st);
 long long mfma_weight_floats_host(int Ci, int Co);
@@ -275,7 +275,7 @@ int rcmvs_pack_conv3d_weight(const float* w, float* packed, int Co, int Ci, int 
 }
 
 // xmax / ymax (the `scaled` entry points): device scalars; xmax = a bound of max|x| (selects the fp16-pair matrix-core form where the
-// channel pair has one), ymax = receives max|y| (only the split-operand matrix-core kernels maintain it: an error elsewhere)
+// channel pair has one), ymax = receives max|y| (the matrix-core kernels -- split-operand and fp32 -- maintain it: an error elsewhere)
 static int conv3d_dispatch(const float* x, const float* w_packed, const float* scale, const float* shift,
                            const float* residual, float* y,
                            int B, int D, int H, int W, int Ci, int Co, int stride, int relu, void* stream, const ConvImpl& im,
@@ -294,12 +294,12 @@ static int conv3d_dispatch(const float* x, const float* w_packed, const float* s
         return conv3d_x3_launch(x, w_packed + x3h_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks, 0, xmax, ymax);
     if (sel == SEL_X3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks, 0, nullptr, ymax);
-    RCMVS_REQUIRE(!ymax, "conv3d_scaled_fwd: no split-operand kernel for Ci=%d Co=%d stride=%d, the output bound cannot be maintained", Ci, Co, stride);
-    if (sel == SEL_LDS)
-        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
     if (sel == SEL_MFMA)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
-                                  mode, relu, st);
+                                  mode, relu, st, ymax);
+    RCMVS_REQUIRE(!ymax, "conv3d_scaled_fwd: no matrix-core kernel for Ci=%d Co=%d stride=%d, the output bound cannot be maintained", Ci, Co, stride);
+    if (sel == SEL_LDS)
+        return conv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, st, im.lds_cfg);
     if (stride == 1) return direct_dispatch<CONV_S1>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
     return direct_dispatch<CONV_S2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, st);
 }
@@ -347,12 +347,12 @@ static int deconv3d_dispatch(const float* x, const float* w_packed, const float*
     if (sel == SEL_X3)
         return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, CONV_T2), scale, shift, residual, y, B, D, H, W, Ci, Co, CONV_T2, relu,
                                 as_stream(stream), im.x3_blocks, 0, nullptr, ymax);
-    RCMVS_REQUIRE(!ymax, "deconv3d_scaled_fwd: no split-operand kernel for Ci=%d Co=%d, the output bound cannot be maintained", Ci, Co);
-    if (sel == SEL_LDS)
-        return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
     if (sel == SEL_MFMA)
         return conv3d_mfma_launch(x, w_packed + direct_weight_floats(Ci, Co), scale, shift, residual, y, B, D, H, W, Ci, Co,
-                                  CONV_T2, relu, as_stream(stream));
+                                  CONV_T2, relu, as_stream(stream), ymax);
+    RCMVS_REQUIRE(!ymax, "deconv3d_scaled_fwd: no matrix-core kernel for Ci=%d Co=%d, the output bound cannot be maintained", Ci, Co);
+    if (sel == SEL_LDS)
+        return deconv3d_lds_launch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, as_stream(stream));
     return direct_dispatch<CONV_T2>(x, w_packed, scale, shift, residual, y, dm, Ci, Co, relu, as_stream(stream));
 }
 

@@ -68,7 +68,7 @@ __global__ void pack_weight_mfma_kernel(const float* __restrict__ w, float* __re
 template <int CIN, int COUT, int MODE, int NT, int KS = 1>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wm, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, MfmaDims dm, int relu) {
+    const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, MfmaDims dm, int relu, float* __restrict__ ymax) {
     constexpr int VEC = (CIN >= 16) ? 4 : 2;
     constexpr int CHUNKS = CIN / (4 * VEC);
     constexpr int MTILES = (COUT + 15) / 16;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     if (m0 >= COUT) return;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (scale) { sc = *reinterpret_cast<const float4*>(scale + m0); sh = *reinterpret_cast<const float4*>(shift + m0); }
+    float vmax = 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (!cv[t]) continue;
@@ -191,6 +192,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
         *reinterpret_cast<float4*>(y + ov * COUT + m0) = v;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    // optional bound of the stored outputs (the slot format of conv3d_x3.hip: 64 slots, 16 floats apart, the bound is their maximum):
+    // one atomic max per finishing wave -- what the fp16-pair form of the NEXT layer scales its activations with
+    if (ymax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(ymax) + ((blockIdx.x * 4 + wave) & 63) * 16, __float_as_uint(vmax));
     }
 }
 
@@ -202,7 +211,7 @@ bool conv3d_mfma_supported(int Ci, int Co, int mode) {
 
 template <int MODE>
 static int mfma_dispatch(const float* x, const float* wm, const float* scale, const float* shift, const float* res,
-                         float* y, const MfmaDims& dm, int Ci, int Co, int relu, hipStream_t st) {
+                         float* y, const MfmaDims& dm, int Ci, int Co, int relu, hipStream_t st, float* ymax) {
     const long long ntiles = cdiv(dm.cells, 16);
     // few tiles (deep U-Net levels): one n-tile per wave so that every SIMD gets work
     const bool small = ntiles < 4096;
@@ -213,9 +222,9 @@ static int mfma_dispatch(const float* x, const float* wm, const float* scale, co
     dim3 grid((unsigned)(ksplit ? ntiles : cdiv(ntiles, 4LL * nt)), (Co + 15) / 16, MODE == MF_T2 ? 8 : 1), block(256);
 #define RCMVS_MFMA_CASE(CI, CO)                                                                                     \
     if (Ci == CI && Co == CO) {                                                                                     \
-        if (ksplit)     hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
-        else if (small) hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
-        else            hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu); \
+        if (ksplit)     hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu, ymax); \
+        else if (small) hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 1>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu, ymax); \
+        else            hipLaunchKernelGGL((conv3d_mfma_kernel<CI, CO, MODE, 4>), grid, block, 0, st, x, wm, scale, shift, res, y, dm, relu, ymax); \
         return launch_status("conv3d_mfma");                                                                        \
     }
     RCMVS_MFMA_CASE(8, 16) RCMVS_MFMA_CASE(8, 32) RCMVS_MFMA_CASE(8, 48) RCMVS_MFMA_CASE(16, 16) RCMVS_MFMA_CASE(16, 32) RCMVS_MFMA_CASE(32, 32)
@@ -227,7 +236,7 @@ static int mfma_dispatch(const float* x, const float* wm, const float* scale, co
 
 // mode: 0 stride-1 conv, 1 stride-2 conv, 2 transposed stride-2
 int conv3d_mfma_launch(const float* x, const float* wm, const float* scale, const float* shift, const float* res,
-                       float* y, int B, int D, int H, int W, int Ci, int Co, int mode, int relu, hipStream_t st) {
+                       float* y, int B, int D, int H, int W, int Ci, int Co, int mode, int relu, hipStream_t st, float* ymax) {
     MfmaDims dm;
     dm.B = B; dm.D = D; dm.H = H; dm.W = W;
     if (mode == MF_T2) { dm.Dg = D; dm.Hg = H; dm.Wg = W; dm.Do = 2 * D; dm.Ho = 2 * H; dm.Wo = 2 * W; }
@@ -238,9 +247,9 @@ int conv3d_mfma_launch(const float* x, const float* wm, const float* scale, cons
     }
     dm.cells = (long long)B * dm.Dg * dm.Hg * dm.Wg;
     if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_mfma: input volume too large for 32-bit offsets");
-    if (mode == MF_S1) return mfma_dispatch<MF_S1>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
-    if (mode == MF_S2) return mfma_dispatch<MF_S2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
-    return mfma_dispatch<MF_T2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st);
+    if (mode == MF_S1) return mfma_dispatch<MF_S1>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st, ymax);
+    if (mode == MF_S2) return mfma_dispatch<MF_S2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st, ymax);
+    return mfma_dispatch<MF_T2>(x, wm, scale, shift, res, y, dm, Ci, Co, relu, st, ymax);
 }
 
 int pack_weight_mfma_launch(const float* w, float* packed, int Co, int Ci, int transposed, hipStream_t st) {

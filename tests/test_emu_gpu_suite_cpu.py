@@ -101,6 +101,11 @@ def test_cascade_vs_reference_golden_small(hip, name):
     GP.test_cascade_vs_reference_golden(hip, name)
 
 
+@pytest.mark.skipif(not FULL, reason="a minute on the emulation: RCMVS_EMU_FULL=1")
+def test_cascade_fp16_pair_form_small(hip, monkeypatch):
+    GP.test_cascade_fp16_pair_form_vs_reference_golden(hip, monkeypatch, "cascade_c1", 1e-4)
+
+
 @pytest.mark.parametrize("ci,co,stride,transposed", [(8, 8, 1, False), (16, 8, 1, False), (8, 16, 2, False), (16, 8, 2, True)])
 @pytest.mark.parametrize("relu,with_res", [(True, True), (False, False)])
 def test_conv_bn_relu_block_forward_backward_small(ci, co, stride, transposed, relu, with_res):

@@ -707,6 +707,28 @@ def test_cascade_c2_smooth_head_vs_reference_golden(hip):
     assert float((cd[stable] > 1e-3).float().mean()) < 0.01
 
 
+@pytest.mark.parametrize("name,l1_tol", [("cascade_c1", 1e-4), ("cascade_c2_smooth", 1e-5)])
+def test_cascade_fp16_pair_form_vs_reference_golden(hip, monkeypatch, name, l1_tol):
+    """The cost regularisation on the two-piece fp16 form of the matrix-core kernels (RCMVS_FP16_PAIR=1: bounds of the activations from
+    the feature maps and from the layers' own epilogues, half the MFMAs) against the reference golden, same tolerances as the exact
+    three-piece form; and the two forms against each other on the well-conditioned head."""
+    if DEV == "cpu" and name != "cascade_c1":
+        pytest.skip("full size: GPU only")
+    monkeypatch.setenv("RCMVS_FP16_PAIR", "1")
+    g, out, rng = _run_cascade(name)
+    dd = (out["depth"].cpu() - g["depth"]).abs()
+    err = float(dd.mean()) / rng
+    print(f"{name} (fp16 pair): depth L1/range = {err:.3e}  max|dd| = {float(dd.max()):.3e} mm  stable = {float((dd < 0.05).float().mean()):.5f}")
+    assert err < l1_tol
+    assert float((dd < 0.05).float().mean()) >= (0.99 if name == "cascade_c2_smooth" else 0.97)
+    if name == "cascade_c2_smooth":
+        monkeypatch.setenv("RCMVS_FP16_PAIR", "0")
+        _, exact, _ = _run_cascade(name)
+        d2 = (out["depth"] - exact["depth"]).abs()
+        print(f"  fp16 pair vs exact triple: depth mean |d| = {float(d2.mean()):.3e} mm, max {float(d2.max()):.3e} mm")
+        assert float(d2.mean()) / rng < 2e-6
+
+
 def test_reference_fp32_homography_depends_on_the_backend(hip):
     """Why the product does not chase the reference's fp32 `torch.inverse` homography (models/modules.py:314-316) bit for bit:
     the reference's own value depends on where it runs.  On 300 random DTU-like rigs the fp32 composition is evaluated with
@@ -914,9 +936,12 @@ def test_warp_variance_backward_vs_oracle_autograd(hip, C, V, D, h, w, with_nore
     assert err < 2e-5
 
 
-def test_cascade_batch_two_equals_two_singles(hip):
+def test_cascade_batch_two_equals_two_singles(hip, monkeypatch):
     """Batch handling end to end (eval-mode BN makes samples independent): a B = 2 forward must reproduce the two B = 1
-    forwards -- FeatureNet over B*V images, per-sample homographies / plane tables, batched volumes."""
+    forwards -- FeatureNet over B*V images, per-sample homographies / plane tables, batched volumes.  (On the exact arithmetic form:
+    batches always take it -- the fp16-pair form scales by a per-launch activation bound -- and the chaotic test head amplifies
+    any rounding difference between the two forms to millimetres at isolated pixels.)"""
+    monkeypatch.setenv("RCMVS_FP16_PAIR", "0")
     from rc_mvsnet_amd import synthetic
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
     m = CascadeMVSNet_eval(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1])

@@ -58,9 +58,10 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     float *dx, *dw, *dimg, *dsc, *dsh, *dres, *dy, *dmax;
     const bool pair = getenv("X3_NP") && atoi(getenv("X3_NP")) == 2 && conv3d_x3h_supported(Ci, Co, kind);     // the fp16-pair form
     long long imgf = pair ? conv3d_x3h_weight_floats(Ci, Co, kind) : conv3d_x3_weight_floats(Ci, Co, kind);
-    CK(hipMalloc(&dmax, 4096 + 64));                 // bound vector (64 slots, 16 floats apart) + the weight-scale scratch
+    CK(hipMalloc(&dmax, 4096 + 64 + 4096)); CK(hipMemset(dmax, 0, 4096 + 64 + 4096));                 // bound vector (64 slots, 16 floats apart) + the weight-scale scratch
     { float m = 0.f; for (auto v : x) m = fmaxf(m, fabsf(v)); std::vector<float> h(1024 + 16, 0.f); h[0] = m; CK(hipMemcpy(dmax, h.data(), 4096 + 64, hipMemcpyHostToDevice)); }
     const float* xmx = pair ? dmax : nullptr;
+    float* ymx = getenv("X3_YMAX") ? dmax + 1024 + 16 : nullptr;       // X3_YMAX=1: the kernel also maintains the bound of its output
     CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dimg, imgf * 4)); CK(hipMalloc(&dsc, Co * 4)); CK(hipMalloc(&dsh, Co * 4));
     CK(hipMalloc(&dres, ny * 4)); CK(hipMalloc(&dy, ny * 4));
     CK(hipMemcpy(dx, x.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), nw * 4, hipMemcpyHostToDevice));
@@ -69,7 +70,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     CK(hipMemset(dy, 0xff, ny * 4));
     if (pair) { if (conv3d_x3_wscale(dw, (int)nw, dmax + 1024, 0) || conv3d_x3h_pack(dw, dimg, Co, Ci, kind, kind == 2 ? 1 : 0, dmax + 1024, 0)) return 1; }
     else if (conv3d_x3_pack(dw, dimg, Co, Ci, kind, kind == 2 ? 1 : 0, 0)) return 1;
-    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr)) return 1;
+    if (conv3d_x3_launch(dx, dimg, dsc, dsh, dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, ymx)) return 1;
     CK(hipDeviceSynchronize());
     int bad = 0;
     if (check) {
@@ -88,7 +89,7 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
     if (reps > 0 && getenv("X3_TRACE")) {      // s_memtime stamps of block 0 (ticks 8..55): where a tick's time goes
         long long* dtr; CK(hipMalloc(&dtr, 64 * 8 * 8)); CK(hipMemset(dtr, 0, 64 * 8 * 8));
         x3_trace_buf = dtr;
-        conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr);
+        conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, ymx);
         CK(hipDeviceSynchronize());
         x3_trace_buf = nullptr;
         std::vector<long long> tr(64 * 8); CK(hipMemcpy(tr.data(), dtr, 64 * 8 * 8, hipMemcpyDeviceToHost)); hipFree(dtr);
@@ -109,9 +110,9 @@ static int run_case(int kind, int Ci, int Co, int D, int H, int W, bool check, i
 #if X3_ABLATION
         x3_ablation_mask = getenv("X3_DBG") ? atoi(getenv("X3_DBG")) : 0;
 #endif
-        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr);
+        for (int i = 0; i < 3; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, ymx);
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, nullptr);
+        for (int i = 0; i < reps; ++i) conv3d_x3_launch(dx, dimg, dsc, dsh, nores ? nullptr : dres, dy, 1, D, H, W, Ci, Co, kind, 1, 0, blocks, 0, xmx, ymx);
 #if X3_ABLATION
         x3_ablation_mask = 0;
 #endif
