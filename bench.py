@@ -71,11 +71,15 @@ BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak
 def conv_roofline(conv_events, nscenes):
     """Second roofline object: the 3-D convolutions that run on the bf16 matrix cores at fp32 accuracy.  `achieved` counts the
     layer's ALGORITHMIC flops (2 x taps x Ci x Co per output voxel / input cell: what an fp32 convolution does) against the
-    fp32 dense peak -- the precision class the results are in; `matrix_pipe_frac` prices the six bf16 MFMAs per product
-    (block-Toeplitz padding not counted) against the dense bf16 peak."""
+    fp32 dense peak -- the precision class the results are in; `matrix_pipe_frac` prices the MFMAs actually issued per product
+    (three on the fp16-pair form the 3-D layers of a B = 1 scene take by default, six on the exact bf16 triple; block-Toeplitz
+    padding not counted) against the dense bf16 / fp16 matrix-pipe peak."""
     if not conv_events or nscenes <= 0:
         return None
-    flops = ms = 0.0
+    from rc_mvsnet_amd import casmvsnet
+    pair = casmvsnet.FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
+    PAIR_LAYERS = {("s1", 8, 8), ("s1", 16, 8), ("s1", 32, 8), ("s1", 16, 16), ("s2", 8, 16), ("s2", 16, 32), ("t2", 16, 8), ("s1", 32, 32), ("t2", 32, 16)}
+    flops = ms = products = 0.0
     per_layer = {}
     for e0, e1, (kind, B, D, H, W, Ci, Co) in conv_events:
         if (kind, Ci, Co) not in X3_LAYERS:
@@ -90,6 +94,7 @@ def conv_roofline(conv_events, nscenes):
         f = 2.0 * taps * Ci * Co * cells
         t = e0.elapsed_time(e1)
         flops += f
+        products += f * (3.0 if (pair and B == 1 and taps == 27 and (kind, Ci, Co) in PAIR_LAYERS) else 6.0)
         ms += t
         k = f"{kind} {Ci}->{Co} {D}x{H}x{W}" + (f" x{B}" if B > 1 else "")
         a = per_layer.setdefault(k, [0.0, 0.0])
@@ -99,10 +104,12 @@ def conv_roofline(conv_events, nscenes):
         return None
     tf = flops / (ms * 1e-3) / 1e12
     top = sorted(per_layer.items(), key=lambda kv: -kv[1][1])[:6]
-    return {"bound": "mfma", "kernel": "rcmvs::conv3d_x3_kernel family (split-bf16 3-D / planar convolutions, all launches of a scene)",
+    return {"bound": "mfma", "kernel": "rcmvs::conv3d_x3_kernel family (split-operand matrix-core 3-D / planar convolutions, all launches of a scene)",
             "achieved": round(tf, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4),
-            "peak_note": "fp32 dense peak: the results are fp32-accurate (exact 3-way bf16 operand split, 6 MFMAs per product)",
-            "matrix_pipe_frac": round(6.0 * tf / BF16_PEAK_TFLOPS, 4), "us_per_scene": round(ms * 1e3 / nscenes, 1),
+            "peak_note": "fp32 dense peak: the results are fp32-accurate (3-D layers: two fp16 pieces per operand after an exact power-of-two "
+                         "pre-scale, 3 MFMAs per product" + ("" if pair else " -- disabled by RCMVS_FP16_PAIR=0") + "; planar layers and the exact form: three bf16 pieces, 6 MFMAs)",
+            "arithmetic": "fp16 pair (default)" if pair else "exact bf16 triple (RCMVS_FP16_PAIR=0)",
+            "matrix_pipe_frac": round(products / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4), "us_per_scene": round(ms * 1e3 / nscenes, 1),
             "gflop_per_scene": round(flops / nscenes / 1e9, 2),
             "largest_layers_us_tflops": {k: [round(v[1] * 1e3 / nscenes, 1), round(v[0] / (v[1] * 1e-3) / 1e12, 1)] for k, v in top},
             "timing": "HIP events on the launch stream around every launch, separate untimed pass of 10 scenes"}
