@@ -13,9 +13,12 @@ The JSON line also carries
   roofline      the fused warp+variance kernel (K1): algorithmic bytes of its three per-scene
                 launches (137.6 + 194.0 + 125.8 MB) / their HIP-event durations
                 recorded on the launch stream inside the timed region, vs the 8 TB/s HBM peak;
-  roofline_conv the 3-D convolutions that run on the bf16 matrix cores at fp32 accuracy (csrc/conv3d_x3.hip): algorithmic flops
-                of every such launch of a scene / HIP-event durations from a separate untimed pass, vs the fp32 dense peak
-                (157 TF; the six bf16 MFMAs per product are priced against the bf16 peak as `matrix_pipe_frac`);
+  roofline_conv the 3-D convolutions that run on the matrix cores at fp32 accuracy (csrc/conv3d_x3.hip: operands split into two
+                fp16 pieces after an exact power-of-two pre-scale -- the default for a B = 1 scene -- or into three bf16 pieces):
+                algorithmic flops of every such launch of a scene / HIP-event durations from a separate untimed pass, vs the
+                fp32 dense peak (157 TF; the three / six MFMAs per product are priced against the matrix-pipe peak as
+                `matrix_pipe_frac`);
+  train_step    a short timing of the config-3 training iteration (5 iterations after 2 warm-ups; --no-train-step skips it);
   cpu_baseline  the oracle's ATen op graph (= the reference's CPU path) timed on the host cores
                 of this box on a bounded sample, rank 0, N=1 only -- a reported baseline, plus
                 the depth-L1 parity of the HIP output against it on the same inputs.

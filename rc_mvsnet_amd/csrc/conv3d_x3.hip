@@ -45,8 +45,10 @@
 //   dropped xl wl is <= 2^-22 |x||w|), two magnitude classes in separate fp32 accumulators, un-scaled by the exact factor
 //   2^-(e_x + e_w) folded into the BatchNorm scale of the epilogue.  Half the matrix-pipe work of the three-piece form, a 12-
 //   instead of 22-instruction split per float4, two thirds of the LDS ring.  Accuracy against fp64: tests/test_gpu_parity.py::
-//   test_conv3d_x3h_*.  The three-piece bf16 form (NP = 3: exact split, no scale, no bound needed) remains for callers without
-//   a bound (training data gradients, stand-alone calls).
+//   test_conv3d_x3h_*.  Since the end of round 3 this is what the CostRegNet layers of a B = 1 inference scene run on (casmvsnet.py:
+//   bound of the variance volume from the feature maps, every layer keeps the bound of its stored outputs: -4.3 % per scene at unchanged
+//   depth parity).  The three-piece bf16 form (NP = 3: exact split, no scale, no bound needed) serves callers without a bound: batches,
+//   the planar FeatureNet layers, training (forward and data gradients), stand-alone calls, RCMVS_FP16_PAIR=0.
 // What bounds it (measured): on gfx950 VALU work -- of another wave on the SIMD or interleaved in the same
 // wave -- does not overlap v_mfma_f32_16x16x32_bf16, so a step costs MFMA time + producer VALU time; the producers are therefore
 // kept to the bare split (22 VALU per float4) and table-driven addressing.
