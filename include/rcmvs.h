@@ -42,6 +42,10 @@ int rcmvs_nhwc_to_nchw(const float* src, float* dst, int N, int C, long long S, 
  * v=1..V-1:  P = (K_v E_v) * inverse(K_0 E_0)  (4x4 with last row 0,0,0,1), evaluated in fp64
  * on the device and rounded to fp32:  rot (B,V-1,9) row-major 3x3, trans (B,V-1,3). */
 int rcmvs_compose_homography(const float* proj, float* rot, float* trans, int B, int V, void* stream);
+/* The same for up to four cascade stages in ONE launch (their projection tensors differ only in the intrinsics scale, casmvsnet.py:
+ * 376-381): rot (nstage, B, V-1, 9), trans (nstage, B, V-1, 3); unused proj pointers may be NULL. */
+int rcmvs_compose_homography_stages(const float* proj0, const float* proj1, const float* proj2, const float* proj3, int nstage,
+                                    float* rot, float* trans, int B, int V, void* stream);
 
 /* ---- hypothesis planes  (models/casmvsnet.py:357-359,383-404; modules.py:549-588) ------ */
 /* Stage 1 (prev_depth == NULL): d_0 = depth_values[b,0], delta = (dv[b,ND-1]-dv[b,0])/(D-1).

@@ -465,6 +465,12 @@ class _CascadeBase(nn.Module):
             feats_cl = self._fpn_outputs_on_side_stream(feats_cl, imgs)
         outputs = {}
         depth = None
+        if homographies is None:                                     # every stage's homographies in one launch (they differ in the intrinsics scale only)
+            if self.num_stage <= 4:
+                rots, transs = ops.compose_homography_stages([proj_matrices["stage{}".format(k + 1)].contiguous().float() for k in range(self.num_stage)])
+            else:
+                rt = [ops.compose_homography(proj_matrices["stage{}".format(k + 1)].contiguous().float()) for k in range(self.num_stage)]
+                rots, transs = [r for r, _ in rt], [t for _, t in rt]
         bounds = None
         pair = FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
         if pair and B == 1:          # (the bounds are per launch: with B > 1 a sample's rounding would depend on its batch mates -> exact form)
@@ -489,7 +495,7 @@ class _CascadeBase(nn.Module):
             if homographies is not None:
                 rot, trans = homographies[key]
             else:
-                rot, trans = ops.compose_homography(proj_matrices[key].contiguous().float())
+                rot, trans = rots[s], transs[s]
             planes = ops.hypothesis_planes(depth, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
             var = ops.warp_variance(f_cl, rot, trans, planes, D)
             cr = self._cr(s)

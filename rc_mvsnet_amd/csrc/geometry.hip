@@ -94,10 +94,15 @@ __device__ static void fold_intrinsics(const float* p, double A[4][4]) {
     for (int j = 0; j < 4; ++j) A[3][j] = (double)p[12 + j];
 }
 
-__global__ void compose_homography_kernel(const float* __restrict__ proj, float* __restrict__ rot,
+// (blockIdx.y = cascade stage when the three stages' projection tensors are composed in ONE launch: rcmvs_compose_homography_stages)
+struct ProjPtrs { const float* p[4]; };
+__global__ void compose_homography_kernel(ProjPtrs pp, float* __restrict__ rot,
                                           float* __restrict__ trans, int B, int V) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * (V - 1)) return;
+    const float* proj = pp.p[blockIdx.y];
+    rot += (long long)blockIdx.y * B * (V - 1) * 9;
+    trans += (long long)blockIdx.y * B * (V - 1) * 3;
     int b = t / (V - 1), v = 1 + t % (V - 1);
     double R[4][4], S[4][4], inv[4][4];
     fold_intrinsics(proj + ((long long)b * V + 0) * 32, R);
@@ -221,9 +226,21 @@ int rcmvs_nhwc_to_nchw(const float* src, float* dst, int N, int C, long long S, 
 int rcmvs_compose_homography(const float* proj, float* rot, float* trans, int B, int V, void* stream) {
     RCMVS_REQUIRE(proj && rot && trans, "compose_homography: null pointer");
     RCMVS_REQUIRE(B > 0 && V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "compose_homography: B=%d V=%d", B, V);
-    int n = B * (V - 1);
-    hipLaunchKernelGGL(compose_homography_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), proj, rot, trans, B, V);
+    const int n = B * (V - 1);
+    ProjPtrs pp{{proj, nullptr, nullptr, nullptr}};
+    hipLaunchKernelGGL(compose_homography_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), pp, rot, trans, B, V);
     return launch_status("compose_homography");
+}
+
+int rcmvs_compose_homography_stages(const float* proj0, const float* proj1, const float* proj2, const float* proj3, int nstage,
+                                    float* rot, float* trans, int B, int V, void* stream) {
+    RCMVS_REQUIRE(rot && trans && nstage >= 1 && nstage <= 4, "compose_homography_stages: bad arguments (1..4 stages)");
+    RCMVS_REQUIRE(B > 0 && V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "compose_homography_stages: B=%d V=%d", B, V);
+    ProjPtrs pp{{proj0, proj1, proj2, proj3}};
+    for (int s = 0; s < nstage; ++s) RCMVS_REQUIRE(pp.p[s], "compose_homography_stages: stage %d has no projection tensor", s);
+    const int n = B * (V - 1);
+    hipLaunchKernelGGL(compose_homography_kernel, dim3((n + 63) / 64, nstage), dim3(64), 0, as_stream(stream), pp, rot, trans, B, V);
+    return launch_status("compose_homography_stages");
 }
 
 int rcmvs_hypothesis_planes(const float* prev_depth, const float* depth_values, float* planes,

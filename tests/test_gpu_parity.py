@@ -49,6 +49,12 @@ def test_compose_homography(hip):
         r, t = warp.compose_homography(pm[:, v].double(), pm[:, 0].double())
         assert rel_err(rot[:, v - 1].cpu().reshape(2, 3, 3), r) < 1e-6
         assert rel_err(trans[:, v - 1].cpu(), t) < 1e-6
+    # the cascade composes its three stages in one launch: bit-identical to the per-stage calls
+    pms = synthetic.proj_matrices(2, 5, 512, 640)
+    rots, transs = hip.compose_homography_stages([gpu(pms[f"stage{k}"]) for k in (1, 2, 3)])
+    for k in (1, 2, 3):
+        r, t = hip.compose_homography(gpu(pms[f"stage{k}"]))
+        assert torch.equal(rots[k - 1], r) and torch.equal(transs[k - 1], t)
 
 
 @pytest.mark.parametrize("name,scale", [("planes_s2", 2), ("planes_s3", 1), ("planes_s2odd", 2)])
