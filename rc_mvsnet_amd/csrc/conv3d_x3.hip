@@ -130,7 +130,7 @@ struct X3 {
     // wave roles: 4 consumer + 4 producer waves; layers whose weight image exceeds 4 x 128 registers take 6 consumer waves (K cut
     // three ways, M two ways) and 2 producer waves -- their volumes are small and the producers have little to do
     static constexpr int NCW = (KSTEPS * MT_ALL * 12 > 512) ? 6 : 4;     // (decided on the three-piece image: both forms share the tile geometry)
-    static constexpr int NPW = 8 - NCW;
+    static constexpr int NPW = 8 - NCW;                                   // (two consumer + six producer waves on the two-piece 16 -> 8 / 8 -> 8 layers: 117.6 -> 136-141 us, 58.6 -> 70 us: not adopted)
     static constexpr int MSPLIT = (MT_ALL >= 2 && WREG > 128 && !SKIP) ? 2 : 1;
     static constexpr int KSPLIT = SKIP ? 1 : ((NCW == 6) ? 3 : ((WREG / MSPLIT > 256) ? 4 / MSPLIT : ((WREG / MSPLIT > 128) ? 2 : 1)));
     static constexpr int MT = MT_ALL / MSPLIT;                           // m-tiles per consumer wave
