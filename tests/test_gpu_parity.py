@@ -735,6 +735,25 @@ def test_cascade_fp16_pair_form_vs_reference_golden(hip, monkeypatch, name, l1_t
         assert float(d2.mean()) / rng < 2e-6
 
 
+def test_scene_pipeline_one_stream_is_the_plain_loop(hip):
+    """rc_mvsnet_amd.scene_pipeline with ONE stream (the supported mode; more streams are experimental, see its docstring) is the plain loop."""
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    from rc_mvsnet_amd.scene_pipeline import ScenePipeline
+
+    def make():
+        m = CascadeMVSNet_eval(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1])
+        m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
+        return m.to(DEV).eval()
+
+    i, p, d = synthetic.cascade_inputs(1, 3, 64, 96, 3)
+    scene = (gpu(i), {k: gpu(v) for k, v in p.items()}, gpu(d))
+    with torch.no_grad():
+        want = make()(*scene)["depth"]
+        out, stream = ScenePipeline(make, 1, DEV)(*scene)
+    assert stream is None and torch.equal(out["depth"], want)
+
+
 def test_reference_fp32_homography_depends_on_the_backend(hip):
     """Why the product does not chase the reference's fp32 `torch.inverse` homography (models/modules.py:314-316) bit for bit:
     the reference's own value depends on where it runs.  On 300 random DTU-like rigs the fp32 composition is evaluated with
