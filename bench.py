@@ -47,8 +47,8 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s achievable)
 H, W, V = 512, 640, 3
 NDEPTHS, RATIOS = (48, 32, 8), (4, 2, 1)
-STREAMS_DEFAULT = 1              # HIP streams the cascade workload issues independent scenes on (--streams).  EXPERIMENTAL above 1: +17-20 % but
-                                 # intermittently corrupted stage-3 outputs at full size, not root-caused (rc_mvsnet_amd/scene_pipeline.py)
+STREAMS_DEFAULT = 1              # HIP streams the cascade workload issues independent scenes on (--streams).  EXPERIMENTAL above 1 (rc_mvsnet_amd/
+                                 # scene_pipeline.py): the stage-3 corruption of round 3 is fixed at its first wrong op, its cause is not understood
 FEAT_C = (32, 16, 8)
 
 
@@ -154,6 +154,53 @@ def timed_region(world, dev, warmup, steps, step):
         dist.barrier()
         dist.destroy_process_group()
     return elapsed
+
+
+def two_scenes_in_flight(make_model, model, scenes, steps, nstreams=2):
+    """Side figure of the cascade workload: `steps` scenes with `nstreams` of them in flight -- one model replica and one HIP stream per
+    slot, one captured hipGraph per (stream, scene) over the resident inputs, replayed round-robin; a scene is still one whole
+    CascadeMVSNet_eval.forward at batch 1.  Every (stream, scene) output is compared bit for bit with the one-stream eager output.
+    Round 3 (profiles/r3_two_streams.txt): this mode used to corrupt stage-3 outputs in 7 % of the scenes; the first wrong op was always
+    the hypothesis-planes kernel reading a stale piece of the previous stage's depth map, fixed by agent-scope loads there (0 of ~7000
+    scenes since).  The cause of the staleness is not understood, so this is reported beside the headline, not as it."""
+    import torch
+    keys = ("depth", "photometric_confidence")
+    with torch.no_grad():
+        want = []
+        for sc in scenes:
+            o = model(*sc)
+            want.append({k: o[k].clone() for k in keys})
+        torch.cuda.synchronize()
+        models = [make_model() for _ in range(nstreams)]
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        graphs, outs = {}, {}
+        for k in range(nstreams):
+            with torch.cuda.stream(streams[k]):
+                for sc in scenes:                             # plans, packed weights, allocator warm-up on the capture stream
+                    models[k](*sc)
+            streams[k].synchronize()
+            for j, sc in enumerate(scenes):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=streams[k]):
+                    o = models[k](*sc)
+                graphs[(k, j)], outs[(k, j)] = g, {key: o[key] for key in keys}
+        torch.cuda.synchronize()
+        order = [(i % nstreams, (i // nstreams) % len(scenes)) for i in range(steps)]
+        for k, j in order[:4 * nstreams]:
+            with torch.cuda.stream(streams[k]):
+                graphs[(k, j)].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k, j in order:
+            with torch.cuda.stream(streams[k]):
+                graphs[(k, j)].replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        same = all(torch.equal(outs[kj][key], want[kj[1]][key]) for kj in set(order) for key in keys)
+    return {"value": round(steps / dt, 3), "unit": "ref-scenes/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "streams": nstreams, "mode": "one hipGraph per (stream, scene), replayed round-robin over resident inputs",
+            "outputs_identical_to_single_stream": bool(same),
+            "note": "side pass after the timed region, NOT `value`: experimental mode (rc_mvsnet_amd/scene_pipeline.py)"}
 
 
 def event_ms(fn, reps=20):
@@ -362,6 +409,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the short config-3 training-iteration timing appended to the default line")
+    ap.add_argument("--no-side-pass", action="store_true", help="skip the two-scenes-in-flight side pass of the cascade workload (N = 1)")
     ap.add_argument("--streams", type=int, default=STREAMS_DEFAULT,
                     help="cascade workload, EXPERIMENTAL above 1: independent scenes issued round-robin on this many HIP streams (one model replica "
                          "per stream); the line then carries `outputs_identical_to_single_stream` from a self-check after the timed region")
@@ -470,6 +518,15 @@ def main():
             pipe.synchronize()
             single["outputs_identical_to_single_stream"] = bool(all(torch.equal(o, want[i % len(scenes)]) for i, o in enumerate(got)))
 
+    # SIDE PASS (N = 1, one stream in the timed region): two scenes in flight on two HIP streams, one captured hipGraph per (stream, scene),
+    # every output compared bit for bit with the one-stream eager outputs.  Not the headline: see rc_mvsnet_amd/scene_pipeline.py for its status.
+    in_flight = None
+    if rank == 0 and world == 1 and nstreams == 1 and not args.no_side_pass:
+        try:
+            in_flight = two_scenes_in_flight(make_model, model, scenes, min(96, max(8, args.steps)))      # (short: its launches share the rocprof averages of this command)
+        except Exception as e:                               # never at the expense of the headline line
+            in_flight = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     rank_rates = None
     if world > 1:
         mine = torch.tensor([own], device=dev, dtype=torch.float64)
@@ -536,6 +593,8 @@ def main():
         "roofline": roofline,
         "roofline_conv": roofline_conv,
     }
+    if in_flight is not None:
+        result["two_scenes_in_flight"] = in_flight
     if single is not None:
         result["outputs_identical_to_single_stream"] = single.pop("outputs_identical_to_single_stream")
         result["single_stream"] = single

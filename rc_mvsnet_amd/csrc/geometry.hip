@@ -142,6 +142,14 @@ __global__ void compose_homography_kernel(ProjPtrs pp, float* __restrict__ rot,
 // ------------------------------------------------------------------------------------------
 // hypothesis planes: planes[b,y,x] = {d_0, delta}
 // ------------------------------------------------------------------------------------------
+__device__ static inline float ld_agent(const float* p) {
+#if defined(__AMDGCN__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;              // host pass / CPU emulator of the tests
+#endif
+}
+
 __device__ static inline float bilinear_up(const float* __restrict__ p, int hp, int wp, float sh, float sw, int Y, int X) {
 #pragma clang fp contract(off)
     // ATen upsample_bilinear2d, align_corners=False: src = max(scale*(dst+0.5)-0.5, 0)
@@ -156,8 +164,13 @@ __device__ static inline float bilinear_up(const float* __restrict__ p, int hp, 
     int x1 = x0 + 1 > wp - 1 ? wp - 1 : x0 + 1;
     float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
     float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-    float top = lx0 * p[y0 * wp + x0] + lx1 * p[y0 * wp + x1];
-    float bot = lx0 * p[y1 * wp + x0] + lx1 * p[y1 * wp + x1];
+    // The previous stage's depth map is read at agent scope (sc1 loads).  Round 3, profiles/r3_two_streams.txt: with two scenes in
+    // flight on two HIP streams this kernel was the FIRST op of every corrupted scene -- it read 32-byte pieces of the depth map's
+    // previous contents (a reused allocator block) although the depth kernel before it on the same stream had completed (explicit
+    // event dependencies did not change that; a release fence at the end of the writer did not either; these loads did: 0 of 1200
+    // scenes against 7 %).  The map is 80-330 KB, the kernel is bound by its stores; the loads cost nothing measurable.
+    float top = lx0 * ld_agent(p + y0 * wp + x0) + lx1 * ld_agent(p + y0 * wp + x1);
+    float bot = lx0 * ld_agent(p + y1 * wp + x0) + lx1 * ld_agent(p + y1 * wp + x1);
     return ly0 * top + ly1 * bot;
 }
 

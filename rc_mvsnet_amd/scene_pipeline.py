@@ -1,18 +1,26 @@
-"""EXPERIMENTAL -- independent reference views on several HIP streams of one GPU.  NOT SAFE FOR RESULTS YET.
+"""EXPERIMENTAL -- independent reference views on several HIP streams of one GPU.
 
 Why: a scene is ~100 dependent launches; about a third of its time goes to the deep U-Net levels and small glue kernels -- launches
 of 10-30 us that occupy a fraction of the 256 CUs -- while the big layers fill the chip.  Two scenes in flight on two streams let one
-scene's small launches run beside the other's large ones: 1.38 -> 1.14-1.21 ms per scene eager (`bench.py --streams 2`), 1.08 ms
-with hipGraph replay (tools/dev/two_stream_graph_probe.py), each scene still one ``CascadeMVSNet_eval.forward`` at batch 1.
-One model replica per stream: a model's activation-bound buffer (fp16-pair form) and plan caches are not re-entrant.
+scene's small launches run beside the other's large ones: 1.38 -> 1.14-1.28 ms per scene eager (host-bound, it varies with the box;
+`bench.py --streams 2`), 1.08 ms with hipGraph replay (bench.py's `two_scenes_in_flight` side pass, tools/dev/two_stream_graph_probe.py),
+each scene still one ``CascadeMVSNet_eval.forward`` at batch 1.  One model replica per stream: a model's activation-bound buffer
+(fp16-pair form) and plan caches are not re-entrant.
 
-OPEN DEFECT (round 3, profiles/r3_two_streams.txt): at the full config-2 size the STAGE-3 outputs of some scenes come out wrong in
-6-8 of 10 runs -- tile-shaped patches (64 x 32 pixels + 8 of spread, 1-25 % of the pixels), stages 1 and 2 always bit-identical, no
-NaN.  It needs library kernels on BOTH streams (scenes next to foreign torch kernels on the other stream: 0 of 24 runs), any
-device-wide synchronisation inside stage 3 hides it, AMD_SERIALIZE_KERNEL=3 hides it, and it is independent of the arithmetic form,
-of the split-operand kernel of stage 3's conv0, of K1's variant, of out-of-range padding loads and of the LDS contents at kernel
-start (all switched off one at a time, tools/dev/two_stream_*.py).  The replicas share no device memory that has been found.  Until
-it is root-caused the one-stream loop is the only supported mode; ``bench.py --streams N`` self-checks its outputs and says so."""
+STATUS (round 3, profiles/r3_two_streams.txt has every probe): at the full config-2 size this mode used to corrupt the STAGE-3 outputs
+of ~7 % of the scenes (tile-shaped patches, stages 1 and 2 always bit-identical).  Root-causing: the allocator never shares a block
+between the streams (address ranges logged), no kernel writes outside its output (guard-band canaries around every tensor), in-stream
+order is intact (explicit event dependencies between all launches change nothing), two PROCESSES on one GPU with the same overlap are
+clean; an asynchronous capture of the ops-layer outputs showed that the FIRST wrong tensor of every corrupted scene (~100 of them) was
+stage 3's hypothesis planes: the kernel had read 32-byte pieces of the PREVIOUS contents of the (reused) allocator block that holds
+stage 2's depth map, although the depth kernel before it on the same stream had completed and a copy taken right after the launch shows
+the right map.  A release fence at the end of the writer changes nothing; agent-scope (sc1) loads of the depth map in the reader remove it:
+0 corrupted scenes in ~7000 since (eager 2 streams, hipGraph replay on 2 and 3 streams, all stages compared) against 7 % before --
+adopted in csrc/geometry.hip (ld_agent).  What is NOT understood is why a stale line survives the kernel-boundary cache invalidation
+only when a second queue of the same process is active, so other readers may be exposed at rates those runs do not show.  Hence: one
+stream is the default and the supported mode; more than one warns; ``bench.py --streams N`` and the side pass self-check their outputs
+against the one-stream run and say so in the line.  Two worker PROCESSES per GPU give the same gain (2 x 2.214 ms per scene measured)
+without sharing a runtime."""
 
 import torch
 
@@ -29,8 +37,9 @@ class ScenePipeline:
         self.wait_inputs = bool(wait_inputs)
         if self.n > 1:
             import warnings
-            warnings.warn("ScenePipeline with more than one stream is experimental: intermittently corrupted stage-3 outputs at full size "
-                          "(see the module docstring); use one stream for results", RuntimeWarning, stacklevel=2)
+            warnings.warn("ScenePipeline with more than one stream is experimental: the stage-3 corruption of round 3 is fixed at its first wrong "
+                          "op but its cause is not understood (see the module docstring); check the outputs against a one-stream run",
+                          RuntimeWarning, stacklevel=2)
 
     def __call__(self, *args, **kwargs):
         """Issue one scene on the next stream; returns (outputs, stream) -- the outputs are valid once `stream` (None = the current

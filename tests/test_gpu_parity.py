@@ -754,6 +754,41 @@ def test_scene_pipeline_one_stream_is_the_plain_loop(hip):
     assert stream is None and torch.equal(out["depth"], want)
 
 
+def test_two_scenes_in_flight_match_the_one_stream_run(hip):
+    """Regression test of round 3's two-stream defect (profiles/r3_two_streams.txt): 24 full-size config-2 scenes on two HIP streams, every
+    stage's outputs bit-identical to the one-stream run.  Before the hypothesis-planes kernel read the previous stage's depth map at
+    agent scope, ~7 % of such scenes had wrong stage-3 outputs (the probability that 24 scenes all passed was ~17 %)."""
+    import warnings
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    from rc_mvsnet_amd.scene_pipeline import ScenePipeline
+
+    def make():
+        m = CascadeMVSNet_eval(ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1])
+        m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
+        return m.to(DEV).eval()
+
+    scenes = []
+    for seed in range(4):
+        i, p, d = synthetic.cascade_inputs(1, 3, 512, 640, seed)
+        scenes.append((gpu(i), {k: gpu(v) for k, v in p.items()}, gpu(d)))
+    keys = [("depth",), ("photometric_confidence",), ("stage1", "depth"), ("stage2", "depth")]
+    pick = lambda o, k: o[k[0]] if len(k) == 1 else o[k[0]][k[1]]
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        one = make()
+        want = [[pick(one(*s), k).clone() for k in keys] for s in scenes]
+        pipe = ScenePipeline(make, 2, DEV)
+        for i in range(2):
+            pipe(*scenes[i])                                 # plans and packed weights of both replicas
+        pipe.synchronize()
+        got = [pipe(*scenes[i % 4])[0] for i in range(24)]
+        pipe.synchronize()
+    for i, o in enumerate(got):
+        for k, w in zip(keys, want[i % 4]):
+            assert torch.equal(pick(o, k), w), f"scene {i} (stream {i % 2}): {'/'.join(k)} differs from the one-stream run"
+
+
 def test_reference_fp32_homography_depends_on_the_backend(hip):
     """Why the product does not chase the reference's fp32 `torch.inverse` homography (models/modules.py:314-316) bit for bit:
     the reference's own value depends on where it runs.  On 300 random DTU-like rigs the fp32 composition is evaluated with
