@@ -19,6 +19,9 @@ The JSON line also carries
                 fp32 dense peak (157 TF; the three / six MFMAs per product are priced against the matrix-pipe peak as
                 `matrix_pipe_frac`);
   train_step    a short timing of the config-3 training iteration (5 iterations after 2 warm-ups; --no-train-step skips it);
+  two_scenes_in_flight   N = 1 only, a side pass after the timed region, never `value`: 96 scenes with two in flight (2 HIP streams, one
+                hipGraph per (stream, scene)), every output compared bit for bit with the one-stream run (--no-side-pass skips it;
+                experimental mode, rc_mvsnet_amd/scene_pipeline.py);
   cpu_baseline  the oracle's ATen op graph (= the reference's CPU path) timed on the host cores
                 of this box on a bounded sample, rank 0, N=1 only -- a reported baseline, plus
                 the depth-L1 parity of the HIP output against it on the same inputs.

@@ -14,7 +14,7 @@ timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/${tag}_bench.json | 
 echo "== bench train_step"
 timeout 600 python bench.py --workload train_step 2>&1 | tail -1 | tee gpurun_out/${tag}_bench_train_step.json | cut -c1-600
 echo "== rocprof (cascade)"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -o ${tag} -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-step > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -o ${tag} -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-step --no-side-pass > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof.log 2>&1 )
 f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" 2>/dev/null | head -n 1)
 if [ -n "$f" ] && [ -f "$f" ]; then cp "$f" gpurun_out/${tag}_kernel_stats.csv; head -n 14 "$f" | cut -c1-160; fi
 find gpurun_out/${tag}_prof -name "*kernel_trace.csv" -delete 2>/dev/null
