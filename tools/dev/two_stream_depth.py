@@ -15,6 +15,7 @@ import torch
 from rc_mvsnet_amd import _lib, synthetic
 from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
 from rc_mvsnet_amd.scene_pipeline import ScenePipeline
+if os.environ.get('RCMVS_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['RCMVS_LIB'])       # a library variant (A/B of a kernel change)
 _lib.load()
 dev = "cuda:0"
 E = lambda k, d: int(os.environ.get(k, d))
@@ -119,5 +120,5 @@ if LOGADDR:
             ov = sum(1 for (l0, h0) in RANGES[ks[a]] for (l1, h1) in RANGES[ks[b]] if l0 < h1 and l1 < h0)
             gap = min((abs(l1 - h0) if l1 >= h0 else abs(l0 - h1)) for (l0, h0) in RANGES[ks[a]] for (l1, h1) in RANGES[ks[b]] if not (l0 < h1 and l1 < h0))
             print(f"  streams {ks[a]:#x} / {ks[b]:#x}: {ov} overlapping range pairs, smallest gap between two ranges {gap} bytes")
-cfg = " ".join(f"{k}={os.environ[k]}" for k in ("SCENES", "KEEPALIVE", "DELAY", "MINBYTES", "MAXBYTES", "AHEAD", "PAD", "LOGADDR", "FENCE") if k in os.environ)
+cfg = " ".join(f"{k}={os.environ[k]}" for k in ("SCENES", "KEEPALIVE", "DELAY", "MINBYTES", "MAXBYTES", "AHEAD", "PAD", "LOGADDR", "FENCE", "RCMVS_LIB") if k in os.environ)
 print(f"[{cfg}] {bad} of {NR} rounds corrupted; {sorted(ms)[len(ms) // 2]:.3f} ms/scene (median round); held {n}; corrupted scene indices per round: {where}")
