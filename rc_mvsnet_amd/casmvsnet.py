@@ -31,8 +31,76 @@ from ._lib import RcmvsError
 
 
 # ----------------------------------------------------------------------------------------------
-# 2-D blocks (models/modules.py:28-116): parameter holders; HIP inference path in FeatureNet.forward_cl
+# 2-D blocks (models/modules.py:28-116, 342-360).  Inside FeatureNet they are parameter holders (its HIP plan reads their conv / bn
+# children); called on their own they run the same kernels one block at a time (eval mode, autograd off, NCHW tensors on the GPU).
 # ----------------------------------------------------------------------------------------------
+def _nhwc(x):
+    """(N,C,H,W) -> channels-last; an RGB image gets a zero fourth channel (the first layer's kernel reads 4-channel pixels)."""
+    x = x.contiguous().float()
+    return ops.rgb_to_nhwc4(x) if x.shape[1] == 3 else ops.to_channels_last(x)
+
+
+def _packed_of(module, make):
+    """Packed weight of a stand-alone block, rebuilt when its parameter changes."""
+    w = module.conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    c = module.__dict__.get("_rcmvs_pack")
+    if c is None or c[0] != key:
+        c = module.__dict__["_rcmvs_pack"] = (key, make(w.detach()))
+    return c[1]
+
+
+def _affine_of(m):
+    """What follows the convolution in eval mode as (scale, shift): the folded BatchNorm, or the conv's bias."""
+    if getattr(m, "gn", None) is not None:
+        raise RcmvsError(f"{type(m).__name__}: GroupNorm blocks are not provided (the reference builds every block with norm='batch_norm')")
+    if m.bn is not None:
+        return _bn_fold(m.bn)
+    b = m.conv.bias
+    if b is None:
+        return None, None
+    return torch.ones_like(b, dtype=torch.float32), b.detach().float().contiguous()
+
+
+def _same2(v, n):
+    return tuple(v) == (n, n)
+
+
+def _conv2d_block_cl(m, t):
+    """One Conv2d block (conv -> [BatchNorm] -> [ReLU], models/modules.py:56-62) on a channels-last map t (N,H,W,Ci).
+    5x5 stride 2 and the RGB layer: the 2-D kernel (csrc/conv2d.hip); 1x1 / 3x3: a one-plane volume on the 3-D family."""
+    conv = m.conv
+    K = conv.kernel_size[0]
+    st = conv.stride[0]
+    if (not _same2(conv.kernel_size, K) or K not in (1, 3, 5) or not _same2(conv.padding, K // 2) or not _same2(conv.stride, st)
+            or st not in (1, 2) or not _same2(conv.dilation, 1) or conv.groups != 1 or conv.padding_mode != "zeros"):
+        raise RcmvsError(f"Conv2d: only square 1x1 / 3x3 / 5x5 kernels with 'same' zero padding, stride 1 or 2, no dilation or groups "
+                         f"(the layers of models/modules.py) run on the HIP path; got {conv}")
+    scale, shift = _affine_of(m)
+    relu = bool(m.relu)
+    if K == 5 or conv.in_channels == 3:
+        pw = _packed_of(m, lambda w: ops.pack_conv2d_weight(w, pad_in_to=4 if w.shape[1] == 3 else None))
+        return ops.conv2d(t, pw, scale, shift, stride=st, relu=relu)
+    pw = _packed_of(m, lambda w: ops.pack_conv3d_weight(FeatureNet._w3(w)))
+    return ops.conv3d(t.unsqueeze(1), pw, scale, shift, stride=st, relu=relu).squeeze(1)
+
+
+def _deconv2d_block_cl(m, t):
+    """One Deconv2d block (models/modules.py:100-110: ConvTranspose2d k3 s2 p1 op1 -> BatchNorm -> [ReLU]) on a channels-last map:
+    the transposed 3-D kernel on a one-plane volume whose weight has only its middle depth slice -- output plane 0 is the 2-D result
+    (plane 1 sees no tap and is discarded: twice the arithmetic, no new kernel for the reference's non-default pyramid)."""
+    conv = m.conv
+    if (not _same2(conv.kernel_size, 3) or not _same2(conv.stride, 2) or not _same2(conv.padding, 1) or not _same2(conv.output_padding, 1)
+            or not _same2(conv.dilation, 1) or conv.groups != 1):
+        raise RcmvsError(f"Deconv2d: only kernel 3, stride 2, padding 1, output_padding 1 (DeConv2dFuse, models/modules.py:346) runs on the "
+                         f"HIP path; got {conv}")
+    if m.bn is None:
+        raise RcmvsError("Deconv2d: bn=False is not provided (the reference's forward returns its INPUT in that case, models/modules.py:106-110)")
+    scale, shift = _bn_fold(m.bn)
+    pw = _packed_of(m, lambda w: ops.pack_conv3d_weight(F.pad(w.unsqueeze(2), (0, 0, 0, 0, 1, 1)), transposed=True))
+    return ops.deconv3d(t.unsqueeze(1), pw, scale, shift, relu=bool(m.relu))[:, 0]
+
+
 class Conv2d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
                  init_method="xavier", **kwargs):
@@ -44,16 +112,64 @@ class Conv2d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        _holder_only(self)
+        """models/modules.py:56-62 as a stand-alone module: (N,Ci,H,W) -> (N,Co,Ho,Wo), eval mode, autograd off."""
+        if _hip_inference(self, x):
+            return ops.to_channels_first(_conv2d_block_cl(self, _nhwc(x)).contiguous())
+        _unsupported(self, x)
+
+
+class Deconv2d(nn.Module):
+    """models/modules.py:71-116 (only DeConv2dFuse of the 'unet' pyramid uses it)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        assert stride in [1, 2]
+        self.out_channels = out_channels
+        self.stride = stride
+        self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        if _hip_inference(self, x):
+            return ops.to_channels_first(_deconv2d_block_cl(self, _nhwc(x)).contiguous())
+        _unsupported(self, x)
+
+
+class DeConv2dFuse(nn.Module):
+    """models/modules.py:342-360: up-sample x by the transposed conv, concatenate with the skip map, 3x3 conv."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, relu=True, bn=True, bn_momentum=0.1):
+        super().__init__()
+        self.deconv = Deconv2d(in_channels, out_channels, kernel_size, stride=2, padding=1, output_padding=1, bn=True, relu=relu,
+                               bn_momentum=bn_momentum)
+        self.conv = Conv2d(2 * out_channels, out_channels, kernel_size, stride=1, padding=1, bn=bn, relu=relu, bn_momentum=bn_momentum)
+
+    def forward_cl(self, x_pre, x):
+        """channels-last twin of forward: x_pre (N,2h,2w,Co), x (N,h,w,Ci) -> (N,2h,2w,Co)."""
+        up = _deconv2d_block_cl(self.deconv, x)
+        if up.shape != x_pre.shape:
+            raise RcmvsError(f"DeConv2dFuse: the skip map {tuple(x_pre.shape)} is not twice the size of the up-sampled one {tuple(up.shape)}")
+        return _conv2d_block_cl(self.conv, torch.cat((up, x_pre), dim=-1))
+
+    def forward(self, x_pre, x):
+        if _hip_inference(self, x_pre, x):
+            return ops.to_channels_first(self.forward_cl(_nhwc(x_pre), _nhwc(x)).contiguous())
+        _unsupported(self, x_pre, x)
 
 
 class FeatureNet(nn.Module):
-    """models/modules.py:363-464, arch_mode='fpn'."""
+    """models/modules.py:363-464.  arch_mode='fpn' is the reference's shipped configuration (CascadeMVSNet passes it,
+    models/casmvsnet.py:354) and the tuned one; 'unet' (the class default of the reference: DeConv2dFuse merges, 1x1 output convs) runs in
+    eval mode on the same kernel families, one block at a time."""
 
     def __init__(self, base_channels, num_stage=3, stride=4, arch_mode="fpn"):
         super().__init__()
-        if arch_mode != "fpn":
-            raise NotImplementedError("only arch_mode='fpn' (the reference's shipped configuration) is provided")
+        if arch_mode not in ("unet", "fpn"):
+            raise ValueError("mode must be in 'unet' or 'fpn', but get:{}".format(arch_mode))
+        if num_stage not in (1, 2, 3):
+            raise ValueError("num_stage must be 1, 2 or 3")
         self.arch_mode = arch_mode
         self.stride = stride
         self.base_channels = base_channels
@@ -67,7 +183,16 @@ class FeatureNet(nn.Module):
         self.out1 = nn.Conv2d(b * 4, b * 4, 1, bias=False)
         self.out_channels = [4 * b]
         final_chs = b * 4
-        if num_stage == 3:
+        if arch_mode == "unet":
+            if num_stage >= 2:
+                self.deconv1 = DeConv2dFuse(b * 4, b * 2, 3)
+                self.out2 = nn.Conv2d(b * 2, b * 2, 1, bias=False)
+                self.out_channels.append(2 * b)
+            if num_stage == 3:
+                self.deconv2 = DeConv2dFuse(b * 2, b, 3)
+                self.out3 = nn.Conv2d(b, b, 1, bias=False)
+                self.out_channels.append(b)
+        elif num_stage == 3:
             self.inner1 = nn.Conv2d(b * 2, final_chs, 1, bias=True)
             self.inner2 = nn.Conv2d(b * 1, final_chs, 1, bias=True)
             self.out2 = nn.Conv2d(final_chs, b * 2, 3, padding=1, bias=False)
@@ -87,10 +212,11 @@ class FeatureNet(nn.Module):
             # incremented in place by every train-mode forward and stands in for them
             tens += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.num_batches_tracked]
         extra = [self.out1.weight]
+        unet = self.arch_mode == "unet"              # (its merge blocks keep their own packed weights: _packed_of)
         if self.num_stage >= 2:
-            extra += [self.inner1.weight, self.inner1.bias, self.out2.weight]
+            extra += [self.out2.weight] if unet else [self.inner1.weight, self.inner1.bias, self.out2.weight]
         if self.num_stage == 3:
-            extra += [self.inner2.weight, self.inner2.bias, self.out3.weight]
+            extra += [self.out3.weight] if unet else [self.inner2.weight, self.inner2.bias, self.out3.weight]
         key = tuple((t.data_ptr(), t._version) for t in tens + extra)
         if getattr(self, "_plan", None) is None or key != self._plan_key:
             plan = {}
@@ -114,7 +240,10 @@ class FeatureNet(nn.Module):
                     continue
                 plan[n] = (ops.pack_conv2d_weight(w, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
-            if self.num_stage >= 2:
+            if unet:
+                for n in ("out2", "out3")[:self.num_stage - 1]:           # 1x1, Co = Ci: the middle tap of a one-plane 3-D kernel
+                    plan[n] = ops.pack_conv3d_weight(self._w3(getattr(self, n).weight.detach()))
+            elif self.num_stage >= 2:
                 plan["inner1"] = (ops.pack_conv2d_weight(self.inner1.weight), self.inner1.bias.detach().float().contiguous())
                 if tuple(self.out2.weight.shape) == (16, 32, 3, 3):       # 32 -> 16 3x3: planar split-bf16 kernel, as the trunk's square layers
                     w3 = self.out2.weight.detach().new_zeros(16, 32, 3, 3, 3)
@@ -122,7 +251,7 @@ class FeatureNet(nn.Module):
                     plan["out2"] = ("mfma3d", ops.pack_conv3d_weight(w3))
                 else:
                     plan["out2"] = ops.pack_conv2d_weight(self.out2.weight)
-            if self.num_stage == 3:
+            if self.num_stage == 3 and not unet:
                 plan["inner2"] = (ops.pack_conv2d_weight(self.inner2.weight), self.inner2.bias.detach().float().contiguous())
                 plan["out3"] = ops.pack_conv2d_weight(self.out3.weight)
                 plan["fuse_out3"] = (os.environ.get("RCMVS_FPN_FUSE", "1") != "0" and tuple(self.inner2.weight.shape[:2]) == (32, 8)
@@ -158,6 +287,15 @@ class FeatureNet(nn.Module):
         c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = cbr(cbr(cbr(c1, "conv2.0"), "conv2.1"), "conv2.2")
         out = {"stage1": (lambda t=c2: ops.conv2d(t, p["out1"]))}
+        if self.arch_mode == "unet":                     # models/modules.py:449-457
+            one = lambda t, n: ops.conv3d(t.unsqueeze(1), p[n]).squeeze(1)
+            if self.num_stage >= 2:
+                intra = self.deconv1.forward_cl(c1, c2)
+                out["stage2"] = (lambda t=intra: one(t, "out2"))
+            if self.num_stage == 3:
+                intra = self.deconv2.forward_cl(c0, intra)
+                out["stage3"] = (lambda t=intra: one(t, "out3"))
+            return out if lazy else {k: f() for k, f in out.items()}
         if self.num_stage >= 2:
             intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
             if isinstance(p["out2"], tuple):
@@ -201,6 +339,9 @@ class FeatureNet(nn.Module):
         train_ops (conv / norm / gradients on the HIP kernels; the 5x5 stride-2 layers as space-to-depth + 3x3, the 2x
         nearest up-sampling and the adds of the FPN merge as PyTorch element-wise ops).  Returns channels-last maps."""
         from .train_ops import ConvPlainFn, conv_bn_train_w
+        if self.arch_mode != "fpn":
+            raise RcmvsError("FeatureNet(arch_mode='unet'): the train-mode HIP path covers the shipped 'fpn' pyramid only (the one-plane form of "
+                             "its transposed convs would put the discarded plane into the batch statistics)")
         N, _, H, W = x.shape
         if H % 4 or W % 4:
             raise RcmvsError("FeatureNet (training): image height and width must be multiples of 4")
@@ -244,7 +385,8 @@ class FeatureNet(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------
-# 3-D blocks (models/modules.py:118-210) -- parameter holders (the HIP plans read their conv / bn children)
+# 3-D blocks (models/modules.py:118-210): inside CostRegNet the network's HIP plan reads their conv / bn children; called on their own
+# they run the same kernels one block at a time (_block3d)
 # ----------------------------------------------------------------------------------------------
 class Conv3d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1, **kwargs):
@@ -259,7 +401,9 @@ class Conv3d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        _holder_only(self)
+        """models/modules.py:149-157 as a stand-alone module: (B,Ci,D,H,W) -> (B,Co,Do,Ho,Wo) on the 3-D conv family (eval mode with
+        autograd off: folded BatchNorm; train mode: batch statistics + autograd, train_ops.ConvBnReluFn)."""
+        return _block3d(self, x)
 
 
 class Deconv3d(nn.Module):
@@ -274,7 +418,36 @@ class Deconv3d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        _holder_only(self)
+        """models/modules.py:196-204 as a stand-alone module: (B,Ci,D,H,W) -> (B,Co,2D,2H,2W)."""
+        return _block3d(self, x)
+
+
+def _block3d(m, x):
+    """A Conv3d / Deconv3d block called on its own (inside CostRegNet the plan of the network runs it)."""
+    conv = m.conv
+    transposed = isinstance(conv, nn.ConvTranspose3d)
+    ok = (_same3(conv.kernel_size, 3) and _same3(conv.padding, 1) and _same3(conv.dilation, 1) and conv.groups == 1
+          and (_same3(conv.stride, 2) and _same3(conv.output_padding, 1) if transposed
+               else conv.stride[0] in (1, 2) and _same3(conv.stride, conv.stride[0]) and conv.padding_mode == "zeros"))
+    if not ok:
+        raise RcmvsError(f"{type(m).__name__}: only kernel 3, padding 1 (transposed: stride 2, output_padding 1) -- the layers of "
+                         f"CostRegNet, models/modules.py:473-487 -- run on the HIP path; got {conv}")
+    if _hip_inference(m, x):
+        scale, shift = _affine_of(m)
+        pw = _packed_of(m, lambda w: ops.pack_conv3d_weight(w, transposed=transposed))
+        t = ops.to_channels_last(x.contiguous().float())
+        y = ops.deconv3d(t, pw, scale, shift, relu=bool(m.relu)) if transposed else ops.conv3d(t, pw, scale, shift, stride=conv.stride[0], relu=bool(m.relu))
+        return ops.to_channels_first(y)
+    if _hip_training(m, x):
+        if m.bn is None or conv.bias is not None:
+            raise RcmvsError(f"{type(m).__name__}: the train-mode HIP path is conv -> BatchNorm (batch statistics) -> [ReLU] without a bias")
+        from .train_ops import conv_bn_relu_train
+        return conv_bn_relu_train(m, x.float().permute(0, 2, 3, 4, 1).contiguous()).permute(0, 4, 1, 2, 3)
+    _unsupported(m, x)
+
+
+def _same3(v, n):
+    return tuple(v) == (n, n, n)
 
 
 def _bn_fold(bn):
@@ -403,20 +576,68 @@ def _unsupported(module, *tensors):
 
 def _holder_only(module):
     raise RcmvsError(f"{type(module).__name__} is a parameter holder: its conv / bn children are executed by the enclosing "
-                     "network's HIP plan (CascadeMVSNet.forward, CostRegNet.forward, FeatureNet.forward)")
+                     "network's HIP plan (Rendering_Consistency_Net.forward and its volume / MLP chains)")
 
 
 class DepthNet(nn.Module):
-    """Parameter-free child kept for API / checkpoint compatibility (models/casmvsnet.py:45-124, 234-311): the per-stage cost
-    volume + depth head it stands for run inside _CascadeBase._forward_hip / _forward_train_hip (warp+variance kernel K1,
-    cost regularisation, fused depth head)."""
+    """models/casmvsnet.py:45-124 (train variant: also returns volume_feature_no_ref) and 234-311 (DepthNet_eval): one stage's cost volume
+    + regularisation + depth head.  Parameter-free.  Inside the cascade the stage loop of _CascadeBase runs these ops itself (it keeps
+    the channels-last maps, the batched homographies and the activation bounds across stages); called on its own it is the same
+    kernels for one stage."""
 
     def __init__(self, train_variant):
         super().__init__()
         self.train_variant = train_variant
 
-    def forward(self, *args, **kwargs):
-        _holder_only(self)
+    def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, imgs=None, pad=0, prob_volume_init=None):
+        """features: V maps (B,C,h,w), reference view first; proj_matrices (B,V,2,4,4); depth_values (B,D,h,w), uniformly spaced along D
+        at every pixel (what get_depth_range_samples produces, models/modules.py:560-620: the kernels take them as {d_0, delta} planes);
+        cost_regularization: a CostRegNet; imgs (B,V,3,H,W), needed by the train variant only."""
+        if pad != 0 or prob_volume_init is not None:
+            raise RcmvsError("DepthNet: pad and prob_volume_init are not provided (no caller of the reference passes them)")
+        V = len(features)
+        B, C, h, w = features[0].shape
+        D = int(num_depth)
+        if proj_matrices.shape[1] != V:
+            raise RcmvsError("DepthNet: different number of images and projection matrices")
+        if tuple(depth_values.shape) != (B, D, h, w):
+            raise RcmvsError(f"DepthNet: depth_values {tuple(depth_values.shape)} is not (B, num_depth, h, w) = {(B, D, h, w)}")
+        dv = depth_values.float()
+        d0 = dv[:, 0]
+        delta = (dv[:, 1] - d0) if D > 1 else torch.zeros_like(d0)
+        k = torch.arange(D, device=dv.device, dtype=torch.float32).view(1, D, 1, 1)
+        if float((dv - (d0.unsqueeze(1) + k * delta.unsqueeze(1))).abs().max()) > 1e-5 * float(dv.abs().max()):
+            raise RcmvsError("DepthNet: depth_values must be uniformly spaced along the depth axis at every pixel (d_0 + k * delta)")
+        planes = torch.stack((d0, delta), dim=-1).contiguous()
+        with torch.no_grad():
+            rot, trans = ops.compose_homography(proj_matrices.contiguous().float())
+            small_cl = None
+            if self.train_variant:
+                if imgs is None:
+                    raise RcmvsError("DepthNet (train variant): imgs (B,V,3,H,W) are needed for volume_feature_no_ref")
+                small = F.interpolate(imgs.float().reshape(B * V, *imgs.shape[2:]), (h, w), mode="bilinear", align_corners=False)
+                small_cl = ops.to_channels_last(small.contiguous()).view(B, V, h, w, 3)
+        if _hip_inference(self, *features, depth_values):
+            f_cl = torch.stack([ops.to_channels_last(f.contiguous().float()) for f in features], dim=1)
+            var = ops.warp_variance(f_cl, rot, trans, planes, D)
+            x8 = cost_regularization.features_cl(var)
+            depth, conf = ops.depth_head(x8, cost_regularization.hip_plan()["prob"], planes)
+            out = {"depth": depth, "photometric_confidence": conf}
+            if self.train_variant:          # eval mode: the reference's in-place pow_ quirk applies (models/casmvsnet.py:95-97)
+                out["volume_feature_no_ref"] = ops.warp_noref(f_cl, small_cl, rot, trans, planes, D, square_first=True)
+            return out
+        if _hip_training(self, *features, depth_values):
+            from . import train_ops
+            f_cl = torch.stack([f.float().permute(0, 2, 3, 1) for f in features], dim=1).contiguous()
+            res = ops.WarpVarianceFn.apply(f_cl, rot, trans, planes, D, small_cl)
+            var, noref = res if self.train_variant else (res, None)
+            x8 = cost_regularization.features_cl_train(var)
+            depth, conf = train_ops.ProbDepthHeadFn.apply(x8, cost_regularization.prob.weight, planes)
+            out = {"depth": depth, "photometric_confidence": conf}
+            if self.train_variant:
+                out["volume_feature_no_ref"] = noref
+            return out
+        _unsupported(self, *features, depth_values)
 
 
 class _CascadeBase(nn.Module):

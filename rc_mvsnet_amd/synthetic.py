@@ -117,6 +117,34 @@ def cascade_state_dict(seed=0, feat_channels=(32, 16, 8), prob_gain=20.0):
     return sd
 
 
+def feature_unet_state_dict(seed=0, base=8, num_stage=3):
+    """State dict of FeatureNet(base, num_stage, arch_mode='unet') (models/modules.py:363-401): the trunk of the 'fpn' form, the
+    DeConv2dFuse merges and the 1x1 output convs; BN statistics randomised."""
+    rng = np.random.RandomState(seed)
+    sd, b = {}, base
+    for name, ci, co, k in (("conv0.0", 3, b, 3), ("conv0.1", b, b, 3), ("conv1.0", b, 2 * b, 5), ("conv1.1", 2 * b, 2 * b, 3),
+                            ("conv1.2", 2 * b, 2 * b, 3), ("conv2.0", 2 * b, 4 * b, 5), ("conv2.1", 4 * b, 4 * b, 3),
+                            ("conv2.2", 4 * b, 4 * b, 3)):
+        sd[f"{name}.conv.weight"] = _w(rng, (co, ci, k, k), ci * k * k, math.sqrt(2.0))
+        _bn(sd, rng, f"{name}.bn", co)
+    sd["out1.weight"] = _w(rng, (4 * b, 4 * b, 1, 1), 4 * b)
+    for n, (name, ci, co) in enumerate((("deconv1", 4 * b, 2 * b), ("deconv2", 2 * b, b))[:num_stage - 1]):
+        sd[f"{name}.deconv.conv.weight"] = _w(rng, (ci, co, 3, 3), ci * 9 / 4, math.sqrt(2.0))        # ConvTranspose2d: (in, out, k, k)
+        _bn(sd, rng, f"{name}.deconv.bn", co)
+        sd[f"{name}.conv.conv.weight"] = _w(rng, (co, 2 * co, 3, 3), 2 * co * 9, math.sqrt(2.0))
+        _bn(sd, rng, f"{name}.conv.bn", co)
+        sd[f"out{n + 2}.weight"] = _w(rng, (co, co, 1, 1), co)
+    return sd
+
+
+def cascade_unet_state_dict(seed=0, prob_gain=1.0):
+    """State dict of CascadeMVSNet[_eval](arch_mode='unet') (3 stages, cr base 8): the 'unet' pyramid + the cost regularisations of
+    cascade_state_dict (a smooth probability head by default)."""
+    sd = {"feature." + k: v for k, v in feature_unet_state_dict(seed).items()}
+    sd.update({k: v for k, v in cascade_state_dict(seed, prob_gain=prob_gain).items() if k.startswith("cost_regularization.")})
+    return sd
+
+
 def cost_reg_state_dict(rng, prefix, cin, base=8, prob_gain=20.0):
     sd = {}
     for name, kind, ci, co in cost_reg_specs(cin, base):

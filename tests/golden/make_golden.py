@@ -12,6 +12,7 @@ rejects 5-D input as shipped; train_rcmvsnet.py:525 applies the same conversion)
     python tests/golden/make_golden.py --full     # + the config-2 (512x640, D=48/32/8) depth map
 """
 import argparse
+import math
 import os
 import re
 import sys
@@ -528,8 +529,93 @@ def dataset_fixture():
     save("dataset", **arrays)
 
 
+@torch.no_grad()
+def blocks_fixture():
+    """The reference's building blocks called on their own (models/modules.py:28-210, 342-360) and its non-default feature pyramid
+    (FeatureNet, arch_mode='unet', models/modules.py:363-464): inputs, weights (blocks) / the seed of the weights (pyramid), outputs."""
+    import_reference()
+    from models import modules as M
+    g = torch.Generator().manual_seed(77)
+    rng = np.random.RandomState(77)
+    arrays = {}
+
+    def fill(m):
+        sd = {}
+        for k, v in m.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                sd[k] = torch.tensor(0, dtype=torch.long)
+            elif k.endswith("running_var") or k.endswith("bn.weight"):
+                sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+            elif v.dim() <= 1:
+                sd[k] = torch.from_numpy((0.1 * rng.standard_normal(tuple(v.shape))).astype(np.float32))
+            else:
+                bound = math.sqrt(6.0 / (v[0].numel() if not isinstance(m.conv, (torch.nn.ConvTranspose2d, torch.nn.ConvTranspose3d)) else v[:, 0].numel()))
+                sd[k] = torch.from_numpy(rng.uniform(-bound, bound, tuple(v.shape)).astype(np.float32))
+        m.load_state_dict(sd, strict=True)
+        return m.eval()
+
+    cases = {
+        "conv3d_s2": (M.Conv3d(8, 16, stride=2, padding=1), (2, 8, 8, 12, 16)),
+        "conv3d_norelu": (M.Conv3d(16, 16, relu=False, padding=1), (1, 16, 4, 8, 12)),
+        "deconv3d": (M.Deconv3d(16, 8, stride=2, padding=1, output_padding=1), (2, 16, 4, 6, 8)),
+        "conv2d_5x5s2": (M.Conv2d(16, 32, 5, stride=2, padding=2), (2, 16, 24, 32)),
+        "conv2d_bias": (M.Conv2d(8, 8, 3, 1, padding=1, bn=False), (2, 8, 12, 20)),
+        "conv2d_rgb": (M.Conv2d(3, 8, 3, 1, padding=1), (2, 3, 16, 24)),
+        "conv2d_1x1": (M.Conv2d(16, 32, 1, relu=False), (1, 16, 12, 16)),
+        "deconv2d": (M.Deconv2d(32, 16, 3, stride=2, padding=1, output_padding=1), (2, 32, 6, 10)),
+    }
+    for name, (m, shape) in cases.items():
+        m = fill(m)
+        x = torch.randn(*shape, generator=g)
+        arrays[name + ":x"] = x
+        arrays[name + ":y"] = m(x.clone())
+        for k, v in m.state_dict().items():
+            arrays[f"{name}:sd:{k}"] = v
+    fuse = M.DeConv2dFuse(32, 16, 3)
+    fill(fuse.deconv), fill(fuse.conv)
+    fuse.eval()
+    xp, x = torch.randn(1, 16, 12, 16, generator=g), torch.randn(1, 32, 6, 8, generator=g)
+    arrays["fuse:x_pre"], arrays["fuse:x"], arrays["fuse:y"] = xp, x, fuse(xp.clone(), x.clone())
+    for k, v in fuse.state_dict().items():
+        arrays[f"fuse:sd:{k}"] = v
+    for ns in (3, 2):
+        net = M.FeatureNet(base_channels=8, num_stage=ns, arch_mode="unet")
+        net.load_state_dict(synthetic.feature_unet_state_dict(5, 8, ns), strict=True)
+        net.eval()
+        img = synthetic.images(1, 2, 32, 48, 9)[0]
+        for k, v in net(img).items():
+            arrays[f"unet{ns}:{k}"] = v
+    # the whole cascade on that pyramid (the reference's CascadeMVSNet_eval takes arch_mode, models/casmvsnet.py:316,354)
+    models = sys.modules["models"]
+    net = models.CascadeMVSNet_eval(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1], arch_mode="unet", cr_base_chs=[8, 8, 8])
+    net.load_state_dict(synthetic.cascade_unet_state_dict(3), strict=True)
+    net.eval()
+    o = net(*synthetic.cascade_inputs(1, 3, 64, 96, 2))
+    arrays["cascade_unet:depth"], arrays["cascade_unet:conf"] = o["depth"], o["photometric_confidence"]
+    # one stage on its own: DepthNet_eval and DepthNet (train variant, eval mode) of models/casmvsnet.py
+    C = sys.modules["models.casmvsnet"]
+    B, V, Cf, D, h, w = 1, 3, 8, 8, 16, 24
+    feats = [torch.randn(B, Cf, h, w, generator=g) for _ in range(V)]
+    pm = synthetic.proj_matrices(B, V, h, w)["stage3"]
+    d0 = 500.0 + 100.0 * torch.rand(B, h, w, generator=g)
+    dvals = (d0.unsqueeze(1) + 2.5 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).contiguous()
+    imgs = synthetic.images(B, V, h, w, 4)
+    cr = M.CostRegNet(Cf, 8)
+    cr.load_state_dict({k[2:]: v for k, v in synthetic.cost_reg_state_dict(np.random.RandomState(12), "x", Cf, prob_gain=1.0).items()}, strict=True)
+    cr.eval()
+    o_eval = C.DepthNet_eval().eval()([f.clone() for f in feats], pm, dvals.clone(), D, cr, imgs)
+    o_train = C.DepthNet().eval()([f.clone() for f in feats], pm, dvals.clone(), D, cr, imgs)
+    for v in range(V):
+        arrays[f"depthnet:feat{v}"] = feats[v]
+    arrays.update({"depthnet:depth_values": dvals, "depthnet:depth": o_eval["depth"], "depthnet:conf": o_eval["photometric_confidence"],
+                   "depthnet:depth_t": o_train["depth"], "depthnet:noref": o_train["volume_feature_no_ref"]})
+    save("blocks", unet_seed=5, image_seed=9, **arrays)
+
+
 if __name__ == "__main__":
-    if "--only-pfm" in sys.argv:
+    if "--only-blocks" in sys.argv:
+        blocks_fixture()
+    elif "--only-pfm" in sys.argv:
         pfm_fixture()
     elif "--only-train-grads" in sys.argv:
         train_grads()
@@ -547,3 +633,4 @@ if __name__ == "__main__":
         unsup_loss_fixture()
         fusion_fixture()
         dataset_fixture()
+        blocks_fixture()

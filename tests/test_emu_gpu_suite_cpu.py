@@ -63,7 +63,9 @@ FAST = {
          "test_warp_variance_vs_oracle", "test_warp_variance_golden_fixture", "test_warp_variance_backward_vs_oracle_autograd",
          "test_conv3d_vs_oracle", "test_conv3d_x3_item_schedule_is_bit_exact", "test_conv3d_x3_planar_vs_fp64", "test_conv3d_x3h_vs_fp64", "test_prob_conv_marching_kernel", "test_prob_conv_z_chunk_does_not_change_the_result", "test_conv2d_s2d_is_the_5x5_stride2_layer", "test_conv3d_lds_halo_kernel", "test_deconv3d_vs_oracle", "test_conv3d_golden_and_linearity",
          "test_costreg_vs_golden", "test_conv2d_vs_torch_cpu", "test_depth_head_vs_oracle", "test_depth_head_golden",
-         "test_fpn_out_fused_is_bit_identical"],
+         "test_fpn_out_fused_is_bit_identical", "test_standalone_blocks_vs_reference_golden",
+         "test_deconv2d_fuse_and_unet_pyramid_vs_reference_golden", "test_standalone_conv3d_block_trains_like_torch",
+         "test_depthnet_on_its_own_vs_reference_golden"],
     GR: ["test_resize_planes", "test_gu_sampler_vs_oracle", "test_nerf_mlp_vs_oracle", "test_composite_vs_oracle"],
     GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel", "test_conv3d_weight_gradient_cout8_paired_columns",
          "test_selective_weight_pack_matches_full_blob_and_is_checked", "test_packed_weight_reuse_follows_the_parameter_version",
@@ -76,7 +78,8 @@ FAST = {
 }
 SLOW = {
     GP: ["test_train_variant_volume_feature", "test_warp_variance_variants_agree", "test_feature_net_vs_oracle",
-         "test_cascade_batch_two_equals_two_singles", "test_conv3d_x3_vs_fp64", "test_conv3d_x3_strided_vs_fp64"],
+         "test_cascade_batch_two_equals_two_singles", "test_conv3d_x3_vs_fp64", "test_conv3d_x3_strided_vs_fp64",
+         "test_cascade_on_the_unet_pyramid_vs_reference_golden"],
     GR: ["test_neural_volume_vs_golden", "test_render_forward_vs_reference_golden"],
     GT: ["test_conv_bn_relu_block_forward_backward", "test_neural_volume_net_train_native_vs_delegated",
          "test_renderer_train_native_vs_delegated", "test_featurenet_train_native_vs_delegated",

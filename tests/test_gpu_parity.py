@@ -615,6 +615,141 @@ def test_feature_net_vs_oracle(hip):
             assert float(e.max()) < 5e-5 * max(1.0, float(ref[k].abs().max()))
 
 
+def _golden_state(g, prefix):
+    return {k[len(prefix):]: torch.as_tensor(np.asarray(v)) for k, v in g.items() if k.startswith(prefix)}
+
+
+def _standalone_block(name):
+    from rc_mvsnet_amd import casmvsnet as C
+    return {"conv3d_s2": lambda: C.Conv3d(8, 16, stride=2, padding=1),
+            "conv3d_norelu": lambda: C.Conv3d(16, 16, relu=False, padding=1),
+            "deconv3d": lambda: C.Deconv3d(16, 8, stride=2, padding=1, output_padding=1),
+            "conv2d_5x5s2": lambda: C.Conv2d(16, 32, 5, stride=2, padding=2),
+            "conv2d_bias": lambda: C.Conv2d(8, 8, 3, 1, padding=1, bn=False),
+            "conv2d_rgb": lambda: C.Conv2d(3, 8, 3, 1, padding=1),
+            "conv2d_1x1": lambda: C.Conv2d(16, 32, 1, relu=False),
+            "deconv2d": lambda: C.Deconv2d(32, 16, 3, stride=2, padding=1, output_padding=1)}[name]()
+
+
+@pytest.mark.parametrize("name", ["conv3d_s2", "conv3d_norelu", "deconv3d", "conv2d_5x5s2", "conv2d_bias", "conv2d_rgb", "conv2d_1x1", "deconv2d"])
+def test_standalone_blocks_vs_reference_golden(hip, name):
+    """The building blocks of models/modules.py called on their own (eval mode): same constructor arguments, the reference's state
+    dict, the reference's output (tests/golden/blocks.npz, made by importing the reference)."""
+    g = load_golden("blocks")
+    m = _standalone_block(name)
+    m.load_state_dict(_golden_state(g, name + ":sd:"), strict=True)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        y = m(gpu(g[name + ":x"]))
+    assert tuple(y.shape) == tuple(g[name + ":y"].shape)
+    assert rel_err(y.cpu(), g[name + ":y"]) < 2e-5
+
+
+def test_deconv2d_fuse_and_unet_pyramid_vs_reference_golden(hip):
+    """DeConv2dFuse (models/modules.py:342-360) and the reference's non-default feature pyramid, FeatureNet(arch_mode='unet')
+    (models/modules.py:363-464), 3 and 2 stages, against the imported reference."""
+    from rc_mvsnet_amd import casmvsnet as C, synthetic
+    g = load_golden("blocks")
+    fuse = C.DeConv2dFuse(32, 16, 3)
+    fuse.load_state_dict(_golden_state(g, "fuse:sd:"), strict=True)
+    fuse = fuse.to(DEV).eval()
+    with torch.no_grad():
+        y = fuse(gpu(g["fuse:x_pre"]), gpu(g["fuse:x"]))
+    assert rel_err(y.cpu(), g["fuse:y"]) < 2e-5
+    img = synthetic.images(1, 2, 32, 48, int(g["image_seed"]))[0]
+    for ns in (3, 2):
+        net = C.FeatureNet(base_channels=8, num_stage=ns, arch_mode="unet")
+        net.load_state_dict(synthetic.feature_unet_state_dict(int(g["unet_seed"]), 8, ns), strict=True)
+        net = net.to(DEV).eval()
+        assert net.out_channels == [32, 16, 8][:ns]
+        with torch.no_grad():
+            out = net(gpu(img))
+        assert sorted(out) == [f"stage{k + 1}" for k in range(ns)]
+        for k, v in out.items():
+            assert tuple(v.shape) == tuple(g[f"unet{ns}:{k}"].shape)
+            assert rel_err(v.cpu(), g[f"unet{ns}:{k}"]) < 5e-5, (ns, k)
+        net.train()
+        with pytest.raises(Exception, match="fpn"):
+            net(gpu(img))
+
+
+def test_cascade_on_the_unet_pyramid_vs_reference_golden(hip):
+    """CascadeMVSNet_eval(arch_mode='unet') end to end against the imported reference (smooth probability head)."""
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    g = load_golden("blocks")
+    m = CascadeMVSNet_eval(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1], arch_mode="unet")
+    m.load_state_dict(synthetic.cascade_unet_state_dict(3), strict=True)
+    m = m.to(DEV).eval()
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 64, 96, 2)
+    with torch.no_grad():
+        out = m(gpu(imgs), {k: gpu(v) for k, v in pm.items()}, gpu(dv))
+    dd = (out["depth"].cpu() - g["cascade_unet:depth"]).abs()
+    rng = float(dv.max() - dv.min())
+    print(f"cascade on the unet pyramid: depth L1/range = {float(dd.mean()) / rng:.3e}, max {float(dd.max()):.3e} mm")
+    assert float(dd.mean()) / rng < 1e-4
+    stable = dd < 0.05
+    assert float(stable.float().mean()) > 0.97
+    assert float(((out["photometric_confidence"].cpu() - g["cascade_unet:conf"]).abs()[stable] > 1e-3).float().mean()) < 0.02
+
+
+def test_depthnet_on_its_own_vs_reference_golden(hip):
+    """DepthNet_eval / DepthNet (models/casmvsnet.py:45-124, 234-311) called like the reference calls them -- a list of per-view maps,
+    (B,V,2,4,4) projections, a (B,D,h,w) sample volume, a CostRegNet -- against the imported reference, eval mode (where the train
+    variant's volume_feature_no_ref carries the reference's in-place pow_ quirk)."""
+    from rc_mvsnet_amd import casmvsnet as C, synthetic
+    g = load_golden("blocks")
+    B, V, Cf, D, h, w = 1, 3, 8, 8, 16, 24
+    feats = [gpu(g[f"depthnet:feat{v}"]) for v in range(V)]
+    pm = gpu(synthetic.proj_matrices(B, V, h, w)["stage3"])
+    dv = gpu(g["depthnet:depth_values"])
+    imgs = gpu(synthetic.images(B, V, h, w, 4))
+    cr = C.CostRegNet(Cf, 8)
+    cr.load_state_dict({k[2:]: v for k, v in synthetic.cost_reg_state_dict(np.random.RandomState(12), "x", Cf, prob_gain=1.0).items()}, strict=True)
+    cr = cr.to(DEV).eval()
+    rng = float(dv.max() - dv.min())
+    with torch.no_grad():
+        o = C.DepthNet(False).eval()(feats, pm, dv, D, cr, imgs)
+        t = C.DepthNet(True).eval()(feats, pm, dv, D, cr, imgs)
+        assert sorted(o) == ["depth", "photometric_confidence"] and sorted(t) == ["depth", "photometric_confidence", "volume_feature_no_ref"]
+        assert float((o["depth"].cpu() - g["depthnet:depth"]).abs().mean()) / rng < 1e-4
+        assert float((o["photometric_confidence"].cpu() - g["depthnet:conf"]).abs().mean()) < 1e-4
+        assert torch.equal(t["depth"], o["depth"])
+        assert float((t["depth"].cpu() - g["depthnet:depth_t"]).abs().mean()) / rng < 1e-4
+        assert rel_err(t["volume_feature_no_ref"].cpu(), g["depthnet:noref"]) < 2e-5
+        with pytest.raises(Exception, match="uniformly spaced"):
+            C.DepthNet(False).eval()(feats, pm, dv * dv / 500.0, D, cr, imgs)
+
+
+def test_standalone_conv3d_block_trains_like_torch(hip):
+    """Conv3d / Deconv3d called on their own in train mode: batch-statistics BatchNorm, autograd through the HIP kernels, running
+    statistics updated -- against the same block in plain PyTorch (fp64) on the host."""
+    from rc_mvsnet_amd import casmvsnet as C
+    g = torch.Generator().manual_seed(11)
+    for make, shape in ((lambda: C.Conv3d(8, 16, stride=2, padding=1), (2, 8, 8, 8, 8)),
+                        (lambda: C.Deconv3d(16, 8, stride=2, padding=1, output_padding=1), (1, 16, 4, 4, 8))):
+        m = make()
+        ref = torch.nn.Sequential(type(m.conv)(m.conv.in_channels, m.conv.out_channels, 3, stride=m.conv.stride, padding=1, bias=False,
+                                               **({"output_padding": 1} if isinstance(m.conv, torch.nn.ConvTranspose3d) else {})),
+                                  torch.nn.BatchNorm3d(m.conv.out_channels, momentum=0.1)).double()
+        ref[0].weight.data.copy_(m.conv.weight.data)
+        x = torch.randn(*shape, generator=g)
+        gy = torch.randn(*ref(x.double()).shape, generator=g)
+        ref.zero_grad()
+        ref[1].running_mean.zero_(); ref[1].running_var.fill_(1.0)
+        xr = x.double().requires_grad_(True)
+        yr = torch.relu(ref(xr))
+        (yr * gy.double()).sum().backward()
+        m = m.to(DEV).train()
+        xg = gpu(x).requires_grad_(True)
+        y = m(xg)
+        (y * gpu(gy)).sum().backward()
+        assert rel_err(y.detach().cpu(), yr.detach()) < 5e-5
+        assert rel_err(xg.grad.cpu(), xr.grad) < 2e-4
+        assert rel_err(m.conv.weight.grad.cpu(), ref[0].weight.grad) < 2e-4
+        assert rel_err(m.bn.running_var.cpu(), ref[1].running_var) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ K4
 @pytest.mark.parametrize("D,h,w", [(8, 12, 16), (48, 16, 24), (32, 9, 130)])
 def test_depth_head_vs_oracle(hip, D, h, w):
