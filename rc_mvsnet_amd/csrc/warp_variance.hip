@@ -348,6 +348,103 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Wave-specialised form of the kernel above (debug variants 4-7; NOT on the production path; UNMEASURED -- written at the end of round 3
+// after the GPU budget was spent, bit-identical to the production kernel on the tests' CPU emulation and ready for the first visit of the
+// next round).  What the round-2 review asked for: phase A (coordinate chains, VALU) and phase B (gathers + blend + stores, vector L1)
+// of one tile no longer alternate behind a block-wide barrier per plane chunk with every wave doing both; a block owns a tile and walks
+// its plane chunks, NPW producer waves computing the tap table of chunk i+1 into the second half of a double-buffered LDS table while
+// the four consumer waves gather / blend / store chunk i -- one barrier per chunk, the two kinds of work on different waves of the
+// same SIMDs at the same time.  Same tap function, same LDS record layout, same consumer code and operation order as the production
+// kernel: every output bit is the same.  gridDim.y splits a tile's chunks over several blocks (cpb chunks each) when there are too
+// few tiles to fill the chip (stage 1: 640 tiles).
+// ------------------------------------------------------------------------------------------
+template <int C, int DKB, bool FAST, int NVT, int NPW>
+__global__ __launch_bounds__(256 + 64 * NPW) void warp_variance_ws_kernel(
+    const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int cpb) {
+#pragma clang fp contract(off)
+    constexpr int LPP = C / 4;
+    constexpr int PIX = 256 / LPP;
+    constexpr int TH = 4, TW = PIX / TH;
+    constexpr int TAB = NVT * DKB * PIX;                 // records per buffer
+    constexpr int NPT = 64 * NPW;                        // producer threads
+    static_assert(NVT == 2 || NVT == 4, "compile-time view count");
+    extern __shared__ __attribute__((aligned(16))) v4i lds_ws[];          // buffer j: TAB offset records at j * 2 * TAB, then TAB weight records
+    const int b = blockIdx.z;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const int hw = h * w;
+    const int nchunks = (D + DKB - 1) / DKB;
+    const int c0 = blockIdx.y * cpb, c1 = min(nchunks, c0 + cpb);
+    K1Geom g;
+    g.w = w; g.h = h;
+    g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
+    g.half_w = g.wm1 / 2.0f; g.half_h = g.hm1 / 2.0f;
+    g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
+    const float* fb = feats + (long long)b * V * hw * C;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
+    const bool producer = threadIdx.x >= 256;
+    // consumer identity (threads 0..255), as in the kernel above
+    const int p = (threadIdx.x & 255) / LPP;
+    const int q4b = ((threadIdx.x & 255) % LPP) * 16;
+    const int x = tx0 + p % TW, y = ty0 + p / TW;
+    const bool inside = !producer && (x < w) && (y < h);
+    v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
+    const float fV = (float)V, rV = rcp_nr(fV);
+    float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
+
+    for (int i = c0; i <= c1; ++i) {
+        if (producer) {
+            if (i < c1) {
+                v4i* lo = lds_ws + ((i - c0) & 1) * 2 * TAB;
+                v4f* lw = reinterpret_cast<v4f*>(lo + TAB);
+                const int k0 = i * DKB;
+                for (int it = threadIdx.x - 256; it < TAB; it += NPT) {           // record index = (va * DKB + ka) * PIX + pa
+                    const int pa = it % PIX, ka = (it / PIX) % DKB, va = it / (PIX * DKB);
+                    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
+                    const float fxa = (float)xa, fya = (float)ya;
+                    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
+                    const float* r = rot + ((long long)b * (V - 1) + va) * 9;
+                    const float* t = trans + ((long long)b * (V - 1) + va) * 3;
+                    const float rx = (r[0] * fxa + r[1] * fya) + r[2];
+                    const float ry = (r[3] * fxa + r[4] * fya) + r[5];
+                    const float rz = (r[6] * fxa + r[7] * fya) + r[8];
+                    const float d = pla.x + (float)(k0 + ka) * pla.y;
+                    v4i o;
+                    v4f wt;
+                    k1_tap<C>(rx, ry, rz, t[0], t[1], t[2], d, g, (1 + va) * hw, o, wt);
+                    lo[it] = o;
+                    lw[it] = wt;
+                }
+            }
+        } else if (i > c0 && inside) {
+            const v4i* lo = lds_ws + ((i - 1 - c0) & 1) * 2 * TAB;
+            const v4f* lw = reinterpret_cast<const v4f*>(lo + TAB);
+            const int k0 = (i - 1) * DKB;
+            // the production kernel's consumer loop (all NVT views in one group)
+            K1Fetch<NVT> f0, f1;
+            k1_issue<NVT, DKB, PIX>(f0, lo, lw, rsrc, 0, p, q4b, 0);
+#pragma unroll
+            for (int k = 0; k < DKB; ++k) {
+                K1Fetch<NVT>& cur = (k & 1) ? f1 : f0;
+                K1Fetch<NVT>& nxt = (k & 1) ? f0 : f1;
+                if (k + 1 < DKB) k1_issue<NVT, DKB, PIX>(nxt, lo, lw, rsrc, k + 1, p, q4b, 0);
+                v4f a = ref, a2 = ref * ref;
+#pragma unroll
+                for (int va = 0; va < NVT; ++va) {
+                    v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], cur.w[va]);
+                    a = a + val;
+                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
+                }
+                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Round 3 (profiles/r3_k1_schedule_variants.txt, bit-identical forms of the kernel above, two source views): bilinear weights re-read
 // from the LDS record at blend time instead of carried with the taps (133-136 instead of 153-156 VGPRs) 155.6 us per scene; the same
 // with two tap sets prefetched 181.2; the same capped at 128 VGPRs for four waves per SIMD (28-36 bytes of scratch) 173.2; against
@@ -445,8 +542,55 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
     RCMVS_REQUIRE((long long)h * w * C < (1LL << 31), "warp_variance_fwd: feature map too large for 32-bit offsets");
-    RCMVS_REQUIRE(variant >= 0 && variant <= 3, "warp_variance_fwd: unknown variant %d", variant);
+    RCMVS_REQUIRE(variant >= 0 && variant <= 7, "warp_variance_fwd: unknown variant %d", variant);
     RCMVS_REQUIRE(C == 8 || C == 16 || C == 32, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+    if (variant >= 4) {
+        // wave-specialised form (see warp_variance_ws_kernel): 4 / 5 = one / two producer waves, a tile's plane chunks split over
+        // gridDim.y so that the launch has at least ~4 blocks per CU; 6 / 7 = the same with one block per tile
+        const int nsrc = V - 1;
+        RCMVS_REQUIRE(nsrc == 2 || nsrc == 4, "warp_variance_fwd: the wave-specialised variants take 2 or 4 source views (got %d)", nsrc);
+        const int LPP = C / 4, PIX = 256 / LPP;
+        const int dkb = (C == 8) ? 4 : 8;
+        const int npw = (variant & 1) ? 2 : 1;
+        const size_t lds = (size_t)2 * 32 * nsrc * dkb * PIX;
+        RCMVS_REQUIRE(lds <= 160 * 1024, "warp_variance_fwd: the double-buffered tap table needs %zu bytes of LDS", lds);
+        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
+        const int TWp = PIX / 4;
+        const int txp = (w + TWp - 1) / TWp, typ = (h + 3) / 4;
+        const int nchunks = (D + dkb - 1) / dkb;
+        int ysplit = 1;
+        if (variant < 6) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            RCMVS_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess, "warp_variance_fwd: no device");
+            while (ysplit < nchunks && (long long)txp * typ * B * ysplit < 4LL * prop.multiProcessorCount) ++ysplit;
+        }
+        const int cpb = (nchunks + ysplit - 1) / ysplit;
+        dim3 gridw(txp * typ, (nchunks + cpb - 1) / cpb, B);
+#define RCMVS_K1WS(CC, DD, NN, PP)                                                                                          \
+    do {                                                                                                                    \
+        static bool attr_done = false;                                                                                      \
+        if (!attr_done) {                                                                                                   \
+            RCMVS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_variance_ws_kernel<CC, DD, false, NN, PP>),  \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,        \
+                          "warp_variance_fwd: cannot raise the dynamic LDS limit");                                         \
+            attr_done = true;                                                                                               \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((warp_variance_ws_kernel<CC, DD, false, NN, PP>), gridw, dim3(256 + 64 * PP), lds, st, feats, rot, \
+                           trans, planes, var, V, D, h, w, txp, cpb);                                                       \
+    } while (0)
+#define RCMVS_K1WS_P(CC, DD, NN) do { if (npw == 2) RCMVS_K1WS(CC, DD, NN, 2); else RCMVS_K1WS(CC, DD, NN, 1); } while (0)
+#define RCMVS_K1WS_N(CC, DD) do { if (nsrc == 2) RCMVS_K1WS_P(CC, DD, 2); else RCMVS_K1WS_P(CC, DD, 4); } while (0)
+        switch (C) {
+            case 8:  RCMVS_K1WS_N(8, 4); break;
+            case 16: RCMVS_K1WS_N(16, 8); break;
+            default: RCMVS_K1WS_N(32, 8); break;
+        }
+#undef RCMVS_K1WS_N
+#undef RCMVS_K1WS_P
+#undef RCMVS_K1WS
+        return launch_status("warp_variance_fwd (wave-specialised)");
+    }
     if (variant <= 1) {
         const bool fastm = variant == 1;
         const int LPP = C / 4, PIX = 256 / LPP;
