@@ -205,18 +205,19 @@ class FeatureNet(nn.Module):
 
     # -- native inference path: channels-last HIP kernels (conv + folded BN + ReLU, FPN merge fused) --------
     def hip_plan(self):
-        mods = [m for seq in (self.conv0, self.conv1, self.conv2) for m in seq]
+        # (tensors read straight from the module dictionaries: nn.Module.__getattr__ made this walk 0.1 ms of host time per scene)
+        sub = self._modules
+        mods = [m for seq in ("conv0", "conv1", "conv2") for m in sub[seq]._modules.values()]
         tens = []
         for m in mods:
             # running statistics are updated by the kernels through raw pointers (no version bump): num_batches_tracked is
             # incremented in place by every train-mode forward and stands in for them
-            tens += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.num_batches_tracked]
-        extra = [self.out1.weight]
+            cp, bn = m._modules["conv"]._parameters, m._modules["bn"]
+            bp, bb = bn._parameters, bn._buffers
+            tens += [cp["weight"], bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"], bb["num_batches_tracked"]]
         unet = self.arch_mode == "unet"              # (its merge blocks keep their own packed weights: _packed_of)
-        if self.num_stage >= 2:
-            extra += [self.out2.weight] if unet else [self.inner1.weight, self.inner1.bias, self.out2.weight]
-        if self.num_stage == 3:
-            extra += [self.out3.weight] if unet else [self.inner2.weight, self.inner2.bias, self.out3.weight]
+        heads = ["out1"] + (["out2", "out3"] if unet else ["inner1", "out2", "inner2", "out3"])
+        extra = [t for n in heads if n in sub for t in sub[n]._parameters.values() if t is not None]
         key = tuple((t.data_ptr(), t._version) for t in tens + extra)
         if getattr(self, "_plan", None) is None or key != self._plan_key:
             plan = {}
@@ -482,11 +483,17 @@ class CostRegNet(nn.Module):
 
     # -- HIP execution plan: packed weights + folded BN, rebuilt only when a tensor changes -----
     def _tensors(self):
+        # read straight from the module dictionaries: nn.Module.__getattr__ costs ~0.4 us per attribute and this list is walked for every
+        # plan validation (61 tensors, six lookups deep, three networks per scene -- it was 0.4 ms of host time per scene in round 3)
         ts = []
+        mods = self._modules
         for n in self._LAYERS:
-            m = getattr(self, n)
-            ts += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var, m.bn.num_batches_tracked]
-        return ts + [self.prob.weight]
+            m = mods[n]._modules
+            cp, bn = m["conv"]._parameters, m["bn"]
+            bp, bb = bn._parameters, bn._buffers
+            ts += [cp["weight"], bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"], bb["num_batches_tracked"]]
+        ts.append(mods["prob"]._parameters["weight"])
+        return ts
 
     def hip_plan(self):
         key = tuple((t.data_ptr(), t._version) for t in self._tensors())
@@ -501,7 +508,7 @@ class CostRegNet(nn.Module):
             self._plan, self._plan_key = plan, key
         return self._plan
 
-    def features_cl(self, x, x_absmax=None):
+    def features_cl(self, x, x_absmax=None, plan=None):
         """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8).
         x_absmax: None = the exact three-piece bf16 form of the matrix-core kernels; or a (7, ops.ABSMAX_FLOATS) tensor whose row 0
         is a bound of max|x| (ops.absmax format; the cascade derives it from the feature maps) and whose rows 1-6 are ZERO: the
@@ -511,7 +518,7 @@ class CostRegNet(nn.Module):
         if D % 8 or h % 8 or w % 8:
             raise RcmvsError(f"CostRegNet: volume {D}x{h}x{w} must be divisible by 8 in every axis "
                              "(three stride-2 levels with skip connections, models/modules.py:492-499)")
-        p = self.hip_plan()
+        p = self.hip_plan() if plan is None else plan          # (the cascade validates a stage's plan once and hands it in)
         if x_absmax is None:
             conv0 = ops.conv3d(x, *p["conv0"], relu=True)
             conv2 = ops.conv3d(ops.conv3d(conv0, *p["conv1"], stride=2, relu=True), *p["conv2"], relu=True)
@@ -727,8 +734,9 @@ class _CascadeBase(nn.Module):
             if bounds is not None:
                 vmax = bounds[s]
                 ops.absmax(f_cl, square=True, out=vmax[0])
-            x8 = cr.features_cl(var, vmax)
-            depth, conf = ops.depth_head(x8, cr.hip_plan()["prob"], planes)
+            plan = cr.hip_plan()
+            x8 = cr.features_cl(var, vmax, plan)
+            depth, conf = ops.depth_head(x8, plan["prob"], planes)
             out = {"depth": depth, "photometric_confidence": conf}
             if self.TRAIN_VARIANT:
                 small = F.interpolate(imgs.reshape(B * V, 3, H, W), (h, w), mode="bilinear", align_corners=False)

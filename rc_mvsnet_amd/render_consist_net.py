@@ -264,7 +264,7 @@ class Rendering_Consistency_Net(nn.Module):
         pseudo = pseudo_depth.reshape(H, W).float()
         if _hip_inference(self, volume_feature_warp, pseudo):
             return self._forward_hip(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
-        if self.MVSNet.hip_trainable(volume_feature_warp) and pseudo.is_cuda:
+        if self.MVSNet.hip_trainable(volume_feature_warp) and _hip_training(self.MVSNet, pseudo):
             return self._forward_train_hip(volume_feature_warp, pseudo, imgs, w2cs, c2ws, intr, nf, pix, eps, u)
         _unsupported(self, volume_feature_warp, pseudo)
 

@@ -65,7 +65,7 @@ FAST = {
          "test_costreg_vs_golden", "test_conv2d_vs_torch_cpu", "test_depth_head_vs_oracle", "test_depth_head_golden",
          "test_fpn_out_fused_is_bit_identical", "test_standalone_blocks_vs_reference_golden",
          "test_deconv2d_fuse_and_unet_pyramid_vs_reference_golden", "test_standalone_conv3d_block_trains_like_torch",
-         "test_depthnet_on_its_own_vs_reference_golden"],
+         "test_depthnet_on_its_own_vs_reference_golden", "test_execution_plans_follow_their_parameters"],
     GR: ["test_resize_planes", "test_gu_sampler_vs_oracle", "test_nerf_mlp_vs_oracle", "test_composite_vs_oracle"],
     GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel", "test_conv3d_weight_gradient_cout8_paired_columns",
          "test_selective_weight_pack_matches_full_blob_and_is_checked", "test_packed_weight_reuse_follows_the_parameter_version",

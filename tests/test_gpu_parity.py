@@ -713,6 +713,40 @@ def test_cascade_on_the_unet_pyramid_vs_reference_golden(hip):
     assert float(((out["photometric_confidence"].cpu() - g["cascade_unet:conf"]).abs()[stable] > 1e-3).float().mean()) < 0.02
 
 
+def test_execution_plans_follow_their_parameters(hip):
+    """The packed-weight plans of CostRegNet / FeatureNet are validated per call against (address, version) of every parameter and
+    buffer they were built from (read straight from the module dictionaries): an in-place update, load_state_dict, a REPLACED Parameter
+    object and a replaced BatchNorm child all rebuild the plan; an untouched module reuses it."""
+    from rc_mvsnet_amd import casmvsnet as C, synthetic
+    torch.manual_seed(3)
+    cr = C.CostRegNet(8, 8).to(DEV).eval()
+    fn = C.FeatureNet(8, num_stage=3, arch_mode="fpn").to(DEV).eval()
+    x = gpu(torch.randn(1, 8, 8, 8, 16))
+    img = gpu(synthetic.images(1, 1, 16, 24, 1)[0])
+    with torch.no_grad():
+        y0, f0 = cr(x), fn(img)
+        p_cr, p_fn = cr.hip_plan(), fn.hip_plan()
+        assert cr.hip_plan() is p_cr and fn.hip_plan() is p_fn and torch.equal(cr(x), y0)
+        cr.conv3.conv.weight.mul_(1.5)                                   # in place: version bump
+        assert cr.hip_plan() is not p_cr and not torch.equal(cr(x), y0)
+        cr.conv3.conv.weight.div_(1.5)
+        p_cr = cr.hip_plan()
+        cr.conv5.conv.weight = torch.nn.Parameter(cr.conv5.conv.weight.detach() * 2.0)      # a new Parameter object
+        assert cr.hip_plan() is not p_cr
+        p_cr = cr.hip_plan()
+        cr.conv0.bn = torch.nn.BatchNorm3d(8).to(DEV).eval()             # a replaced child module (what SyncBatchNorm conversion does)
+        assert cr.hip_plan() is not p_cr
+        sd = {k: v.clone() for k, v in fn.state_dict().items()}
+        sd["out3.weight"] *= 0.5
+        fn.load_state_dict(sd)                                           # copies in place: version bump
+        assert fn.hip_plan() is not p_fn
+        f1 = fn(img)
+        assert torch.equal(f1["stage1"], f0["stage1"]) and not torch.equal(f1["stage3"], f0["stage3"])
+        p_fn = fn.hip_plan()
+        fn.conv1[1].bn.running_var.add_(0.25)                            # a buffer of the trunk
+        assert fn.hip_plan() is not p_fn
+
+
 def test_depthnet_on_its_own_vs_reference_golden(hip):
     """DepthNet_eval / DepthNet (models/casmvsnet.py:45-124, 234-311) called like the reference calls them -- a list of per-view maps,
     (B,V,2,4,4) projections, a (B,D,h,w) sample volume, a CostRegNet -- against the imported reference, eval mode (where the train
