@@ -721,8 +721,8 @@ def test_execution_plans_follow_their_parameters(hip):
     torch.manual_seed(3)
     cr = C.CostRegNet(8, 8).to(DEV).eval()
     fn = C.FeatureNet(8, num_stage=3, arch_mode="fpn").to(DEV).eval()
-    x = gpu(torch.randn(1, 8, 8, 8, 16))
-    img = gpu(synthetic.images(1, 1, 16, 24, 1)[0])
+    x = gpu(torch.randn(1, 8, 8, 16, 24))                    # (the shapes of costreg_eval.npz / test_feature_net_vs_oracle)
+    img = gpu(synthetic.images(1, 1, 64, 96, 1)[0])
     with torch.no_grad():
         y0, f0 = cr(x), fn(img)
         p_cr, p_fn = cr.hip_plan(), fn.hip_plan()
