@@ -16,7 +16,9 @@ stage 3's hypothesis planes: the kernel had read 32-byte pieces of the PREVIOUS 
 stage 2's depth map, although the depth kernel before it on the same stream had completed and a copy taken right after the launch shows
 the right map.  A release fence at the end of the writer changes nothing; agent-scope (sc1) loads of the depth map in the reader remove it:
 0 corrupted scenes in ~7000 since (eager 2 streams, hipGraph replay on 2 and 3 streams, all stages compared) against 7 % before --
-adopted in csrc/geometry.hip (ld_agent).  What is NOT understood is why a stale line survives the kernel-boundary cache invalidation
+adopted in csrc/geometry.hip (ld_agent).  By the hardware guide sc1 loads bypass the vector L1 only (they are served by the L2): the stale
+sector sat in the reading CU's L1, which the dispatch's own acquire should have invalidated and -- with the other queue's waves on that CU --
+did not.  What is NOT understood is why a stale line survives the kernel-boundary cache invalidation
 only when a second queue of the same process is active, so other readers may be exposed at rates those runs do not show.  Hence: one
 stream is the default and the supported mode; more than one warns; ``bench.py --streams N`` and the side pass self-check their outputs
 against the one-stream run and say so in the line.  Two worker PROCESSES per GPU give the same gain (2 x 2.214 ms per scene measured)
