@@ -178,6 +178,10 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ p
                                                       float* __restrict__ planes, int hp, int wp, int H, int W,
                                                       int scale, int D, float ratio, int ND) {
 #pragma clang fp contract(off)
+#ifdef RCMVS_EXP_PLANES_ACQUIRE      // experiment of tools/dev/build_plain_planes_variant.sh (two-stream investigation): invalidate this CU's L1 first
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+#endif
     const int h = H / scale, w = W / scale;
     const int b = blockIdx.y;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
