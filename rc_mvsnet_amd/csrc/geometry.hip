@@ -25,6 +25,7 @@ int fail(int code, const char* fmt, ...) {
 template <bool TO_LAST>
 __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       int C, long long S) {
+    RCMVS_KERNEL_ENTRY();
     const int Q = C >> 2;
     const int n = blockIdx.y;
     // lanes: s fastest inside a group of 64 so the planar accesses coalesce
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ s
 template <bool TO_LAST>
 __global__ __launch_bounds__(256) void layout_scalar_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                              int C, long long S) {
+    RCMVS_KERNEL_ENTRY();
     const int n = blockIdx.y;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S * C) return;
@@ -98,6 +100,7 @@ __device__ static void fold_intrinsics(const float* p, double A[4][4]) {
 struct ProjPtrs { const float* p[4]; };
 __global__ void compose_homography_kernel(ProjPtrs pp, float* __restrict__ rot,
                                           float* __restrict__ trans, int B, int V) {
+    RCMVS_KERNEL_ENTRY();
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * (V - 1)) return;
     const float* proj = pp.p[blockIdx.y];
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ p
                                                       float* __restrict__ planes, int hp, int wp, int H, int W,
                                                       int scale, int D, float ratio, int ND) {
 #pragma clang fp contract(off)
+    RCMVS_KERNEL_ENTRY();
 #ifdef RCMVS_EXP_PLANES_ACQUIRE      // experiment of tools/dev/build_plain_planes_variant.sh (two-stream investigation): invalidate this CU's L1 first
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void warp_variance_ref_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int tiles_y) {
 #pragma clang fp contract(off)
+    RCMVS_KERNEL_ENTRY();
     constexpr int LPP = C / 4;          // lanes per pixel
     constexpr int TW = 256 / C;         // pixels per wave = tile width  (1 KiB of output per plane)
     constexpr int TH = 4;               // one wave per tile row
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
 #pragma clang fp contract(off)
+    RCMVS_KERNEL_ENTRY();
     constexpr int LPP = C / 4;
     constexpr int PIX = 256 / LPP;          // pixels per block
     constexpr int TH = 4, TW = PIX / TH;
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void warp_variance_ws_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int cpb) {
 #pragma clang fp contract(off)
+    RCMVS_KERNEL_ENTRY();
     constexpr int LPP = C / 4;
     constexpr int PIX = 256 / LPP;
     constexpr int TH = 4, TW = PIX / TH;
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(256) void warp_noref_kernel(
     const float* __restrict__ trans, const float* __restrict__ planes, float* __restrict__ out,
     int V, int D, int h, int w, int square_first) {
 #pragma clang fp contract(off)
+    RCMVS_KERNEL_ENTRY();
     const int b = blockIdx.z, k = blockIdx.y;
     const long long hw = (long long)h * w;
     long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
