@@ -69,10 +69,7 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
 
 /* Test / profiling twin of rcmvs_warp_variance_fwd with an explicit code variant (stateless, re-entrant): 0 = the production
  * kernel, 1 = production with FMA-contracted blend (<= 2e-7 relative), 2 = reference-order kernel (one full coordinate chain per
- * lane, compiler IEEE division -- the kernel the production one is held bit-identical to), 3 = store-only ablation, 4-7 = the
- * wave-specialised form (2 or 4 source views only; producer waves build the tap table of plane chunk i+1 while the consumer waves
- * gather / blend / store chunk i: 4 / 5 = one / two producer waves with a tile's chunks split over blocks to fill the chip, 6 / 7 = the
- * same with one block per tile) -- bit-identical to variant 0. */
+ * lane, compiler IEEE division -- the kernel the production one is held bit-identical to), 3 = store-only ablation. */
 int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                                   const float* planes, float* var,
                                   int B, int V, int C, int D, int h, int w, int variant, void* stream);

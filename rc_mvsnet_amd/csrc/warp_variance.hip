@@ -223,22 +223,55 @@ __device__ __forceinline__ void k1_store_variance(v4f a, v4f a2, float fV, float
     __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dst));
 }
 
-template <int C, int DKB, bool FAST, int NVT, int NG = (NVT == 0 ? 1 : (NVT > 4 ? 3 : NVT))>
+// Common prologue of the two kernels below: geometry constants, the block's tile and the two thread identities.
+template <int C>
+struct K1Tile {
+    static constexpr int LPP = C / 4;
+    static constexpr int PIX = 256 / LPP;          // pixels per block
+    static constexpr int TH = 4, TW = PIX / TH;
+    static constexpr int GRP = 256 / PIX;          // phase-A threads per pixel
+};
+
+// one view's share of phase A for this thread: KPT planes of pixel (xa, ya) -> LDS records [slot][ka][pa]
+template <int C, int DKB>
+__device__ __forceinline__ void k1_phase_a(const float* __restrict__ rot, const float* __restrict__ trans, int b, int V, int view, int slot,
+                                           float fxa, float fya, float2 pla, int k0, int hw, const K1Geom& g, v4i* lds_o, v4f* lds_w) {
+#pragma clang fp contract(off)
+    constexpr int PIX = K1Tile<C>::PIX, GRP = K1Tile<C>::GRP, KPT = DKB / GRP;
+    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
+    const float* r = rot + ((long long)b * (V - 1) + (view - 1)) * 9;
+    const float* t = trans + ((long long)b * (V - 1) + (view - 1)) * 3;
+    const float rx = (r[0] * fxa + r[1] * fya) + r[2];
+    const float ry = (r[3] * fxa + r[4] * fya) + r[5];
+    const float rz = (r[6] * fxa + r[7] * fya) + r[8];
+    const float t0 = t[0], t1 = t[1], t2 = t[2];
+    const int vrow = view * hw;
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk) {
+        const int ka = ga + kk * GRP;
+        const float d = pla.x + (float)(k0 + ka) * pla.y;
+        v4i o;
+        v4f wt;
+        k1_tap<C>(rx, ry, rz, t0, t1, t2, d, g, vrow, o, wt);
+        const int idx = (slot * DKB + ka) * PIX + pa;
+        lds_o[idx] = o;
+        lds_w[idx] = wt;
+    }
+}
+
+// compile-time view count (2, 4 or 6 source views): straight-line body.  Kept apart from the runtime-view kernel below because sharing
+// one function cost 30-40 VGPRs (128 / 156 / 153 against 98 / 116 / 116 at C = 8 / 16 / 32 with two source views) and 4 % of the time
+// (profiles/r4_k1_walls.txt).
+template <int C, int DKB, bool FAST, int NVT, int NG = (NVT > 4 ? 3 : NVT)>
 __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
-    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x) {
 #pragma clang fp contract(off)
     RCMVS_KERNEL_ENTRY();
-    constexpr int LPP = C / 4;
-    constexpr int PIX = 256 / LPP;          // pixels per block
-    constexpr int TH = 4, TW = PIX / TH;
-    constexpr int GRP = 256 / PIX;          // phase-A threads per pixel
-    constexpr int KPT = DKB / GRP;          // planes per phase-A thread
-    constexpr bool MULTI = (NVT == 0);
-    static_assert(DKB % GRP == 0, "DKB must be a multiple of 256/PIX");
-    extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [nv][DKB][PIX] offsets, then weights
-    const int nvmax = MULTI ? VC : NVT;
-    v4f* lds_w = reinterpret_cast<v4f*>(lds_o + nvmax * DKB * PIX);
+    constexpr int LPP = K1Tile<C>::LPP, PIX = K1Tile<C>::PIX, TH = K1Tile<C>::TH, TW = K1Tile<C>::TW, GRP = K1Tile<C>::GRP;
+    static_assert(NVT > 0 && DKB % GRP == 0, "DKB must be a multiple of 256/PIX");
+    extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [NVT][DKB][PIX] offsets, then weights
+    v4f* lds_w = reinterpret_cast<v4f*>(lds_o + NVT * DKB * PIX);
     const int b = blockIdx.z;
     const int k0 = blockIdx.y * DKB;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -251,7 +284,6 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
     const float* fb = feats + (long long)b * V * hw * C;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
-
     // ---- phase-B identity
     const int p = threadIdx.x / LPP;
     const int q4b = (threadIdx.x % LPP) * 16;                    // byte offset of this lane's channel quad
@@ -261,124 +293,58 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
     const float fV = (float)V, rV = rcp_nr(fV);
     float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
-    // ---- phase-A identity
-    const int pa = threadIdx.x % PIX, ga = threadIdx.x / PIX;
-    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
-    const float fxa = (float)xa, fya = (float)ya;
-    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
-
-    v4f s[MULTI ? DKB : 1], sq[MULTI ? DKB : 1];
-    if (MULTI) {
-#pragma unroll
-        for (int k = 0; k < DKB; ++k) { s[k] = ref; sq[k] = ref * ref; }
+    // ---------------- phase A
+    {
+        const int pa = threadIdx.x % PIX;
+        const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
+        const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
+        for (int va = 0; va < NVT; ++va)
+            k1_phase_a<C, DKB>(rot, trans, b, V, 1 + va, va, (float)xa, (float)ya, pla, k0, hw, g, lds_o, lds_w);
     }
-
-    for (int v0 = 1; v0 < V; v0 += nvmax) {
-        const int nv = MULTI ? min(VC, V - v0) : NVT;
-        if (MULTI && v0 > 1) __syncthreads();
-        // ---------------- phase A
-        for (int va = 0; va < nv; ++va) {
-            const float* r = rot + ((long long)b * (V - 1) + (v0 + va - 1)) * 9;
-            const float* t = trans + ((long long)b * (V - 1) + (v0 + va - 1)) * 3;
-            const float rx = (r[0] * fxa + r[1] * fya) + r[2];
-            const float ry = (r[3] * fxa + r[4] * fya) + r[5];
-            const float rz = (r[6] * fxa + r[7] * fya) + r[8];
-            const float t0 = t[0], t1 = t[1], t2 = t[2];
-            const int vrow = (v0 + va) * hw;
+    __syncthreads();
+    if (!inside) return;
+    // ---------------- phase B: double-buffered gathers over the flattened (plane, view group) sequence: the group after the current one
+    // (same plane or the next) is in flight while the current one is blended.  NG = views per group: all of them for 2 / 4 source
+    // views, 3 for the 7-view setting (two full tap sets of 6 views exceed the register file).  Views are accumulated in ascending
+    // order whatever the grouping, so the result is bit-identical.
+    constexpr int NGRP = NVT / NG, NS = DKB * NGRP;
+    static_assert(NVT % NG == 0, "view groups must divide the view count");
+    K1Fetch<NG> f0, f1;
+    k1_issue<NG, DKB, PIX>(f0, lds_o, lds_w, rsrc, 0, p, q4b, 0);
+    v4f a = ref, a2 = ref * ref;
 #pragma unroll
-            for (int kk = 0; kk < KPT; ++kk) {
-                const int ka = ga + kk * GRP;
-                const float d = pla.x + (float)(k0 + ka) * pla.y;
-                v4i o;
-                v4f wt;
-                k1_tap<C>(rx, ry, rz, t0, t1, t2, d, g, vrow, o, wt);
-                const int idx = (va * DKB + ka) * PIX + pa;
-                lds_o[idx] = o;
-                lds_w[idx] = wt;
-            }
+    for (int st = 0; st < NS; ++st) {
+        const int k = st / NGRP, gi = st % NGRP;
+        K1Fetch<NG>& cur = (st & 1) ? f1 : f0;
+        K1Fetch<NG>& nxt = (st & 1) ? f0 : f1;
+        if (st + 1 < NS) k1_issue<NG, DKB, PIX>(nxt, lds_o, lds_w, rsrc, (st + 1) / NGRP, p, q4b, ((st + 1) % NGRP) * NG);
+        if (gi == 0) { a = ref; a2 = ref * ref; }
+#pragma unroll
+        for (int va = 0; va < NG; ++va) {
+            v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], cur.w[va]);
+            a = a + val;
+            if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
         }
-        __syncthreads();
-        // ---------------- phase B
-        if (!inside) continue;
-        if constexpr (!MULTI) {
-            // double-buffered gathers over the flattened (plane, view group) sequence: the group after the current one
-            // (same plane or the next) is in flight while the current one is blended.  NG = views per group: all of them
-            // for 2 / 4 source views, 3 for the 7-view setting (two full tap sets of 6 views exceed the register file).
-            // Views are accumulated in ascending order whatever the grouping, so the result is bit-identical.
-            constexpr int NGRP = NVT / NG, NS = DKB * NGRP;
-            static_assert(NVT % NG == 0, "view groups must divide the view count");
-            K1Fetch<NG> f0, f1;
-            k1_issue<NG, DKB, PIX>(f0, lds_o, lds_w, rsrc, 0, p, q4b, 0);
-            v4f a = ref, a2 = ref * ref;
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                const int k = st / NGRP, gi = st % NGRP;
-                K1Fetch<NG>& cur = (st & 1) ? f1 : f0;
-                K1Fetch<NG>& nxt = (st & 1) ? f0 : f1;
-                if (st + 1 < NS) k1_issue<NG, DKB, PIX>(nxt, lds_o, lds_w, rsrc, (st + 1) / NGRP, p, q4b, ((st + 1) % NGRP) * NG);
-                if (gi == 0) { a = ref; a2 = ref * ref; }
-#pragma unroll
-                for (int va = 0; va < NG; ++va) {
-                    v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], cur.w[va]);
-                    a = a + val;
-                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
-                }
-                if (gi == NGRP - 1 && k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < DKB; ++k) {
-                v4f a = s[k], a2 = sq[k];
-                for (int va = 0; va < nv; ++va) {
-                    K1Fetch<1> f;
-                    const int idx = (va * DKB + k) * PIX + p;
-                    const v4i o = lds_o[idx];
-                    f.w[0] = lds_w[idx];
-                    f.t[0][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + q4b, 0, 0));
-                    f.t[0][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + q4b, 0, 0));
-                    f.t[0][2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + q4b, 0, 0));
-                    f.t[0][3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + q4b, 0, 0));
-                    v4f val = blend4<FAST>(f.t[0][0], f.t[0][1], f.t[0][2], f.t[0][3], f.w[0]);
-                    a = a + val;
-                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
-                }
-                if (v0 + nv < V) { s[k] = a; sq[k] = a2; continue; }
-                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
-            }
-        }
+        if (gi == NGRP - 1 && k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Wave-specialised form of the kernel above (debug variants 4-7; NOT on the production path; UNMEASURED -- written at the end of round 3
-// after the GPU budget was spent, bit-identical to the production kernel on the tests' CPU emulation and ready for the first visit of the
-// next round).  What the round-2 review asked for: phase A (coordinate chains, VALU) and phase B (gathers + blend + stores, vector L1)
-// of one tile no longer alternate behind a block-wide barrier per plane chunk with every wave doing both; a block owns a tile and walks
-// its plane chunks, NPW producer waves computing the tap table of chunk i+1 into the second half of a double-buffered LDS table while
-// the four consumer waves gather / blend / store chunk i -- one barrier per chunk, the two kinds of work on different waves of the
-// same SIMDs at the same time.  Same tap function, same LDS record layout, same consumer code and operation order as the production
-// kernel: every output bit is the same.  gridDim.y splits a tile's chunks over several blocks (cpb chunks each) when there are too
-// few tiles to fill the chip (stage 1: 640 tiles).
-// ------------------------------------------------------------------------------------------
-template <int C, int DKB, bool FAST, int NVT, int NPW>
-__global__ __launch_bounds__(256 + 64 * NPW) void warp_variance_ws_kernel(
+// runtime view count (any V): views in LDS-sized chunks of VC, the sums carried in registers across the chunks
+template <int C, int DKB, bool FAST>
+__global__ __launch_bounds__(256) void warp_variance_mv_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
-    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int cpb) {
+    const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
 #pragma clang fp contract(off)
     RCMVS_KERNEL_ENTRY();
-    constexpr int LPP = C / 4;
-    constexpr int PIX = 256 / LPP;
-    constexpr int TH = 4, TW = PIX / TH;
-    constexpr int TAB = NVT * DKB * PIX;                 // records per buffer
-    constexpr int NPT = 64 * NPW;                        // producer threads
-    static_assert(NVT == 2 || NVT == 4, "compile-time view count");
-    extern __shared__ __attribute__((aligned(16))) v4i lds_ws[];          // buffer j: TAB offset records at j * 2 * TAB, then TAB weight records
+    constexpr int LPP = K1Tile<C>::LPP, PIX = K1Tile<C>::PIX, TH = K1Tile<C>::TH, TW = K1Tile<C>::TW, GRP = K1Tile<C>::GRP;
+    static_assert(DKB % GRP == 0, "DKB must be a multiple of 256/PIX");
+    extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [VC][DKB][PIX] offsets, then weights
+    v4f* lds_w = reinterpret_cast<v4f*>(lds_o + VC * DKB * PIX);
     const int b = blockIdx.z;
+    const int k0 = blockIdx.y * DKB;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int hw = h * w;
-    const int nchunks = (D + DKB - 1) / DKB;
-    const int c0 = blockIdx.y * cpb, c1 = min(nchunks, c0 + cpb);
     K1Geom g;
     g.w = w; g.h = h;
     g.wm1 = (float)(w - 1); g.hm1 = (float)(h - 1);
@@ -386,67 +352,48 @@ __global__ __launch_bounds__(256 + 64 * NPW) void warp_variance_ws_kernel(
     g.r_half_w = rcp_nr(g.half_w); g.r_half_h = rcp_nr(g.half_h);
     const float* fb = feats + (long long)b * V * hw * C;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fb), (short)0, 0x7fffffff, 0x00020000);
-    const bool producer = threadIdx.x >= 256;
-    // consumer identity (threads 0..255), as in the kernel above
-    const int p = (threadIdx.x & 255) / LPP;
-    const int q4b = ((threadIdx.x & 255) % LPP) * 16;
+    const int p = threadIdx.x / LPP;
+    const int q4b = (threadIdx.x % LPP) * 16;
     const int x = tx0 + p % TW, y = ty0 + p / TW;
-    const bool inside = !producer && (x < w) && (y < h);
+    const bool inside = (x < w) && (y < h);
     v4f ref = (v4f){0.f, 0.f, 0.f, 0.f};
     if (inside) ref = *reinterpret_cast<const v4f*>(fb + ((long long)y * w + x) * C + (q4b >> 2));
     const float fV = (float)V, rV = rcp_nr(fV);
     float* ob = var + (((long long)b * D) * hw + (long long)y * w + x) * C + (q4b >> 2);
-
-    for (int i = c0; i <= c1; ++i) {
-        if (producer) {
-            if (i < c1) {
-                v4i* lo = lds_ws + ((i - c0) & 1) * 2 * TAB;
-                v4f* lw = reinterpret_cast<v4f*>(lo + TAB);
-                const int k0 = i * DKB;
-                for (int it = threadIdx.x - 256; it < TAB; it += NPT) {           // record index = (va * DKB + ka) * PIX + pa
-                    const int pa = it % PIX, ka = (it / PIX) % DKB, va = it / (PIX * DKB);
-                    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
-                    const float fxa = (float)xa, fya = (float)ya;
-                    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
-                    const float* r = rot + ((long long)b * (V - 1) + va) * 9;
-                    const float* t = trans + ((long long)b * (V - 1) + va) * 3;
-                    const float rx = (r[0] * fxa + r[1] * fya) + r[2];
-                    const float ry = (r[3] * fxa + r[4] * fya) + r[5];
-                    const float rz = (r[6] * fxa + r[7] * fya) + r[8];
-                    const float d = pla.x + (float)(k0 + ka) * pla.y;
-                    v4i o;
-                    v4f wt;
-                    k1_tap<C>(rx, ry, rz, t[0], t[1], t[2], d, g, (1 + va) * hw, o, wt);
-                    lo[it] = o;
-                    lw[it] = wt;
-                }
-            }
-        } else if (i > c0 && inside) {
-            const v4i* lo = lds_ws + ((i - 1 - c0) & 1) * 2 * TAB;
-            const v4f* lw = reinterpret_cast<const v4f*>(lo + TAB);
-            const int k0 = (i - 1) * DKB;
-            // the production kernel's consumer loop (all NVT views in one group)
-            K1Fetch<NVT> f0, f1;
-            k1_issue<NVT, DKB, PIX>(f0, lo, lw, rsrc, 0, p, q4b, 0);
+    const int pa = threadIdx.x % PIX;
+    const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
+    const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
+    v4f s[DKB], sq[DKB];
 #pragma unroll
-            for (int k = 0; k < DKB; ++k) {
-                K1Fetch<NVT>& cur = (k & 1) ? f1 : f0;
-                K1Fetch<NVT>& nxt = (k & 1) ? f0 : f1;
-                if (k + 1 < DKB) k1_issue<NVT, DKB, PIX>(nxt, lo, lw, rsrc, k + 1, p, q4b, 0);
-                v4f a = ref, a2 = ref * ref;
-#pragma unroll
-                for (int va = 0; va < NVT; ++va) {
-                    v4f val = blend4<FAST>(cur.t[va][0], cur.t[va][1], cur.t[va][2], cur.t[va][3], cur.w[va]);
-                    a = a + val;
-                    if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
-                }
-                if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
-            }
-        }
+    for (int k = 0; k < DKB; ++k) { s[k] = ref; sq[k] = ref * ref; }
+    for (int v0 = 1; v0 < V; v0 += VC) {
+        const int nv = min(VC, V - v0);
+        if (v0 > 1) __syncthreads();
+        for (int va = 0; va < nv; ++va)
+            k1_phase_a<C, DKB>(rot, trans, b, V, v0 + va, va, (float)xa, (float)ya, pla, k0, hw, g, lds_o, lds_w);
         __syncthreads();
+        if (!inside) continue;
+#pragma unroll
+        for (int k = 0; k < DKB; ++k) {
+            v4f a = s[k], a2 = sq[k];
+            for (int va = 0; va < nv; ++va) {
+                K1Fetch<1> f;
+                k1_issue<1, DKB, PIX>(f, lds_o, lds_w, rsrc, k, p, q4b, va);
+                v4f val = blend4<FAST>(f.t[0][0], f.t[0][1], f.t[0][2], f.t[0][3], f.w[0]);
+                a = a + val;
+                if (FAST) a2 = __builtin_elementwise_fma(val, val, a2); else a2 = a2 + val * val;
+            }
+            if (v0 + nv < V) { s[k] = a; sq[k] = a2; continue; }
+            if (k0 + k < D) k1_store_variance<FAST>(a, a2, fV, rV, ob + (long long)(k0 + k) * hw * C);
+        }
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4 (profiles/r4_k1_walls.txt): the wave-specialised form of this kernel (producer waves running phase A of plane chunk i+1 into a
+// double-buffered tap table while consumer waves gather / blend / store chunk i; written at the end of round 3) was timed and REMOVED:
+// 81 / 162 / 115 us per stage with one producer wave, 60 / 100 / 77 us with two, against 42 / 57 / 39 us for the two-phase kernel --
+// phase A is ~40 % of the VALU work, so one or two producer waves feeding four consumers are the bottleneck.
 // ------------------------------------------------------------------------------------------
 // Round 3 (profiles/r3_k1_schedule_variants.txt, bit-identical forms of the kernel above, two source views): bilinear weights re-read
 // from the LDS record at blend time instead of carried with the taps (133-136 instead of 153-156 VGPRs) 155.6 us per scene; the same
@@ -546,55 +493,8 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
     RCMVS_REQUIRE((long long)h * w * C < (1LL << 31), "warp_variance_fwd: feature map too large for 32-bit offsets");
-    RCMVS_REQUIRE(variant >= 0 && variant <= 7, "warp_variance_fwd: unknown variant %d", variant);
+    RCMVS_REQUIRE(variant >= 0 && variant <= 3, "warp_variance_fwd: unknown variant %d", variant);
     RCMVS_REQUIRE(C == 8 || C == 16 || C == 32, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
-    if (variant >= 4) {
-        // wave-specialised form (see warp_variance_ws_kernel): 4 / 5 = one / two producer waves, a tile's plane chunks split over
-        // gridDim.y so that the launch has at least ~4 blocks per CU; 6 / 7 = the same with one block per tile
-        const int nsrc = V - 1;
-        RCMVS_REQUIRE(nsrc == 2 || nsrc == 4, "warp_variance_fwd: the wave-specialised variants take 2 or 4 source views (got %d)", nsrc);
-        const int LPP = C / 4, PIX = 256 / LPP;
-        const int dkb = (C == 8) ? 4 : 8;
-        const int npw = (variant & 1) ? 2 : 1;
-        const size_t lds = (size_t)2 * 32 * nsrc * dkb * PIX;
-        RCMVS_REQUIRE(lds <= 160 * 1024, "warp_variance_fwd: the double-buffered tap table needs %zu bytes of LDS", lds);
-        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-        const int TWp = PIX / 4;
-        const int txp = (w + TWp - 1) / TWp, typ = (h + 3) / 4;
-        const int nchunks = (D + dkb - 1) / dkb;
-        int ysplit = 1;
-        if (variant < 6) {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            RCMVS_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess, "warp_variance_fwd: no device");
-            while (ysplit < nchunks && (long long)txp * typ * B * ysplit < 4LL * prop.multiProcessorCount) ++ysplit;
-        }
-        const int cpb = (nchunks + ysplit - 1) / ysplit;
-        dim3 gridw(txp * typ, (nchunks + cpb - 1) / cpb, B);
-#define RCMVS_K1WS(CC, DD, NN, PP)                                                                                          \
-    do {                                                                                                                    \
-        static bool attr_done = false;                                                                                      \
-        if (!attr_done) {                                                                                                   \
-            RCMVS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_variance_ws_kernel<CC, DD, false, NN, PP>),  \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,        \
-                          "warp_variance_fwd: cannot raise the dynamic LDS limit");                                         \
-            attr_done = true;                                                                                               \
-        }                                                                                                                   \
-        hipLaunchKernelGGL((warp_variance_ws_kernel<CC, DD, false, NN, PP>), gridw, dim3(256 + 64 * PP), lds, st, feats, rot, \
-                           trans, planes, var, V, D, h, w, txp, cpb);                                                       \
-    } while (0)
-#define RCMVS_K1WS_P(CC, DD, NN) do { if (npw == 2) RCMVS_K1WS(CC, DD, NN, 2); else RCMVS_K1WS(CC, DD, NN, 1); } while (0)
-#define RCMVS_K1WS_N(CC, DD) do { if (nsrc == 2) RCMVS_K1WS_P(CC, DD, 2); else RCMVS_K1WS_P(CC, DD, 4); } while (0)
-        switch (C) {
-            case 8:  RCMVS_K1WS_N(8, 4); break;
-            case 16: RCMVS_K1WS_N(16, 8); break;
-            default: RCMVS_K1WS_N(32, 8); break;
-        }
-#undef RCMVS_K1WS_N
-#undef RCMVS_K1WS_P
-#undef RCMVS_K1WS
-        return launch_status("warp_variance_fwd (wave-specialised)");
-    }
     if (variant <= 1) {
         const bool fastm = variant == 1;
         const int LPP = C / 4, PIX = 256 / LPP;
@@ -610,8 +510,9 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
         const int txp = (w + TWp - 1) / TWp, typ = (h + 3) / 4;
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
         dim3 gridp(txp * typ, (D + dkb - 1) / dkb, B);
-#define RCMVS_K1TP(CC, DD, FF, NN) hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, FF, NN>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC)
-#define RCMVS_K1TP_N(CC, DD, FF) do { if (nvt == 2) RCMVS_K1TP(CC, DD, FF, 2); else if (nvt == 4) RCMVS_K1TP(CC, DD, FF, 4); else RCMVS_K1TP(CC, DD, FF, 0); } while (0)
+#define RCMVS_K1TP(CC, DD, FF, NN) hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, FF, NN>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp)
+#define RCMVS_K1MV(CC, DD, FF) hipLaunchKernelGGL((warp_variance_mv_kernel<CC, DD, FF>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC)
+#define RCMVS_K1TP_N(CC, DD, FF) do { if (nvt == 2) RCMVS_K1TP(CC, DD, FF, 2); else if (nvt == 4) RCMVS_K1TP(CC, DD, FF, 4); else RCMVS_K1MV(CC, DD, FF); } while (0)
 #define RCMVS_K1TP_F(CC, DD) do { if (fastm) RCMVS_K1TP_N(CC, DD, true); else RCMVS_K1TP_N(CC, DD, false); } while (0)
 #define RCMVS_K1TP_6(CC, DD) do { if (fastm) RCMVS_K1TP(CC, DD, true, 6); else RCMVS_K1TP(CC, DD, false, 6); } while (0)
         if (nvt == 6) {

@@ -104,7 +104,7 @@ def absmax(x, square=False, out=None):
 
 def warp_variance(feats, rot, trans, planes, ndepth, variant=0):
     """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C).  variant != 0: the test / profiling code variants of
-    rcmvs_debug_warp_variance_fwd (1 FMA blend, 2 reference-order kernel, 3 store-only, 4-7 the wave-specialised form)."""
+    rcmvs_debug_warp_variance_fwd (1 FMA blend, 2 reference-order kernel, 3 store-only)."""
     B, V, h, w, C = feats.shape
     var = torch.empty((B, ndepth, h, w, C), device=feats.device, dtype=torch.float32)
     ev = None

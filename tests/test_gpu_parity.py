@@ -175,26 +175,6 @@ def test_warp_variance_variants_agree(hip):
         hip.warp_variance(feats, rot, trans, planes, D, variant=9)
 
 
-@pytest.mark.parametrize("C,D,h,w,V", [(32, 16, 20, 37, 3), (16, 20, 33, 50, 3), (8, 10, 30, 70, 3), (8, 8, 20, 40, 5), (16, 16, 18, 30, 5),
-                                       (32, 24, 12, 20, 5), (8, 48, 64, 96, 3)])
-def test_warp_variance_wave_specialised_form_is_bit_identical(hip, C, D, h, w, V):
-    """The wave-specialised form of K1 (debug variants 4-7: producer waves build the tap table of plane chunk i+1 while the consumer waves
-    gather / blend / store chunk i; one or two producer waves; a tile's chunks on one block or split over several) against the production
-    kernel: every bit, ragged tiles, D that is not a multiple of the chunk, 2 and 4 source views.  (Its speed is unmeasured: DESIGN.md §4.)"""
-    from rc_mvsnet_amd import synthetic
-    g = torch.Generator().manual_seed(C + V + D)
-    feats = gpu(torch.randn(2, V, h, w, C, generator=g))
-    pm = gpu(synthetic.proj_matrices(2, V, h * 4, w * 4)["stage1"])
-    rot, trans = hip.compose_homography(pm)
-    planes = gpu(torch.stack((425.0 + 100.0 * torch.rand(2, h, w, generator=g), 2.0 + 8.0 * torch.rand(2, h, w, generator=g)), dim=-1))
-    v0 = hip.warp_variance(feats, rot, trans, planes, D)
-    for variant in (4, 5, 6, 7):
-        assert torch.equal(hip.warp_variance(feats, rot, trans, planes, D, variant=variant), v0), variant
-    if V == 3:
-        with pytest.raises(Exception, match="2 or 4 source views"):
-            hip.warp_variance(feats[:, :2].contiguous(), rot[:, :1].contiguous(), trans[:, :1].contiguous(), planes, D, variant=4)
-
-
 # ------------------------------------------------------------------------------------------ K2/K3
 @pytest.mark.parametrize("Ci,Co,mode", [(8, 16, "s2"), (16, 16, "s1"), (16, 32, "s2"), (32, 32, "s1"), (32, 64, "s2"),
                                         (64, 64, "s1"), (64, 32, "t2"), (32, 16, "t2")])

@@ -9,9 +9,7 @@ from rc_mvsnet_amd import _lib, ops, synthetic
 lib = _lib.load()
 dev = "cuda:0"
 V, H, W = int(os.environ.get('K1_V', '3')), 512, 640
-names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 4: "wave-specialised, 1 producer wave, chunks split over blocks",
-         5: "wave-specialised, 2 producer waves, chunks split", 6: "wave-specialised, 1 producer wave, one block per tile",
-         7: "wave-specialised, 2 producer waves, one block per tile", 100: "torch zero_ (memset)"}
+names = {0: "production exact", 1: "production fma", 2: "reference-order", 3: "store only", 100: "torch zero_ (memset)"}
 variants = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 100]
 dv = synthetic.depth_values(1).to(dev)
 tot = {}
