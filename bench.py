@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- ref-scenes/s of the MI355X plane-sweep hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]                    (N > 1 without WORLD_SIZE: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one CascadeMVSNet_eval.forward at batch 1 = one reference view ("ref-scene") of
@@ -19,9 +19,12 @@ The JSON line also carries
                 fp32 dense peak (157 TF; the three / six MFMAs per product are priced against the matrix-pipe peak as
                 `matrix_pipe_frac`);
   train_step    a short timing of the config-3 training iteration (5 iterations after 2 warm-ups; --no-train-step skips it);
-  two_scenes_in_flight   N = 1 only, a side pass after the timed region, never `value`: 96 scenes with two in flight (2 HIP streams, one
-                hipGraph per (stream, scene)), every output compared bit for bit with the one-stream run (--no-side-pass skips it;
-                experimental mode, rc_mvsnet_amd/scene_pipeline.py);
+  two_procs_per_gpu      N = 1 only, a side pass after the timed region, never `value`: `bench.py --procs-per-gpu 2` run as a child -- two worker
+                processes on the GPU, whole scenes each (--no-side-pass skips it);
+  two_scenes_in_flight   only with --in-flight-side-pass: 96 scenes with two in flight in ONE process (2 HIP streams, one hipGraph per
+                (stream, scene)), every output compared bit for bit with the one-stream run (experimental, rc_mvsnet_amd/scene_pipeline.py);
+  timed_rounds  when K steps take less than 0.5 s the barrier-bracketed region of exactly K steps is repeated and the MEDIAN round is
+                reported (`value`, `ms_per_step`, `timed_region_s`), so that a short --steps still keeps the GPU busy for half a second;
   cpu_baseline  the oracle's ATen op graph (= the reference's CPU path) timed on the host cores
                 of this box on a bounded sample, rank 0, N=1 only -- a reported baseline, plus
                 the depth-L1 parity of the HIP output against it on the same inputs.
@@ -134,29 +137,59 @@ def k1_algorithmic_bytes():
     return per_stage
 
 
+MIN_TIMED_S = 0.5               # a timed region shorter than this is repeated in rounds (each exactly K steps) and the median round reported
+MAX_ROUNDS = 64
+
+
+def timed_rounds(world, dev, steps, step, sync):
+    """The contract's timed region -- exactly K steps between barrier + synchronize pairs, max over ranks -- repeated while the
+    rounds so far add up to less than MIN_TIMED_S (the driver's --steps 20 is 28 ms of cascade forwards: too short for an external
+    utilisation sampler to see the GPU busy).  Returns (median round's max-over-ranks seconds, this rank's own seconds of that
+    round, every round's max-over-ranks seconds).  The process group stays up."""
+    import torch.distributed as dist
+    rounds, owns = [], []
+    while True:
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        sync()
+        own = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)          # every rank sees the same round time, hence takes the same decision below
+            elapsed = float(t.item())
+        rounds.append(elapsed)
+        owns.append(own)
+        if sum(rounds) >= MIN_TIMED_S or len(rounds) >= MAX_ROUNDS:
+            break
+    order = sorted(range(len(rounds)), key=lambda i: rounds[i])
+    mid = order[len(order) // 2]
+    return rounds[mid], owns[mid], rounds
+
+
+def rounds_fields(rounds):
+    return {"timed_rounds": len(rounds), "rounds_total_s": round(sum(rounds), 4),
+            "round_s_min_max": [round(min(rounds), 5), round(max(rounds), 5)]}
+
+
 def timed_region(world, dev, warmup, steps, step):
-    """The contract's timing: W untimed steps, then exactly K steps between barrier + synchronize pairs, max over ranks."""
+    """W untimed steps, then timed_rounds; tears the process group down.  Returns (median round seconds, all rounds)."""
     import torch.distributed as dist
     for i in range(warmup):
         step(i)
-    torch.cuda.synchronize()
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    elapsed, _, rounds = timed_rounds(world, dev, steps, step, sync)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         dist.barrier()
         dist.destroy_process_group()
-    return elapsed
+    return elapsed, rounds
 
 
 def two_scenes_in_flight(make_model, model, scenes, steps, nstreams=2):
@@ -206,6 +239,23 @@ def two_scenes_in_flight(make_model, model, scenes, steps, nstreams=2):
             "note": "side pass after the timed region, NOT `value`: experimental mode (rc_mvsnet_amd/scene_pipeline.py)"}
 
 
+def two_procs_side_pass(steps):
+    """`python bench.py --gpus 1 --procs-per-gpu 2` as a child of the N = 1 run (its two ranks rendezvous over gloo on 127.0.0.1)."""
+    import subprocess
+    from rc_mvsnet_amd.sharding import clean_env
+    env = clean_env()
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--procs-per-gpu", "2", "--steps", str(steps), "--warmup", "10",
+           "--no-cpu-baseline", "--no-train-step", "--no-side-pass"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": f"child exited with {out.returncode}: {out.stderr[-300:]}"}
+    b = json.loads(lines[-1])
+    return {"value": b["value"], "unit": b["unit"], "ms_per_step": b["ms_per_step"], "steps_per_process": b["steps"], "processes": 2,
+            "per_rank_scenes_per_s": b.get("per_rank_scenes_per_s"), "timed_rounds": b.get("timed_rounds"),
+            "note": "side pass, NOT `value`: two worker processes on the one GPU, each running whole scenes one at a time (python bench.py --procs-per-gpu 2)"}
+
+
 def event_ms(fn, reps=20):
     """Average duration of ``fn`` (library launches on torch's current stream) from HIP events on that stream."""
     fn()
@@ -242,7 +292,7 @@ def bench_unsup_loss(args, rank, world, dev):
         total.backward()
         last["total"] = total
 
-    elapsed = timed_region(world, dev, args.warmup, args.steps, step)
+    elapsed, rounds = timed_region(world, dev, args.warmup, args.steps, step)
     if rank != 0:
         return None
     # dominant launch group: one full-resolution stage forward (rcmvs_unsup_loss_fwd, 2 Vs + 3 launches)
@@ -261,7 +311,7 @@ def bench_unsup_loss(args, rank, world, dev):
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": "SURVEY 8f-2: losses/unsup_loss.py UnsupLossMultiStage on BASELINE configs[2] shapes (batch 1 per GPU)",
                          "views": Vl, "height": H, "width": W, "parallelism": f"sample-per-gpu x{world}"},
-              "roofline": roofline}
+              "roofline": roofline, **rounds_fields(rounds)}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import unsup_loss as O
         nthreads = host_threads()
@@ -304,7 +354,7 @@ def bench_fusion(args, rank, world, dev):
         xyz, _ = fusion.compact_points(r["masks"][2], r["xyz"], r["rgb"])
         kept["n"] = len(xyz)
 
-    elapsed = timed_region(world, dev, args.warmup, args.steps, step)
+    elapsed, rounds = timed_region(world, dev, args.warmup, args.steps, step)
     if rank != 0:
         return None
     ms = event_ms(lambda: fuse(0))
@@ -318,7 +368,7 @@ def bench_fusion(args, rank, world, dev):
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
               "config": {"workload": "SURVEY 8f-3: eval_rcmvsnet_dtu.py filter_depth per-reference-view body, DTU evaluation shape", "height": Hf,
                          "width": Wf, "source_views": n_src, "points_kept": kept.get("n"), "parallelism": f"scan-per-gpu x{world}"},
-              "roofline": roofline}
+              "roofline": roofline, **rounds_fields(rounds)}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import fusion as O
         ref, srcs = s["pairs"][0]
@@ -355,7 +405,7 @@ def bench_train_step(args, rank, world, dev):
     def step(i):
         last.update(ts.train_step(model, model_nerf, opt, imgs, proj, dv, batch, grad_sync=sync))
 
-    elapsed = timed_region(world, dev, args.warmup, args.steps, step)
+    elapsed, rounds = timed_region(world, dev, args.warmup, args.steps, step)
     if rank != 0:
         return None
     # dominant memory-bound kernel of the iteration: the K1 backward scatter at stage 3 (two calls per iteration)
@@ -380,8 +430,8 @@ def bench_train_step(args, rank, world, dev):
                                      "Rendering_Consistency_Net.forward, UnsupLoss + AugLoss + render losses, backward, Adam), batch 1 per GPU",
                          "views": Vt, "height": H, "width": W, "ndepths": list(NDEPTHS), "rays": 1024, "samples": 128,
                          "parallelism": f"dp{world}" + (" (SyncBatchNorm + one reduce-scatter/all-gather gradient message over RCCL)" if world > 1 else ""),
-                         "rccl_ranks": world},
-              "roofline": roofline, "losses": {k: round(v, 5) for k, v in last.items()}}
+                         "rccl_ranks": world, "gpus": args.gpus},
+              "roofline": roofline, "losses": {k: round(v, 5) for k, v in last.items()}, **rounds_fields(rounds)}
     if world == 1 and not args.no_cpu_baseline:
         # bounded sample of the reference's CPU path: forward + backward of ONE of the iteration's two CascadeMVSNet passes
         # (oracle/aten_graph.py on the host cores); the iteration has two of them plus the renderer and the losses, so
@@ -403,33 +453,83 @@ def bench_train_step(args, rank, world, dev):
     return result
 
 
-def main():
+def bench_stub(args, rank, world, dev):
+    """The contract without a GPU (tests/test_bench_contract_cpu.py): a step is one small CPU matmul, ranks rendezvous over gloo.  Exercises
+    what the real workloads share -- the self-spawn of N ranks, the barrier-bracketed rounds, max over ranks, one JSON line from rank 0."""
+    x = torch.randn(64, 64, generator=torch.Generator().manual_seed(rank))
+    acc = {"n": 0}
+
+    def step(i):
+        acc["y"] = x @ x
+        acc["n"] += 1
+
+    elapsed, rounds = timed_region(world, dev, args.warmup, args.steps, step)
+    if rank != 0:
+        return None
+    return {"metric": "stub steps/sec (64x64 CPU matmul; contract self-test, not a benchmark)", "value": round(world * args.steps / elapsed, 3),
+            "unit": "steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 6),
+            "timed_region_s": round(elapsed, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stub", "parallelism": f"x{world}", "ranks": world, "procs_per_gpu": args.procs_per_gpu},
+            "steps_run_by_rank0": acc["n"], **rounds_fields(rounds)}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="cascade", choices=["cascade", "train_step", "unsup_loss", "fusion"],
-                    help="cascade = BASELINE.json's metric (default); the others are the SURVEY 8f rows either side of the path")
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "train_step", "unsup_loss", "fusion", "stub"],
+                    help="cascade = BASELINE.json's metric (default); train_step / unsup_loss / fusion are the SURVEY 8f rows either side of the "
+                         "path; stub = the contract's plumbing on CPU + gloo (tests)")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--procs-per-gpu", type=int, default=1,
+                    help="worker processes per GPU (cascade workload): independent (scene, view) items need no collective, so P processes on one "
+                         "GPU overlap each other's latency-bound phases like HIP streams would, without sharing an address space")
     ap.add_argument("--steps", type=int, default=600, help="timed steps (default: ~1 s of cascade forwards)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the short config-3 training-iteration timing appended to the default line")
-    ap.add_argument("--no-side-pass", action="store_true", help="skip the two-scenes-in-flight side pass of the cascade workload (N = 1)")
+    ap.add_argument("--no-side-pass", action="store_true", help="skip the side passes of the cascade workload (N = 1): two worker processes on the GPU, "
+                                                                "and (with --in-flight-side-pass) two scenes in flight on two HIP streams")
+    ap.add_argument("--in-flight-side-pass", action="store_true", help="also run the experimental two-scenes-in-flight side pass (two HIP streams in one process)")
     ap.add_argument("--streams", type=int, default=STREAMS_DEFAULT,
                     help="cascade workload, EXPERIMENTAL above 1: independent scenes issued round-robin on this many HIP streams (one model replica "
                          "per stream); the line then carries `outputs_identical_to_single_stream` from a self-check after the timed region")
     ap.add_argument("--cpu-scenes", type=int, default=5, help="scenes timed on the CPU baseline after 2 warm-ups (bounded sample, BASELINE.md section 3)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1 or args.procs_per_gpu < 1:
+        ap.error("--gpus and --procs-per-gpu must be >= 1")
+    nproc = args.gpus * args.procs_per_gpu
+    if "WORLD_SIZE" not in os.environ and nproc > 1:
+        from rc_mvsnet_amd.sharding import launch_ranks
+        sys.exit(launch_ranks(__file__, nproc, argv))          # our own N (x P) ranks, like train_rcmvsnet.py:632-636 spawns its own
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != nproc:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} x --procs-per-gpu {args.procs_per_gpu} = {nproc} ranks, but WORLD_SIZE={world} "
+                         f"(launch torch.distributed.run with --nproc-per-node {nproc}, or drop WORLD_SIZE and let bench.py start them)")
+    if args.workload == "stub":
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo")
+        result = bench_stub(args, rank, world, dev)
+        if result is not None:
+            print(json.dumps(result), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    from rc_mvsnet_amd.sharding import device_index as _device_index
+    device_index = _device_index(local_rank, args.procs_per_gpu)           # ranks g*P .. g*P+P-1 share GPU g
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")          # RCCL; used only for the barrier / max-time reduction
+        # RCCL needs one device per rank: with several processes per GPU the rendezvous (barrier, max-time reduction -- there is no data-path
+        # collective in the cascade workload) goes over gloo instead
+        dist.init_process_group(backend="nccl" if args.procs_per_gpu == 1 else "gloo")
         assert dist.get_world_size() == world
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with torch.distributed.run --nproc-per-node N"
+    if args.procs_per_gpu > 1 and args.workload != "cascade":
+        raise SystemExit("bench.py: --procs-per-gpu applies to the cascade workload (independent items); training ranks own one GPU each")
 
     from rc_mvsnet_amd import _lib, ops, synthetic
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
@@ -439,7 +539,7 @@ def main():
             args.steps, args.warmup = 10, 3                       # an iteration is ~80 ms: the defaults of the cascade workload are overkill
         result = {"unsup_loss": bench_unsup_loss, "fusion": bench_fusion, "train_step": bench_train_step}[args.workload](args, rank, world, dev)
         if result is not None:
-            print(json.dumps(result))
+            print(json.dumps(result), flush=True)
         return
 
     sd = synthetic.cascade_state_dict(0)
@@ -467,24 +567,13 @@ def main():
         imgs, pm, dv = scenes[(i + rank) % len(scenes)]
         return pipe(imgs, pm, dv)[0]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
+    cdev = dev if args.procs_per_gpu == 1 else torch.device("cpu")      # where the rendezvous tensors live (RCCL / gloo)
     with torch.no_grad():
         for i in range(args.warmup):
             out = step(i)
         torch.cuda.synchronize()
-        barrier()
-        ops.K1_EVENTS = []                                  # HIP events around every K1 launch
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = step(i)
-        torch.cuda.synchronize()
-        own = time.perf_counter() - t0                      # this rank's K steps (reported per rank; `value` uses the max after the barrier)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        ops.K1_EVENTS = []                                  # HIP events around every K1 launch of the timed rounds
+        elapsed, own, rounds = timed_rounds(world, cdev, args.steps, step, torch.cuda.synchronize)
     events, ops.K1_EVENTS = ops.K1_EVENTS, None
     # second, UNTIMED pass with HIP events around every 3-D convolution launch (80 event records per scene would perturb `value`)
     conv_events = []
@@ -521,24 +610,30 @@ def main():
             pipe.synchronize()
             single["outputs_identical_to_single_stream"] = bool(all(torch.equal(o, want[i % len(scenes)]) for i, o in enumerate(got)))
 
-    # SIDE PASS (N = 1, one stream in the timed region): two scenes in flight on two HIP streams, one captured hipGraph per (stream, scene),
-    # every output compared bit for bit with the one-stream eager outputs.  Not the headline: see rc_mvsnet_amd/scene_pipeline.py for its status.
-    in_flight = None
+    # SIDE PASSES (N = 1, one process, one stream in the timed region; never `value`).
+    #  two_procs_per_gpu: the same workload as `python bench.py --procs-per-gpu 2` in a child -- two worker processes on this GPU, each issuing
+    #      whole scenes on its own queue from its own address space: the safe way of keeping two scenes in flight (the item list is sharded
+    #      over the processes like over GPUs: rc_mvsnet_amd/sharding.py, eval_driver --procs-per-gpu);
+    #  two_scenes_in_flight (--in-flight-side-pass): two HIP streams in ONE process, hipGraph replay, outputs compared bit for bit with the
+    #      one-stream run; experimental, see rc_mvsnet_amd/scene_pipeline.py for its status.
+    two_procs = in_flight = None
     if rank == 0 and world == 1 and nstreams == 1 and not args.no_side_pass:
         try:
-            in_flight = two_scenes_in_flight(make_model, model, scenes, min(96, max(8, args.steps)))      # (short: its launches share the rocprof averages of this command)
+            two_procs = two_procs_side_pass(min(300, max(20, args.steps)))
         except Exception as e:                               # never at the expense of the headline line
-            in_flight = {"error": f"{type(e).__name__}: {e}"[:300]}
+            two_procs = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if args.in_flight_side_pass:
+            try:
+                in_flight = two_scenes_in_flight(make_model, model, scenes, min(96, max(8, args.steps)))      # (short: its launches share the rocprof averages of this command)
+            except Exception as e:
+                in_flight = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     rank_rates = None
     if world > 1:
-        mine = torch.tensor([own], device=dev, dtype=torch.float64)
+        mine = torch.tensor([own], device=cdev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)                        # every rank's own time: per-rank scenes/s (min / max) in the line
+        dist.all_gather(every, mine)                        # every rank's own time of the median round: per-rank scenes/s (min / max) in the line
         rank_rates = [args.steps / float(t.item()) for t in every]
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         dist.barrier()
         dist.destroy_process_group()                         # before rank 0 spends ~25 s on the CPU baseline alone
 
@@ -560,7 +655,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": "rcmvs::warp_variance_tp_kernel (K1, 3 launches per scene)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_note": "bytes per scene (sum of the 3 launches), rocprofv3 PMC passes of profiles/r3_k1_traffic.json (re-measured in round 3)",
+                "traffic_source": "profiles/r3_k1_traffic.json -- rocprofv3 PMC passes of an earlier run (FETCH_SIZE x2 + WRITE_SIZE per launch, summed over the "
+                                  "3 launches of a scene); a committed measurement, NOT taken in this run",
                 "algorithmic_bytes_per_scene": sum(bytes_stage),
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)]}
@@ -579,7 +675,7 @@ def main():
         "metric": "ref-scenes/sec (DTU 3-view 512x640, D=48/32/8)",
         "value": round(world * args.steps / elapsed, 3),
         "unit": "ref-scenes/s",
-        "n_gpus": world,
+        "n_gpus": args.gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -591,11 +687,15 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: CascadeMVSNet_eval.forward, DTU-shaped 3 views 512x640, "
                                "D=(48,32,8), batch 1 per GPU, fp32, random-init seeded weights",
-                   "views": V, "height": H, "width": W, "ndepths": list(NDEPTHS), "parallelism": f"scene-per-gpu x{world}",
-                   "streams_per_gpu": nstreams},
+                   "views": V, "height": H, "width": W, "ndepths": list(NDEPTHS),
+                   "parallelism": f"scene-per-gpu x{args.gpus}" + (f", {args.procs_per_gpu} worker processes per GPU" if args.procs_per_gpu > 1 else ""),
+                   "ranks": world, "procs_per_gpu": args.procs_per_gpu, "streams_per_gpu": nstreams},
         "roofline": roofline,
         "roofline_conv": roofline_conv,
     }
+    result.update(rounds_fields(rounds))
+    if two_procs is not None:
+        result["two_procs_per_gpu"] = two_procs
     if in_flight is not None:
         result["two_scenes_in_flight"] = in_flight
     if single is not None:

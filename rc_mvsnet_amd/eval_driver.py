@@ -10,6 +10,7 @@ so that a rank owns every depth map its fusion needs.
 
     python -m rc_mvsnet_amd.eval_driver --outdir out --scans 4 --views 3 --height 512 --width 640
     python -m rc_mvsnet_amd.eval_driver --outdir out --testpath /data/dtu_test --testlist lists/dtu/test.txt --loadckpt model.ckpt --filter
+    python -m rc_mvsnet_amd.eval_driver --gpus 8 --procs-per-gpu 2 --outdir out ...          (starts its own 16 ranks, two per GPU)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m rc_mvsnet_amd.eval_driver --outdir out ...
 """
 import argparse
@@ -20,7 +21,7 @@ import torch
 
 from . import synthetic
 from .data_io import save_pfm
-from .sharding import shard_items
+from .sharding import device_index, launch_ranks, launched, rank_env, shard_items
 
 
 def output_paths(outdir, scan, view):
@@ -134,12 +135,19 @@ def main(argv=None):
     ap.add_argument("--ndepths", default="48,32,8")
     ap.add_argument("--depth_inter_r", default="4,2,1")
     ap.add_argument("--loadckpt", default=None, help="a reference checkpoint ({'model': state_dict}); seeded weights otherwise")
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node; above 1 rank (with --procs-per-gpu) the driver starts its own ranks "
+                                                        "unless a launcher already did (WORLD_SIZE in the environment)")
+    ap.add_argument("--procs-per-gpu", type=int, default=1, help="worker processes per GPU: items are independent, two processes per GPU overlap "
+                                                                 "each other's latency-bound phases (rc_mvsnet_amd/sharding.py)")
     args = ap.parse_args(argv)
+    nproc = args.gpus * args.procs_per_gpu
+    if nproc > 1 and not launched():
+        import sys
+        raise SystemExit(launch_ranks("rc_mvsnet_amd.eval_driver", nproc, sys.argv[1:] if argv is None else argv, module=True))
 
     from .casmvsnet import CascadeMVSNet_eval
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    rank, local, world = rank_env()
+    device = torch.device("cuda", device_index(local, args.procs_per_gpu)) if torch.cuda.is_available() else torch.device("cpu")
     if device.type == "cuda":
         torch.cuda.set_device(device)
     model = CascadeMVSNet_eval(ndepths=[int(n) for n in args.ndepths.split(",")],

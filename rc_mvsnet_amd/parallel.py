@@ -28,6 +28,10 @@ import torch.distributed as dist
 # would never execute before the first RCCL run.  With COMPOSE_ON_GLOO = True the two-step branch runs on gloo as well, its
 # reduce-scatter composed from the collectives gloo does have (`_reduce_scatter` below).
 COMPOSE_ON_GLOO = False
+# Test hook (tests/test_gpu_wrappers.py): a group of ONE rank needs no exchange, so both entry points return early and the one-GPU test box
+# would never issue an RCCL collective.  With RUN_AT_WORLD_ONE = True the reduce-scatter + all-gather pair runs on a world-size-1 "nccl"
+# group too (a degenerate but real RCCL launch of each).
+RUN_AT_WORLD_ONE = False
 
 
 def _has_reduce_scatter(group):
@@ -68,7 +72,7 @@ def _direct_allreduce(flat, group):
     algorithm RCCL runs underneath each of the two collectives (direct / ring / tree over the xGMI links) is RCCL's choice
     (NCCL_ALGO / its tuner); nothing here controls it."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not RUN_AT_WORLD_ONE:
         return
     if not _has_reduce_scatter(group):
         dist.all_reduce(flat, group=group)
@@ -137,7 +141,7 @@ def flat_allreduce_hook(state, bucket):
     world = dist.get_world_size(group)
     buf = bucket.buffer()
     buf.div_(world)
-    if _has_reduce_scatter(group) and world > 1:
+    if _has_reduce_scatter(group) and (world > 1 or RUN_AT_WORLD_ONE):
         # DDP's bucket size is whatever its parameters add up to: pad the message to a multiple of the world size
         n = buf.numel()
         padded = (n + world - 1) // world * world

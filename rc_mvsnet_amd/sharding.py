@@ -1,6 +1,18 @@
-"""Multi-GPU inference = independent (scene, reference-view) items, one process per GPU, no
-data-path collective: each rank takes a round-robin slice of the item list
-(what eval_rcmvsnet_dtu.py:157-165 iterates serially on one GPU)."""
+"""Multi-GPU inference = independent (scene, reference-view) items, one process per rank, no data-path collective:
+each rank takes a round-robin slice of the item list (what eval_rcmvsnet_dtu.py:157-165 iterates serially on one GPU).
+
+Ranks are one per GPU by default; ``procs_per_gpu`` P > 1 puts P worker processes on every GPU (ranks g*P .. g*P+P-1 share GPU g): the items
+are independent, so two processes on one GPU overlap each other's latency-bound phases (the deep levels of the cost regularisation run on a
+fraction of the CUs) the way two HIP streams would, without sharing an address space -- measured +27 % scenes/s on one MI355X
+(profiles/r3_two_streams.txt, two_process_check).  The reference starts its own worker processes (train_rcmvsnet.py:632-636, mp.spawn);
+``launch_ranks`` does the same for the evaluation driver and bench.py through torch.distributed.run on 127.0.0.1."""
+import os
+import socket
+import subprocess
+import sys
+
+_RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK",
+             "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")
 
 
 def shard_items(items, rank, world_size):
@@ -8,3 +20,43 @@ def shard_items(items, rank, world_size):
     if not (0 <= rank < world_size):
         raise ValueError(f"rank {rank} outside world of size {world_size}")
     return list(items[rank::world_size])
+
+
+def device_index(local_rank, procs_per_gpu=1):
+    """GPU of a local rank when every GPU hosts ``procs_per_gpu`` consecutive ranks."""
+    if procs_per_gpu < 1 or local_rank < 0:
+        raise ValueError(f"local_rank {local_rank}, procs_per_gpu {procs_per_gpu}")
+    return local_rank // procs_per_gpu
+
+
+def rank_env():
+    """(rank, local_rank, world_size) from the launcher's environment; (0, 0, 1) when there is none."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def launched():
+    """True inside a rank started by a launcher (torch.distributed.run exports WORLD_SIZE)."""
+    return "WORLD_SIZE" in os.environ
+
+
+def clean_env(env=None):
+    """The environment without a launcher's rank variables (for a child that starts its own ranks)."""
+    return {k: v for k, v in (os.environ if env is None else env).items() if k not in _RANK_ENV}
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(target, nproc, argv, module=False):
+    """Start ``nproc`` ranks of ``target`` (a script path, or a module name with ``module=True``) on this node under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), and return the launcher's exit code."""
+    env = clean_env()
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver supports dmabuf IPC only (RCCL, tensor sharing)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port())]
+    cmd += (["-m", target] if module else [os.path.abspath(target)]) + list(argv)
+    return subprocess.run(cmd, env=env).returncode

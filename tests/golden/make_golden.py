@@ -60,6 +60,30 @@ def folded(p):
     return q
 
 
+def make_run_eval(models, sd_default):
+    """run_eval(H, W, ndepths, ratios, V, sd): the reference's CascadeMVSNet_eval on the seeded scene (seed 0) of that shape."""
+    def run_eval(H, W, nd, ratio, V=3, sd=sd_default):
+        m = models.CascadeMVSNet_eval(ndepths=list(nd), depth_interals_ratio=list(ratio), cr_base_chs=[8] * len(nd))
+        keep = {k: v for k, v in sd.items() if not k.startswith("cost_regularization.") or int(k.split(".")[1]) < len(nd)}
+        if len(nd) == 1:                                    # a 1-stage FeatureNet has no lateral / out2 / out3 convs
+            keep = {k: v for k, v in keep.items() if not re.match(r"feature\.(inner|out[23])", k)}
+        m.load_state_dict(keep, strict=True)
+        m.eval()
+        imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, 0)
+        return m(imgs, pm, dv)
+    return run_eval
+
+
+def cascade_v7_fixture(run_eval):
+    """BASELINE config 5's arithmetic at a small size (eval_rcmvsnet_tanks.py:47,53-55: 7 views, ndepths 64,32,8): the six-source-view
+    path of the warp + variance kernel inside a cascade and a 64-plane depth head, with the seeded x20 probability head and with the
+    well-conditioned x1 head."""
+    for name, gain in (("cascade_v7_d64", 20.0), ("cascade_v7_d64_smooth", 1.0)):
+        o = run_eval(64, 96, (64, 32, 8), (4, 2, 1), V=7, sd=synthetic.cascade_state_dict(0, prob_gain=gain))
+        save(name, H=64, W=96, V=7, ndepths=(64, 32, 8), ratios=(4, 2, 1), prob_gain=gain, depth=o["depth"], conf=o["photometric_confidence"],
+             depth1=o["stage1"]["depth"], depth2=o["stage2"]["depth"], conf1=o["stage1"]["photometric_confidence"])
+
+
 @torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
@@ -145,16 +169,7 @@ def main():
 
     # ---- a6: end-to-end cascades -----------------------------------------------------------
     sd = synthetic.cascade_state_dict(0)
-
-    def run_eval(H, W, nd, ratio, V=3, sd=sd):
-        m = models.CascadeMVSNet_eval(ndepths=list(nd), depth_interals_ratio=list(ratio), cr_base_chs=[8] * len(nd))
-        keep = {k: v for k, v in sd.items() if not k.startswith("cost_regularization.") or int(k.split(".")[1]) < len(nd)}
-        if len(nd) == 1:                                    # a 1-stage FeatureNet has no lateral / out2 / out3 convs
-            keep = {k: v for k, v in keep.items() if not re.match(r"feature\.(inner|out[23])", k)}
-        m.load_state_dict(keep, strict=True)
-        m.eval()
-        imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, 0)
-        return m(imgs, pm, dv)
+    run_eval = make_run_eval(models, sd)
 
     o = run_eval(128, 160, (8,), (1,))                      # BASELINE config 1
     save("cascade_c1", H=128, W=160, V=3, ndepths=(8,), ratios=(1,), depth=o["depth"], conf=o["photometric_confidence"])
@@ -165,6 +180,7 @@ def main():
     o = run_eval(96, 128, (16, 8, 8), (4, 2, 1), V=5)
     save("cascade_v5", H=96, W=128, V=5, ndepths=(16, 8, 8), ratios=(4, 2, 1), depth=o["depth"],
          conf=o["photometric_confidence"])
+    cascade_v7_fixture(run_eval)
     if args.full:
         o = run_eval(512, 640, (48, 32, 8), (4, 2, 1))      # BASELINE config 2
         save("cascade_c2", H=512, W=640, V=3, ndepths=(48, 32, 8), ratios=(4, 2, 1), depth=o["depth"],
@@ -615,6 +631,11 @@ def blocks_fixture():
 if __name__ == "__main__":
     if "--only-blocks" in sys.argv:
         blocks_fixture()
+    elif "--only-v7" in sys.argv:
+        with torch.no_grad():
+            torch.set_num_threads(8)
+            ref_models = import_reference()
+            cascade_v7_fixture(make_run_eval(ref_models, synthetic.cascade_state_dict(0)))
     elif "--only-pfm" in sys.argv:
         pfm_fixture()
     elif "--only-train-grads" in sys.argv:

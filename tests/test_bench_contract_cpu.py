@@ -30,8 +30,52 @@ def test_k1_algorithmic_bytes_are_the_survey_figures(bench):
 def test_command_line_parses_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--streams", "--no-side-pass", "--no-cpu-baseline"):
+    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--streams", "--no-side-pass", "--no-cpu-baseline", "--procs-per-gpu"):
         assert flag in out.stdout
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout                       # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gpus,ppg", [(2, 1), (1, 2), (2, 2)])
+def test_bench_starts_its_own_ranks(gpus, ppg):
+    """`python bench.py --gpus N` the way the driver invokes N = 1 (no torch.distributed.run in front, no WORLD_SIZE): bench.py starts the
+    N x P ranks itself; the stub workload runs the shared plumbing (rendezvous on 127.0.0.1, barrier-bracketed rounds of exactly K steps,
+    max over ranks, one JSON line from rank 0) on CPU + gloo."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--gpus", str(gpus), "--procs-per-gpu", str(ppg),
+                          "--steps", "40", "--warmup", "3"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    b = _json_line(out.stdout)
+    assert b["n_gpus"] == gpus and b["config"]["ranks"] == gpus * ppg and b["config"]["procs_per_gpu"] == ppg
+    assert b["steps"] == 40 and b["warmup"] == 3 and b["scaling"] == "weak" and b["higher_is_better"] is True
+    assert abs(b["value"] * b["ms_per_step"] * 1e-3 - gpus * ppg) < 1e-2 * gpus * ppg                 # value = ranks * K / median round
+    # a 40-step round of the stub is far below 0.5 s: the region is repeated in rounds of exactly K steps, the median is reported
+    assert 1 < b["timed_rounds"] <= 64 and b["round_s_min_max"][0] <= b["timed_region_s"] <= b["round_s_min_max"][1]
+    assert b["steps_run_by_rank0"] == 3 + 40 * b["timed_rounds"]
+
+
+def test_bench_under_torch_distributed_run_still_works():
+    """The driver's N > 1 form: torch.distributed.run in front, RANK / WORLD_SIZE in the environment -- no second spawn."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--workload", "stub", "--gpus", "2", "--steps", "30",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    b = _json_line(out.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["ranks"] == 2 and b["steps"] == 30
+
+
+def test_world_size_mismatch_is_an_error_message_not_a_crash():
+    env = dict(_clean_env(), WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--gpus", "2"], capture_output=True, text=True,
+                         timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr and "Traceback" not in out.stderr
 
 
 def _latest_line():

@@ -844,7 +844,7 @@ def _run_cascade(name, train_variant=False):
     return g, out, float(dv[0, -1] - dv[0, 0])
 
 
-@pytest.mark.parametrize("name", ["cascade_c1", "cascade_small", "cascade_v5", "cascade_c2"])
+@pytest.mark.parametrize("name", ["cascade_c1", "cascade_small", "cascade_v5", "cascade_v7_d64", "cascade_c2"])
 def test_cascade_vs_reference_golden(hip, name):
     g, out, rng = _run_cascade(name)
     err = float((out["depth"].cpu() - g["depth"]).abs().mean()) / rng
@@ -880,6 +880,21 @@ def test_cascade_c2_smooth_head_vs_reference_golden(hip):
     assert err < 1e-5
     assert float(stable.float().mean()) >= 0.99
     assert float((cd[stable] > 1e-3).float().mean()) < 0.01
+
+
+def test_cascade_config5_arithmetic_vs_reference_golden(hip):
+    """BASELINE config 5's arithmetic (eval_rcmvsnet_tanks.py:47,53-55: 7 views, ndepths 64,32,8) at a small size against the imported
+    reference, well-conditioned head: the six-source-view form of K1 inside a cascade (two view groups of three per plane), the 64-plane
+    depth head (stage-1 depth map and confidence compared on their own) and the hand-over of the stage depth maps."""
+    g, out, rng = _run_cascade("cascade_v7_d64_smooth")
+    for key, ref in (("depth", g["depth"]), ("stage1", g["depth1"]), ("stage2", g["depth2"])):
+        got = out[key]["depth"] if key != "depth" else out["depth"]
+        dd = (got.cpu() - ref).abs()
+        print(f"cascade_v7_d64_smooth {key}: depth L1/range = {float(dd.mean()) / rng:.3e}  max = {float(dd.max()):.3e} mm")
+        assert float(dd.mean()) / rng < 1e-5 and float((dd < 0.05).float().mean()) >= 0.99, key
+    c1 = (out["stage1"]["photometric_confidence"].cpu() - g["conf1"]).abs()
+    cd = (out["photometric_confidence"].cpu() - g["conf"]).abs()
+    assert float((c1 > 1e-3).float().mean()) < 0.01 and float((cd > 1e-3).float().mean()) < 0.01
 
 
 @pytest.mark.parametrize("name,l1_tol", [("cascade_c1", 1e-4), ("cascade_c2_smooth", 1e-5)])

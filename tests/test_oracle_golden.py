@@ -87,14 +87,14 @@ def test_depth_head():
     assert float((conf - g["conf"]).abs()[safe].max()) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["cascade_c1", "cascade_small", "cascade_v5"])
+@pytest.mark.parametrize("name", ["cascade_c1", "cascade_small", "cascade_v5", "cascade_v7_d64", "cascade_v7_d64_smooth"])
 @pytest.mark.parametrize("impl", ["spec", "aten"])
 def test_cascade_eval(name, impl):
     g = load_golden(name)
     H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
     nd, ra = [int(v) for v in g["ndepths"]], [int(v) for v in g["ratios"]]
     imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, 0)
-    sd = synthetic.cascade_state_dict(0)
+    sd = synthetic.cascade_state_dict(0, prob_gain=float(g["prob_gain"])) if "prob_gain" in g else synthetic.cascade_state_dict(0)
     if len(nd) == 1:
         # 1-stage FeatureNet: only stage1 is produced/used
         pass
