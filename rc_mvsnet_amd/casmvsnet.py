@@ -40,6 +40,13 @@ def _nhwc(x):
     return ops.rgb_to_nhwc4(x) if x.shape[1] == 3 else ops.to_channels_last(x)
 
 
+def _param(mod, name):
+    """A parameter by name, dictionary-fast: nn.Module._parameters for a real module, the plain attribute for a DataParallel replica
+    (torch.nn.parallel.replicate empties a replica's _parameters and sets the per-device copies as ordinary attributes)."""
+    p = mod._parameters.get(name)
+    return p if p is not None else getattr(mod, name)
+
+
 def _packed_of(module, make):
     """Packed weight of a stand-alone block, rebuilt when its parameter changes."""
     w = module.conv.weight
@@ -212,12 +219,12 @@ class FeatureNet(nn.Module):
         for m in mods:
             # running statistics are updated by the kernels through raw pointers (no version bump): num_batches_tracked is
             # incremented in place by every train-mode forward and stands in for them
-            cp, bn = m._modules["conv"]._parameters, m._modules["bn"]
-            bp, bb = bn._parameters, bn._buffers
-            tens += [cp["weight"], bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"], bb["num_batches_tracked"]]
+            cv, bn = m._modules["conv"], m._modules["bn"]
+            bb = bn._buffers
+            tens += [_param(cv, "weight"), _param(bn, "weight"), _param(bn, "bias"), bb["running_mean"], bb["running_var"], bb["num_batches_tracked"]]
         unet = self.arch_mode == "unet"              # (its merge blocks keep their own packed weights: _packed_of)
         heads = ["out1"] + (["out2", "out3"] if unet else ["inner1", "out2", "inner2", "out3"])
-        extra = [t for n in heads if n in sub for t in sub[n]._parameters.values() if t is not None]
+        extra = [t for n in heads if n in sub for t in (_param(sub[n], "weight"), getattr(sub[n], "bias", None)) if t is not None]
         key = tuple((t.data_ptr(), t._version) for t in tens + extra)
         if getattr(self, "_plan", None) is None or key != self._plan_key:
             plan = {}
@@ -489,10 +496,10 @@ class CostRegNet(nn.Module):
         mods = self._modules
         for n in self._LAYERS:
             m = mods[n]._modules
-            cp, bn = m["conv"]._parameters, m["bn"]
-            bp, bb = bn._parameters, bn._buffers
-            ts += [cp["weight"], bp["weight"], bp["bias"], bb["running_mean"], bb["running_var"], bb["num_batches_tracked"]]
-        ts.append(mods["prob"]._parameters["weight"])
+            cv, bn = m["conv"], m["bn"]
+            bb = bn._buffers
+            ts += [_param(cv, "weight"), _param(bn, "weight"), _param(bn, "bias"), bb["running_mean"], bb["running_var"], bb["num_batches_tracked"]]
+        ts.append(_param(mods["prob"], "weight"))
         return ts
 
     def hip_plan(self):
@@ -705,7 +712,9 @@ class _CascadeBase(nn.Module):
             # activation bounds of the fp16-pair kernels: one persistent (stage, 7, 1024) buffer per model, ONE fill per scene
             # (row 0 of a stage: bound of the variance volume; rows 1-6: written by the layers).  Not re-entrant across streams.
             bounds = getattr(self, "_pair_bounds", None)
-            if bounds is None or bounds.device != imgs.device:
+            if getattr(self, "_is_replica", False):                  # a DataParallel replica shares its attributes with its siblings (shallow copy) and runs beside them
+                bounds = torch.zeros(self.num_stage, 7, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
+            elif bounds is None or bounds.device != imgs.device:
                 bounds = self._pair_bounds = torch.zeros(self.num_stage, 7, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
             else:
                 bounds.zero_()

@@ -76,4 +76,5 @@ def train_step(model, model_nerf, opt, imgs, proj, depth_values, batch, w_aug=0.
     if grad_sync is not None:
         grad_sync.sync()
     opt.step()
-    return {"loss": float(loss), "base": float(loss_base), "aug": float(loss_aug), "render": float(img_loss + depth_loss)}
+    return {"loss": float(loss.detach()), "base": float(loss_base.detach()), "aug": float(loss_aug.detach()),
+            "render": float((img_loss + depth_loss).detach())}

@@ -130,10 +130,13 @@ def _one_step(wrap, dist=None):
         model_nerf = nn.SyncBatchNorm.convert_sync_batchnorm(model_nerf)
         opt = torch.optim.Adam(list(model.parameters()) + list(model_nerf.parameters()), lr=1e-4, betas=(0.9, 0.999))
         sync = parallel.GradSync([model, model_nerf])
-    torch.manual_seed(1234)                                                             # the mask / ray draws of the iteration
+    import numpy as np
+    torch.manual_seed(1234)                                                             # the ray draws of the iteration
+    np.random.seed(1234)                                                                # the blanked rectangle (losses/aug_loss.py draws it with numpy)
     losses = ts.train_step(model, model_nerf, opt, imgs, proj, dv, batch, grad_sync=sync)
     torch.cuda.synchronize()
     inner = [m.module if hasattr(m, "module") else m for m in (model, model_nerf)]
+    assert all(p.grad is not None for m in inner for p in m.parameters() if p.requires_grad)      # find_unused_parameters=False holds: every parameter took part
     weights = {f"{i}.{n}": p.detach().clone() for i, m in enumerate(inner) for n, p in m.named_parameters()}
     return losses, _grads(*inner), weights
 
@@ -142,7 +145,7 @@ def _one_step(wrap, dist=None):
 def test_training_script_wrapping_on_a_world_one_rccl_group(nccl_world_one, wrap):
     base_losses, base_g, base_w = _one_step("bare")
     losses, g, w = _one_step(wrap, nccl_world_one)
-    assert set(g) == set(base_g) and len(g) > 200                       # every parameter of both models received a gradient (find_unused_parameters=False holds)
+    assert set(g) == set(base_g) and len(g) > 150
     for k in ("loss", "base", "aug", "render"):
         assert abs(losses[k] - base_losses[k]) <= 1e-5 * max(1.0, abs(base_losses[k])), (k, losses, base_losses)
     worst = 0.0
@@ -154,7 +157,7 @@ def test_training_script_wrapping_on_a_world_one_rccl_group(nccl_world_one, wrap
         worst = max(worst, float((g[name] - want).abs().max()) / scale)
     print(f"{wrap}: worst relative gradient difference to the un-wrapped step = {worst:.2e}")
     # the SyncBatchNorm branch sums in fp64 over the (one-rank) group where plain BatchNorm sums per launch: not bit-equal, but tight
-    assert worst < 5e-4
+    assert worst < 2e-5
     for name, want in base_w.items():                                   # and the Adam step landed on the wrapped module's parameters
         assert torch.allclose(w[name], want, rtol=0, atol=2.5e-4), name
 
