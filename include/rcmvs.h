@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 100          /* 0.1.0 */
+#define RCMVS_VERSION 101          /* 0.1.1 -- 101: rcmvs_bn_stats writes 2C + 1 doubles (the row count joined the sums: one SyncBatchNorm message);
+                                      rcmvs_debug_warp_variance_fwd takes variants 0-3 only.  A caller built against 100 must be rebuilt: check
+                                      rcmvs_version() >= the RCMVS_VERSION it was compiled with. */
 #define RCMVS_MAX_SRC_VIEWS 10     /* V-1 */
 
 int         rcmvs_version(void);
@@ -178,7 +180,7 @@ int rcmvs_deconv3d_scaled_fwd(const float* x, const float* x_absmax, const float
  * backward of the block is rcmvs_bn_bwd_* + the data gradient (the same forward kernels on re-packed
  * weights: dgrad(conv s1) = conv with flipped, transposed weights; dgrad(conv s2) = deconv; dgrad(deconv) =
  * conv s2) + rcmvs_conv3d_wgrad.  All tensors channels-last, rows = B*D*H*W.
- *   rcmvs_bn_stats:          sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2, sums[2C] += rows     (fp64; these 2C + 1
+ *   rcmvs_bn_stats:          sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2, sums[2C] += rows     (fp64; SINCE VERSION 101 these 2C + 1
  *                            doubles are what a SyncBatchNorm all-reduce exchanges).  The buffer starts at zero ONCE: the
  *                            finalize calls below clear what they consumed, so one buffer per layer serves every step.
  *   rcmvs_scale_shift_relu:  y = [relu](x*scale[c] + shift[c]) + residual   (scale/shift/residual may be NULL)

@@ -142,7 +142,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, ctypes.c_int)
-    if lib.rcmvs_version() < 100:
+    if lib.rcmvs_version() < 101:          # 101: rcmvs_bn_stats' buffer grew to 2C + 1 doubles (include/rcmvs.h)
         raise RcmvsError("librcmvs_hip.so is older than this package")
     _lib = lib
     return lib

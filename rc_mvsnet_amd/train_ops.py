@@ -13,6 +13,7 @@ into mean / invstd / running statistics (a few dozen floats), and all-reduces th
 a SyncBatchNorm replica.
 """
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -64,7 +65,8 @@ def conv3d_wgrad(x, dy, stride, out=None):
     return dw
 
 
-# packed-gradient accumulation buffers by shape: zero when created, re-zeroed by rcmvs_wgrad_finish after every use (stream-ordered)
+# packed-gradient accumulation buffers by (shape, device): [buffer, known-zero flag]; zero when created, re-zeroed by rcmvs_wgrad_finish
+# after every use (stream-ordered); a use that aborts before its finish launch leaves the flag down and the next use fills the buffer first
 _WGRAD_SCRATCH = {}
 
 
@@ -73,12 +75,17 @@ def _wgrad_to_param_layout(big, small, stride, w_shape):
     of that shape, then one launch that permutes it out and clears the buffer (no zero fill, no permute copy)."""
     P, Q = big.shape[-1], small.shape[-1]
     key = (P, Q, str(big.device))
-    buf = _WGRAD_SCRATCH.get(key)
-    if buf is None:
-        buf = _WGRAD_SCRATCH[key] = torch.zeros((27, P, Q), device=big.device, dtype=torch.float32)
+    ent = _WGRAD_SCRATCH.get(key)
+    if ent is None:
+        ent = _WGRAD_SCRATCH[key] = [torch.zeros((27, P, Q), device=big.device, dtype=torch.float32), True]
+    buf = ent[0]
+    if not ent[1]:                   # the previous use of this shape aborted before its finish launch cleared the buffer
+        buf.zero_()
+    ent[1] = False
     conv3d_wgrad(big, small, stride, out=buf)
     out = torch.empty(tuple(w_shape), device=big.device, dtype=torch.float32)
     _lib.check(_lib.load().rcmvs_wgrad_finish(_chk(buf, "packed"), _chk(out, "dw"), P, Q, int(w_shape[1]), _stream()), "wgrad_finish")
+    ent[1] = True
     return out
 
 
@@ -109,15 +116,28 @@ def _pad_in_channels(w, cx):
 
 
 # Packed images of PARAMETERS, reused while the parameter is unchanged: an iteration runs two cascade passes (standard and augmented
-# views) over the same weights, forward and backward.  Keyed by the parameter object (kept alive by the entry, so its id cannot be
-# recycled) and its autograd version counter, which every in-place optimizer update bumps.  Derived weight tensors (FeatureNet's
+# views) over the same weights, forward and backward.  An entry is valid while the parameter object is alive (weak reference: a model
+# that is dropped takes its entries with it) and its autograd version counter, storage pointer and device are what they were -- an
+# in-place optimizer update bumps the counter, `.to(device)` / a dtype change moves the storage.  A write through `.data`
+# (`p.data.add_(...)`: legacy optimizers, EMA / weight-swap code) changes NONE of these, so the cache is ALSO emptied after every
+# torch.optim.Optimizer.step() (a global post-step hook, whatever the optimizer subclass does inside); code that writes `.data`
+# outside an optimizer step must call clear_pack_cache() itself.  Derived weight tensors (FeatureNet's
 # embedded 2-D kernels, channel-padded copies) are new tensors every call and are packed every call.
-# (An update through `.data` does not bump the counter: call clear_pack_cache() after such a write.)
 _PACK_CACHE = {}
+_PACK_HOOK = [None]
 
 
 def clear_pack_cache():
     _PACK_CACHE.clear()
+
+
+def _install_pack_hook():
+    if _PACK_HOOK[0] is None:
+        try:
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+            _PACK_HOOK[0] = register_optimizer_step_post_hook(lambda opt, args, kwargs: _PACK_CACHE.clear())
+        except Exception:                      # an older torch without global optimizer hooks: the version counter alone
+            _PACK_HOOK[0] = False
 
 
 def _param_of(w):
@@ -128,10 +148,14 @@ def _packed(w, transposed, stride, planar, param=None):
     """PackedWeight of `w` holding the one image a production call (stride, planar) reads."""
     if param is None or ops._CONV_IMPL:
         return ops.pack_conv3d_weight(w, transposed=transposed, use=(stride, planar))
+    _install_pack_hook()
     key = (int(transposed), int(stride), bool(planar))
-    ent = _PACK_CACHE.get(id(param))
-    if ent is None or ent[0] is not param or ent[1] != param._version:
-        ent = _PACK_CACHE[id(param)] = (param, param._version, {})
+    pid = id(param)
+    state = (param._version, param.data_ptr(), param.device)
+    ent = _PACK_CACHE.get(pid)
+    if ent is None or ent[0]() is not param or ent[1] != state:
+        ref = weakref.ref(param, lambda _, pid=pid: _PACK_CACHE.pop(pid, None))      # the id may be recycled once the parameter is gone
+        ent = _PACK_CACHE[pid] = (ref, state, {})
     pk = ent[2].get(key)
     if pk is None:
         pk = ent[2][key] = ops.pack_conv3d_weight(w, transposed=transposed, use=(stride, planar))
@@ -171,20 +195,30 @@ def _conv_wgrad(x, dy, w_shape, transposed, stride):
 
 
 def _bn_scratch(cfg, which, S, n, device):
-    """-> (cur, other): the layer's two fp64 accumulation buffers (S segments x n doubles each), created zero once and kept on the
+    """-> (cur, other, done): the layer's two fp64 accumulation buffers (S segments x n doubles each), created zero once and kept on the
     BatchNorm module.  A call accumulates into `cur` and hands `other` -- the buffer the previous call of this layer consumed -- to
-    the fused normalisation kernel, which clears it (rcmvs_bn_norm_fwd / _bwd): no call fills a buffer again.  Calls of one
-    module are stream-ordered."""
+    the fused normalisation kernel, which clears it (rcmvs_bn_norm_fwd / _bwd): no call fills a buffer again.  Calls of one module are
+    stream-ordered.  A call that ABORTS between its accumulation and its normalisation launch (out of memory with a skip-batch
+    handler, KeyboardInterrupt, a failing all_reduce) would leave `cur` part-filled and `other` uncleared: each buffer therefore
+    carries a host-side "known zero" flag -- cleared when a call starts accumulating into it, set by `done()` once the launch that
+    clears it has been enqueued -- and a buffer that is not known to be zero is re-zeroed before use (one extra fill, after an abort only)."""
     store = cfg.get("scratch")
     if store is None:
         z = torch.zeros((2, S, n), device=device, dtype=torch.float64)
-        return z[0], z[1]
+        return z[0], z[1], (lambda: None)
     key = (which, S, n, str(device))
     ent = store.get(key)
     if ent is None:
-        ent = store[key] = [torch.zeros((2, S, n), device=device, dtype=torch.float64), 0]
+        ent = store[key] = [torch.zeros((2, S, n), device=device, dtype=torch.float64), 0, [True, True]]
     ent[1] ^= 1
-    return ent[0][ent[1]], ent[0][ent[1] ^ 1]
+    i = ent[1]
+    if not ent[2][i]:
+        ent[0][i].zero_()
+    ent[2][i] = False
+
+    def done(ent=ent, j=i ^ 1):
+        ent[2][j] = True
+    return ent[0][i], ent[0][i ^ 1], done
 
 
 class ConvBnReluFn(torch.autograd.Function):
@@ -203,7 +237,7 @@ class ConvBnReluFn(torch.autograd.Function):
         C = y.shape[-1]
         S = int(cfg.get("segments", 1))
         nb = y.shape[0] // S
-        pack, spent = _bn_scratch(cfg, "fwd", S, 2 * C + 1, x.device)            # per segment [sum | sum of squares | rows]; `spent`: the previous call's
+        pack, spent, done = _bn_scratch(cfg, "fwd", S, 2 * C + 1, x.device)      # per segment [sum | sum of squares | rows]; `spent`: the previous call's
         cnt = torch.empty((S,), device=x.device, dtype=torch.float64)           # rows behind the statistics (all ranks), for the backward pass
         stats = torch.empty((S, 5, C), device=x.device, dtype=torch.float32)     # mean, var, invstd, scale, shift
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
@@ -221,6 +255,7 @@ class ConvBnReluFn(torch.autograd.Function):
                                              float(cfg["eps"]), float(cfg.get("momentum", 0.0)), ptr(stats[sgm]), ptr(cnt[sgm:]),
                                              _opt(running_mean, "running_mean"), _opt(running_var, "running_var"), _opt(rs, "residual"),
                                              _chk(zs, "z"), ys.numel() // C, C, int(bool(cfg["relu"])), _stream()), "bn_norm_fwd")
+        done()                                                                   # every segment's `spent` row has its clearing launch enqueued
         ctx.save_for_backward(x, w, y, stats, cnt)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
@@ -234,7 +269,7 @@ class ConvBnReluFn(torch.autograd.Function):
         S = int(cfg.get("segments", 1))
         nb = y.shape[0] // S
         dz = dz.contiguous()
-        sums, spent = _bn_scratch(cfg, "bwd", S, 2 * C, y.device)
+        sums, spent, done = _bn_scratch(cfg, "bwd", S, 2 * C, y.device)
         out = torch.empty((S, 2, C), device=y.device, dtype=torch.float32)        # per segment: dgamma, dbeta
         dy = torch.empty_like(y)
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -249,6 +284,7 @@ class ConvBnReluFn(torch.autograd.Function):
             _lib.check(_lib.load().rcmvs_bn_norm_bwd(_chk(y[sl], "y"), _chk(dz[sl], "dz"), ptr(stats[sgm]), ptr(sums[sgm]), ptr(tot), ptr(cnt[sgm:]),
                                                      ptr(spent[sgm]), ptr(out[sgm, 0]), ptr(out[sgm, 1]), _chk(dy[sl], "dy"), y[sl].numel() // C, C,
                                                      int(bool(cfg["relu"])), _stream()), "bn_norm_bwd")
+        done()
         dgamma, dbeta = (out[0, 0], out[0, 1]) if S == 1 else (out[:, 0].sum(0), out[:, 1].sum(0))
         dx = _conv_dgrad(dy, w, cfg["transposed"], cfg["stride"], x.shape[-1], _param_of(w)) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad(x, dy, w.shape, cfg["transposed"], cfg["stride"]) if ctx.needs_input_grad[1] else None
@@ -416,10 +452,12 @@ class NerfMlpFn(torch.autograd.Function):
         M = N * S
         graw = graw.contiguous().float()
         key = (M, raw.device)              # backward scratch (415 MB at 1024 x 128 points): one buffer per (size, device), reused every step
-        gws = _NERF_BWD_SCRATCH.get(key)
+        gws = _NERF_BWD_SCRATCH.pop(key, None)
         if gws is None:
-            _NERF_BWD_SCRATCH.clear()
-            gws = _NERF_BWD_SCRATCH[key] = torch.empty((lib.rcmvs_nerf_bwd_workspace_floats(M),), device=raw.device, dtype=torch.float32)
+            while len(_NERF_BWD_SCRATCH) >= _NERF_BWD_SCRATCH_MAX:          # least recently used first (dicts keep insertion order)
+                _NERF_BWD_SCRATCH.pop(next(iter(_NERF_BWD_SCRATCH)))
+            gws = torch.empty((lib.rcmvs_nerf_bwd_workspace_floats(M),), device=raw.device, dtype=torch.float32)
+        _NERF_BWD_SCRATCH[key] = gws                                        # (re-)inserted as the most recent
         dfeat = torch.empty_like(feat)
         grads = [torch.empty_like(p) for p in ps]
         warr = (ctypes.c_void_p * 22)(*[_chk(t, "nerf weight").value for t in ps])
@@ -429,7 +467,8 @@ class NerfMlpFn(torch.autograd.Function):
         return (None, dfeat, None, None, *grads)
 
 
-_NERF_BWD_SCRATCH = {}
+_NERF_BWD_SCRATCH = {}             # (points, device) -> workspace, at most _NERF_BWD_SCRATCH_MAX entries (two devices / two ray counts alternate without re-allocating)
+_NERF_BWD_SCRATCH_MAX = 4
 
 
 def nerf_mlp_train(net, ndc, feat, dirs, w2c_ref):

@@ -68,7 +68,7 @@ FAST = {
          "test_depthnet_on_its_own_vs_reference_golden", "test_execution_plans_follow_their_parameters"],
     GR: ["test_resize_planes", "test_gu_sampler_vs_oracle", "test_nerf_mlp_vs_oracle", "test_composite_vs_oracle"],
     GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel", "test_conv3d_weight_gradient_cout8_paired_columns",
-         "test_selective_weight_pack_matches_full_blob_and_is_checked", "test_packed_weight_reuse_follows_the_parameter_version",
+         "test_selective_weight_pack_matches_full_blob_and_is_checked", "test_packed_weight_reuse_follows_the_parameter_version", "test_pack_cache_follows_data_writes_of_a_legacy_optimizer_and_dies_with_its_parameter", "test_batchnorm_and_wgrad_scratch_survive_an_aborted_call",
          "test_fused_batchnorm_forms_equal_the_two_launch_forms", "test_weight_gradient_finish_permutes_and_clears"],
     GL: ["test_unsup_loss_multi_stage_matches_reference", "test_inverse_warping_matches_reference", "test_aug_loss_and_sl1_match_reference",
          "test_unsup_loss_argument_checks"],

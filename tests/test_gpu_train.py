@@ -629,6 +629,92 @@ def test_packed_weight_reuse_follows_the_parameter_version():
     train_ops.clear_pack_cache()
 
 
+def test_pack_cache_follows_data_writes_of_a_legacy_optimizer_and_dies_with_its_parameter():
+    """A write through `.data` bumps no version counter.  An optimizer that updates that way (p.data.add_) is still followed, because every
+    torch.optim.Optimizer.step() empties the cache (global post-step hook); a bare `.data` write needs clear_pack_cache(), as documented;
+    moving the parameter's storage invalidates its entry; and entries do not outlive their parameter."""
+    import gc
+    from rc_mvsnet_amd import train_ops, _lib
+    _lib.load()
+    train_ops.clear_pack_cache()
+    g = torch.Generator().manual_seed(9)
+    w = torch.nn.Parameter((torch.randn(8, 16, 3, 3, 3, generator=g) / 20).to(DEV))
+    x = torch.randn(1, 4, 9, 20, 16, generator=g).to(DEV)
+    y0 = train_ops._conv_raw(x, w.detach(), False, 1, w)
+
+    class LegacySGD(torch.optim.Optimizer):
+        def __init__(self, params):
+            super().__init__(params, {})
+
+        def step(self, closure=None):
+            for grp in self.param_groups:
+                for p in grp["params"]:
+                    p.data.mul_(2.0)                                                   # no version bump
+
+    v = w._version
+    LegacySGD([w]).step()
+    assert w._version == v                                                             # the counter really did not move
+    y1 = train_ops._conv_raw(x, w.detach(), False, 1, w)
+    assert float((y1 - 2.0 * y0).abs().max()) <= 1e-5 * float(y1.abs().max())         # ... and the new weights were used all the same
+    w.data.mul_(0.5)                                                                   # outside any optimizer: stale until told
+    assert torch.equal(train_ops._conv_raw(x, w.detach(), False, 1, w), y1)
+    train_ops.clear_pack_cache()
+    y2 = train_ops._conv_raw(x, w.detach(), False, 1, w)
+    assert float((y2 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+    a = train_ops._packed(w.detach(), False, 1, False, w)
+    w.data = w.data.clone()                                                            # same values, other storage (what .to(device) does)
+    assert train_ops._packed(w.detach(), False, 1, False, w) is not a
+    n = len(train_ops._PACK_CACHE)
+    assert n >= 1
+    del w, a
+    gc.collect()
+    assert len(train_ops._PACK_CACHE) == n - 1                                         # the entry went with the parameter
+    train_ops.clear_pack_cache()
+
+
+def test_batchnorm_and_wgrad_scratch_survive_an_aborted_call(monkeypatch):
+    """A call that dies between its accumulation launch and the launch that consumes / clears the buffers (OOM with a skip-batch handler,
+    KeyboardInterrupt) must not poison the layer's next call: forward statistics, backward sums and the packed weight-gradient buffer."""
+    from rc_mvsnet_amd import train_ops, _lib
+    from rc_mvsnet_amd.casmvsnet import Conv3d
+    _lib.load()
+    torch.manual_seed(3)
+    blk = Conv3d(16, 8).to(DEV).train()
+    x = torch.randn(2, 4, 8, 12, 16, device=DEV)
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        for p in blk.parameters():
+            p.grad = None
+        z = train_ops.conv_bn_relu_train(blk, xx)
+        z.square().sum().backward()
+        return z.detach().clone(), xx.grad.clone(), blk.conv.weight.grad.clone(), blk.bn.weight.grad.clone()
+
+    run()                                                                              # buffers exist, ping-pong state advanced once
+    blk.bn.running_mean.zero_(); blk.bn.running_var.fill_(1.0)
+    want = run()
+    real_stats, real_reduce, real_wgrad = train_ops.bn_stats, train_ops.bn_bwd_reduce, train_ops.conv3d_wgrad
+
+    class Boom(RuntimeError):
+        pass
+
+    def failing(real):
+        def f(*a, **k):
+            real(*a, **k)                                                              # the accumulation launch is enqueued ...
+            raise Boom()                                                               # ... and the call never reaches its finishing launch
+        return f
+
+    for name, real in (("bn_stats", real_stats), ("bn_bwd_reduce", real_reduce), ("conv3d_wgrad", real_wgrad)):
+        monkeypatch.setattr(train_ops, name, failing(real))
+        with pytest.raises(Boom):
+            run()
+        monkeypatch.setattr(train_ops, name, real)
+        blk.bn.running_mean.zero_(); blk.bn.running_var.fill_(1.0)
+        got = run()
+        for a, b, what in zip(got, want, ("z", "dx", "dw", "dgamma")):
+            assert torch.equal(a, b), (name, what, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("C,rows,relu", [(8, 1000, True), (32, 77, False), (64, 513, True)])
 def test_fused_batchnorm_forms_equal_the_two_launch_forms(C, rows, relu):
     """rcmvs_bn_norm_fwd / _bwd = finalize + apply in one launch: bit-identical statistics, outputs and gradients; the accumulation
