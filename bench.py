@@ -90,7 +90,7 @@ def conv_roofline(conv_events, nscenes):
     from rc_mvsnet_amd import casmvsnet
     pair = casmvsnet.FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
     PAIR_LAYERS = {("s1", 8, 8), ("s1", 16, 8), ("s1", 32, 8), ("s1", 16, 16), ("s2", 8, 16), ("s2", 16, 32), ("t2", 16, 8), ("s1", 32, 32), ("t2", 32, 16)}
-    flops = ms = products = 0.0
+    flops = ms = products = act_bytes = 0.0
     per_layer = {}
     for e0, e1, (kind, B, D, H, W, Ci, Co) in conv_events:
         if (kind, Ci, Co) not in X3_LAYERS:
@@ -104,6 +104,11 @@ def conv_roofline(conv_events, nscenes):
             cells = B * D * H * W
         f = 2.0 * taps * Ci * Co * cells
         t = e0.elapsed_time(e1)
+        # ideal activation traffic of the layer: read the input once, write the output once, and -- the transposed layers of CostRegNet add
+        # their skip connection in the epilogue (models/modules.py:496-498) -- read the skip tensor once
+        vin = B * D * H * W
+        vout = 8 * vin if kind == "t2" else cells
+        act_bytes += 4.0 * (vin * Ci + vout * Co * (2 if kind == "t2" else 1))
         flops += f
         products += f * (3.0 if (pair and B == 1 and taps == 27 and (kind, Ci, Co) in PAIR_LAYERS) else 6.0)
         ms += t
@@ -120,7 +125,11 @@ def conv_roofline(conv_events, nscenes):
             "peak_note": "fp32 dense peak: the results are fp32-accurate (3-D layers: two fp16 pieces per operand after an exact power-of-two "
                          "pre-scale, 3 MFMAs per product" + ("" if pair else " -- disabled by RCMVS_FP16_PAIR=0") + "; planar layers and the exact form: three bf16 pieces, 6 MFMAs)",
             "arithmetic": "fp16 pair (default)" if pair else "exact bf16 triple (RCMVS_FP16_PAIR=0)",
-            "matrix_pipe_frac": round(products / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4), "us_per_scene": round(ms * 1e3 / nscenes, 1),
+            "matrix_pipe_frac": round(products / (ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4),
+            # once the arithmetic is on the 2.5 PF pipe the layers' bound is their activation traffic: ideal bytes / time against the 8 TB/s HBM peak
+            "frac_hbm": round(act_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "activation_GB_per_scene": round(act_bytes / nscenes / 1e9, 3),
+            "hbm_bound_us_per_scene": round(act_bytes / nscenes / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
+            "us_per_scene": round(ms * 1e3 / nscenes, 1),
             "gflop_per_scene": round(flops / nscenes / 1e9, 2),
             "largest_layers_us_tflops": {k: [round(v[1] * 1e3 / nscenes, 1), round(v[0] / (v[1] * 1e-3) / 1e12, 1)] for k, v in top},
             "timing": "HIP events on the launch stream around every launch, separate untimed pass of 10 scenes"}
@@ -551,7 +560,7 @@ def main(argv=None):
         m.load_state_dict(sd, strict=True)
         return m.to(dev).eval()
 
-    pipe = ScenePipeline(make_model, nstreams, dev, wait_inputs=False)      # the scenes are resident and synchronised before the timed region
+    pipe = ScenePipeline(make_model, nstreams, dev, wait_inputs=False, experimental=nstreams > 1)      # the scenes are resident and synchronised before the timed region
     model = pipe.models[0]
 
     # a few distinct scenes resident in HBM; rank r starts at a different one

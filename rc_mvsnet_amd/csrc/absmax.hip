@@ -7,7 +7,6 @@
 namespace rcmvs {
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n4, long long n, int square, float* __restrict__ amax) {
-    RCMVS_KERNEL_ENTRY();
     __shared__ float red[4];
     float m = 0.0f;
     const long long stride = (long long)gridDim.x * 256;

@@ -38,17 +38,3 @@ __device__ inline unsigned xcd_remap(unsigned bid, unsigned nblk) {
 }
 
 }  // namespace rcmvs
-
-// Experiment switch of the two-stream investigation (tools/dev/build_plain_planes_variant.sh builds a library with
-// -DRCMVS_L1_ACQUIRE): one lane invalidates its CU's vector L1 before the block reads anything -- what the dispatch's own acquire
-// normally guarantees, and apparently does not while a second queue of the same process keeps the CU busy.  First statement of every
-// kernel of the inference path; expands to nothing in the product build and on the tests' CPU emulation.
-#if defined(RCMVS_L1_ACQUIRE) && defined(__AMDGCN__)
-#define RCMVS_KERNEL_ENTRY()                                                                                            \
-    do {                                                                                                                \
-        if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); \
-        __syncthreads();                                                                                                \
-    } while (0)
-#else
-#define RCMVS_KERNEL_ENTRY() do { } while (0)
-#endif

@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ up, float* __restrict__ y,
     int H, int W, int Ho, int Wo, int tiles_w, int relu) {
-    RCMVS_KERNEL_ENTRY();
     static_assert(TH * TW == 256, "tile must have 256 threads");
     constexpr int PAD = K / 2;
     constexpr int HH = (TH * PPT - 1) * S + K, HW = (TW - 1) * S + K;     // halo tile
@@ -154,7 +153,6 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
 
 // (Co,Ci,K,K) -> [K*K][Cip][Co], input channels zero-padded to Cip
 __global__ void pack_weight2d_kernel(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int Cip, int KK) {
-    RCMVS_KERNEL_ENTRY();
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= KK * Cip * Co) return;
     int co = t % Co, ci = (t / Co) % Cip, tap = t / (Co * Cip);
@@ -163,7 +161,6 @@ __global__ void pack_weight2d_kernel(const float* __restrict__ w, float* __restr
 
 // NCHW (3 channels) -> channels-last padded to 4
 __global__ __launch_bounds__(256) void rgb_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, long long HW) {
-    RCMVS_KERNEL_ENTRY();
     const int n = blockIdx.y;
     long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;

@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     ConvDims dm, int relu) {
-    RCMVS_KERNEL_ENTRY();
     constexpr int VW = (CI % 4 == 0) ? 4 : 1;      // input channel vector width
     const long long nvox = (long long)dm.B * dm.Do * dm.Ho * dm.Wo;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,7 +101,6 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
 // weight repack: conv (Co,Ci,27) / deconv (Ci,Co,27) -> [27][Ci][Co]; transposed == 2 additionally flips the taps
 // (the adjoint of a stride-1 conv: data gradient on the forward kernels)
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int transposed) {
-    RCMVS_KERNEL_ENTRY();
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int n = 27 * Ci * Co;
     if (t >= n) return;

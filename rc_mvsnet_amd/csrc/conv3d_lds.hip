@@ -29,7 +29,6 @@ __global__ __launch_bounds__(256 * SPLIT) void conv3d_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     int D, int H, int W, int tiles_w, int tiles_h, int relu) {
-    RCMVS_KERNEL_ENTRY();
     constexpr int CK = (CI < CKT) ? CI : CKT;                       // channel chunk staged at a time
     constexpr int STRIDE = CK + 4;                                  // floats per staged voxel (padding kills bank conflicts)
     constexpr int TD = LT_D * PPT;                                  // output tile depth
@@ -158,7 +157,6 @@ constexpr int PM_NLD = (PM_HH * PM_HW * 2 + 255) / 256;      // float4 per threa
 __global__ __launch_bounds__(256, 5) void prob_conv_march_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ res, float* __restrict__ y, int D, int H, int W, int tiles_w, int tiles_h, int relu, int zchunk) {
-    RCMVS_KERNEL_ENTRY();
     typedef float f2v __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) float plane[2][PM_PLANE];
     const int b = blockIdx.z, zc = blockIdx.y;

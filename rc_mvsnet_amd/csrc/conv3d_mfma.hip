@@ -41,7 +41,6 @@ __host__ __device__ inline long long mfma_weight_floats(int Ci, int Co) {
 }
 
 __global__ void pack_weight_mfma_kernel(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int transposed) {
-    RCMVS_KERNEL_ENTRY();
     const int vec = mfma_vec(Ci);
     const int chunks = Ci / (4 * vec), mtiles = (Co + 15) / 16;
     long long n = 27LL * chunks * mtiles * 64 * vec;
@@ -70,7 +69,6 @@ template <int CIN, int COUT, int MODE, int NT, int KS = 1>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wm, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, MfmaDims dm, int relu, float* __restrict__ ymax) {
-    RCMVS_KERNEL_ENTRY();
     constexpr int VEC = (CIN >= 16) ? 4 : 2;
     constexpr int CHUNKS = CIN / (4 * VEC);
     constexpr int MTILES = (COUT + 15) / 16;

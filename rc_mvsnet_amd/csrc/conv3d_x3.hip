@@ -207,7 +207,6 @@ __host__ __device__ inline int x3_swz(int hc) {
 // `wsc`, which x3_wscale_kernel filled) followed by the fp16 pieces of s_w * w in the same fragment order.
 template <int CIN, int COUT, int KIND, int NP>
 __global__ void x3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, int transposed, const float* __restrict__ wsc) {
-    RCMVS_KERNEL_ENTRY();
     using C = X3<CIN, COUT, KIND, NP>;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= C::KSTEPS * C::MT_ALL * 64 * 8) return;
@@ -268,7 +267,6 @@ __device__ __forceinline__ float x3_pow2_scale(float m, float& inv) {
 
 // one block: out[0] = scale of max|w| over n weights, out[1] = its inverse
 __global__ void x3_wscale_kernel(const float* __restrict__ w, int n, float* __restrict__ out) {
-    RCMVS_KERNEL_ENTRY();
     __shared__ float red[256];
     float m = 0.0f;
     for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
@@ -395,7 +393,6 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     const float* __restrict__ x, const x3_u32x4* __restrict__ wimg, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y, X3Dims dm,
     const float* __restrict__ xmax, float* __restrict__ ymax) {
-    RCMVS_KERNEL_ENTRY();
     using C = X3<CIN, COUT, KIND, NP>;
     constexpr int MT = C::MT, KSW = C::KSW, KSPLIT = C::KSPLIT, TP = C::TP, NSLOT = C::NSLOT, NKD = C::NKD, ZADV = C::ZADV;
     extern __shared__ __attribute__((aligned(16))) x3_byte smem[];

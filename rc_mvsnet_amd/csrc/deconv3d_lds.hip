@@ -72,7 +72,6 @@ __global__ __launch_bounds__(256) void deconv3d_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
     int D, int H, int W, int tiles_w, int tiles_h, int relu) {
-    RCMVS_KERNEL_ENTRY();
     constexpr int STRIDE = CI + 4;
     __shared__ __attribute__((aligned(16))) float tile[DH_VOX * STRIDE];
     const int b = blockIdx.z, td = blockIdx.y;

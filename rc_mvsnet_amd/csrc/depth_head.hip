@@ -30,7 +30,6 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
 template <int LP>
 __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict__ prob, const float* __restrict__ planes,
                                                                float* __restrict__ depth, float* __restrict__ conf, int D, long long hw) {
-    RCMVS_KERNEL_ENTRY();
     constexpr int MAXK = 16;
     const int b = blockIdx.y;
     const int j = threadIdx.x % LP;

@@ -17,7 +17,6 @@ template <int CL, int CM, int CO>
 __global__ __launch_bounds__(256) void fpn_out_fused_kernel(
     const float* __restrict__ lat, const float* __restrict__ up, const float* __restrict__ w_in, const float* __restrict__ b_in,
     const float* __restrict__ w_out, float* __restrict__ y, int H, int W, int tiles_w) {
-    RCMVS_KERNEL_ENTRY();
     static_assert(CL == 8 && CM % 8 == 0 && CO % 4 == 0, "lateral map has 8 channels");
     constexpr int TH = 16, TW = 16, K = 3, HH = TH + 2, HW = TW + 2, NP = HH * HW;
     constexpr int CK = 8, ST = CK + 4;                                  // channels per pass, floats per staged pixel

@@ -25,7 +25,6 @@ int fail(int code, const char* fmt, ...) {
 template <bool TO_LAST>
 __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       int C, long long S) {
-    RCMVS_KERNEL_ENTRY();
     const int Q = C >> 2;
     const int n = blockIdx.y;
     // lanes: s fastest inside a group of 64 so the planar accesses coalesce
@@ -58,7 +57,6 @@ __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ s
 template <bool TO_LAST>
 __global__ __launch_bounds__(256) void layout_scalar_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                              int C, long long S) {
-    RCMVS_KERNEL_ENTRY();
     const int n = blockIdx.y;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S * C) return;
@@ -100,7 +98,6 @@ __device__ static void fold_intrinsics(const float* p, double A[4][4]) {
 struct ProjPtrs { const float* p[4]; };
 __global__ void compose_homography_kernel(ProjPtrs pp, float* __restrict__ rot,
                                           float* __restrict__ trans, int B, int V) {
-    RCMVS_KERNEL_ENTRY();
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * (V - 1)) return;
     const float* proj = pp.p[blockIdx.y];
@@ -172,6 +169,9 @@ __device__ static inline float bilinear_up(const float* __restrict__ p, int hp, 
     // previous contents (a reused allocator block) although the depth kernel before it on the same stream had completed (explicit
     // event dependencies did not change that; a release fence at the end of the writer did not either; these loads did: 0 of 1200
     // scenes against 7 %).  The map is 80-330 KB, the kernel is bound by its stores; the loads cost nothing measurable.
+    // Round 4 (profiles/r4_two_streams_ab.txt): a one-lane agent-scope acquire at the top of EVERY inference kernel with plain loads
+    // here does NOT remove the corruption (84 of 90 rounds) and costs 18 % on one stream: the stale data is not in the reader's vector
+    // L1, the mechanism stays unexplained, and the multi-stream mode stays off (rc_mvsnet_amd/scene_pipeline.py).
     float top = lx0 * ld_agent(p + y0 * wp + x0) + lx1 * ld_agent(p + y0 * wp + x1);
     float bot = lx0 * ld_agent(p + y1 * wp + x0) + lx1 * ld_agent(p + y1 * wp + x1);
     return ly0 * top + ly1 * bot;
@@ -181,11 +181,6 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ p
                                                       float* __restrict__ planes, int hp, int wp, int H, int W,
                                                       int scale, int D, float ratio, int ND) {
 #pragma clang fp contract(off)
-    RCMVS_KERNEL_ENTRY();
-#ifdef RCMVS_EXP_PLANES_ACQUIRE      // experiment of tools/dev/build_plain_planes_variant.sh (two-stream investigation): invalidate this CU's L1 first
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-#endif
     const int h = H / scale, w = W / scale;
     const int b = blockIdx.y;
     int t = blockIdx.x * blockDim.x + threadIdx.x;

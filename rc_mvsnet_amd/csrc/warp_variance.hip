@@ -91,7 +91,6 @@ __global__ __launch_bounds__(256) void warp_variance_ref_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int tiles_y) {
 #pragma clang fp contract(off)
-    RCMVS_KERNEL_ENTRY();
     constexpr int LPP = C / 4;          // lanes per pixel
     constexpr int TW = 256 / C;         // pixels per wave = tile width  (1 KiB of output per plane)
     constexpr int TH = 4;               // one wave per tile row
@@ -267,7 +266,6 @@ __global__ __launch_bounds__(256) void warp_variance_tp_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x) {
 #pragma clang fp contract(off)
-    RCMVS_KERNEL_ENTRY();
     constexpr int LPP = K1Tile<C>::LPP, PIX = K1Tile<C>::PIX, TH = K1Tile<C>::TH, TW = K1Tile<C>::TW, GRP = K1Tile<C>::GRP;
     static_assert(NVT > 0 && DKB % GRP == 0, "DKB must be a multiple of 256/PIX");
     extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [NVT][DKB][PIX] offsets, then weights
@@ -335,7 +333,6 @@ __global__ __launch_bounds__(256) void warp_variance_mv_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, int VC) {
 #pragma clang fp contract(off)
-    RCMVS_KERNEL_ENTRY();
     constexpr int LPP = K1Tile<C>::LPP, PIX = K1Tile<C>::PIX, TH = K1Tile<C>::TH, TW = K1Tile<C>::TW, GRP = K1Tile<C>::GRP;
     static_assert(DKB % GRP == 0, "DKB must be a multiple of 256/PIX");
     extern __shared__ __attribute__((aligned(16))) v4i lds_o[];          // [VC][DKB][PIX] offsets, then weights
@@ -417,7 +414,6 @@ __global__ __launch_bounds__(256) void warp_noref_kernel(
     const float* __restrict__ trans, const float* __restrict__ planes, float* __restrict__ out,
     int V, int D, int h, int w, int square_first) {
 #pragma clang fp contract(off)
-    RCMVS_KERNEL_ENTRY();
     const int b = blockIdx.z, k = blockIdx.y;
     const long long hw = (long long)h * w;
     long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;

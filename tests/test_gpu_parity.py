@@ -962,7 +962,9 @@ def test_two_scenes_in_flight_match_the_one_stream_run(hip):
         warnings.simplefilter("ignore", RuntimeWarning)
         one = make()
         want = [[pick(one(*s), k).clone() for k in keys] for s in scenes]
-        pipe = ScenePipeline(make, 2, DEV)
+        with pytest.raises(RuntimeError, match="experimental"):
+            ScenePipeline(make, 2, DEV)                                  # the mode needs an explicit opt-in
+        pipe = ScenePipeline(make, 2, DEV, experimental=True)
         for i in range(2):
             pipe(*scenes[i])                                 # plans and packed weights of both replicas
         pipe.synchronize()

@@ -87,7 +87,7 @@ with torch.no_grad():
     torch.cuda.synchronize(); KEEP.clear()
     bad, where, ms = 0, [], []
     for rnd in range(NR):
-        pipe = ScenePipeline(make, 2, dev)
+        pipe = ScenePipeline(make, 2, dev, experimental=True)
         for i in range(2): pipe(*scenes[i])            # plans / packed weights of both replicas outside the timed, checked part
         pipe.synchronize(); KEEP.clear()
         got, hist, done = [], [], []
