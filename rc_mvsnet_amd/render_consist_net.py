@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .casmvsnet import _bn_fold, _hip_inference, _hip_training, _holder_only, _unsupported
+from .casmvsnet import _block3d, _bn_fold, _hip_inference, _hip_training, _holder_only, _unsupported
 
 N_RAYS = 1024                               # hard-coded in the reference (render_consist_net.py:68)
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -36,9 +36,23 @@ class ConvBnReLU3D(nn.Module):
         super().__init__()
         self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = norm_act(out_channels)
+        self.relu = False
+        self.gn = None
 
     def forward(self, x):
-        _holder_only(self)
+        """Called on its own (inside CostReg the network's plan runs it): (B,Ci,D,H,W) -> (B,Co,Do,Ho,Wo) on the 3-D conv family, eval mode
+        under no_grad (folded norm) or train mode (batch statistics + autograd); a channel count that is not a multiple of 4 (the 41
+        channels of the volume network's first layer) is zero-padded on both operands."""
+        pad = (-x.shape[1]) % 4
+        if pad and _hip_inference(self, x):
+            w = self.conv.weight
+            key = (w.data_ptr(), w._version, str(w.device))
+            c = self.__dict__.get("_rcmvs_pack")
+            if c is None or c[0] != key:
+                wp = torch.cat((w.detach(), w.new_zeros(w.shape[0], pad, *w.shape[2:])), dim=1)
+                self.__dict__["_rcmvs_pack"] = (key, ops.pack_conv3d_weight(wp))
+            x = F.pad(x, (0, 0, 0, 0, 0, 0, 0, pad))
+        return _block3d(self, x)
 
 
 class CostReg(nn.Module):
@@ -222,16 +236,26 @@ class RenderNet(nn.Module):
 
 
 class Rendering_Consistency_Net(nn.Module):
+    """models/render_consist_net.py:11-76.  One flagged extension beyond the reference: ``args.num_views`` (default 4).  The reference's
+    volume network is built for the warped volume feature of a FOUR-view CascadeMVSNet pass (CostReg(32+9), models/render_models.py:750),
+    so its training script cannot feed it a five-view pass (BASELINE configs[2] as worded); with ``args.num_views = V`` the volume network
+    takes the 32 + 3 (V - 1) channels of a V-view pass.  Everything after it is the reference's, quirks included: decode_batch's
+    idx = arange(4) selects nothing (models/render_utils.py:378 tests the key, not the tensor), so the renderer reads the images of the
+    LAST three views of the batch (imgs[:, -3:], :74) with the poses of the FIRST three (render_utils.py:260)."""
+
     def __init__(self, args):
         super().__init__()
         self.args = args
         self.args.feat_dim = 8 + 3 * 4
         self.idx = 0
+        self.num_views = int(getattr(args, "num_views", 4))
+        if self.num_views < 4:
+            raise NotImplementedError("the renderer reads three source views (models/render_consist_net.py:74): num_views >= 4")
         if getattr(args, "net_type", "v0") != "v0" or getattr(args, "N_importance", 0) != 0:
             raise NotImplementedError("only net_type='v0', N_importance=0 (the shipped configuration) is provided")
         if getattr(args, "multires", 10) != 10 or getattr(args, "netdepth", 6) != 6 or getattr(args, "netwidth", 128) != 128:
             raise NotImplementedError("the MLP kernels are built for multires=10, netdepth=6, netwidth=128 (the shipped configuration)")
-        self.MVSNet = Neural_Volume_Net()
+        self.MVSNet = Neural_Volume_Net(in_channels=32 + 3 * (self.num_views - 1))
         self.network_fn = RenderNet(D=args.netdepth, W=args.netwidth, input_ch_pts=63, skips=[4], input_ch_views=args.dir_dim,
                                     input_ch_feat=self.args.feat_dim, net_type=args.net_type)
         self.white_bkgd = getattr(args, "white_bkgd", False)
@@ -252,6 +276,8 @@ class Rendering_Consistency_Net(nn.Module):
         if "scan" in batch:
             batch.pop("scan")
         dev = volume_feature_warp.device
+        # (decode_batch's idx = arange(4) selects nothing: sub_selete_data tests torch.is_tensor on the KEY, models/render_utils.py:378 --
+        # every view of the batch reaches the renderer, which reads the LAST three images and the FIRST three poses)
         imgs = batch["imgs"].float().to(dev)
         w2cs = batch["w2cs"].float().to(dev).squeeze(0)
         c2ws = batch["c2ws"].float().to(dev).squeeze(0)

@@ -155,12 +155,14 @@ def cost_reg_state_dict(rng, prefix, cin, base=8, prob_gain=20.0):
     return sd
 
 
-def render_state_dict(seed=1, n_src=3):
-    """82 tensors named like Rendering_Consistency_Net.state_dict() (netdepth 6, width 128)."""
+def render_state_dict(seed=1, n_src=3, vol_src=None):
+    """82 tensors named like Rendering_Consistency_Net.state_dict() (netdepth 6, width 128).  vol_src: source views behind the warped
+    volume feature the volume network reads (32 + 3 vol_src input channels; default n_src = the reference's 3; 4 = the five-view
+    extension of Neural_Volume_Net, models/render_models.py:750)."""
     rng = np.random.RandomState(seed)
     sd = {}
     p = "MVSNet.cost_reg_2"
-    for name, kind, ci, co in cost_reg_specs(32 + 3 * n_src, 8):
+    for name, kind, ci, co in cost_reg_specs(32 + 3 * (n_src if vol_src is None else vol_src), 8):
         if kind == "conv":
             sd[f"{p}.{name}.conv.weight"] = _w(rng, (co, ci, 3, 3, 3), ci * 27)
             _bn(sd, rng, f"{p}.{name}.bn", co)

@@ -74,6 +74,56 @@ def make_run_eval(models, sd_default):
     return run_eval
 
 
+def _patched_randoms(pix, eps, u):
+    """torch.randint / normal / rand replaced by the injected draws of the sampler (restored by the returned function)."""
+    calls, ray_i = {"randint": 0}, {"i": 0}
+    orig = (torch.randint, torch.normal, torch.rand)
+
+    def f_randint(lo, hi, size, **kw):
+        r = pix[calls["randint"]]
+        calls["randint"] += 1
+        return r.clone()
+
+    def f_normal(mean=None, std=None, **kw):
+        i = ray_i["i"]
+        ray_i["i"] += 1
+        return mean + std * eps[i]
+
+    torch.randint, torch.normal, torch.rand = f_randint, f_normal, (lambda shape, **kw: u.clone())
+
+    def restore():
+        torch.randint, torch.normal, torch.rand = orig
+    return restore
+
+
+def render_v5_fixture(models, ns):
+    """The flagged five-view extension of the rendering branch (models/render_models.py:750): the reference's own
+    Rendering_Consistency_Net with ONE constructor argument changed -- its volume network's CostReg built for the 32 + 3*4 = 44 channels
+    of a five-view CascadeMVSNet pass instead of 32 + 9 -- on a five-view batch (every view reaches the renderer: decode_batch selects nothing)."""
+    from models.render_consist_net import Rendering_Consistency_Net
+    from models.render_models import CostReg
+    g = torch.Generator().manual_seed(23)
+    rn = Rendering_Consistency_Net(ns)
+    rn.MVSNet.cost_reg_2 = CostReg(32 + 12, torch.nn.BatchNorm2d, base_channels=8)
+    rn = torch.nn.SyncBatchNorm.convert_sync_batchnorm(rn)
+    rn.load_state_dict(synthetic.render_state_dict(1, vol_src=4), strict=True)
+    rn.eval()
+    H, W, V = 64, 96, 5
+    batch = synthetic.render_batch(V, H, W, 0)
+    pix, eps, u = synthetic.render_randoms(H, W, 1024, 16, 7)
+    vfw = 0.5 * torch.randn(1, 44, 6, H // 4, W // 4, generator=g)
+    pseudo = 500.0 + 300.0 * torch.rand(1, H, W, generator=g)
+    restore = _patched_randoms(pix, eps, u)
+    try:
+        out = rn(vfw, pseudo, dict(batch))
+    finally:
+        restore()
+    rgb, feat, wts, dpred, alpha, _, rdepth, target = out
+    vol = rn.MVSNet(vfw)
+    save("render_v5", H=H, W=W, V=V, n_samples=16, seed=7, vfw=vfw, pseudo=pseudo, volume=vol[:, :, ::8], rgb=rgb, feat=feat[::4], weights=wts,
+         depth=dpred, alpha=alpha, rays_depth=rdepth, target=target)
+
+
 def cascade_v7_fixture(run_eval):
     """BASELINE config 5's arithmetic at a small size (eval_rcmvsnet_tanks.py:47,53-55: 7 views, ndepths 64,32,8): the six-source-view
     path of the warp + variance kernel inside a cascade and a 64-plane depth head, with the seeded x20 probability head and with the
@@ -249,6 +299,7 @@ def main():
     vol = rn.MVSNet(vfw)
     save("render", H=H, W=W, V=V, n_samples=16, vfw=vfw, pseudo=pseudo, pix=pix, eps=eps, u=u, volume=vol[:, :, ::8],
          rgb=rgb, feat=feat[::4], weights=wts, depth=dpred, alpha=alpha, rays_depth=rdepth, target=target)
+    render_v5_fixture(models, ns)
     # MLP alone on 64 rays (a11)
     x86 = torch.randn(64, 16, 86, generator=g) * 0.5
     save("nerf_mlp", x=x86, out=rn.network_fn(x86.reshape(-1, 86)).reshape(64, 16, 4))
@@ -631,6 +682,14 @@ def blocks_fixture():
 if __name__ == "__main__":
     if "--only-blocks" in sys.argv:
         blocks_fixture()
+    elif "--only-render-v5" in sys.argv:
+        with torch.no_grad():
+            torch.set_num_threads(8)
+            ref_models = import_reference()
+            render_v5_fixture(ref_models, types.SimpleNamespace(multires=10, i_embed=0, pts_dim=3, dir_dim=3, netdepth=6, netwidth=128, net_type="v0",
+                                                                netchunk=1024, ckpt=None, N_samples=16, N_importance=0, perturb=1.0, use_viewdirs=True,
+                                                                white_bkgd=False, raw_noise_std=0.0, pad=0, img_downscale=1.0, use_color_volume=False,
+                                                                multires_views=4))
     elif "--only-v7" in sys.argv:
         with torch.no_grad():
             torch.set_num_threads(8)

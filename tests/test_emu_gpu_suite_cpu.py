@@ -80,7 +80,7 @@ SLOW = {
     GP: ["test_train_variant_volume_feature", "test_warp_variance_variants_agree", "test_feature_net_vs_oracle",
          "test_cascade_batch_two_equals_two_singles", "test_conv3d_x3_vs_fp64", "test_conv3d_x3_strided_vs_fp64",
          "test_cascade_on_the_unet_pyramid_vs_reference_golden"],
-    GR: ["test_neural_volume_vs_golden", "test_render_forward_vs_reference_golden"],
+    GR: ["test_neural_volume_vs_golden", "test_render_forward_vs_reference_golden", "test_render_forward_five_view_extension_vs_reference_golden"],
     GT: ["test_conv_bn_relu_block_forward_backward", "test_neural_volume_net_train_native_vs_delegated",
          "test_renderer_train_native_vs_delegated", "test_featurenet_train_native_vs_delegated",
          "test_cascade_train_native_vs_delegated_gradients", "test_hip_training_path_vs_reference_gradients",

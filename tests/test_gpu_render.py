@@ -176,6 +176,60 @@ def test_render_forward_vs_reference_golden(hip):
     assert float(dd.max()) / 500.0 < 5e-4
 
 
+@pytest.mark.parametrize("ci,co,stride", [(41, 8, 1), (8, 16, 2), (16, 16, 1)])
+def test_conv_bn_relu3d_block_on_its_own(hip, ci, co, stride):
+    """ConvBnReLU3D (models/render_models.py:675-686: conv + norm, no ReLU) called as a module of its own -- what `CostReg` runs through
+    its plan -- against the same layer in PyTorch-CPU fp64."""
+    from rc_mvsnet_amd.render_consist_net import ConvBnReLU3D
+    torch.manual_seed(ci + co)
+    m = ConvBnReLU3D(ci, co, stride=stride)
+    with torch.no_grad():
+        m.bn.running_mean.normal_(0, 0.1); m.bn.running_var.uniform_(0.5, 1.5); m.bn.weight.uniform_(0.5, 1.5); m.bn.bias.normal_(0, 0.1)
+    x = torch.randn(1, ci, 8, 16, 24)
+    with torch.no_grad():
+        want = torch.nn.functional.batch_norm(torch.nn.functional.conv3d(x.double(), m.conv.weight.double(), stride=stride, padding=1),
+                                              m.bn.running_mean.double(), m.bn.running_var.double(), m.bn.weight.double(), m.bn.bias.double(),
+                                              False, 0.0, m.bn.eps)
+        got = m.to(DEV).eval()(gpu(x))
+        again = m(gpu(x))
+    assert tuple(got.shape) == tuple(want.shape) and torch.equal(got, again)
+    assert rel_err(got.cpu().double(), want) < 2e-5
+
+
+def test_render_forward_five_view_extension_vs_reference_golden(hip):
+    """The flagged extension `args.num_views = 5` (BASELINE configs[2] as worded): the volume network takes the 44-channel warped volume
+    feature of a five-view CascadeMVSNet pass; the renderer behind it is the reference's (last three images, first three poses of the batch).  Golden: the reference's own module with
+    that one constructor argument changed (tests/golden/make_golden.py: render_v5_fixture), five-view batch, injected draws."""
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.render_consist_net import Rendering_Consistency_Net
+    g = load_golden("render_v5")
+    H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
+    assert V == 5
+    a = _args(16)
+    a.num_views = 5
+    m = Rendering_Consistency_Net(a)
+    assert m.MVSNet.cost_reg_2.conv0.conv.weight.shape[1] == 44
+    m.load_state_dict(synthetic.render_state_dict(1, vol_src=4), strict=True)
+    m = m.to(DEV).eval()
+    batch = {k: gpu(v) for k, v in synthetic.render_batch(V, H, W, 0).items()}
+    pix, eps, u = synthetic.render_randoms(H, W, 1024, 16, int(g["seed"]))
+    with torch.no_grad():
+        vol = m.MVSNet(gpu(g["vfw"]))
+        rgb, feat, wts, dpred, alpha, _, rdepth, target = m(gpu(g["vfw"]), gpu(g["pseudo"]), batch, randoms=(gpu(pix), gpu(eps), gpu(u)))
+    assert rel_err(vol.cpu()[:, :, ::8], g["volume"]) < 5e-5
+    assert torch.equal(rdepth.cpu(), g["rays_depth"]) and rel_err(target.cpu(), g["target"]) < 1e-6
+    interior = (pix[0] > 0) & (pix[0] < W - 1) & (pix[1] > 0) & (pix[1] < H - 1)
+    other = [c for c in range(20) if c not in (11, 15, 19)]
+    assert rel_err(feat.cpu()[::4][..., other], g["feat"][..., other]) < 2e-4
+    for got, key in ((alpha, "alpha"), (wts, "weights"), (rgb, "rgb")):
+        assert rel_err(got.cpu()[interior], g[key][interior]) < 5e-4, key
+    assert float((dpred.cpu() - g["depth"]).abs()[interior].max()) / 500.0 < 5e-4
+    with pytest.raises(NotImplementedError):
+        b = _args(16)
+        b.num_views = 3
+        Rendering_Consistency_Net(b)
+
+
 def test_render_forward_full_size_properties(hip):
     """BASELINE config-3 shape (V=4, 512x640, 1024 rays x 128 samples): runs, finite, invariants hold."""
     from rc_mvsnet_amd import synthetic
