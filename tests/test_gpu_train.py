@@ -712,7 +712,10 @@ def test_batchnorm_and_wgrad_scratch_survive_an_aborted_call(monkeypatch):
         blk.bn.running_mean.zero_(); blk.bn.running_var.fill_(1.0)
         got = run()
         for a, b, what in zip(got, want, ("z", "dx", "dw", "dgamma")):
-            assert torch.equal(a, b), (name, what, float((a - b).abs().max()))
+            if what in ("z", "dx"):
+                assert torch.equal(a, b), (name, what, float((a - b).abs().max()))
+            else:            # sums of atomics: the order, hence the last bits, vary from launch to launch on the GPU; stale sums would be O(1) off
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), (name, what, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("C,rows,relu", [(8, 1000, True), (32, 77, False), (64, 513, True)])
