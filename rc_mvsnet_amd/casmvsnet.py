@@ -264,6 +264,10 @@ class FeatureNet(nn.Module):
                 plan["out3"] = ops.pack_conv2d_weight(self.out3.weight)
                 plan["fuse_out3"] = (os.environ.get("RCMVS_FPN_FUSE", "1") != "0" and tuple(self.inner2.weight.shape[:2]) == (32, 8)
                                      and tuple(self.out3.weight.shape[:2]) == (8, 32))
+                # the same level with the 1x1 lateral conv folded into the 3x3 output conv (1600 instead of 2628 multiply-adds per pixel;
+                # equal up to fp32 rounding): the default; RCMVS_FPN_FOLD=0 keeps the bit-identical-to-unfused kernel
+                if plan["fuse_out3"] and os.environ.get("RCMVS_FPN_FOLD", "1") != "0":
+                    plan["fold_out3"] = ops.pack_fpn_folded(self.inner2.weight, self.inner2.bias, self.out3.weight)
             self._plan, self._plan_key = plan, key
         return self._plan
 
@@ -313,7 +317,10 @@ class FeatureNet(nn.Module):
         if self.num_stage == 3:
             if p.get("fuse_out3") and c0.shape[1] % 2 == 0 and c0.shape[2] % 2 == 0:
                 # the full-resolution 32-channel merge is never stored: 1x1 lateral + up-add + 3x3 output conv in one launch
-                out["stage3"] = (lambda a=c0, b=intra: ops.fpn_out_fused(a, b, p["inner2"][0], p["inner2"][1], p["out3"]))
+                if p.get("fold_out3") is not None:
+                    out["stage3"] = (lambda a=c0, b=intra: ops.fpn_out_folded(a, b, p["fold_out3"]))
+                else:
+                    out["stage3"] = (lambda a=c0, b=intra: ops.fpn_out_fused(a, b, p["inner2"][0], p["inner2"][1], p["out3"]))
             else:
                 intra = ops.conv2d(c0, p["inner2"][0], None, p["inner2"][1], up_add=intra)
                 out["stage3"] = (lambda t=intra: ops.conv2d(t, p["out3"]))

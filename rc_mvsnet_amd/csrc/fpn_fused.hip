@@ -98,6 +98,112 @@ __global__ __launch_bounds__(256) void fpn_out_fused_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same level with the two convolutions FOLDED (round 4).  The fused kernel above is VALU-bound (62 % busy, 82 us per scene for
+// three 512x640 views): per output pixel 9 x 32 x 8 multiply-adds of the 3x3 conv plus the 1x1 conv of its 18 x 18 halo.  Both
+// convolutions are linear and nothing sits between them, so
+//   out3(up2(prev) + inner2(lat) + b) = (W3 o W2) * lat                  a 3x3 conv 8 -> 8 on the lateral map         (WB, 576 weights)
+//                                     + W3 * up2(prev)                   on a nearest-upsampled map: per output parity (py, px) the
+//                                                                        nine taps fall on a 2 x 2 block of `prev`, whose combined
+//                                                                        weights are sums of W3 taps                   (WA, 4 x 4 x 32 x 8)
+//                                     + sum over the taps INSIDE the image of W3[tap] b   (zero padding applies to the merged map,
+//                                                                        so border pixels miss some taps: nine classes, BS)
+// = 576 + 1024 multiply-adds per pixel instead of 2304 + 324, and neither the merged map nor its halo is ever formed.  H and W are even,
+// so two taps that share a source pixel of `prev` are inside or outside the image together and the zero-filled tiles handle the borders.
+// The tables are built once per weight set on the host side (ops.pack_fpn_folded, fp64 products); the result differs from the
+// two-kernel path by fp32 rounding only (1e-6 relative: test_fpn_out_folded_matches_the_unfused_path).
+// Mapping: a block owns 16 x 16 outputs; wave w owns the 64 pixels of parity class (py, px) = (w >> 1, w & 1), so its WA block is
+// wave-uniform (scalar-cache operands of v_pk_fma_f32, as above).  LDS: the lateral halo tile de-interleaved by pixel parity
+// (4 x 9 x 9 pixels: a wave's nine taps are unit-stride reads of one parity plane each) and the 10 x 10 x 32 tile of `prev`;
+// strides 12 / 160 and 36 / 416 floats make every ds_read_b128 lane group conflict-free (exhaustive search over the strides).
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int FF_LST = 12, FF_LRS = 160, FF_LPL = 9 * FF_LRS;          // lateral tile: floats per pixel / row / parity plane
+constexpr int FF_UST = 36, FF_URS = 416;                               // `prev` tile: floats per pixel / row
+constexpr int FF_WB = 0, FF_BS = 576, FF_WA = 576 + 72, FF_TABLE = 576 + 72 + 4096;
+
+__global__ __launch_bounds__(256) void fpn_out_folded_kernel(
+    const float* __restrict__ lat, const float* __restrict__ up, const float* __restrict__ tab, float* __restrict__ y, int H, int W, int tiles_w) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float lat_s[4 * FF_LPL];
+    __shared__ __attribute__((aligned(16))) float up_s[10 * FF_URS];
+    const int n = blockIdx.y;
+    const unsigned t2 = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = t2 % tiles_w, th = t2 / tiles_w;
+    const int oy0 = th * 16, ox0 = tw * 16;
+    const int Hh = H / 2, Wh = W / 2;
+    const float* lb = lat + (long long)n * H * W * 8;
+    const float* ub = up + (long long)n * Hh * Wh * 32;
+    for (int e = threadIdx.x; e < 18 * 18 * 2; e += 256) {              // lateral halo: image pixel (oy0 - 1 + hy, ox0 - 1 + hx), zero outside
+        const int v = e >> 1, c4 = e & 1;
+        const int hy = v / 18, hx = v % 18;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        f4v val = (f4v){0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = *reinterpret_cast<const f4v*>(lb + ((long long)iy * W + ix) * 8 + c4 * 4);
+        *reinterpret_cast<f4v*>(lat_s + ((hy & 1) * 2 + (hx & 1)) * FF_LPL + (hy >> 1) * FF_LRS + (hx >> 1) * FF_LST + c4 * 4) = val;
+    }
+    for (int e = threadIdx.x; e < 10 * 10 * 8; e += 256) {              // `prev` tile: half-resolution pixel (oy0 / 2 - 1 + ur, ox0 / 2 - 1 + uc)
+        const int v = e >> 3, c4 = e & 7;
+        const int ur = v / 10, uc = v % 10;
+        const int iy = oy0 / 2 - 1 + ur, ix = ox0 / 2 - 1 + uc;
+        f4v val = (f4v){0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < Hh && ix >= 0 && ix < Wh) val = *reinterpret_cast<const f4v*>(ub + ((long long)iy * Wh + ix) * 32 + c4 * 4);
+        *reinterpret_cast<f4v*>(up_s + ur * FF_URS + uc * FF_UST + c4 * 4) = val;
+    }
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int py = wv >> 1, px = wv & 1;
+    const int li = threadIdx.x & 7, lj = (threadIdx.x >> 3) & 7;
+    const int oy = oy0 + 2 * lj + py, ox = ox0 + 2 * li + px;
+    // bias of the lateral conv through the taps that are inside the image
+    const int cy = oy == 0 ? 0 : (oy == H - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == W - 1 ? 2 : 1);
+    const float* bs = tab + FF_BS + (cy * 3 + cx) * 8;
+    f2v acc2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc2[c] = (f2v){bs[2 * c], bs[2 * c + 1]};
+    __syncthreads();
+    // ---- (W3 o W2) * lat: 3x3, 8 -> 8
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hy = py + ky, hx = px + kx;                        // halo coordinates minus (2 lj, 2 li): wave-uniform parity plane
+            const float* xp = lat_s + ((hy & 1) * 2 + (hx & 1)) * FF_LPL + (lj + (hy >> 1)) * FF_LRS + (li + (hx >> 1)) * FF_LST;
+            const f4v x0 = *reinterpret_cast<const f4v*>(xp), x1 = *reinterpret_cast<const f4v*>(xp + 4);
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const float* wt = tab + FF_WB + (ky * 3 + kx) * 64;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+                for (int co = 0; co < 8; co += 2)
+                    acc2[co / 2] = __builtin_elementwise_fma((f2v){xs[ci], xs[ci]}, (f2v){wt[ci * 8 + co], wt[ci * 8 + co + 1]}, acc2[co / 2]);
+        }
+    }
+    // ---- W3 * up2(prev): the 2 x 2 block of `prev` under this parity class, 32 -> 8
+    const float* wa = tab + FF_WA + wv * 1024;
+#pragma unroll 1
+    for (int ry = 0; ry < 2; ++ry) {
+#pragma unroll 1
+        for (int rx = 0; rx < 2; ++rx) {
+            const float* xp = up_s + (lj + py + ry) * FF_URS + (li + px + rx) * FF_UST;
+            const float* wt = wa + (ry * 2 + rx) * 256;
+#pragma unroll 2
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const f4v xv = *reinterpret_cast<const f4v*>(xp + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int co = 0; co < 8; co += 2)
+                        acc2[co / 2] = __builtin_elementwise_fma((f2v){xv[j], xv[j]}, (f2v){wt[(c4 * 4 + j) * 8 + co], wt[(c4 * 4 + j) * 8 + co + 1]}, acc2[co / 2]);
+            }
+        }
+    }
+    if (oy < H && ox < W) {
+        float* yp = y + (((long long)n * H + oy) * W + ox) * 8;
+        *reinterpret_cast<float4*>(yp) = make_float4(acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y);
+        *reinterpret_cast<float4*>(yp + 4) = make_float4(acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y);
+    }
+}
+
 }  // namespace rcmvs
 
 using namespace rcmvs;
@@ -111,4 +217,12 @@ extern "C" int rcmvs_fpn_out_fused(const float* lat, const float* up, const floa
     hipLaunchKernelGGL((fpn_out_fused_kernel<8, 32, 8>), dim3(tiles_w * tiles_h, N), dim3(256), 0, as_stream(stream), lat, up, w_inner,
                        b_inner, w_out, y, H, W, tiles_w);
     return launch_status("fpn_out_fused");
+}
+
+extern "C" int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables, float* y, int N, int H, int W, void* stream) {
+    RCMVS_REQUIRE(lat && up && tables && y, "fpn_out_folded: null pointer");
+    RCMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_out_folded: H and W must be even (got %d x %d)", H, W);
+    const int tiles_w = (W + 15) / 16, tiles_h = (H + 15) / 16;
+    hipLaunchKernelGGL(fpn_out_folded_kernel, dim3(tiles_w * tiles_h, N), dim3(256), 0, as_stream(stream), lat, up, tables, y, H, W, tiles_w);
+    return launch_status("fpn_out_folded");
 }

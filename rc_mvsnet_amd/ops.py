@@ -382,6 +382,45 @@ def fpn_out_fused(lat, up, w_inner_packed, b_inner, w_out_packed):
     return y
 
 
+FPN_FOLDED_FLOATS = 4744      # RCMVS_FPN_FOLDED_FLOATS of include/rcmvs.h
+
+
+def pack_fpn_folded(w_inner, b_inner, w_out):
+    """Tables of rcmvs_fpn_out_folded from the modules' weights: w_inner (32,8,1,1), b_inner (32,), w_out (8,32,3,3) -> (4744,) fp32.
+    The products are formed in fp64 and rounded once."""
+    wi = w_inner.detach().double().reshape(32, 8)                      # [cm][ci]
+    wo = w_out.detach().double()                                       # [co][cm][ky][kx]
+    b = b_inner.detach().double()
+    wb = torch.einsum("mi,omyx->yxio", wi, wo)                         # [ky][kx][ci][co]
+    bt = torch.einsum("m,omyx->yxo", b, wo)                            # [ky][kx][co]
+    inside = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}                     # taps inside the image for the first / an interior / the last row (column)
+    bs = torch.stack([torch.stack([sum(bt[ky, kx] for ky in inside[cy] for kx in inside[cx]) for cx in range(3)]) for cy in range(3)])
+    rows = lambda p: ((0,), (1, 2)) if p == 0 else ((0, 1), (2,))     # 3x3 taps that land on source row r of the 2x2 block, per output parity
+    wa = torch.zeros(2, 2, 2, 2, 32, 8, dtype=torch.float64, device=wo.device)
+    for py in range(2):
+        for px in range(2):
+            for ry in range(2):
+                for rx in range(2):
+                    for ky in rows(py)[ry]:
+                        for kx in rows(px)[rx]:
+                            wa[py, px, ry, rx] += wo[:, :, ky, kx].t()
+    tab = torch.cat((wb.reshape(-1), bs.reshape(-1), wa.reshape(-1))).float().contiguous()
+    assert tab.numel() == FPN_FOLDED_FLOATS
+    return tab
+
+
+def fpn_out_folded(lat, up, tables):
+    """conv3x3(up2(up) + conv1x1(lat) + bias) with the two convolutions folded (rcmvs_fpn_out_folded): lat (N,H,W,8), up (N,H/2,W/2,32)
+    -> (N,H,W,8)."""
+    N, H, W, CL = lat.shape
+    if CL != 8 or tuple(up.shape) != (N, H // 2, W // 2, 32) or tables.numel() != FPN_FOLDED_FLOATS:
+        raise _lib.RcmvsError(f"fpn_out_folded: lat {tuple(lat.shape)} / up {tuple(up.shape)} / {tables.numel()} table floats do not fit 8 -> 32 -> 8")
+    y = torch.empty((N, H, W, 8), device=lat.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_fpn_out_folded(_chk(lat, "lat"), _chk(up, "up"), _chk(tables, "tables"), _chk(y, "y"), N, H, W, _stream()),
+               "fpn_out_folded")
+    return y
+
+
 # ------------------------------------------------------------------------------- K4
 def depth_head(x8, w_prob_packed, planes, want_prob=False):
     """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)]."""

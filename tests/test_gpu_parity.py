@@ -1252,3 +1252,30 @@ def test_fpn_out_fused_is_bit_identical(N, H, W):
     assert got.shape == want.shape and torch.equal(got, want)
     with pytest.raises(_lib.RcmvsError):
         ops.fpn_out_fused(lat[:, :-1], up, w_in, b_in, w_out)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 36, 44), (1, 16, 16), (3, 128, 160), (1, 18, 50), (1, 2, 2), (1, 4, 34)])
+def test_fpn_out_folded_matches_the_unfused_path(N, H, W):
+    """rcmvs_fpn_out_folded -- the last FPN level with the 1x1 lateral conv folded into the 3x3 output conv (one 3x3 conv 8 -> 8 on the
+    lateral map, one 2x2 conv 32 -> 8 per output parity on the half-resolution map, the lateral bias through the taps inside the image) --
+    against the same level in PyTorch fp64 (models/modules.py:448-462) and against the two-kernel path: ragged tiles, every border class
+    (first / last row and column, 2-pixel images), several images."""
+    from rc_mvsnet_amd import _lib, ops
+    _lib.load()
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    lat = torch.randn(N, H, W, 8, generator=g)
+    up = torch.randn(N, H // 2, W // 2, 32, generator=g)
+    w_in_t, b_in_t = 0.3 * torch.randn(32, 8, 1, 1, generator=g), 0.5 * torch.randn(32, generator=g)
+    w_out_t = 0.1 * torch.randn(8, 32, 3, 3, generator=g)
+    F = torch.nn.functional
+    intra = F.interpolate(up.permute(0, 3, 1, 2).double(), scale_factor=2, mode="nearest") + F.conv2d(lat.permute(0, 3, 1, 2).double(), w_in_t.double(), b_in_t.double())
+    want = F.conv2d(intra, w_out_t.double(), padding=1).permute(0, 2, 3, 1)
+    tab = ops.pack_fpn_folded(w_in_t.to(DEV), b_in_t.to(DEV), w_out_t.to(DEV))
+    assert tab.numel() == ops.FPN_FOLDED_FLOATS
+    got = ops.fpn_out_folded(lat.to(DEV), up.to(DEV), tab).cpu()
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) < 2e-6 * scale
+    two = ops.conv2d(ops.conv2d(lat.to(DEV), ops.pack_conv2d_weight(w_in_t.to(DEV)), None, b_in_t.to(DEV), up_add=up.to(DEV)), ops.pack_conv2d_weight(w_out_t.to(DEV))).cpu()
+    assert float((got - two).abs().max()) < 4e-6 * scale
+    with pytest.raises(_lib.RcmvsError):
+        ops.fpn_out_folded(lat.to(DEV)[:, :-1], up.to(DEV), tab)
