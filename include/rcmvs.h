@@ -165,7 +165,9 @@ int rcmvs_absmax_fwd(const float* x, long long n, int square, float* amax, void*
  * that; three MFMAs per product instead of the six of the exact three-piece bf16 split; csrc/conv3d_x3.hip).  y_absmax (NULL = not
  * wanted): bound vector that receives max|y| -- the caller zero-fills it and hands it to the next layer as its
  * x_absmax; only the split-operand matrix-core kernels maintain it (error for channel pairs without one).  impl: the kernel
- * selector of rcmvs_debug_conv3d_fwd (0 = production).  A bound that is too small by a factor 2^k costs k bits of fp16 range at the
+ * selector of rcmvs_debug_conv3d_fwd (0 = production); bit 24 (planar layers only): y_absmax receives the SQUARE of max|y| -- the bound of
+ * a variance volume from the bound of its samples, so FeatureNet's output convs leave the bound the cost regularisation needs and no
+ * pass over the feature maps is required.  A bound that is too small by a factor 2^k costs k bits of fp16 range at the
  * top (overflow to inf beyond 2^1), one that is too large only raises the absolute floor: pass a true upper bound. */
 int rcmvs_conv3d_scaled_fwd(const float* x, const float* x_absmax, const float* w_packed, const float* scale, const float* shift,
                             const float* residual, float* y, float* y_absmax,
@@ -256,7 +258,8 @@ int rcmvs_fpn_out_fused(const float* lat, const float* up, const float* w_inner,
  *   [648, 4744)  WA[py][px][ry][rx][cm][co] = sum of w_out[co][cm][ky][kx] over the taps (ky, kx) with ((py + ky - 1) >> 1) - ((py - 1) >> 1) == ry, same in x
  * Equal to rcmvs_fpn_out_fused up to fp32 rounding (1e-6 relative). */
 #define RCMVS_FPN_FOLDED_FLOATS 4744
-int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables, float* y, int N, int H, int W, void* stream);
+int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables, float* y, float* ysq_absmax, int N, int H, int W, void* stream);
+/* ysq_absmax (may be NULL): bound vector (RCMVS_ABSMAX_FLOATS floats, zero-filled by the caller) that receives the square of max|y|. */
 
 
 /* ---- K4: prob conv + softmax + soft-argmin + photometric confidence ---------------------- */

@@ -47,7 +47,7 @@ SIGNATURES = {
     "rcmvs_compact_points": [_p, _p, _p, _p, _p, _p, _ll, _p],
     "rcmvs_prepare_image": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     "rcmvs_fpn_out_fused": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "rcmvs_fpn_out_folded": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "rcmvs_fpn_out_folded": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "rcmvs_bn_stats": [_p, _p, _ll, _i, _p],
     "rcmvs_bn_finalize": [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "rcmvs_bn_bwd_finalize": [_p, _p, _p, _p, _p, _p, _i, _p],

@@ -248,6 +248,8 @@ class FeatureNet(nn.Module):
                     continue
                 plan[n] = (ops.pack_conv2d_weight(w, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
+            if tuple(self.out1.weight.shape) == (32, 32, 1, 1):           # the same 1x1 conv as the middle tap of a one-plane 3-D kernel: the planar
+                plan["out1_3d"] = ops.pack_conv3d_weight(self._w3(self.out1.weight.detach()))      # matrix-core form keeps the bound of its output (below)
             if unet:
                 for n in ("out2", "out3")[:self.num_stage - 1]:           # 1x1, Co = Ci: the middle tap of a one-plane 3-D kernel
                     plan[n] = ops.pack_conv3d_weight(self._w3(getattr(self, n).weight.detach()))
@@ -298,33 +300,44 @@ class FeatureNet(nn.Module):
         c0 = cbr(cbr(t, "conv0.0"), "conv0.1")
         c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = cbr(cbr(cbr(c1, "conv2.0"), "conv2.1"), "conv2.2")
-        out = {"stage1": (lambda t=c2: ops.conv2d(t, p["out1"]))}
+        # A thunk takes an optional activation-bound vector (ops.ABSMAX_FLOATS floats, zero-filled): the output conv then leaves (max|f|)^2
+        # there -- the bound of the variance volume built from the map, which the fp16-pair cost regularisation needs -- in its epilogue
+        # and returns (map, True); (map, False) = no bound was kept (the caller runs ops.absmax over the map).
+        def out1(bound=None, t=c2):
+            if bound is not None and "out1_3d" in p and not ops._CONV_IMPL:
+                return ops.conv3d(t.unsqueeze(1), p["out1_3d"], y_absmax=bound, y_absmax_square=True).squeeze(1), True
+            return ops.conv2d(t, p["out1"]), False
+        out = {"stage1": out1}
+        plain = lambda f: (lambda bound=None: (f(), False))
         if self.arch_mode == "unet":                     # models/modules.py:449-457
             one = lambda t, n: ops.conv3d(t.unsqueeze(1), p[n]).squeeze(1)
             if self.num_stage >= 2:
                 intra = self.deconv1.forward_cl(c1, c2)
-                out["stage2"] = (lambda t=intra: one(t, "out2"))
+                out["stage2"] = plain(lambda t=intra: one(t, "out2"))
             if self.num_stage == 3:
                 intra = self.deconv2.forward_cl(c0, intra)
-                out["stage3"] = (lambda t=intra: one(t, "out3"))
-            return out if lazy else {k: f() for k, f in out.items()}
+                out["stage3"] = plain(lambda t=intra: one(t, "out3"))
+            return out if lazy else {k: f()[0] for k, f in out.items()}
         if self.num_stage >= 2:
             intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
             if isinstance(p["out2"], tuple):
-                out["stage2"] = (lambda t=intra: ops.conv3d(t.unsqueeze(1), p["out2"][1]).squeeze(1))
+                def out2(bound=None, t=intra):
+                    keep = bound is not None and not ops._CONV_IMPL
+                    return ops.conv3d(t.unsqueeze(1), p["out2"][1], y_absmax=bound if keep else None, y_absmax_square=keep).squeeze(1), keep
+                out["stage2"] = out2
             else:
-                out["stage2"] = (lambda t=intra: ops.conv2d(t, p["out2"]))
+                out["stage2"] = plain(lambda t=intra: ops.conv2d(t, p["out2"]))
         if self.num_stage == 3:
             if p.get("fuse_out3") and c0.shape[1] % 2 == 0 and c0.shape[2] % 2 == 0:
                 # the full-resolution 32-channel merge is never stored: 1x1 lateral + up-add + 3x3 output conv in one launch
                 if p.get("fold_out3") is not None:
-                    out["stage3"] = (lambda a=c0, b=intra: ops.fpn_out_folded(a, b, p["fold_out3"]))
+                    out["stage3"] = (lambda bound=None, a=c0, b=intra: (ops.fpn_out_folded(a, b, p["fold_out3"], ysq_absmax=bound), bound is not None))
                 else:
-                    out["stage3"] = (lambda a=c0, b=intra: ops.fpn_out_fused(a, b, p["inner2"][0], p["inner2"][1], p["out3"]))
+                    out["stage3"] = plain(lambda a=c0, b=intra: ops.fpn_out_fused(a, b, p["inner2"][0], p["inner2"][1], p["out3"]))
             else:
                 intra = ops.conv2d(c0, p["inner2"][0], None, p["inner2"][1], up_add=intra)
-                out["stage3"] = (lambda t=intra: ops.conv2d(t, p["out3"]))
-        return out if lazy else {k: f() for k, f in out.items()}
+                out["stage3"] = plain(lambda t=intra: ops.conv2d(t, p["out3"]))
+        return out if lazy else {k: f()[0] for k, f in out.items()}
 
     # ---- training on the library: every layer as a one-plane volume on the 3-D conv family -----------------------
     @staticmethod
@@ -704,7 +717,6 @@ class _CascadeBase(nn.Module):
         feats_cl = None
         if features is None:
             feats_cl = self.feature.forward_cl(imgs.reshape(B * V, 3, H, W), lazy=True)
-            feats_cl = self._fpn_outputs_on_side_stream(feats_cl, imgs)
         outputs = {}
         depth = None
         if homographies is None:                                     # every stage's homographies in one launch (they differ in the intrinsics scale only)
@@ -729,8 +741,11 @@ class _CascadeBase(nn.Module):
             key = "stage{}".format(s + 1)
             scale = int(self.stage_infos[key]["scale"])
             D = self.ndepths[s]
+            bound_kept = False
             if feats_cl is not None:
-                fk = feats_cl[key]()                                 # this stage's output conv, just in time
+                # this stage's output conv, just in time; with the fp16-pair form it also leaves the bound of the variance volume
+                # ((max|f|)^2 over the V maps) in row 0 of the stage's bounds
+                fk, bound_kept = feats_cl[key](bounds[s][0] if bounds is not None else None)
                 h, w, C = fk.shape[1:]
                 f_cl = fk.view(B, V, h, w, C)
             else:
@@ -749,7 +764,8 @@ class _CascadeBase(nn.Module):
             vmax = None
             if bounds is not None:
                 vmax = bounds[s]
-                ops.absmax(f_cl, square=True, out=vmax[0])
+                if not bound_kept:                                   # (test hooks, pyramids whose output conv keeps no bound)
+                    ops.absmax(f_cl, square=True, out=vmax[0])
             plan = cr.hip_plan()
             x8 = cr.features_cl(var, vmax, plan)
             depth, conf = ops.depth_head(x8, plan["prob"], planes)
@@ -762,37 +778,6 @@ class _CascadeBase(nn.Module):
             outputs[key] = out
             outputs.update(out)
         return outputs
-
-    def _fpn_outputs_on_side_stream(self, thunks, imgs):
-        """The output convs of pyramid levels 2 and 3 (0.11 ms per scene, a third of FeatureNet) depend on the trunk only, not on
-        the cascade: enqueue them on a second HIP stream right after the trunk so that they run beside stage 1's cost
-        regularisation, whose deep U-Net levels (N/64 and N/512 voxels: 120-160 persistent blocks, latency-bound) leave most of the
-        256 CUs idle.  Each later stage waits on its level's event before its warp; stage 1's own output conv stays on the
-        launch stream (it is needed at once).  MEASURED (MI355X, round 3, profiles/r3_side_stream_ab.txt): 1.546 ms per scene
-        against 1.506 ms for the single-stream just-in-time order -- the two extra kernels contend with conv0 / K1 for the
-        CUs and the caches instead of filling idle ones -- so this is OFF unless RCMVS_SIDE_STREAM=1 (kept as the A/B switch)."""
-        if not imgs.is_cuda or os.environ.get("RCMVS_SIDE_STREAM", "0") != "1" or len(thunks) < 2:
-            return thunks
-        main = torch.cuda.current_stream(imgs.device)
-        side = getattr(self, "_side", None)
-        if side is None or side.device != imgs.device:
-            side = self._side = torch.cuda.Stream(device=imgs.device)
-        trunk_done = torch.cuda.Event()
-        trunk_done.record(main)
-        out = {"stage1": thunks["stage1"]}
-        with torch.cuda.stream(side):
-            side.wait_event(trunk_done)
-            for key in [k for k in thunks if k != "stage1"]:
-                fk = thunks[key]()
-                done = torch.cuda.Event()
-                done.record(side)
-                fk.record_stream(main)            # allocated on the side stream's pool, consumed on the launch stream
-
-                def take(fk=fk, done=done, keep=thunks):      # `keep`: the trunk maps the side-stream kernels read stay allocated
-                    torch.cuda.current_stream(fk.device).wait_event(done)      # until every level has been handed over
-                    return fk
-                out[key] = take
-        return out
 
     # ---------------------------------------------------------------- native training path
     def _forward_train_hip(self, imgs, proj_matrices, depth_values):

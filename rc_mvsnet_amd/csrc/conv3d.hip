@@ -185,10 +185,10 @@ using namespace rcmvs;
 // exist; bit 6 = skip the split-bf16 MFMA kernels (conv3d_x3.hip); bits 8-15 = block count of the x3 kernels; bits 16-23 = z chunk
 // of the marching prob conv.  Passed by value: the library keeps no dispatch state.
 struct ConvImpl {
-    bool direct, prefer_lds, no_x3;
+    bool direct, prefer_lds, no_x3, ysq;
     int lds_cfg, x3_blocks;
-    explicit ConvImpl(int on) : direct(on & 1), prefer_lds(!(on & 16)), no_x3((on >> 6) & 1), lds_cfg(((on >> 1) & 7) | (((on >> 5) & 1) << 3) | (((on >> 16) & 0xff) << 8)),
-                                x3_blocks((on >> 8) & 0xff) {}
+    explicit ConvImpl(int on) : direct(on & 1), prefer_lds(!(on & 16)), no_x3((on >> 6) & 1), ysq((on >> 24) & 1),
+                                lds_cfg(((on >> 1) & 7) | (((on >> 5) & 1) << 3) | (((on >> 16) & 0xff) << 8)), x3_blocks((on >> 8) & 0xff) {}
 };
 
 extern "C" {
@@ -288,8 +288,9 @@ static int conv3d_dispatch(const float* x, const float* w_packed, const float* s
     hipStream_t st = as_stream(stream);
     const int mode = stride == 1 ? CONV_S1 : CONV_S2;
     const ConvSel sel = conv_select(Ci, Co, mode, stride == 1 && D == 1, xmax != nullptr, im);
+    RCMVS_REQUIRE(!im.ysq || (sel == SEL_X3_PLANAR && ymax), "conv3d_scaled_fwd: the squared output bound (impl bit 24) is kept by the planar matrix-core kernels only");
     if (sel == SEL_X3_PLANAR)
-        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, X3_KIND_PLANAR), scale, shift, residual, y, B, D, H, W, Ci, Co, X3_KIND_PLANAR, relu, st, im.x3_blocks, 0, nullptr, ymax);
+        return conv3d_x3_launch(x, w_packed + x3_image_offset(Ci, Co, X3_KIND_PLANAR), scale, shift, residual, y, B, D, H, W, Ci, Co, X3_KIND_PLANAR, relu, st, im.x3_blocks, im.ysq ? 2 : 0, nullptr, ymax);
     if (sel == SEL_X3H)
         return conv3d_x3_launch(x, w_packed + x3h_image_offset(Ci, Co, mode), scale, shift, residual, y, B, D, H, W, Ci, Co, mode, relu, st, im.x3_blocks, 0, xmax, ymax);
     if (sel == SEL_X3)

@@ -331,6 +331,7 @@ struct X3Dims {
     int itemcap, stepcap;   // capacities of the block's schedule tables in LDS (items / steps per block, rounded up)
     int dbg;            // phase-ablation mask (0 in the library; X3_ABLATION builds only)
     long long* trace;   // s_memtime stamps of block 0 (nullptr in the library; X3_ABLATION builds only)
+    int ysq;            // ymax receives the SQUARE of max|y| (the bound of a variance volume from the bound of its samples: FeatureNet's output convs)
     int s2d;            // planar kind only: the input is physically (B, D, 2H, 2W, CIN / 4) and is read through a space-to-depth view
                         // (channel (py, px, c) of voxel (y, x) = channel c of pixel (2y + py, 2x + px)): a 5x5 stride-2 layer as a 3x3 one
 };
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
             float m = redmax[0];
 #pragma unroll
             for (int i = 1; i < 8; ++i) m = fmaxf(m, redmax[i]);
+            if (dm.ysq) m = m * m;
             atomicMax(reinterpret_cast<unsigned int*>(ymax) + (blockIdx.x & 63) * 16, __float_as_uint(m));
         }
     }
@@ -947,6 +949,8 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
                      int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d,
                      const float* xmax, float* ymax) {
+    const int ysq = (s2d >> 1) & 1;            // `s2d` carries two flags: bit 0 = space-to-depth view of the input, bit 1 = square the output bound
+    s2d &= 1;
     if (s2d && (kind != X3_P1 || Ci % 16 != 0)) return fail(-1, "conv3d_x3: the space-to-depth view needs the planar kind and Ci a multiple of 16");
     if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_x3: input tensor too large for 32-bit offsets");
     {
@@ -967,7 +971,7 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     const int n_cu = cu_of[dev];
     const int n_blk = max_blocks > 0 ? max_blocks : n_cu;      // max_blocks: test / tuning hook (few blocks = many items per block)
     X3Dims dm;
-    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d; dm.dbg = 0; dm.trace = nullptr;
+    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d; dm.ysq = ysq; dm.dbg = 0; dm.trace = nullptr;
 #if X3_ABLATION
     dm.dbg = x3_ablation_mask;
     dm.trace = x3_trace_buf;

@@ -123,8 +123,9 @@ constexpr int FF_UST = 36, FF_URS = 416;                               // `prev`
 constexpr int FF_WB = 0, FF_BS = 576, FF_WA = 576 + 72, FF_TABLE = 576 + 72 + 4096;
 
 __global__ __launch_bounds__(256) void fpn_out_folded_kernel(
-    const float* __restrict__ lat, const float* __restrict__ up, const float* __restrict__ tab, float* __restrict__ y, int H, int W, int tiles_w) {
+    const float* __restrict__ lat, const float* __restrict__ up, const float* __restrict__ tab, float* __restrict__ y, float* __restrict__ ysq, int H, int W, int tiles_w) {
     typedef float f2v __attribute__((ext_vector_type(2)));
+    __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) float lat_s[4 * FF_LPL];
     __shared__ __attribute__((aligned(16))) float up_s[10 * FF_URS];
     const int n = blockIdx.y;
@@ -202,6 +203,21 @@ __global__ __launch_bounds__(256) void fpn_out_folded_kernel(
         *reinterpret_cast<float4*>(yp) = make_float4(acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y);
         *reinterpret_cast<float4*>(yp + 4) = make_float4(acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y);
     }
+    if (ysq) {                                                          // (max |y|)^2 of the block: one atomic max into slot (block & 63)
+        float m = 0.0f;
+        if (oy < H && ox < W) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m = fmaxf(m, fmaxf(fabsf(acc2[c].x), fabsf(acc2[c].y)));
+        }
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+        if ((threadIdx.x & 63) == 0) red[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            atomicMax(reinterpret_cast<unsigned int*>(ysq) + ((blockIdx.x + blockIdx.y * gridDim.x) & 63) * 16, __float_as_uint(m * m));
+        }
+    }
 }
 
 }  // namespace rcmvs
@@ -219,10 +235,10 @@ extern "C" int rcmvs_fpn_out_fused(const float* lat, const float* up, const floa
     return launch_status("fpn_out_fused");
 }
 
-extern "C" int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables, float* y, int N, int H, int W, void* stream) {
+extern "C" int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables, float* y, float* ysq_absmax, int N, int H, int W, void* stream) {
     RCMVS_REQUIRE(lat && up && tables && y, "fpn_out_folded: null pointer");
     RCMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fpn_out_folded: H and W must be even (got %d x %d)", H, W);
     const int tiles_w = (W + 15) / 16, tiles_h = (H + 15) / 16;
-    hipLaunchKernelGGL(fpn_out_folded_kernel, dim3(tiles_w * tiles_h, N), dim3(256), 0, as_stream(stream), lat, up, tables, y, H, W, tiles_w);
+    hipLaunchKernelGGL(fpn_out_folded_kernel, dim3(tiles_w * tiles_h, N), dim3(256), 0, as_stream(stream), lat, up, tables, y, ysq_absmax, H, W, tiles_w);
     return launch_status("fpn_out_folded");
 }

@@ -246,10 +246,11 @@ def _check_image(w_packed, ci, co, stride, transposed, planar, scaled, who):
         raise _lib.RcmvsError(f"{who}: the weight was packed for another call (pack_conv3d_weight(use=...)): the image this call reads was not written")
 
 
-def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False, x_absmax=None, y_absmax=None):
+def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=False, x_absmax=None, y_absmax=None, y_absmax_square=False):
     """x (B,D,H,W,Ci) -> (B,Do,Ho,Wo,Co) with fused [relu](v*scale+shift) + residual.
     x_absmax / y_absmax ((1024,) bound vectors, ops.absmax / rcmvs_conv3d_scaled_fwd): a bound of max|x| selects the fp16-pair
-    matrix-core form where the channel pair has one; y_absmax (zero-filled by the caller) receives max|y| for the next layer."""
+    matrix-core form where the channel pair has one; y_absmax (zero-filled by the caller) receives max|y| for the next layer --
+    its square with y_absmax_square (one-plane volumes only: the FeatureNet output convs, whose maps the variance volume is built from)."""
     B, D, H, W, Ci = x.shape
     Co = w_packed.co
     if w_packed.ci != Ci:
@@ -268,7 +269,8 @@ def conv3d(x, w_packed, scale=None, shift=None, residual=None, stride=1, relu=Fa
     if x_absmax is not None or y_absmax is not None:
         _lib.check(_lib.load().rcmvs_conv3d_scaled_fwd(_chk(x, "x"), _opt(x_absmax, "x_absmax"), _chk(w_packed.blob, "w"), _opt(scale, "scale"),
                                                        _opt(shift, "shift"), _opt(residual, "residual"), _chk(y, "y"), _opt(y_absmax, "y_absmax"),
-                                                       B, D, H, W, Ci, Co, stride, int(relu), _CONV_IMPL, _stream()), "conv3d_scaled_fwd")
+                                                       B, D, H, W, Ci, Co, stride, int(relu), _CONV_IMPL | ((1 << 24) if y_absmax_square else 0), _stream()),
+                   "conv3d_scaled_fwd")
     elif _CONV_IMPL:
         _lib.check(_lib.load().rcmvs_debug_conv3d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"),
                                                       _opt(residual, "residual"), _chk(y, "y"), B, D, H, W, Ci, Co, stride, int(relu),
@@ -409,14 +411,14 @@ def pack_fpn_folded(w_inner, b_inner, w_out):
     return tab
 
 
-def fpn_out_folded(lat, up, tables):
+def fpn_out_folded(lat, up, tables, ysq_absmax=None):
     """conv3x3(up2(up) + conv1x1(lat) + bias) with the two convolutions folded (rcmvs_fpn_out_folded): lat (N,H,W,8), up (N,H/2,W/2,32)
-    -> (N,H,W,8)."""
+    -> (N,H,W,8).  ysq_absmax: a zero-filled (1024,) bound vector that receives (max|y|)^2."""
     N, H, W, CL = lat.shape
     if CL != 8 or tuple(up.shape) != (N, H // 2, W // 2, 32) or tables.numel() != FPN_FOLDED_FLOATS:
         raise _lib.RcmvsError(f"fpn_out_folded: lat {tuple(lat.shape)} / up {tuple(up.shape)} / {tables.numel()} table floats do not fit 8 -> 32 -> 8")
     y = torch.empty((N, H, W, 8), device=lat.device, dtype=torch.float32)
-    _lib.check(_lib.load().rcmvs_fpn_out_folded(_chk(lat, "lat"), _chk(up, "up"), _chk(tables, "tables"), _chk(y, "y"), N, H, W, _stream()),
+    _lib.check(_lib.load().rcmvs_fpn_out_folded(_chk(lat, "lat"), _chk(up, "up"), _chk(tables, "tables"), _chk(y, "y"), _opt(ysq_absmax, "ysq_absmax"), N, H, W, _stream()),
                "fpn_out_folded")
     return y
 

@@ -1254,6 +1254,31 @@ def test_fpn_out_fused_is_bit_identical(N, H, W):
         ops.fpn_out_fused(lat[:, :-1], up, w_in, b_in, w_out)
 
 
+def test_feature_output_convs_keep_the_variance_bound(hip):
+    """FeatureNet's three output convs leave (max|f|)^2 of their maps -- the bound of the variance volume the fp16-pair cost regularisation
+    needs -- in the bound vector they are handed, bit-equal to what rcmvs_absmax_fwd(square=1) computes in a pass over the map (the launch
+    the cascade no longer needs), and the maps themselves are what the bound-less thunks produce (stage 1 goes through the planar
+    matrix-core form of its 1x1 conv when a bound is wanted: equal to 1e-6)."""
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import FeatureNet
+    net = FeatureNet(base_channels=8, num_stage=3, arch_mode="fpn")
+    net.load_state_dict({k[len("feature."):]: v for k, v in synthetic.cascade_state_dict(0).items() if k.startswith("feature.")}, strict=True)
+    net = net.to(DEV).eval()
+    img = gpu(synthetic.images(1, 3, 64, 96, 3)[0])
+    with torch.no_grad():
+        plain = net.forward_cl(img)
+        thunks = net.forward_cl(img, lazy=True)
+        for key in ("stage1", "stage2", "stage3"):
+            bound = torch.zeros(hip.ABSMAX_FLOATS, device=DEV)
+            f, kept = thunks[key](bound)
+            assert kept, key
+            want = hip.absmax(f, square=True)
+            assert float(bound.max()) == float(want.max()) > 0.0, key
+            assert rel_err(f.cpu(), plain[key].cpu()) < 2e-6, key
+            f2, kept2 = thunks[key]()
+            assert not kept2 and torch.equal(f2, plain[key]), key
+
+
 @pytest.mark.parametrize("N,H,W", [(2, 36, 44), (1, 16, 16), (3, 128, 160), (1, 18, 50), (1, 2, 2), (1, 4, 34)])
 def test_fpn_out_folded_matches_the_unfused_path(N, H, W):
     """rcmvs_fpn_out_folded -- the last FPN level with the 1x1 lateral conv folded into the 3x3 output conv (one 3x3 conv 8 -> 8 on the
