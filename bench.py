@@ -658,14 +658,15 @@ def main(argv=None):
     achieved = sum(bytes_stage) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     traffic = None                      # HBM bytes per scene from the committed PMC profile (FETCH_SIZE x2 + WRITE_SIZE)
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_k1_traffic.json")))["bytes_per_scene"]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r4_k1_traffic.json")))["bytes_per_scene"]
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": "rcmvs::warp_variance_tp_kernel (K1, 3 launches per scene)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r3_k1_traffic.json -- rocprofv3 PMC passes of an earlier run (FETCH_SIZE x2 + WRITE_SIZE per launch, summed over the "
-                                  "3 launches of a scene); a committed measurement, NOT taken in this run",
+                "traffic_source": "profiles/r4_k1_traffic.json -- rocprofv3 PMC passes over this command line in an earlier visit of the round "
+                                  "(tools/visits/r4_k1_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE per launch, summed over the 3 launches of a scene); "
+                                  "a committed measurement, NOT taken in this run (a profiler cannot wrap its own process)",
                 "algorithmic_bytes_per_scene": sum(bytes_stage),
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)]}
