@@ -726,7 +726,11 @@ class _CascadeBase(nn.Module):
                 rt = [ops.compose_homography(proj_matrices["stage{}".format(k + 1)].contiguous().float()) for k in range(self.num_stage)]
                 rots, transs = [r for r, _ in rt], [t for _, t in rt]
         bounds = None
-        pair = FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
+        # arithmetic of the cost regularisation: the module attribute `fp16_pair` (True / False) if the caller set one, else RCMVS_FP16_PAIR
+        # (read per forward so that a process can switch), else the default
+        pair = getattr(self, "fp16_pair", None)
+        if pair is None:
+            pair = FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
         if pair and B == 1:          # (the bounds are per launch: with B > 1 a sample's rounding would depend on its batch mates -> exact form)
             # activation bounds of the fp16-pair kernels: one persistent (stage, 7, 1024) buffer per model, ONE fill per scene
             # (row 0 of a stage: bound of the variance volume; rows 1-6: written by the layers).  Not re-entrant across streams.

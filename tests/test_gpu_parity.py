@@ -882,6 +882,32 @@ def test_cascade_c2_smooth_head_vs_reference_golden(hip):
     assert float((cd[stable] > 1e-3).float().mean()) < 0.01
 
 
+@pytest.mark.parametrize("gain", [0.0, 1e-4, 1.0, 3e3])
+def test_cascade_fp16_pair_form_on_extreme_activation_ranges(hip, gain):
+    """The fp16-pair form of the cost regularisation rests on activation bounds (a power-of-two pre-scale per layer).  Ranges the seeded
+    goldens do not reach: all-zero images (every bound from constants), tiny and huge image magnitudes (feature maps 1e-4 x / 3e3 x the
+    usual: variances 1e-8 x / 1e7 x) -- the depth map must stay finite and agree with the exact bf16-triple form like on ordinary inputs
+    (well-conditioned head; `model.fp16_pair` selects the form per module)."""
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    sd = synthetic.cascade_state_dict(0, prob_gain=1.0)
+    imgs, pm, dv = synthetic.cascade_inputs(1, 3, 64, 96, 0)
+    outs = {}
+    for pair in (True, False):
+        m = CascadeMVSNet_eval(ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1])
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        m.fp16_pair = pair
+        with torch.no_grad():
+            outs[pair] = m(gpu(imgs * gain), {k: gpu(v) for k, v in pm.items()}, gpu(dv))
+    rng = float(dv[0, -1] - dv[0, 0])
+    for key in ("depth", "photometric_confidence"):
+        assert torch.isfinite(outs[True][key]).all() and torch.isfinite(outs[False][key]).all(), key
+    dd = (outs[True]["depth"] - outs[False]["depth"]).abs()
+    print(f"gain {gain:g}: pair vs exact depth L1/range = {float(dd.mean()) / rng:.2e}, max {float(dd.max()):.2e} mm")
+    assert float(dd.mean()) / rng < 1e-5 and float((dd < 0.05).float().mean()) >= 0.99
+
+
 def test_cascade_config5_arithmetic_vs_reference_golden(hip):
     """BASELINE config 5's arithmetic (eval_rcmvsnet_tanks.py:47,53-55: 7 views, ndepths 64,32,8) at a small size against the imported
     reference, well-conditioned head: the six-source-view form of K1 inside a cascade (two view groups of three per plane), the 64-plane
