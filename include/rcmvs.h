@@ -241,7 +241,9 @@ int rcmvs_pack_conv2d_weight(const float* w, float* packed, int Co, int Ci, int 
 /* y = [relu]( up2(up_add) + conv2d(x, w, K, pad K/2, stride) * scale + shift ),  x (N,H,W,Ci) -> y (N,Ho,Wo,Co);
  * scale / shift / up_add may be NULL (shift alone = plain bias; up_add (N,Ho/2,Wo/2,Co) is added after
  * nearest x2 up-sampling: the FPN merge `F.interpolate(intra) + inner(conv)`, modules.py:448-455).
- * Replaces Conv2d.forward = conv + BN(eval) + ReLU (modules.py:53-59) and the bare 1x1 / 3x3 output convs. */
+ * Replaces Conv2d.forward = conv + BN(eval) + ReLU (modules.py:53-59) and the bare 1x1 / 3x3 output convs.
+ * Ci == 3 (3 -> 8, K = 3, stride 1: FeatureNet's first layer): x is the planar (N, 3, H, W) image batch as the network receives it and
+ * w_packed the layer's weight packed with Cip = 4 -- no rcmvs_rgb_to_nhwc4 pass in front. */
 int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
                      float* y, int N, int H, int W, int Ci, int Co, int K, int stride, int relu, void* stream);
 /* Last FPN level in one launch: y = conv3x3(up2(up) + conv1x1(lat) + b_inner) without materialising the 32-channel

@@ -296,8 +296,12 @@ class FeatureNet(nn.Module):
             w, sc, sh, stride = p[n]
             return ops.conv2d(t, w, sc, sh, stride=stride, relu=True)
 
-        t = ops.rgb_to_nhwc4(x.contiguous().float())
-        c0 = cbr(cbr(t, "conv0.0"), "conv0.1")
+        if len(p["conv0.0"]) == 4 and p["conv0.0"][0].ci == 4 and not ops._CONV_IMPL:
+            w, sc, sh, _ = p["conv0.0"]                              # the first layer reads the planar images itself (no NHWC4 pass)
+            c00 = ops.conv2d_rgb(x.contiguous().float(), w, sc, sh, relu=True)
+        else:
+            c00 = cbr(ops.rgb_to_nhwc4(x.contiguous().float()), "conv0.0")
+        c0 = cbr(c00, "conv0.1")
         c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = cbr(cbr(cbr(c1, "conv2.0"), "conv2.1"), "conv2.2")
         # A thunk takes an optional activation-bound vector (ops.ABSMAX_FLOATS floats, zero-filled): the output conv then leaves (max|f|)^2

@@ -20,11 +20,14 @@ constexpr int C2_STRIDE = C2_CK + 4;     // floats per staged pixel
 // The tap loops stay rolled (UKY / UKX = 1) where a fully unrolled body would need more weights than there are SGPRs:
 // the compiler otherwise hoists all K*K*CK*CO scalar loads and spills them through v_writelane/v_readlane (2560 spill
 // instructions against 288 packed FMAs in the 8 -> 8 layer: 95 -> 24 us once rolled).
-template <int CI, int CO, int K, int S, int TH, int TW, int PPT, int UKY, int UKX>
+// RGB3 (first layer only, CI = 4): x is the network's input as it arrives, (N, 3, H, W) planar -- the halo tile is staged straight from
+// the three planes (zero fourth channel), which saves the NCHW -> NHWC4 pass over the images (rcmvs_rgb_to_nhwc4: a launch and 27 MB).
+template <int CI, int CO, int K, int S, int TH, int TW, int PPT, int UKY, int UKX, bool RGB3 = false>
 __global__ __launch_bounds__(256) void conv2d_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ up, float* __restrict__ y,
     int H, int W, int Ho, int Wo, int tiles_w, int relu) {
+    static_assert(!RGB3 || CI == 4, "planar RGB input feeds the 4-channel first layer");
     static_assert(TH * TW == 256, "tile must have 256 threads");
     constexpr int PAD = K / 2;
     constexpr int HH = (TH * PPT - 1) * S + K, HW = (TW - 1) * S + K;     // halo tile
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
     const int oy0 = th * TH * PPT, ox0 = tw * TW;
     const int lx = threadIdx.x % TW, ly = threadIdx.x / TW;
     const int ox = ox0 + lx;
-    const float* xb = x + (long long)n * H * W * CI;
+    const float* xb = x + (long long)n * H * W * (RGB3 ? 3 : CI);
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
 
     // output channel PAIRS per v_pk_fma_f32: acc2[co / 2] += splat(x) * (w[co], w[co + 1]) -- the splat is an operand selector of the
@@ -60,8 +63,14 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
             const int hx = v % HW, hy = v / HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                val = *reinterpret_cast<const float4*>(xb + ((long long)iy * W + ix) * CI + c0 + c4 * 4);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                if constexpr (RGB3) {
+                    const long long pix = (long long)iy * W + ix, hw = (long long)H * W;
+                    val = make_float4(xb[pix], xb[hw + pix], xb[2 * hw + pix], 0.0f);
+                } else {
+                    val = *reinterpret_cast<const float4*>(xb + ((long long)iy * W + ix) * CI + c0 + c4 * 4);
+                }
+            }
             *reinterpret_cast<float4*>(tile + v * C2_STRIDE + c4 * 4) = val;
         }
         __syncthreads();
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void rgb_to_nhwc4_kernel(const float* __restri
     *reinterpret_cast<float4*>(y + ((long long)n * HW + p) * 4) = make_float4(xb[p], xb[HW + p], xb[2 * HW + p], 0.0f);
 }
 
-template <int CI, int CO, int K, int S, int TH, int TW, int PPT, int UKY, int UKX>
+template <int CI, int CO, int K, int S, int TH, int TW, int PPT, int UKY, int UKX, bool RGB3 = false>
 static int conv2d_launch_t(const float* x, const float* wp, const float* scale, const float* shift, const float* up, float* y,
                            int N, int H, int W, int relu, hipStream_t st) {
     constexpr int PAD = K / 2;
@@ -176,7 +185,7 @@ static int conv2d_launch_t(const float* x, const float* wp, const float* scale, 
     const int tiles_w = (Wo + TW - 1) / TW, tiles_h = (Ho + TH * PPT - 1) / (TH * PPT);
     constexpr int HH = (TH * PPT - 1) * S + K, HW = (TW - 1) * S + K;
     const size_t lds = (size_t)HH * HW * C2_STRIDE * sizeof(float);
-    hipLaunchKernelGGL((conv2d_lds_kernel<CI, CO, K, S, TH, TW, PPT, UKY, UKX>), dim3(tiles_w * tiles_h, N), dim3(256), lds, st, x, wp, scale,
+    hipLaunchKernelGGL((conv2d_lds_kernel<CI, CO, K, S, TH, TW, PPT, UKY, UKX, RGB3>), dim3(tiles_w * tiles_h, N), dim3(256), lds, st, x, wp, scale,
                        shift, up, y, H, W, Ho, Wo, tiles_w, relu);
     return launch_status("conv2d");
 }
@@ -206,6 +215,9 @@ int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, 
     RCMVS_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
     RCMVS_REQUIRE(N > 0 && H > 0 && W > 0, "conv2d_fwd: bad sizes");
     hipStream_t st = as_stream(stream);
+    // Ci == 3: the first layer on the planar (N, 3, H, W) input itself; w_packed is the layer's weight packed with Cip = 4
+    if (Ci == 3 && Co == 8 && K == 3 && stride == 1)
+        return conv2d_launch_t<4, 8, 3, 1, 16, 16, 1, 1, 3, true>(x, w_packed, scale, shift, up_add, y, N, H, W, relu, st);
 #define RCMVS_C2(CI, CO, KK, SS, TH, TW, PPT, UY, UX)                                                             \
     if (Ci == CI && Co == CO && K == KK && stride == SS)                                                          \
         return conv2d_launch_t<CI, CO, KK, SS, TH, TW, PPT, UY, UX>(x, w_packed, scale, shift, up_add, y, N, H, W, relu, st);

@@ -370,6 +370,18 @@ def conv2d(x, w_packed, scale=None, shift=None, up_add=None, stride=1, relu=Fals
     return y
 
 
+def conv2d_rgb(x, w_packed, scale=None, shift=None, relu=False):
+    """FeatureNet's first layer on the planar input itself: x (N,3,H,W) -> (N,H,W,8) channels-last; w_packed = the 3 -> 8 3x3 weight packed
+    with pad_in_to=4 (rcmvs_conv2d_fwd with Ci = 3: the NCHW -> NHWC4 pass is folded into the tile staging)."""
+    N, C, H, W = x.shape
+    if C != 3 or w_packed.ci != 4 or w_packed.co != 8 or w_packed.k != 3:
+        raise _lib.RcmvsError(f"conv2d_rgb: expected a (N,3,H,W) input and a 3 -> 8 3x3 weight packed to 4 input channels (got {tuple(x.shape)}, {w_packed.ci} -> {w_packed.co}, k={w_packed.k})")
+    y = torch.empty((N, H, W, 8), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_conv2d_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"), None,
+                                            _chk(y, "y"), N, H, W, 3, 8, 3, 1, int(relu), _stream()), "conv2d_fwd")
+    return y
+
+
 def fpn_out_fused(lat, up, w_inner_packed, b_inner, w_out_packed):
     """conv3x3(up2(up) + conv1x1(lat) + bias): lat (N,H,W,8), up (N,H/2,W/2,32) -> (N,H,W,8), the 32-channel merge never stored."""
     N, H, W, CL = lat.shape

@@ -1280,6 +1280,21 @@ def test_fpn_out_fused_is_bit_identical(N, H, W):
         ops.fpn_out_fused(lat[:, :-1], up, w_in, b_in, w_out)
 
 
+@pytest.mark.parametrize("N,H,W", [(3, 64, 96), (1, 17, 33), (2, 16, 16)])
+def test_first_layer_reads_the_planar_images_itself(hip, N, H, W):
+    """rcmvs_conv2d_fwd with Ci = 3: FeatureNet's first layer staged straight from the (N,3,H,W) input equals the NHWC4 pass + the same
+    layer, bit for bit (same kernel body, same arithmetic), ragged tiles and borders included."""
+    g = torch.Generator().manual_seed(N + H)
+    x = gpu(torch.randn(N, 3, H, W, generator=g))
+    w = hip.pack_conv2d_weight(gpu(0.2 * torch.randn(8, 3, 3, 3, generator=g)), pad_in_to=4)
+    sc, sh = gpu(torch.rand(8, generator=g) + 0.5), gpu(0.1 * torch.randn(8, generator=g))
+    want = hip.conv2d(hip.rgb_to_nhwc4(x), w, sc, sh, relu=True)
+    got = hip.conv2d_rgb(x, w, sc, sh, relu=True)
+    assert torch.equal(got, want)
+    with pytest.raises(Exception):
+        hip.conv2d_rgb(x[:, :2].contiguous(), w, sc, sh)
+
+
 def test_feature_output_convs_keep_the_variance_bound(hip):
     """FeatureNet's three output convs leave (max|f|)^2 of their maps -- the bound of the variance volume the fp16-pair cost regularisation
     needs -- in the bound vector they are handed, bit-equal to what rcmvs_absmax_fwd(square=1) computes in a pass over the map (the launch
