@@ -45,9 +45,11 @@ int rcmvs_nhwc_to_nchw(const float* src, float* dst, int N, int C, long long S, 
  * on the device and rounded to fp32:  rot (B,V-1,9) row-major 3x3, trans (B,V-1,3). */
 int rcmvs_compose_homography(const float* proj, float* rot, float* trans, int B, int V, void* stream);
 /* The same for up to four cascade stages in ONE launch (their projection tensors differ only in the intrinsics scale, casmvsnet.py:
- * 376-381): rot (nstage, B, V-1, 9), trans (nstage, B, V-1, 3); unused proj pointers may be NULL. */
+ * 376-381): rot (nstage, B, V-1, 9), trans (nstage, B, V-1, 3); unused proj pointers may be NULL.  zero / zero_n: an optional float
+ * buffer (NULL / 0 = none) the launch clears on the side -- the scene's activation-bound rows, so that the first launch of a scene also
+ * does its one fill. */
 int rcmvs_compose_homography_stages(const float* proj0, const float* proj1, const float* proj2, const float* proj3, int nstage,
-                                    float* rot, float* trans, int B, int V, void* stream);
+                                    float* rot, float* trans, int B, int V, float* zero, long long zero_n, void* stream);
 
 /* ---- hypothesis planes  (models/casmvsnet.py:357-359,383-404; modules.py:549-588) ------ */
 /* Stage 1 (prev_depth == NULL): d_0 = depth_values[b,0], delta = (dv[b,ND-1]-dv[b,0])/(D-1).

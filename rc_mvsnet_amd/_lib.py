@@ -25,7 +25,7 @@ SIGNATURES = {
     "rcmvs_nchw_to_nhwc": [_p, _p, _i, _i, _ll, _p],
     "rcmvs_nhwc_to_nchw": [_p, _p, _i, _i, _ll, _p],
     "rcmvs_compose_homography": [_p, _p, _p, _i, _i, _p],
-    "rcmvs_compose_homography_stages": [_p, _p, _p, _p, _i, _p, _p, _i, _i, _p],
+    "rcmvs_compose_homography_stages": [_p, _p, _p, _p, _i, _p, _p, _i, _i, _p, ctypes.c_longlong, _p],
     "rcmvs_hypothesis_planes": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

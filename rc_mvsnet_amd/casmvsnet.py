@@ -723,28 +723,34 @@ class _CascadeBase(nn.Module):
             feats_cl = self.feature.forward_cl(imgs.reshape(B * V, 3, H, W), lazy=True)
         outputs = {}
         depth = None
-        if homographies is None:                                     # every stage's homographies in one launch (they differ in the intrinsics scale only)
-            if self.num_stage <= 4:
-                rots, transs = ops.compose_homography_stages([proj_matrices["stage{}".format(k + 1)].contiguous().float() for k in range(self.num_stage)])
-            else:
-                rt = [ops.compose_homography(proj_matrices["stage{}".format(k + 1)].contiguous().float()) for k in range(self.num_stage)]
-                rots, transs = [r for r, _ in rt], [t for _, t in rt]
         bounds = None
+        need_fill = False
         # arithmetic of the cost regularisation: the module attribute `fp16_pair` (True / False) if the caller set one, else RCMVS_FP16_PAIR
         # (read per forward so that a process can switch), else the default
         pair = getattr(self, "fp16_pair", None)
         if pair is None:
             pair = FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
         if pair and B == 1:          # (the bounds are per launch: with B > 1 a sample's rounding would depend on its batch mates -> exact form)
-            # activation bounds of the fp16-pair kernels: one persistent (stage, 7, 1024) buffer per model, ONE fill per scene
-            # (row 0 of a stage: bound of the variance volume; rows 1-6: written by the layers).  Not re-entrant across streams.
+            # activation bounds of the fp16-pair kernels: one persistent (stage, 7, 1024) buffer per model, cleared ONCE per scene -- by the
+            # homography launch below, on the side -- (row 0 of a stage: bound of the variance volume, left there by FeatureNet's output
+            # conv; rows 1-6: written by the layers).  Not re-entrant across streams.
             bounds = getattr(self, "_pair_bounds", None)
             if getattr(self, "_is_replica", False):                  # a DataParallel replica shares its attributes with its siblings (shallow copy) and runs beside them
                 bounds = torch.zeros(self.num_stage, 7, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
             elif bounds is None or bounds.device != imgs.device:
                 bounds = self._pair_bounds = torch.zeros(self.num_stage, 7, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
             else:
-                bounds.zero_()
+                need_fill = True
+        if homographies is None:                                     # every stage's homographies in one launch (they differ in the intrinsics scale only)
+            if self.num_stage <= 4:
+                rots, transs = ops.compose_homography_stages([proj_matrices["stage{}".format(k + 1)].contiguous().float() for k in range(self.num_stage)],
+                                                             zero=bounds if need_fill else None)
+                need_fill = False
+            else:
+                rt = [ops.compose_homography(proj_matrices["stage{}".format(k + 1)].contiguous().float()) for k in range(self.num_stage)]
+                rots, transs = [r for r, _ in rt], [t for _, t in rt]
+        if need_fill:
+            bounds.zero_()
         for s in range(self.num_stage):
             key = "stage{}".format(s + 1)
             scale = int(self.stage_infos[key]["scale"])

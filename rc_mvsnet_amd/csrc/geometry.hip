@@ -96,8 +96,10 @@ __device__ static void fold_intrinsics(const float* p, double A[4][4]) {
 
 // (blockIdx.y = cascade stage when the three stages' projection tensors are composed in ONE launch: rcmvs_compose_homography_stages)
 struct ProjPtrs { const float* p[4]; };
+// zero / zero_n: an optional float buffer the launch clears on the side (the cascade's activation-bound rows: one fill launch per scene less)
 __global__ void compose_homography_kernel(ProjPtrs pp, float* __restrict__ rot,
-                                          float* __restrict__ trans, int B, int V) {
+                                          float* __restrict__ trans, int B, int V, float* __restrict__ zero, int zero_n) {
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * gridDim.y * blockDim.x) zero[i] = 0.0f;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * (V - 1)) return;
     const float* proj = pp.p[blockIdx.y];
@@ -244,18 +246,19 @@ int rcmvs_compose_homography(const float* proj, float* rot, float* trans, int B,
     RCMVS_REQUIRE(B > 0 && V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "compose_homography: B=%d V=%d", B, V);
     const int n = B * (V - 1);
     ProjPtrs pp{{proj, nullptr, nullptr, nullptr}};
-    hipLaunchKernelGGL(compose_homography_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), pp, rot, trans, B, V);
+    hipLaunchKernelGGL(compose_homography_kernel, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), pp, rot, trans, B, V, (float*)nullptr, 0);
     return launch_status("compose_homography");
 }
 
 int rcmvs_compose_homography_stages(const float* proj0, const float* proj1, const float* proj2, const float* proj3, int nstage,
-                                    float* rot, float* trans, int B, int V, void* stream) {
+                                    float* rot, float* trans, int B, int V, float* zero, long long zero_n, void* stream) {
+    RCMVS_REQUIRE(zero_n >= 0 && zero_n < (1LL << 24) && (zero || zero_n == 0), "compose_homography_stages: bad side buffer (%lld floats)", zero_n);
     RCMVS_REQUIRE(rot && trans && nstage >= 1 && nstage <= 4, "compose_homography_stages: bad arguments (1..4 stages)");
     RCMVS_REQUIRE(B > 0 && V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "compose_homography_stages: B=%d V=%d", B, V);
     ProjPtrs pp{{proj0, proj1, proj2, proj3}};
     for (int s = 0; s < nstage; ++s) RCMVS_REQUIRE(pp.p[s], "compose_homography_stages: stage %d has no projection tensor", s);
     const int n = B * (V - 1);
-    hipLaunchKernelGGL(compose_homography_kernel, dim3((n + 63) / 64, nstage), dim3(64), 0, as_stream(stream), pp, rot, trans, B, V);
+    hipLaunchKernelGGL(compose_homography_kernel, dim3((n + 63) / 64, nstage), dim3(zero_n ? 256 : 64), 0, as_stream(stream), pp, rot, trans, B, V, zero, (int)zero_n);
     return launch_status("compose_homography_stages");
 }
 

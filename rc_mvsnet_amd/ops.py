@@ -66,15 +66,16 @@ def compose_homography(proj):
     return rot, trans
 
 
-def compose_homography_stages(projs):
-    """[proj (B,V,2,4,4)] x nstage (<= 4) -> rot (nstage,B,V-1,9), trans (nstage,B,V-1,3): the cascade's stages in one launch."""
+def compose_homography_stages(projs, zero=None):
+    """[proj (B,V,2,4,4)] x nstage (<= 4) -> rot (nstage,B,V-1,9), trans (nstage,B,V-1,3): the cascade's stages in one launch.
+    zero: an optional fp32 tensor the launch clears on the side (the scene's activation-bound rows)."""
     B, V = projs[0].shape[:2]
     n = len(projs)
     rot = torch.empty((n, B, V - 1, 9), device=projs[0].device, dtype=torch.float32)
     trans = torch.empty((n, B, V - 1, 3), device=projs[0].device, dtype=torch.float32)
     ptrs = [_chk(p, "proj") for p in projs] + [ctypes.c_void_p(0)] * (4 - n)
     _lib.check(_lib.load().rcmvs_compose_homography_stages(ptrs[0], ptrs[1], ptrs[2], ptrs[3], n, _chk(rot, "rot"), _chk(trans, "trans"), B, V,
-                                                           _stream()), "compose_homography_stages")
+                                                           _opt(zero, "zero"), 0 if zero is None else zero.numel(), _stream()), "compose_homography_stages")
     return rot, trans
 
 
