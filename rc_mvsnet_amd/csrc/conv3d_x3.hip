@@ -53,6 +53,7 @@
 // wave -- does not overlap v_mfma_f32_16x16x32_bf16, so a step costs MFMA time + producer VALU time; the producers are therefore
 // kept to the bare split (22 VALU per float4) and table-driven addressing.
 #include "common.h"
+#include <cstdlib>
 
 #ifndef X3_ABLATION
 #define X3_ABLATION 0       // tools/dev/x3_test.hip builds with 1: the phase-ablation switches of X3Dims::dbg (timing experiments only)
@@ -329,6 +330,7 @@ struct X3Dims {
     int tiles_x, zchunk, relu;
     int B, ntiles, nchunks, nitems;   // work items = B x xy tiles x z chunks
     int itemcap, stepcap;   // capacities of the block's schedule tables in LDS (items / steps per block, rounded up)
+    int bal;                // 1 = balanced schedule: block r walks steps [T r / n, T (r + 1) / n) of the flattened (batch, tile, z) sequence (see the kernel)
     int dbg;            // phase-ablation mask (0 in the library; X3_ABLATION builds only)
     long long* trace;   // s_memtime stamps of block 0 (nullptr in the library; X3_ABLATION builds only)
     int ysq;            // ymax receives the SQUARE of max|y| (the bound of a variance volume from the bound of its samples: FeatureNet's output convs)
@@ -418,12 +420,43 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
         it_first = bid; it_stride = nblk; it_limit = dm.nitems;
     }
     const bool relu = dm.relu != 0;
-    if (it_first >= it_limit) return;            // (more blocks than items in this XCD's range)
     // ---- schedule tables
-    const int nloc = (it_limit - it_first + it_stride - 1) / it_stride;
-    for (int k = tid; k < nloc; k += 512) {
-        const X3Item w = x3_item<C>(dm, it_first + k * it_stride);
-        itab_w[k] = make_int4(w.b, w.x0, w.y0, w.zb | (w.ze << 16));
+    int nloc;
+    if (dm.bal) {
+        // Balanced schedule (round 4).  With (batch, tile, z chunk) items dealt to the blocks, a block's work is a whole number of items:
+        // the mid-size layers have 1-5 items per block and the longest block sets the launch time (16 -> 16 at 16 x 128 x 160: 160 tiles,
+        // 3 items of 4 steps on some blocks = 16.5 step-equivalents where the average is 10).  Here the steps of ALL tiles form one
+        // sequence (tile-major, z inside) and block r takes the contiguous range [T r / n, T (r + 1) / n): every block gets the same
+        // number of steps (+- 1), a block's first and last item are partial tiles, and the ring runs across the item boundaries as
+        // before (an item is any z range of a tile).  Cuts that would leave a one-step fragment at a tile's start or end move by one.
+        const long long T = (long long)dm.B * dm.ntiles * dm.Dt;
+        const int r = ((nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;      // an XCD's blocks (bid & 7) take neighbouring ranges
+        auto cut = [&](int i) -> long long {
+            long long c = T * i / nblk;
+            if (dm.Dt >= 4 && i > 0 && i < nblk) {
+                const int m = (int)(c % dm.Dt);
+                if (m == 1) c -= 1; else if (m == dm.Dt - 1) c += 1;
+            }
+            return c;
+        };
+        const long long lo = cut(r), hi = cut(r + 1);
+        if (hi <= lo) return;
+        const int t0 = (int)(lo / dm.Dt), t1 = (int)((hi - 1) / dm.Dt);
+        nloc = t1 - t0 + 1;
+        for (int k = tid; k < nloc; k += 512) {
+            const int t = t0 + k;
+            const int zb = (k == 0) ? (int)(lo - (long long)t0 * dm.Dt) : 0;
+            const int ze = (t == t1) ? (int)(hi - (long long)t1 * dm.Dt) : dm.Dt;
+            const int tile = t % dm.ntiles;
+            itab_w[k] = make_int4(t / dm.ntiles, (tile % dm.tiles_x) * C::TX, (tile / dm.tiles_x) * C::TY, zb | (ze << 16));
+        }
+    } else {
+        if (it_first >= it_limit) return;            // (more blocks than items in this XCD's range)
+        nloc = (it_limit - it_first + it_stride - 1) / it_stride;
+        for (int k = tid; k < nloc; k += 512) {
+            const X3Item w = x3_item<C>(dm, it_first + k * it_stride);
+            itab_w[k] = make_int4(w.b, w.x0, w.y0, w.zb | (w.ze << 16));
+        }
     }
     __syncthreads();
     X3Sched sch;
@@ -924,6 +957,31 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
     const long long items = (long long)dm.B * dm.ntiles * dm.nchunks;
     if (items >= 0x7fffffffLL) return fail(-1, "conv3d_x3: too many work items");
     dm.nitems = (int)items;
+    // the balanced schedule (see the kernel): every block the same number of steps; taken when the model says it is shorter than the best
+    // chunked split (cost in half steps: steps + 1.5 per item start, a block of a balanced launch starts ceil(steps / Dt) + 1 items at most)
+    dm.bal = 0;
+    {
+        static int mode = -1;                                               // RCMVS_X3_BALANCE=0 / 1: off / forced (A/B); default: by the model
+        if (mode < 0) { const char* e = getenv("RCMVS_X3_BALANCE"); mode = e ? (e[0] == '0' ? 0 : 1) : 2; }
+        const long long T = (long long)dm.B * dm.ntiles * dm.Dt;
+        const long long spb = (T + n_blk - 1) / n_blk + 1;                   // steps of the longest block
+        const long long ipb = (spb + dm.Dt - 1) / dm.Dt + 1;                 // item starts of a block, at most
+        const long long cost_bal = 2 * spb + (C::NKD > 1 ? 3 : 0) * ipb;
+        if (T < 0x7fffffffLL && spb < 32768 && (mode == 1 || (mode == 2 && cost_bal < best))) {
+            dm.bal = 1;
+            dm.itemcap = (int)((ipb + 1 + 3) & ~3LL);
+            dm.stepcap = (int)((spb + 2 + 3) & ~3LL);
+            const size_t ldsb = (size_t)C::LDSB + (size_t)dm.itemcap * 16 + (size_t)dm.stepcap * 4 + 64;
+            if (ldsb <= 160 * 1024) {
+                const int grid_b = (int)(T < n_blk ? T : n_blk);
+                static bool attr_set_b[64];
+                if (!attr_set_b[dev]) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b[dev] = true; }
+                hipLaunchKernelGGL((conv3d_x3_kernel<CI, CO, K, NP>), dim3((unsigned)grid_b), dim3(512), ldsb, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, res, y, dm, xmax, ymax);
+                return launch_status("conv3d_x3");
+            }
+            dm.bal = 0;
+        }
+    }
     // schedule tables of a block (LDS, behind the ring and the partial tiles): items per block (an XCD's share is split over
     // grid / 8 blocks: + 1 for the remainders), steps per block; more blocks than CUs when the tables would not fit
     int grid_n = dm.nitems < n_blk ? dm.nitems : n_blk;
