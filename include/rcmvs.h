@@ -248,6 +248,11 @@ int rcmvs_pack_conv2d_weight(const float* w, float* packed, int Co, int Ci, int 
  * w_packed the layer's weight packed with Cip = 4 -- no rcmvs_rgb_to_nhwc4 pass in front. */
 int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
                      float* y, int N, int H, int W, int Ci, int Co, int K, int stride, int relu, void* stream);
+/* The 1x1 layers of the pyramid (out1 32 -> 32, inner1 16 -> 32, inner2 8 -> 32; models/modules.py:437-447) on a streaming kernel: same
+ * arguments and results as rcmvs_conv2d_fwd with K = 1 (which routes here), plus ysq_absmax (may be NULL): a zero-filled bound vector
+ * (RCMVS_ABSMAX_FLOATS floats) that receives (max |y|)^2 -- the bound of the variance volume built from the map. */
+int rcmvs_conv1x1_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
+                      float* y, float* ysq_absmax, int N, int H, int W, int Ci, int Co, int relu, void* stream);
 /* Last FPN level in one launch: y = conv3x3(up2(up) + conv1x1(lat) + b_inner) without materialising the 32-channel
  * intermediate (models/modules.py:448-462: `intra_feat = F.interpolate(intra_feat) + self.inner2(conv0)`,
  * `self.out3(intra_feat)`).  lat (N,H,W,CL), up (N,H/2,W/2,CM), w_inner packed [1][CL][CM], b_inner (CM), w_out packed

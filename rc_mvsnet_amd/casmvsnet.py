@@ -248,8 +248,6 @@ class FeatureNet(nn.Module):
                     continue
                 plan[n] = (ops.pack_conv2d_weight(w, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
-            if tuple(self.out1.weight.shape) == (32, 32, 1, 1):           # the same 1x1 conv as the middle tap of a one-plane 3-D kernel: the planar
-                plan["out1_3d"] = ops.pack_conv3d_weight(self._w3(self.out1.weight.detach()))      # matrix-core form keeps the bound of its output (below)
             if unet:
                 for n in ("out2", "out3")[:self.num_stage - 1]:           # 1x1, Co = Ci: the middle tap of a one-plane 3-D kernel
                     plan[n] = ops.pack_conv3d_weight(self._w3(getattr(self, n).weight.detach()))
@@ -308,8 +306,8 @@ class FeatureNet(nn.Module):
         # there -- the bound of the variance volume built from the map, which the fp16-pair cost regularisation needs -- in its epilogue
         # and returns (map, True); (map, False) = no bound was kept (the caller runs ops.absmax over the map).
         def out1(bound=None, t=c2):
-            if bound is not None and "out1_3d" in p and not ops._CONV_IMPL:
-                return ops.conv3d(t.unsqueeze(1), p["out1_3d"], y_absmax=bound, y_absmax_square=True).squeeze(1), True
+            if bound is not None and tuple(self.out1.weight.shape) == (32, 32, 1, 1):      # the streaming 1x1 kernel keeps the bound in its epilogue
+                return ops.conv1x1(t, p["out1"], ysq_absmax=bound), True
             return ops.conv2d(t, p["out1"]), False
         out = {"stage1": out1}
         plain = lambda f: (lambda bound=None: (f(), False))

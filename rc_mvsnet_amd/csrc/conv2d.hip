@@ -160,6 +160,88 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
     }
 }
 
+// ---- 1x1 layers (round 4): a streaming kernel.  The tile kernel above stages a halo in LDS 8 channels at a time behind barriers, which a
+// 1x1 conv has no use for: the 16 -> 32 lateral merge ran 22 us per scene for 55 MB of traffic and 0.13 GFLOP (fewer than two blocks per
+// CU, four staging rounds each).  Here a thread owns one pixel: its CI channels arrive with CI / 4 16-byte loads, the CI x CO weights are
+// wave-uniform scalar operands consumed one input channel at a time (CO SGPRs live), all CO accumulators stay in registers; bias /
+// BatchNorm, the nearest x2 up-add of the FPN merge, ReLU and -- optionally -- the block's (max |y|)^2 into a bound vector (one atomic max
+// per block: the bound of the variance volume, csrc/absmax.hip) follow in the epilogue.  Same accumulation order (ascending input channel,
+// fmaf) as the tile kernel's 1x1 form: bit-identical results.
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv1x1_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ up, float* __restrict__ y, float* __restrict__ ysq, long long npix, int H, int W, int relu) {
+    __shared__ float red[4];
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < npix;
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+    float m = 0.0f;
+    if (live) {
+        f4v xv[CI / 4];
+#pragma unroll
+        for (int c = 0; c < CI / 4; ++c) xv[c] = *reinterpret_cast<const f4v*>(x + p * CI + c * 4);
+#pragma unroll 2
+        for (int c = 0; c < CI / 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* wt = wp + (c * 4 + j) * CO;
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv[c][j], wt[co], acc[co]);
+            }
+        }
+        if (scale) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[co] = acc[co] * scale[co];
+        }
+        if (shift) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[co] = acc[co] + shift[co];
+        }
+        if (up) {                                                       // F.interpolate(intra) + inner(conv): pixel (n, oy, ox) <- up[n, oy / 2, ox / 2]
+            const long long hw = (long long)H * W;
+            const long long n = p / hw;
+            const int r = (int)(p - n * hw), oy = r / W, ox = r - oy * W;
+            const float* upp = up + ((n * (H / 2) + oy / 2) * (W / 2) + ox / 2) * CO;
+#pragma unroll
+            for (int co = 0; co < CO; co += 4) {
+                const f4v u4 = *reinterpret_cast<const f4v*>(upp + co);
+                acc[co] = u4.x + acc[co]; acc[co + 1] = u4.y + acc[co + 1]; acc[co + 2] = u4.z + acc[co + 2]; acc[co + 3] = u4.w + acc[co + 3];
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[co] = fmaxf(acc[co], 0.0f);
+        }
+        float* yp = y + p * CO;
+#pragma unroll
+        for (int co = 0; co < CO; co += 4) *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+        if (ysq) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) m = fmaxf(m, fabsf(acc[co]));
+        }
+    }
+    if (ysq) {
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            atomicMax(reinterpret_cast<unsigned int*>(ysq) + (blockIdx.x & 63) * 16, __float_as_uint(m * m));
+        }
+    }
+}
+
+template <int CI, int CO>
+static int conv1x1_launch_t(const float* x, const float* wp, const float* scale, const float* shift, const float* up, float* y, float* ysq,
+                            int N, int H, int W, int relu, hipStream_t st) {
+    const long long npix = (long long)N * H * W;
+    hipLaunchKernelGGL((conv1x1_kernel<CI, CO>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, wp, scale, shift, up, y, ysq, npix, H, W, relu);
+    return launch_status("conv1x1");
+}
+
 // (Co,Ci,K,K) -> [K*K][Cip][Co], input channels zero-padded to Cip
 __global__ void pack_weight2d_kernel(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int Cip, int KK) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,11 +292,25 @@ int rcmvs_pack_conv2d_weight(const float* w, float* packed, int Co, int Ci, int 
     return launch_status("pack_conv2d_weight");
 }
 
+int rcmvs_conv1x1_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
+                      float* y, float* ysq_absmax, int N, int H, int W, int Ci, int Co, int relu, void* stream) {
+    RCMVS_REQUIRE(x && w_packed && y, "conv1x1_fwd: null pointer");
+    RCMVS_REQUIRE(N > 0 && H > 0 && W > 0, "conv1x1_fwd: bad sizes");
+    RCMVS_REQUIRE(!up_add || (H % 2 == 0 && W % 2 == 0), "conv1x1_fwd: the up-add merge needs even H and W (got %d x %d)", H, W);
+    hipStream_t st = as_stream(stream);
+    if (Ci == 16 && Co == 32) return conv1x1_launch_t<16, 32>(x, w_packed, scale, shift, up_add, y, ysq_absmax, N, H, W, relu, st);
+    if (Ci == 32 && Co == 32) return conv1x1_launch_t<32, 32>(x, w_packed, scale, shift, up_add, y, ysq_absmax, N, H, W, relu, st);
+    if (Ci == 8 && Co == 32) return conv1x1_launch_t<8, 32>(x, w_packed, scale, shift, up_add, y, ysq_absmax, N, H, W, relu, st);
+    return fail(-1, "conv1x1_fwd: unsupported layer Ci=%d Co=%d (16 -> 32, 32 -> 32, 8 -> 32)", Ci, Co);
+}
+
 int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
                      float* y, int N, int H, int W, int Ci, int Co, int K, int stride, int relu, void* stream) {
     RCMVS_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
     RCMVS_REQUIRE(N > 0 && H > 0 && W > 0, "conv2d_fwd: bad sizes");
     hipStream_t st = as_stream(stream);
+    if (K == 1 && stride == 1 && Co == 32 && (Ci == 8 || Ci == 16 || Ci == 32) && (!up_add || (H % 2 == 0 && W % 2 == 0)))
+        return rcmvs_conv1x1_fwd(x, w_packed, scale, shift, up_add, y, nullptr, N, H, W, Ci, Co, relu, stream);      // the streaming 1x1 kernel (bit-identical to the tile kernel's 1x1 form)
     // Ci == 3: the first layer on the planar (N, 3, H, W) input itself; w_packed is the layer's weight packed with Cip = 4
     if (Ci == 3 && Co == 8 && K == 3 && stride == 1)
         return conv2d_launch_t<4, 8, 3, 1, 16, 16, 1, 1, 3, true>(x, w_packed, scale, shift, up_add, y, N, H, W, relu, st);

@@ -371,6 +371,21 @@ def conv2d(x, w_packed, scale=None, shift=None, up_add=None, stride=1, relu=Fals
     return y
 
 
+def conv1x1(x, w_packed, scale=None, shift=None, up_add=None, relu=False, ysq_absmax=None):
+    """x (N,H,W,Ci) -> (N,H,W,Co) = [relu](up2(up_add) + conv1x1 * scale + shift) on the streaming 1x1 kernel (what conv2d routes its K = 1
+    layers to); ysq_absmax: a zero-filled (1024,) bound vector that receives (max|y|)^2."""
+    N, H, W, Ci = x.shape
+    Co = w_packed.co
+    if w_packed.ci != Ci or w_packed.k != 1:
+        raise _lib.RcmvsError(f"conv1x1: input has {Ci} channels, weight is {w_packed.ci} -> {Co} with k={w_packed.k}")
+    if up_add is not None and tuple(up_add.shape) != (N, H // 2, W // 2, Co):
+        raise _lib.RcmvsError(f"conv1x1: up_add {tuple(up_add.shape)} does not match half of the output")
+    y = torch.empty((N, H, W, Co), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_conv1x1_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"), _opt(up_add, "up_add"),
+                                             _chk(y, "y"), _opt(ysq_absmax, "ysq_absmax"), N, H, W, Ci, Co, int(relu), _stream()), "conv1x1_fwd")
+    return y
+
+
 def conv2d_rgb(x, w_packed, scale=None, shift=None, relu=False):
     """FeatureNet's first layer on the planar input itself: x (N,3,H,W) -> (N,H,W,8) channels-last; w_packed = the 3 -> 8 3x3 weight packed
     with pad_in_to=4 (rcmvs_conv2d_fwd with Ci = 3: the NCHW -> NHWC4 pass is folded into the tile staging)."""
