@@ -167,12 +167,12 @@ __global__ __launch_bounds__(256) void conv2d_lds_kernel(
 // BatchNorm, the nearest x2 up-add of the FPN merge, ReLU and -- optionally -- the block's (max |y|)^2 into a bound vector (one atomic max
 // per block: the bound of the variance volume, csrc/absmax.hip) follow in the epilogue.  Same accumulation order (ascending input channel,
 // fmaf) as the tile kernel's 1x1 form: bit-identical results.
-template <int CI, int CO>
+template <int CI, int CO, bool TRS>
 __global__ __launch_bounds__(256) void conv1x1_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ up, float* __restrict__ y, float* __restrict__ ysq, long long npix, int H, int W, int relu) {
     __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) float tr[256 * (CO + 4)];
+    __shared__ __attribute__((aligned(16))) float tr[TRS ? 256 * (CO + 4) : 4];
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = p < npix;
     float acc[CO];
@@ -222,8 +222,16 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(
     }
     // store through a wave-private LDS transpose: a lane holds its pixel's CO channels (CO * 4 contiguous bytes), so storing from the
     // registers would put 64 scattered 16-byte pieces into every store instruction (measured: 21 us for the 16 -> 32 layer, no faster than
-    // the tile kernel); after the transpose instruction i of a wave writes float4 i * 64 + lane of the wave's 64 x CO block: 1 KiB contiguous
-    {
+    // the tile kernel); after the transpose instruction i of a wave writes float4 i * 64 + lane of the wave's 64 x CO block: 1 KiB contiguous.
+    // (TRS = false: plain per-lane stores, for maps so small that the launch is latency-bound and the LDS round trip only adds to it:
+    // the 32 -> 32 output conv of stage 1 at 3 x 128 x 160, 11.8 against 13.3 us)
+    if constexpr (!TRS) {
+        if (live) {
+            float* yp = y + p * CO;
+#pragma unroll
+            for (int co = 0; co < CO; co += 4) *reinterpret_cast<float4*>(yp + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+        }
+    } else {
         constexpr int STR = CO + 4;                                     // floats per pixel row in LDS (16-byte aligned, bank-staggered)
         float* tw = tr + (threadIdx.x >> 6) * 64 * STR;
         const int lane = threadIdx.x & 63;
@@ -254,7 +262,10 @@ template <int CI, int CO>
 static int conv1x1_launch_t(const float* x, const float* wp, const float* scale, const float* shift, const float* up, float* y, float* ysq,
                             int N, int H, int W, int relu, hipStream_t st) {
     const long long npix = (long long)N * H * W;
-    hipLaunchKernelGGL((conv1x1_kernel<CI, CO>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, wp, scale, shift, up, y, ysq, npix, H, W, relu);
+    if (npix >= 131072)
+        hipLaunchKernelGGL((conv1x1_kernel<CI, CO, true>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, wp, scale, shift, up, y, ysq, npix, H, W, relu);
+    else
+        hipLaunchKernelGGL((conv1x1_kernel<CI, CO, false>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, wp, scale, shift, up, y, ysq, npix, H, W, relu);
     return launch_status("conv1x1");
 }
 
