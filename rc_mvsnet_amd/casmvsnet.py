@@ -21,6 +21,7 @@ Execution:
 import os
 
 FP16_PAIR_DEFAULT = True       # inference CostRegNet on the fp16-pair matrix-core form unless RCMVS_FP16_PAIR=0 (the exact bf16 triple)
+DEEP_PAIR = os.environ.get("RCMVS_DEEP_PAIR", "1") != "0"       # ... its deep levels (conv5-7) included (csrc/conv3d_deep.hip); 0 = fp32 MFMAs there
 
 import torch
 import torch.nn as nn
@@ -492,6 +493,7 @@ class CostRegNet(nn.Module):
     (B,1,D,h,w) logits); the cascade uses ``features_cl`` + the fused depth head instead."""
 
     _LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")
+    BOUND_ROWS = 10         # rows of the activation-bound buffer of the fp16-pair form: the input volume + nine layer outputs
 
     def __init__(self, in_channels, base_channels):
         super().__init__()
@@ -539,8 +541,8 @@ class CostRegNet(nn.Module):
 
     def features_cl(self, x, x_absmax=None, plan=None):
         """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8).
-        x_absmax: None = the exact three-piece bf16 form of the matrix-core kernels; or a (7, ops.ABSMAX_FLOATS) tensor whose row 0
-        is a bound of max|x| (ops.absmax format; the cascade derives it from the feature maps) and whose rows 1-6 are ZERO: the
+        x_absmax: None = the exact three-piece bf16 form of the matrix-core kernels; or a (BOUND_ROWS, ops.ABSMAX_FLOATS) tensor whose row 0
+        is a bound of max|x| (ops.absmax format; the cascade derives it from the feature maps) and whose other rows are ZERO: the
         layers then run on the fp16-pair form (half the matrix-pipe work) and every layer leaves the bound of its output in the
         next row for its consumer (one atomic max per block, inside the kernel)."""
         B, D, h, w, _ = x.shape
@@ -556,15 +558,21 @@ class CostRegNet(nn.Module):
             t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True)
             t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True)
             return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True)
-        b = [x_absmax[i] for i in range(1, 7)]                    # bounds of conv0, 1, 2, 3, 9, 7 (zero on entry: the caller's one fill per scene)
+        b = [x_absmax[i] for i in range(1, self.BOUND_ROWS)]      # bounds of conv0, 1, 2, 3, 9, 7, 4, 5, 6 (zero on entry: the caller's one fill per scene)
         x_absmax = x_absmax[0]
         conv0 = ops.conv3d(x, *p["conv0"], relu=True, x_absmax=x_absmax, y_absmax=b[0])
         conv1 = ops.conv3d(conv0, *p["conv1"], stride=2, relu=True, x_absmax=b[0], y_absmax=b[1])
         conv2 = ops.conv3d(conv1, *p["conv2"], relu=True, x_absmax=b[1], y_absmax=b[2])
         conv3 = ops.conv3d(conv2, *p["conv3"], stride=2, relu=True, x_absmax=b[2], y_absmax=b[3])
-        conv4 = ops.conv3d(conv3, *p["conv4"], relu=True, x_absmax=b[3])
-        t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)          # fp32-MFMA deep levels: no bounds kept
-        t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True, y_absmax=b[5])                             # (the fp32 kernel keeps the bound too)
+        if DEEP_PAIR:               # the deep levels on their own fp16-pair kernels (csrc/conv3d_deep.hip)
+            conv4 = ops.conv3d(conv3, *p["conv4"], relu=True, x_absmax=b[3], y_absmax=b[6])
+            t = ops.conv3d(conv4, *p["conv5"], stride=2, relu=True, x_absmax=b[6], y_absmax=b[7])
+            t = ops.conv3d(t, *p["conv6"], relu=True, x_absmax=b[7], y_absmax=b[8])
+            t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True, x_absmax=b[8], y_absmax=b[5])
+        else:                       # RCMVS_DEEP_PAIR=0: fp32-MFMA deep levels, no bounds needed (the kernel keeps the bound of conv7 too)
+            conv4 = ops.conv3d(conv3, *p["conv4"], relu=True, x_absmax=b[3])
+            t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)
+            t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True, y_absmax=b[5])
         t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True, x_absmax=b[5], y_absmax=b[4])
         return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True, x_absmax=b[4])
 
@@ -729,14 +737,14 @@ class _CascadeBase(nn.Module):
         if pair is None:
             pair = FP16_PAIR_DEFAULT if os.environ.get("RCMVS_FP16_PAIR") is None else os.environ["RCMVS_FP16_PAIR"] == "1"
         if pair and B == 1:          # (the bounds are per launch: with B > 1 a sample's rounding would depend on its batch mates -> exact form)
-            # activation bounds of the fp16-pair kernels: one persistent (stage, 7, 1024) buffer per model, cleared ONCE per scene -- by the
+            # activation bounds of the fp16-pair kernels: one persistent (stage, BOUND_ROWS, 1024) buffer per model, cleared ONCE per scene -- by the
             # homography launch below, on the side -- (row 0 of a stage: bound of the variance volume, left there by FeatureNet's output
-            # conv; rows 1-6: written by the layers).  Not re-entrant across streams.
+            # conv; the other rows: written by the layers).  Not re-entrant across streams.
             bounds = getattr(self, "_pair_bounds", None)
             if getattr(self, "_is_replica", False):                  # a DataParallel replica shares its attributes with its siblings (shallow copy) and runs beside them
-                bounds = torch.zeros(self.num_stage, 7, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
+                bounds = torch.zeros(self.num_stage, CostRegNet.BOUND_ROWS, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
             elif bounds is None or bounds.device != imgs.device:
-                bounds = self._pair_bounds = torch.zeros(self.num_stage, 7, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
+                bounds = self._pair_bounds = torch.zeros(self.num_stage, CostRegNet.BOUND_ROWS, ops.ABSMAX_FLOATS, device=imgs.device, dtype=torch.float32)
             else:
                 need_fill = True
         if homographies is None:                                     # every stage's homographies in one launch (they differ in the intrinsics scale only)

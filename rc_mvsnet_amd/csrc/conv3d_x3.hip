@@ -53,6 +53,7 @@
 // wave -- does not overlap v_mfma_f32_16x16x32_bf16, so a step costs MFMA time + producer VALU time; the producers are therefore
 // kept to the bare split (22 VALU per float4) and table-driven addressing.
 #include "common.h"
+#include "x3_pieces.h"
 #include <cstdlib>
 
 #ifndef X3_ABLATION
@@ -70,11 +71,6 @@ long long* x3_trace_buf = nullptr;      // device buffer [64 ticks][8 stamps] of
 #endif
 #define X3_DBG(BIT) (X3_ABLATION == 1 && ((dm.dbg >> (BIT)) & 1))       // (X3_ABLATION == 2: time stamps only, no switches)
 
-typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int x3_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int x3_u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned char x3_byte;
 
 // stride-1 conv, stride-2 conv, transposed stride-2 conv, planar stride-1 conv (kd = 1 taps only: a 3x3 conv of every z-plane,
 // what a 3x3x3 conv of a one-plane volume reduces to -- the FeatureNet layers, models/modules.py:413-424)
@@ -256,16 +252,6 @@ __global__ void x3_pack_kernel(const float* __restrict__ w, unsigned short* __re
     }
 }
 
-// power-of-two scale of a tensor bound: s = 2^e with s * m in [2^14, 2^15); 1 for m = 0, denormal or non-finite bounds.
-// The same function serves the weights (pack time) and the activations (every launch, from the caller's bound).
-__device__ __forceinline__ float x3_pow2_scale(float m, float& inv) {
-    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
-    int e = (ex == 0 || ex == 255) ? 0 : 14 - (ex - 127);
-    e = e < -100 ? -100 : (e > 100 ? 100 : e);
-    inv = __uint_as_float((unsigned)(127 - e) << 23);
-    return __uint_as_float((unsigned)(127 + e) << 23);
-}
-
 // one block: out[0] = scale of max|w| over n weights, out[1] = its inverse
 __global__ void x3_wscale_kernel(const float* __restrict__ w, int n, float* __restrict__ out) {
     __shared__ float red[256];
@@ -303,26 +289,6 @@ __device__ __forceinline__ void x3_split4(x3_f32x4 v, x3_u32x2& h, x3_u32x2& m, 
     l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
 }
 
-// four fp32 (already multiplied by the power-of-two scale) -> the two fp16 piece quadruples: h = rne(xs), l = rne(xs - h).
-// 2 v_cvt_pk_f16_f32 + 4 v_cvt_f32_f16 + 2 v_pk_add_f32 + 2 v_cvt_pk_f16_f32 (+ the 2 v_pk_mul_f32 of the scale at the call site)
-typedef _Float16 x3_f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void x3_split4h(x3_f32x4 xs, x3_u32x2& h, x3_u32x2& l) {
-    const x3_f16x4 hh = __builtin_convertvector(xs, x3_f16x4);
-    const x3_f32x4 r = xs - __builtin_convertvector(hh, x3_f32x4);                  // exact
-    const x3_f16x4 ll = __builtin_convertvector(r, x3_f16x4);
-    h = __builtin_bit_cast(x3_u32x2, hh);
-    l = __builtin_bit_cast(x3_u32x2, ll);
-}
-
-template <int NP>
-__device__ __forceinline__ x3_f32x4 x3_mfma(x3_u32x4 a, x3_u32x4 b, x3_f32x4 c) {
-    if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, a), __builtin_bit_cast(x3_bf16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x3_f16x8, a), __builtin_bit_cast(x3_f16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ float x3_absmax4(float m, x3_f32x4 v) {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-}
 struct X3Dims {
     int D, H, W;        // input volume
     int Do, Ho, Wo;     // output volume
@@ -889,7 +855,16 @@ bool conv3d_x3_supported(int Ci, int Co, int kind) {
     return false;
 }
 
+// conv3d_deep.hip: the deep U-Net levels (32 -> 64 stride 2, 64 -> 64, 64 -> 32 transposed) in the same arithmetic, one tile-owning block
+// per 32 cells instead of z-marching persistent blocks; they share the x3h slot of the packed-weight blob and of the dispatch
+bool conv3d_deep_supported(int Ci, int Co, int kind);
+long long conv3d_deep_weight_floats(int Ci, int Co, int kind);
+int conv3d_deep_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, const float* wsc, hipStream_t st);
+int conv3d_deep_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
+                       int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, const float* xmax, float* ymax);
+
 bool conv3d_x3h_supported(int Ci, int Co, int kind) {
+    if (conv3d_deep_supported(Ci, Co, kind)) return true;
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;
     RCMVS_X3H_LIST(X3_CASE)
 #undef X3_CASE
@@ -904,6 +879,7 @@ long long conv3d_x3_weight_floats(int Ci, int Co, int kind) {      // size of on
 }
 
 long long conv3d_x3h_weight_floats(int Ci, int Co, int kind) {     // header (4 floats) + the fp16 pairs
+    if (conv3d_deep_supported(Ci, Co, kind)) return conv3d_deep_weight_floats(Ci, Co, kind);
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return 4 + (long long)X3<CI, CO, K, 2>::KSTEPS * 2 * X3<CI, CO, K, 2>::MT_ALL * 64 * 8 / 2;
     RCMVS_X3H_LIST(X3_CASE)
 #undef X3_CASE
@@ -922,6 +898,7 @@ int conv3d_x3_pack(const float* w, float* img, int Co, int Ci, int kind, int tra
 
 // wsc: two device floats {scale, 1 / scale} of the weight tensor (conv3d_x3_wscale)
 int conv3d_x3h_pack(const float* w, float* img, int Co, int Ci, int kind, int transposed, const float* wsc, hipStream_t st) {
+    if (conv3d_deep_supported(Ci, Co, kind)) return conv3d_deep_pack(w, img, Co, Ci, kind, transposed, wsc, st);
 #define X3_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) { \
         const int nthr = X3<CI, CO, K, 2>::KSTEPS * X3<CI, CO, K, 2>::MT_ALL * 64 * 8; \
         hipLaunchKernelGGL((x3_pack_kernel<CI, CO, K, 2>), dim3((nthr + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(img), transposed, wsc); \
@@ -1007,6 +984,7 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
 int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
                      int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d,
                      const float* xmax, float* ymax) {
+    if (xmax && conv3d_deep_supported(Ci, Co, kind)) return conv3d_deep_launch(x, wimg, scale, shift, res, y, B, D, H, W, Ci, Co, kind, relu, st, xmax, ymax);
     const int ysq = (s2d >> 1) & 1;            // `s2d` carries two flags: bit 0 = space-to-depth view of the input, bit 1 = square the output bound
     s2d &= 1;
     if (s2d && (kind != X3_P1 || Ci % 16 != 0)) return fail(-1, "conv3d_x3: the space-to-depth view needs the planar kind and Ci a multiple of 16");
