@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 101          /* 0.1.1 -- 101: rcmvs_bn_stats writes 2C + 1 doubles (the row count joined the sums: one SyncBatchNorm message);
+#define RCMVS_VERSION 102          /* 0.1.2 -- 102: rcmvs_depth_head_fwd accepts prob == NULL for D = 8; 101: rcmvs_bn_stats writes 2C + 1 doubles (the row count joined the sums: one SyncBatchNorm message);
                                       rcmvs_debug_warp_variance_fwd takes variants 0-3 only.  A caller built against 100 must be rebuilt: check
                                       rcmvs_version() >= the RCMVS_VERSION it was compiled with. */
 #define RCMVS_MAX_SRC_VIEWS 10     /* V-1 */
@@ -275,10 +275,16 @@ int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables,
 /* replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression and the
  * confidence gather of DepthNet_eval.forward (models/casmvsnet.py:293-309).
  *   x (B,D,h,w,8) channels-last, w_prob packed [27][8][1];  depth, conf (B,h,w);
- *   prob (B,D,h,w): required -- receives the logits, then the probabilities in place. */
+ *   prob (B,D,h,w): receives the logits, then the probabilities in place; required except for D = 8 (the cascade's last stage),
+ *   which runs as one launch with the logits in registers -- there it may be NULL (probabilities not stored). */
 int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
                          float* depth, float* conf, float* prob,
                          int B, int D, int h, int w, void* stream);
+/* the same with a dispatch override for tests and A/B timing: impl bit 0 = two launches also for D = 8, bit 1 = the generic
+ * (predicated) marching prob conv instead of the depth head's plain one */
+int rcmvs_debug_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
+                               float* depth, float* conf, float* prob,
+                               int B, int D, int h, int w, int impl, void* stream);
 
 /* ---- rendering-consistency branch --------------------------------------------------------- */
 /* F.interpolate(size=[Do,h,w], trilinear, align_corners=True) along the plane axis only

@@ -74,6 +74,7 @@ SIGNATURES = {
     "rcmvs_pack_conv2d_weight": [_p, _p, _i, _i, _i, _i, _p],
     "rcmvs_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_depth_head_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_debug_depth_head_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rcmvs_resize_planes_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_gu_sample_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_point_feats_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -144,7 +145,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, ctypes.c_int)
-    if lib.rcmvs_version() < 101:          # 101: rcmvs_bn_stats' buffer grew to 2C + 1 doubles (include/rcmvs.h)
+    if lib.rcmvs_version() < 102:          # 102: depth head without a probability buffer for D = 8 (include/rcmvs.h)
         raise RcmvsError("librcmvs_hip.so is older than this package")
     _lib = lib
     return lib

@@ -183,12 +183,12 @@ using namespace rcmvs;
 // `impl` of the rcmvs_debug_* twins (tests, A/B benches; 0 = the production dispatch): bit 0 = direct kernels only;
 // bits 1-3 and 5 = tuning configuration of the LDS-halo kernel; bit 4 = fp32-MFMA kernel before the LDS kernel where both
 // exist; bit 6 = skip the split-bf16 MFMA kernels (conv3d_x3.hip); bits 8-15 = block count of the x3 kernels; bits 16-23 = z chunk
-// of the marching prob conv.  Passed by value: the library keeps no dispatch state.
+// of the marching prob conv; bit 25 = its generic (predicated) form where the plain one would run.  Passed by value: the library keeps no dispatch state.
 struct ConvImpl {
     bool direct, prefer_lds, no_x3, ysq;
     int lds_cfg, x3_blocks;
     explicit ConvImpl(int on) : direct(on & 1), prefer_lds(!(on & 16)), no_x3((on >> 6) & 1), ysq((on >> 24) & 1),
-                                lds_cfg(((on >> 1) & 7) | (((on >> 5) & 1) << 3) | (((on >> 16) & 0xff) << 8)), x3_blocks((on >> 8) & 0xff) {}
+                                lds_cfg(((on >> 1) & 7) | (((on >> 5) & 1) << 3) | (((on >> 25) & 1) << 4) | (((on >> 16) & 0xff) << 8)), x3_blocks((on >> 8) & 0xff) {}
 };
 
 extern "C" {

@@ -151,6 +151,47 @@ constexpr int PM_TH = 8, PM_TW = 32, PM_HH = PM_TH + 2, PM_HW = PM_TW + 2, PM_ST
 constexpr int PM_PLANE = PM_HH * PM_HW * PM_STRIDE;          // floats per staged plane (16,320 B)
 constexpr int PM_NLD = (PM_HH * PM_HW * 2 + 255) / 256;      // float4 per thread per plane
 
+typedef float pm_f2v __attribute__((ext_vector_type(2)));
+// One halo row of a plane against its 72 weights (taps (kd, kh, 0..2) x 8 channels, 24 consecutive floats per kd at wrow, wrow + 72,
+// wrow + 144): 36 v_pk_fma_f32 into the three rolling accumulators (see prob_conv_march_kernel for why this is hand-placed).
+__device__ __forceinline__ void pm_row_fma(pm_f2v& acc_next, pm_f2v& acc_cur, pm_f2v& acc_prev, const pm_f2v (&xq)[3][4], const float* wrow) {
+    typedef pm_f2v f2v;
+#if defined(__AMDGCN__)
+    asm volatile("s_load_dwordx16 s[16:31], %[wp], 0x0\n\ts_load_dwordx8 s[32:39], %[wp], 0x40\n\t"
+                 "s_load_dwordx16 s[40:55], %[wp], 0x120\n\ts_load_dwordx8 s[56:63], %[wp], 0x160\n\t"
+                 "s_load_dwordx16 s[64:79], %[wp], 0x240\n\ts_load_dwordx8 s[80:87], %[wp], 0x280\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_pk_fma_f32 %[a0], %[x00], s[16:17], %[a0]\n\tv_pk_fma_f32 %[a1], %[x00], s[40:41], %[a1]\n\tv_pk_fma_f32 %[a2], %[x00], s[64:65], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x01], s[18:19], %[a0]\n\tv_pk_fma_f32 %[a1], %[x01], s[42:43], %[a1]\n\tv_pk_fma_f32 %[a2], %[x01], s[66:67], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x02], s[20:21], %[a0]\n\tv_pk_fma_f32 %[a1], %[x02], s[44:45], %[a1]\n\tv_pk_fma_f32 %[a2], %[x02], s[68:69], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x03], s[22:23], %[a0]\n\tv_pk_fma_f32 %[a1], %[x03], s[46:47], %[a1]\n\tv_pk_fma_f32 %[a2], %[x03], s[70:71], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x10], s[24:25], %[a0]\n\tv_pk_fma_f32 %[a1], %[x10], s[48:49], %[a1]\n\tv_pk_fma_f32 %[a2], %[x10], s[72:73], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x11], s[26:27], %[a0]\n\tv_pk_fma_f32 %[a1], %[x11], s[50:51], %[a1]\n\tv_pk_fma_f32 %[a2], %[x11], s[74:75], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x12], s[28:29], %[a0]\n\tv_pk_fma_f32 %[a1], %[x12], s[52:53], %[a1]\n\tv_pk_fma_f32 %[a2], %[x12], s[76:77], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x13], s[30:31], %[a0]\n\tv_pk_fma_f32 %[a1], %[x13], s[54:55], %[a1]\n\tv_pk_fma_f32 %[a2], %[x13], s[78:79], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x20], s[32:33], %[a0]\n\tv_pk_fma_f32 %[a1], %[x20], s[56:57], %[a1]\n\tv_pk_fma_f32 %[a2], %[x20], s[80:81], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x21], s[34:35], %[a0]\n\tv_pk_fma_f32 %[a1], %[x21], s[58:59], %[a1]\n\tv_pk_fma_f32 %[a2], %[x21], s[82:83], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x22], s[36:37], %[a0]\n\tv_pk_fma_f32 %[a1], %[x22], s[60:61], %[a1]\n\tv_pk_fma_f32 %[a2], %[x22], s[84:85], %[a2]\n\t"
+                 "v_pk_fma_f32 %[a0], %[x23], s[38:39], %[a0]\n\tv_pk_fma_f32 %[a1], %[x23], s[62:63], %[a1]\n\tv_pk_fma_f32 %[a2], %[x23], s[86:87], %[a2]\n\t"
+                 : [a0] "+v"(acc_next), [a1] "+v"(acc_cur), [a2] "+v"(acc_prev)
+                 : [wp] "s"(wrow),
+                   [x00] "v"(xq[0][0]), [x01] "v"(xq[0][1]), [x02] "v"(xq[0][2]), [x03] "v"(xq[0][3]),
+                   [x10] "v"(xq[1][0]), [x11] "v"(xq[1][1]), [x12] "v"(xq[1][2]), [x13] "v"(xq[1][3]),
+                   [x20] "v"(xq[2][0]), [x21] "v"(xq[2][1]), [x22] "v"(xq[2][2]), [x23] "v"(xq[2][3])
+                 : "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
+#else       // host pass of hipcc / the CPU emulation of the tests (tests/emu): the same 36 fused multiply-adds in the same order
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const float* wt = wrow + kw * 8 + 2 * pr;
+            acc_next = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[0], wt[1]}, acc_next);
+            acc_cur = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[72], wt[73]}, acc_cur);
+            acc_prev = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[144], wt[145]}, acc_prev);
+        }
+#endif
+}
+
 // Occupancy: 32.6 KB of LDS per block = five blocks per CU, and the register budget is held to five waves per SIMD to match
 // (round 3: at 107 VGPRs four blocks were resident, and the 1280 blocks of the two large stages ran as 1024 + 256 -- two rounds
 // for 1.25 rounds of work).  The z chunk is chosen per launch (prob_zchunk below) so that the grid fills those 1280 slots once.
@@ -224,40 +265,7 @@ __global__ __launch_bounds__(256, 5) void prob_conv_march_kernel(
         for (int kh = 0; kh < 3; ++kh) {
             if (kh < 2) read_row(kh + 1, xr[(kh + 1) & 1]);
             f2v (&xq)[3][4] = xr[kh & 1];
-#if defined(__AMDGCN__)
-            asm volatile("s_load_dwordx16 s[16:31], %[wp], 0x0\n\ts_load_dwordx8 s[32:39], %[wp], 0x40\n\t"
-                         "s_load_dwordx16 s[40:55], %[wp], 0x120\n\ts_load_dwordx8 s[56:63], %[wp], 0x160\n\t"
-                         "s_load_dwordx16 s[64:79], %[wp], 0x240\n\ts_load_dwordx8 s[80:87], %[wp], 0x280\n\t"
-                         "s_waitcnt lgkmcnt(0)\n\t"
-                         "v_pk_fma_f32 %[a0], %[x00], s[16:17], %[a0]\n\tv_pk_fma_f32 %[a1], %[x00], s[40:41], %[a1]\n\tv_pk_fma_f32 %[a2], %[x00], s[64:65], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x01], s[18:19], %[a0]\n\tv_pk_fma_f32 %[a1], %[x01], s[42:43], %[a1]\n\tv_pk_fma_f32 %[a2], %[x01], s[66:67], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x02], s[20:21], %[a0]\n\tv_pk_fma_f32 %[a1], %[x02], s[44:45], %[a1]\n\tv_pk_fma_f32 %[a2], %[x02], s[68:69], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x03], s[22:23], %[a0]\n\tv_pk_fma_f32 %[a1], %[x03], s[46:47], %[a1]\n\tv_pk_fma_f32 %[a2], %[x03], s[70:71], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x10], s[24:25], %[a0]\n\tv_pk_fma_f32 %[a1], %[x10], s[48:49], %[a1]\n\tv_pk_fma_f32 %[a2], %[x10], s[72:73], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x11], s[26:27], %[a0]\n\tv_pk_fma_f32 %[a1], %[x11], s[50:51], %[a1]\n\tv_pk_fma_f32 %[a2], %[x11], s[74:75], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x12], s[28:29], %[a0]\n\tv_pk_fma_f32 %[a1], %[x12], s[52:53], %[a1]\n\tv_pk_fma_f32 %[a2], %[x12], s[76:77], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x13], s[30:31], %[a0]\n\tv_pk_fma_f32 %[a1], %[x13], s[54:55], %[a1]\n\tv_pk_fma_f32 %[a2], %[x13], s[78:79], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x20], s[32:33], %[a0]\n\tv_pk_fma_f32 %[a1], %[x20], s[56:57], %[a1]\n\tv_pk_fma_f32 %[a2], %[x20], s[80:81], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x21], s[34:35], %[a0]\n\tv_pk_fma_f32 %[a1], %[x21], s[58:59], %[a1]\n\tv_pk_fma_f32 %[a2], %[x21], s[82:83], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x22], s[36:37], %[a0]\n\tv_pk_fma_f32 %[a1], %[x22], s[60:61], %[a1]\n\tv_pk_fma_f32 %[a2], %[x22], s[84:85], %[a2]\n\t"
-                         "v_pk_fma_f32 %[a0], %[x23], s[38:39], %[a0]\n\tv_pk_fma_f32 %[a1], %[x23], s[62:63], %[a1]\n\tv_pk_fma_f32 %[a2], %[x23], s[86:87], %[a2]\n\t"
-                         : [a0] "+v"(acc_next), [a1] "+v"(acc_cur), [a2] "+v"(acc_prev)
-                         : [wp] "s"(wp + kh * 24),
-                           [x00] "v"(xq[0][0]), [x01] "v"(xq[0][1]), [x02] "v"(xq[0][2]), [x03] "v"(xq[0][3]),
-                           [x10] "v"(xq[1][0]), [x11] "v"(xq[1][1]), [x12] "v"(xq[1][2]), [x13] "v"(xq[1][3]),
-                           [x20] "v"(xq[2][0]), [x21] "v"(xq[2][1]), [x22] "v"(xq[2][2]), [x23] "v"(xq[2][3])
-                         : "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
-#else       // host pass of hipcc / the CPU emulation of the tests (tests/emu): the same 36 fused multiply-adds in the same order
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    const float* wt = wp + kh * 24 + kw * 8 + 2 * pr;
-                    acc_next = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[0], wt[1]}, acc_next);
-                    acc_cur = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[72], wt[73]}, acc_cur);
-                    acc_prev = __builtin_elementwise_fma(xq[kw][pr], (f2v){wt[144], wt[145]}, acc_prev);
-                }
-#endif
+            pm_row_fma(acc_next, acc_cur, acc_prev, xq, wp + kh * 24);
         }
         const int zo = z - 1;                                       // complete now
         if (live && zo >= z0 && zo < z1) {
@@ -275,6 +283,142 @@ __global__ __launch_bounds__(256, 5) void prob_conv_march_kernel(
         }
         __syncthreads();
         buf ^= 1;
+    }
+}
+
+// ---- the same march for the depth head (no BatchNorm, no skip tensor: models/modules.py:489 `prob`), round 4 -------------------------
+// What the generic kernel above spends next to its 108 v_pk_fma_f32 per plane and wave (profiles/r3_prob_conv.txt: 178 VALU) is
+// mostly bookkeeping of its predicates: the in-range tests of the three halo loads, of the LDS stores and of the output live in
+// 64-bit masks, the row block's 72 scalar weights leave no SGPRs for them, and every plane restores them with ~24 v_readlane_b32.
+// Here nothing is predicated: halo loads and the logit store go through buffer descriptors (out of range -> zero / dropped), a lane
+// with no halo element writes the PAD float4 of a voxel it owns (the row stride of 12 floats has one), planes are float4 arrays
+// (ds_write_b128 instead of the conflicting ds_write2_b32 pairs).
+// FUSE_D = 8: the last stage of the cascade (D = 8 in ONE chunk): the z loop is unrolled, the eight logits of a pixel stay in
+// registers and the softmax / soft-argmin / 4-plane confidence of softmax_regress_kernel (depth_head.hip; same operations in the
+// same order: bit-identical) finish in the same thread -- no logit round trip, no second launch; `prob` is optional then.
+template <int FUSE_D>
+__global__ __launch_bounds__(256, 5) void prob_conv_march_plain_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int D, int H, int W, int tiles_w, int tiles_h, int zchunk,
+    const float* __restrict__ planes, float* __restrict__ depth, float* __restrict__ conf) {
+    typedef pm_f2v f2v;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float4 plane4[2][PM_PLANE / 4];
+    constexpr int OOB = 0x7ffffff0;
+    const int b = blockIdx.z, zc = blockIdx.y;
+    const unsigned t2 = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = t2 % tiles_w, th = t2 / tiles_w;
+    const int h0 = th * PM_TH, w0 = tw * PM_TW, z0 = zc * zchunk;
+    const int z1 = min(D, z0 + zchunk);                          // outputs z0 .. z1-1, input planes z0-1 .. z1
+    const int lw = threadIdx.x % PM_TW, lh = threadIdx.x / PM_TW;
+    const int plane_bytes = H * W * 32;
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)b * D * H * W * 8), (short)0, D * plane_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y ? y + (long long)b * D * H * W : nullptr, (short)0, y ? D * H * W * 4 : 0, 0x00020000);
+    // this thread's share of a plane's halo: element e = (halo voxel, float4 half)
+    int goff[PM_NLD], l4[PM_NLD];
+#pragma unroll
+    for (int i = 0; i < PM_NLD; ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int v = e >> 1, c4 = e & 1;
+        const int hh = v / PM_HW, hw_ = v - hh * PM_HW;
+        const int ih = h0 + hh - 1, iw = w0 + hw_ - 1;
+        const bool has = e < PM_HH * PM_HW * 2;
+        goff[i] = (has && ih >= 0 && ih < H && iw >= 0 && iw < W) ? ((ih * W + iw) * 8 + c4 * 4) * 4 : OOB;
+        l4[i] = has ? v * 3 + c4 : (threadIdx.x >> 1) * 3 + 2;    // no element: the pad float4 of a voxel this thread writes anyway
+    }
+    u32x4 pf[PM_NLD];
+    auto fetch = [&](int z) {
+        const bool zin = z >= 0 && z < D;
+        const int zoff = zin ? z * plane_bytes : 0;
+#pragma unroll
+        for (int i = 0; i < PM_NLD; ++i) pf[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, zin ? goff[i] : OOB, zoff, 0);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PM_NLD; ++i) plane4[buf][l4[i]] = __builtin_bit_cast(float4, pf[i]);
+    };
+    fetch(z0 - 1);
+    stash(0);
+    fetch(z0);
+    __syncthreads();
+    f2v acc_prev = (f2v){0.f, 0.f}, acc_cur = (f2v){0.f, 0.f};      // out[z-1] and out[z] while plane z is processed
+    const int oh = h0 + lh, ow = w0 + lw;
+    const bool live = oh < H && ow < W;
+    const int ooff = live ? (oh * W + ow) * 4 : OOB;
+    float lg[FUSE_D > 0 ? FUSE_D : 1];
+    auto plane_step = [&](int z, int buf) {
+        f2v acc_next = (f2v){0.f, 0.f};                             // out[z+1]
+        const float* tp0 = reinterpret_cast<const float*>(&plane4[buf][0]) + (lh * PM_HW + lw) * PM_STRIDE;
+        f2v xr[2][3][4];
+        auto read_row = [&](int kh, f2v (&q)[3][4]) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* tp = tp0 + (kh * PM_HW + kw) * PM_STRIDE;
+                const float4 xa = *reinterpret_cast<const float4*>(tp), xc = *reinterpret_cast<const float4*>(tp + 4);
+                q[kw][0] = (f2v){xa.x, xa.y}; q[kw][1] = (f2v){xa.z, xa.w}; q[kw][2] = (f2v){xc.x, xc.y}; q[kw][3] = (f2v){xc.z, xc.w};
+            }
+        };
+        read_row(0, xr[0]);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            if (kh < 2) read_row(kh + 1, xr[(kh + 1) & 1]);
+            pm_row_fma(acc_next, acc_cur, acc_prev, xr[kh & 1], wp + kh * 24);
+        }
+        const float v = acc_prev.x + acc_prev.y;                    // out[z - 1] is complete now
+        acc_prev = acc_cur; acc_cur = acc_next;
+        return v;
+    };
+    if constexpr (FUSE_D == 0) {
+        int buf = 0;
+        for (int z = z0 - 1; z <= z1; ++z) {
+            const float v = plane_step(z, buf);
+            const int zo = z - 1;
+            if (zo >= z0 && zo < z1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, ooff, zo * H * W * 4, 0);
+            if (z < z1) {
+                stash(buf ^ 1);                                     // plane z+1 (fetched during the previous iteration)
+                if (z + 2 <= z1) fetch(z + 2);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+#pragma unroll
+        for (int z = -1; z <= FUSE_D; ++z) {                        // (z0 = 0, z1 = D = FUSE_D)
+            const float v = plane_step(z, (z + 1) & 1);
+            if (z >= 1) lg[z - 1] = v;
+            if (z < FUSE_D) {
+                stash(z & 1);
+                if (z + 2 <= FUSE_D) fetch(z + 2);
+            }
+            __syncthreads();
+        }
+        // softmax over the planes, soft-argmin depth, confidence window (models/casmvsnet.py:293-309; depth_head.hip, LP = 1)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < FUSE_D; ++k) mx = fmaxf(mx, lg[k]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FUSE_D; ++k) { lg[k] = expf(lg[k] - mx); sum += lg[k]; }
+        const long long hw = (long long)H * W;
+        const long long pix = live ? (long long)oh * W + ow : 0;
+        const float2 pl = reinterpret_cast<const float2*>(planes)[(long long)b * hw + pix];
+        float dsum = 0.0f, isum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FUSE_D; ++k) {
+            lg[k] = lg[k] / sum;
+            if (y) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[k]), yrs, ooff, k * H * W * 4, 0);
+            dsum = fmaf(lg[k], fmaf((float)k, pl.y, pl.x), dsum);
+            isum = fmaf(lg[k], (float)k, isum);
+        }
+        int idx = (int)isum;                       // .long(): truncation
+        idx = idx < 0 ? 0 : (idx > FUSE_D - 1 ? FUSE_D - 1 : idx);
+        float c = 0.0f;                            // p[i-1] + p[i] + p[i+1] + p[i+2], zero padded
+#pragma unroll
+        for (int k = 0; k < FUSE_D; ++k)
+            if (k >= idx - 1 && k <= idx + 2) c += lg[k];
+        if (live) {
+            depth[(long long)b * hw + pix] = dsum;
+            conf[(long long)b * hw + pix] = c;
+        }
     }
 }
 
@@ -340,6 +484,11 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
         const int tw_ = (W + PM_TW - 1) / PM_TW, th_ = (H + PM_TH - 1) / PM_TH;
         const int zc_force = (g_lds_cfg >> 8) & 0xff;           // test / tuning override of the z chunk
         const int zc = zc_force ? (zc_force < D ? zc_force : D) : prob_zchunk(B * tw_ * th_, D);
+        if (!scale && !shift && !res && !relu && !(g_lds_cfg & 16) && (long long)D * H * W * 32 < 0x7ffffff0LL) {      // the depth head's form (bit 4 of lds_cfg: the generic kernel)
+            hipLaunchKernelGGL(prob_conv_march_plain_kernel<0>, dim3(tw_ * th_, (D + zc - 1) / zc, B), dim3(256), 0, st, x, wp, y, D, H, W, tw_, th_, zc,
+                               (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+            return launch_status("conv3d_lds(prob, marching, plain)");
+        }
         hipLaunchKernelGGL(prob_conv_march_kernel, dim3(tw_ * th_, (D + zc - 1) / zc, B), dim3(256), 0, st, x, wp, scale, shift, res, y,
                            D, H, W, tw_, th_, relu, zc);
         return launch_status("conv3d_lds(prob, marching)");
@@ -355,6 +504,16 @@ int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const
 #undef RCMVS_LDS_LAUNCH
     (void)Co;
     return fail(-1, "conv3d_lds: unsupported Ci=%d", Ci);
+}
+
+// depth head with D = 8 in one launch: prob conv + softmax + soft-argmin + confidence (prob_conv_march_plain_kernel<8>); prob may be null
+bool prob_head_fused_supported(int D, int H, int W) { return D == 8 && (long long)D * H * W * 32 < 0x7ffffff0LL; }
+int prob_head_fused_launch(const float* x, const float* wp, const float* planes, float* depth, float* conf, float* prob,
+                           int B, int D, int H, int W, hipStream_t st) {
+    if (!prob_head_fused_supported(D, H, W)) return fail(-1, "prob_head_fused: D = %d is not the fused form", D);
+    const int tw_ = (W + PM_TW - 1) / PM_TW, th_ = (H + PM_TH - 1) / PM_TH;
+    hipLaunchKernelGGL(prob_conv_march_plain_kernel<8>, dim3(tw_ * th_, 1, B), dim3(256), 0, st, x, wp, prob, D, H, W, tw_, th_, D, planes, depth, conf);
+    return launch_status("depth_head(fused, D = 8)");
 }
 
 }  // namespace rcmvs

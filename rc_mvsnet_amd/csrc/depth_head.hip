@@ -4,6 +4,8 @@
 // Replaces CostRegNet.prob (models/modules.py:489,500), F.softmax, depth_regression (x2),
 // F.pad + avg_pool3d and torch.gather in DepthNet_eval.forward (models/casmvsnet.py:293-309).
 //
+// Round 4: with D = 8 (the last stage) ONE launch: the marching prob conv keeps a pixel's eight logits in registers and finishes
+// them itself (conv3d_lds.hip, prob_conv_march_plain_kernel<8>; bit-identical to the two launches; `prob` optional).  Otherwise:
 // Two launches: (1) the prob conv runs on the LDS-staged halo kernel of conv3d_lds.hip (Cout = 1: the
 // logits land in the caller's (B,D,h,w) probability buffer); (2) one thread per pixel turns its logit
 // column into probabilities IN PLACE (max, exp, sum, divide -- coalesced plane-major accesses, the
@@ -22,6 +24,9 @@ namespace rcmvs {
 
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                       int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int lds_cfg);   // conv3d_lds.hip
+bool prob_head_fused_supported(int D, int H, int W);                                                       // conv3d_lds.hip
+int prob_head_fused_launch(const float* x, const float* wp, const float* planes, float* depth, float* conf, float* prob,
+                           int B, int D, int H, int W, hipStream_t st);
 
 // LP adjacent lanes share one pixel and own the planes k = j, j + LP, ... (at most 16 each, held in registers): the logit
 // column is read ONCE with all of a lane's loads in flight, max / sum / soft-argmin / window sums are combined across the
@@ -62,8 +67,8 @@ __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict_
         v[i] = v[i] / sum;
         if (k < D) {
             if (live) col[(long long)k * hw] = v[i];
-            dsum += v[i] * (pl.x + (float)k * pl.y);
-            isum += v[i] * (float)k;
+            dsum = fmaf(v[i], fmaf((float)k, pl.y, pl.x), dsum);       // (explicit: the one-launch form of conv3d_lds.hip must round alike)
+            isum = fmaf(v[i], (float)k, isum);
         }
     }
 #pragma unroll
@@ -88,13 +93,15 @@ __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict_
 
 using namespace rcmvs;
 
-extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
-                                    float* depth, float* conf, float* prob,
-                                    int B, int D, int h, int w, void* stream) {
-    RCMVS_REQUIRE(x && w_prob && planes && depth && conf && prob, "depth_head_fwd: null pointer (prob is required: it doubles as the logit scratch)");
+/* impl (tests, A/B): bit 0 = two launches even where the one-launch form exists (D = 8); bit 1 = the generic marching prob conv */
+static int depth_head_fwd(const float* x, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
+                          int B, int D, int h, int w, int impl, void* stream) {
+    RCMVS_REQUIRE(x && w_prob && planes && depth && conf, "depth_head_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "depth_head_fwd: bad sizes");
     hipStream_t st = as_stream(stream);
-    int rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st, 0);
+    if (!(impl & 1) && prob_head_fused_supported(D, h, w)) return prob_head_fused_launch(x, w_prob, planes, depth, conf, prob, B, D, h, w, st);
+    RCMVS_REQUIRE(prob, "depth_head_fwd: prob is required for D = %d (it doubles as the logit scratch; only the D = 8 form runs without)", D);
+    int rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st, (impl & 2) ? 16 : 0);
     if (rc) return rc;
     const long long hw = (long long)h * w;
     RCMVS_REQUIRE(D <= 64, "depth_head_fwd: at most 64 depth hypotheses per stage (got %d)", D);
@@ -102,4 +109,13 @@ extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const f
     else if (D <= 32) hipLaunchKernelGGL(softmax_regress_kernel<2>, dim3((unsigned)cdiv(hw * 2, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
     else              hipLaunchKernelGGL(softmax_regress_kernel<4>, dim3((unsigned)cdiv(hw * 4, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
     return launch_status("depth_head_fwd");
+}
+
+extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
+                                    int B, int D, int h, int w, void* stream) {
+    return depth_head_fwd(x, w_prob, planes, depth, conf, prob, B, D, h, w, 0, stream);
+}
+extern "C" int rcmvs_debug_depth_head_fwd(const float* x, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
+                                          int B, int D, int h, int w, int impl, void* stream) {
+    return depth_head_fwd(x, w_prob, planes, depth, conf, prob, B, D, h, w, impl, stream);
 }

@@ -452,17 +452,24 @@ def fpn_out_folded(lat, up, tables, ysq_absmax=None):
 
 
 # ------------------------------------------------------------------------------- K4
+DEPTH_HEAD_IMPL = 0          # tests / A-B timing: bit 0 = two launches also for D = 8, bit 1 = the generic marching prob conv
+
+
 def depth_head(x8, w_prob_packed, planes, want_prob=False):
-    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)]."""
+    """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)].  With D = 8 (the cascade's last stage) the head is one
+    launch that keeps the logits in registers; the probability volume is then stored only when asked for."""
     B, D, h, w, C = x8.shape
     if C != 8:
         raise _lib.RcmvsError("depth_head: the prob conv takes 8 channels")
     depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
-    prob = torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32)     # logit scratch -> probabilities
-    _lib.check(_lib.load().rcmvs_depth_head_fwd(_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
-                                                _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
-                                                _stream()), "depth_head_fwd")
+    one_launch = D == 8 and not (DEPTH_HEAD_IMPL & 1)
+    prob = None if one_launch and not want_prob else torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32)     # logit scratch -> probabilities
+    args = (_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"), _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w)
+    if DEPTH_HEAD_IMPL:
+        _lib.check(_lib.load().rcmvs_debug_depth_head_fwd(*args, DEPTH_HEAD_IMPL, _stream()), "debug_depth_head_fwd")
+    else:
+        _lib.check(_lib.load().rcmvs_depth_head_fwd(*args, _stream()), "depth_head_fwd")
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 

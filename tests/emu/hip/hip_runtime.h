@@ -334,6 +334,11 @@ inline void __builtin_amdgcn_raw_buffer_store_b128_emu(emu_v4u v, __amdgpu_buffe
 }
 #define __builtin_amdgcn_raw_buffer_store_b128(d, r, v, s, a) __builtin_amdgcn_raw_buffer_store_b128_emu((d), (r), (v), (s), (a))
 #define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b64_emu((r), (v), (s), (a))
+inline void __builtin_amdgcn_raw_buffer_store_b32_emu(unsigned v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    const unsigned off = (unsigned)voffset + (unsigned)soffset;
+    if (off < r.num_records && off + 4u <= r.num_records) std::memcpy(const_cast<char*>(r.base) + off, &v, 4);
+}
+#define __builtin_amdgcn_raw_buffer_store_b32(d, r, v, s, a) __builtin_amdgcn_raw_buffer_store_b32_emu((d), (r), (v), (s), (a))
 
 // buffer_load ... lds (direct-to-LDS DMA): lane i of the wave writes `size` bytes at ldsptr + i * size.  Emulated synchronously,
 // which is what the data looks like once the s_waitcnt vmcnt(0) + barrier that must follow on hardware have passed.

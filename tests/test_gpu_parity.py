@@ -809,6 +809,30 @@ def test_depth_head_vs_oracle(hip, D, h, w):
     assert float((conf.cpu() - conf_ref).abs()[safe].max()) < 1e-4
 
 
+@pytest.mark.parametrize("D,h,w", [(8, 12, 16), (8, 21, 70), (48, 16, 24), (32, 9, 130)])
+def test_depth_head_forms_are_bit_identical(hip, D, h, w):
+    """The depth head's own marching prob conv (buffer loads / stores, nothing predicated) gives the bits of the generic one, and the
+    one-launch form of the last stage (D = 8: logits kept in registers, softmax / soft-argmin / confidence in the same thread) the
+    bits of the two launches -- with and without the probability volume."""
+    g = torch.Generator().manual_seed(D + h)
+    x = gpu(torch.randn(2, D, h, w, 8, generator=g))
+    wp = hip.pack_conv3d_weight(gpu(torch.randn(1, 8, 3, 3, 3, generator=g) * 0.5))
+    planes = gpu(torch.stack((425.0 + 50 * torch.rand(2, h, w, generator=g), 1.0 + 5 * torch.rand(2, h, w, generator=g)), dim=-1))
+    outs = {}
+    try:
+        for impl in (0, 1, 2, 3):
+            hip.DEPTH_HEAD_IMPL = impl
+            outs[impl] = [t.cpu() for t in hip.depth_head(x, wp, planes, want_prob=True)]
+        hip.DEPTH_HEAD_IMPL = 0
+        outs["noprob"] = [t.cpu() for t in hip.depth_head(x, wp, planes)]
+    finally:
+        hip.DEPTH_HEAD_IMPL = 0
+    for key in (1, 2, 3):
+        for a, b_ in zip(outs[0], outs[key]):
+            assert torch.equal(a, b_), (key, float((a - b_).abs().max()))
+    assert torch.equal(outs["noprob"][0], outs[0][0]) and torch.equal(outs["noprob"][1], outs[0][1])
+
+
 def test_depth_head_golden(hip):
     g = load_golden("depth_head")
     # feed the golden logits through a 1-hot prob conv: x channel 0 = logits, centre tap weight 1
