@@ -280,11 +280,15 @@ int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables,
 int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
                          float* depth, float* conf, float* prob,
                          int B, int D, int h, int w, void* stream);
-/* the same with a dispatch override for tests and A/B timing: impl bit 0 = two launches also for D = 8, bit 1 = the generic
- * (predicated) marching prob conv instead of the depth head's plain one */
-int rcmvs_debug_depth_head_fwd(const float* x, const float* w_prob, const float* planes,
-                               float* depth, float* conf, float* prob,
-                               int B, int D, int h, int w, int impl, void* stream);
+/* the same with an activation bound and a dispatch override.
+ *   x_absmax (may be NULL): bound of max|x| in the RCMVS_ABSMAX_FLOATS slot format (rcmvs_absmax_fwd, or the y_absmax a scaled
+ *     convolution left) -> the prob conv runs on the matrix cores in fp16 pairs (csrc/prob_pair.hip; w_prob must be the full blob
+ *     of rcmvs_pack_conv3d_weight(Co = 1, Ci = 8)); NULL -> the exact fp32 form, as rcmvs_depth_head_fwd.
+ *   impl (0 in production; tests and A/B timing): bit 0 = two launches also for D = 8, bit 1 = the generic (predicated) marching
+ *     prob conv instead of the depth head's plain one, bit 2 = the fp32 form although a bound was given, bits 8-15 = z chunk. */
+int rcmvs_depth_head_scaled_fwd(const float* x, const float* x_absmax, const float* w_prob, const float* planes,
+                                float* depth, float* conf, float* prob,
+                                int B, int D, int h, int w, int impl, void* stream);
 
 /* ---- rendering-consistency branch --------------------------------------------------------- */
 /* F.interpolate(size=[Do,h,w], trilinear, align_corners=True) along the plane axis only

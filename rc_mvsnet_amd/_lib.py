@@ -74,7 +74,7 @@ SIGNATURES = {
     "rcmvs_pack_conv2d_weight": [_p, _p, _i, _i, _i, _i, _p],
     "rcmvs_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_depth_head_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "rcmvs_debug_depth_head_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rcmvs_depth_head_scaled_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rcmvs_resize_planes_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_gu_sample_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_point_feats_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

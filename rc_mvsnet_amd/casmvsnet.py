@@ -21,6 +21,7 @@ Execution:
 import os
 
 FP16_PAIR_DEFAULT = True       # inference CostRegNet on the fp16-pair matrix-core form unless RCMVS_FP16_PAIR=0 (the exact bf16 triple)
+HEAD_PAIR = os.environ.get("RCMVS_HEAD_PAIR", "1") != "0"       # ... and the depth head's prob conv (csrc/prob_pair.hip); 0 = fp32 FMA chains there
 DEEP_PAIR = os.environ.get("RCMVS_DEEP_PAIR", "1") != "0"       # ... its deep levels (conv5-7) included (csrc/conv3d_deep.hip); 0 = fp32 MFMAs there
 
 import torch
@@ -493,7 +494,7 @@ class CostRegNet(nn.Module):
     (B,1,D,h,w) logits); the cascade uses ``features_cl`` + the fused depth head instead."""
 
     _LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")
-    BOUND_ROWS = 10         # rows of the activation-bound buffer of the fp16-pair form: the input volume + nine layer outputs
+    BOUND_ROWS = 11         # rows of the activation-bound buffer of the fp16-pair form: the input volume + ten layer outputs (the last one: the depth head's input)
 
     def __init__(self, in_channels, base_channels):
         super().__init__()
@@ -558,7 +559,7 @@ class CostRegNet(nn.Module):
             t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True)
             t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True)
             return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True)
-        b = [x_absmax[i] for i in range(1, self.BOUND_ROWS)]      # bounds of conv0, 1, 2, 3, 9, 7, 4, 5, 6 (zero on entry: the caller's one fill per scene)
+        b = [x_absmax[i] for i in range(1, self.BOUND_ROWS)]      # bounds of conv0, 1, 2, 3, 9, 7, 4, 5, 6, 11 (zero on entry: the caller's one fill per scene)
         x_absmax = x_absmax[0]
         conv0 = ops.conv3d(x, *p["conv0"], relu=True, x_absmax=x_absmax, y_absmax=b[0])
         conv1 = ops.conv3d(conv0, *p["conv1"], stride=2, relu=True, x_absmax=b[0], y_absmax=b[1])
@@ -574,7 +575,7 @@ class CostRegNet(nn.Module):
             t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)
             t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True, y_absmax=b[5])
         t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True, x_absmax=b[5], y_absmax=b[4])
-        return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True, x_absmax=b[4])
+        return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True, x_absmax=b[4], y_absmax=b[9])      # (the depth head's bound)
 
     def features_cl_train(self, x):
         """Train-mode twin of ``features_cl`` (batch-statistics BatchNorm, autograd through the HIP kernels:
@@ -788,7 +789,8 @@ class _CascadeBase(nn.Module):
                     ops.absmax(f_cl, square=True, out=vmax[0])
             plan = cr.hip_plan()
             x8 = cr.features_cl(var, vmax, plan)
-            depth, conf = ops.depth_head(x8, plan["prob"], planes)
+            # ... and so does the depth head (prob conv on the matrix cores, csrc/prob_pair.hip; RCMVS_HEAD_PAIR=0: the fp32 form)
+            depth, conf = ops.depth_head(x8, plan["prob"], planes, x_absmax=vmax[CostRegNet.BOUND_ROWS - 1] if vmax is not None and HEAD_PAIR else None)
             out = {"depth": depth, "photometric_confidence": conf}
             if self.TRAIN_VARIANT:
                 small = F.interpolate(imgs.reshape(B * V, 3, H, W), (h, w), mode="bilinear", align_corners=False)

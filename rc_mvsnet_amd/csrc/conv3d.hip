@@ -163,7 +163,8 @@ int conv3d_x3_wscale(const float* w, int n, float* out, hipStream_t st);
 
 // packed weight blob = [27][Ci][Co] (direct kernels), then the fp32-MFMA image when the pair has one, then the x3 images of
 // the four kinds (each present when the pair has that kernel), then the fp16-pair images of the four kinds, then 4 floats
-// {weight scale, 1 / scale, -, -} (what conv3d_x3_wscale computed for the pack kernels)
+// {weight scale, 1 / scale, -, -} (what conv3d_x3_wscale computed for the pack kernels), then -- (Ci, Co) = (8, 1) only -- the
+// depth head's fp16-pair image (prob_pair.hip)
 static inline long long direct_weight_floats(int Ci, int Co) { return 27LL * Ci * Co; }
 static inline long long x3_image_offset(int Ci, int Co, int kind) {
     long long off = direct_weight_floats(Ci, Co) + (conv3d_mfma_supported(Ci, Co, 0) ? mfma_weight_floats_host(Ci, Co) : 0);
@@ -175,6 +176,12 @@ static inline long long x3h_image_offset(int Ci, int Co, int kind) {
     for (int k = 0; k < kind; ++k) off += conv3d_x3h_weight_floats(Ci, Co, k);
     return off;
 }
+// prob_pair.hip: the depth head's prob conv (8 -> 1) on the matrix cores; its weight image closes the blob of that channel pair
+long long prob_pair_weight_floats();
+int prob_pair_pack(const float* w, float* img, const float* wsc, hipStream_t st);
+static inline bool has_prob_pair(int Ci, int Co) { return Ci == 8 && Co == 1; }
+static inline long long prob_pair_image_offset(int Ci, int Co) { return x3h_image_offset(Ci, Co, X3_NKINDS) + 4; }
+long long prob_pair_blob_offset() { return prob_pair_image_offset(8, 1); }           // (for depth_head.hip)
 
 }  // namespace rcmvs
 
@@ -198,7 +205,7 @@ long long rcmvs_packed_weight_floats(int Co, int Ci) {
     long long n = direct_weight_floats(Ci, Co);
     if (conv3d_mfma_supported(Ci, Co, 0)) n += mfma_weight_floats_host(Ci, Co);
     for (int k = 0; k < X3_NKINDS; ++k) n += conv3d_x3_weight_floats(Ci, Co, k) + conv3d_x3h_weight_floats(Ci, Co, k);
-    return n + 4;
+    return n + 4 + (has_prob_pair(Ci, Co) ? prob_pair_weight_floats() : 0);
 }
 
 // Which kernel family a forward call lands on (shared by the dispatchers and by the selective weight pack below, so the two cannot
@@ -224,8 +231,8 @@ static ConvSel conv_select(int Ci, int Co, int mode, bool planar, bool scaled, c
 }
 
 // Images of a packed-weight blob as a bit mask: 1 = direct / LDS-halo layout, 2 = fp32-MFMA fragments, 4 << k = split-bf16 image of
-// kind k, 256 << k = fp16-pair image of kind k.
-enum { IMG_DIRECT = 1, IMG_MFMA = 2, IMG_X3 = 4, IMG_X3H = 256, IMG_ALL = 0x7fffffff };
+// kind k, 256 << k = fp16-pair image of kind k, 1 << 16 = the depth head's fp16-pair image (8 -> 1 only).
+enum { IMG_DIRECT = 1, IMG_MFMA = 2, IMG_X3 = 4, IMG_X3H = 256, IMG_PROB_PAIR = 1 << 16, IMG_ALL = 0x7fffffff };
 
 int rcmvs_conv3d_images(int Co, int Ci, int stride, int transposed, int planar) {
     // the image the PRODUCTION dispatch (rcmvs_conv3d_fwd / rcmvs_deconv3d_fwd, no activation bound) reads for this layer
@@ -265,6 +272,11 @@ int rcmvs_pack_conv3d_weight_sel(const float* w, float* packed, int Co, int Ci, 
         if (!(images & (IMG_X3H << k)) || !conv3d_x3h_supported(Ci, Co, k) || ((k == 2) != (transposed == 1))) continue;
         if (!scaled) { rc = conv3d_x3_wscale(w, n, wsc, as_stream(stream)); if (rc) return rc; scaled = true; }
         rc = conv3d_x3h_pack(w, packed + x3h_image_offset(Ci, Co, k), Co, Ci, k, transposed, wsc, as_stream(stream));
+        if (rc) return rc;
+    }
+    if ((images & IMG_PROB_PAIR) && has_prob_pair(Ci, Co) && !transposed) {
+        if (!scaled) { rc = conv3d_x3_wscale(w, n, wsc, as_stream(stream)); if (rc) return rc; }
+        rc = prob_pair_pack(w, packed + prob_pair_image_offset(Ci, Co), wsc, as_stream(stream));
         if (rc) return rc;
     }
     return 0;

@@ -25,6 +25,10 @@ namespace rcmvs {
 int conv3d_lds_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                       int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int lds_cfg);   // conv3d_lds.hip
 bool prob_head_fused_supported(int D, int H, int W);                                                       // conv3d_lds.hip
+bool prob_pair_supported(int D, int H, int W);                                                             // prob_pair.hip
+int prob_pair_launch(const float* x, const float* wimg, const float* xmax, float* y, const float* planes, float* depth, float* conf,
+                     int B, int D, int H, int W, bool fuse, int zc_force, hipStream_t st);
+long long prob_pair_blob_offset();                                                                         // conv3d.hip
 int prob_head_fused_launch(const float* x, const float* wp, const float* planes, float* depth, float* conf, float* prob,
                            int B, int D, int H, int W, hipStream_t st);
 
@@ -93,18 +97,26 @@ __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict_
 
 using namespace rcmvs;
 
-/* impl (tests, A/B): bit 0 = two launches even where the one-launch form exists (D = 8); bit 1 = the generic marching prob conv */
-static int depth_head_fwd(const float* x, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
+/* impl (tests, A/B): bit 0 = two launches even where the one-launch form exists (D = 8); bit 1 = the generic marching prob conv;
+ * bit 2 = the VALU prob conv although a bound was given; bits 8-15 = z chunk of the prob conv (0 = chosen per launch).
+ * xmax: bound of max|x| (ABSMAX slot format) -> the matrix-core prob conv of prob_pair.hip (fp16 pairs); NULL -> the exact VALU form */
+static int depth_head_fwd(const float* x, const float* xmax, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
                           int B, int D, int h, int w, int impl, void* stream) {
     RCMVS_REQUIRE(x && w_prob && planes && depth && conf, "depth_head_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "depth_head_fwd: bad sizes");
+    RCMVS_REQUIRE(D <= 64, "depth_head_fwd: at most 64 depth hypotheses per stage (got %d)", D);
     hipStream_t st = as_stream(stream);
-    if (!(impl & 1) && prob_head_fused_supported(D, h, w)) return prob_head_fused_launch(x, w_prob, planes, depth, conf, prob, B, D, h, w, st);
+    const int zc_force = (impl >> 8) & 0xff;
+    const bool pair = xmax && !(impl & 4) && prob_pair_supported(D, h, w);
+    int rc;
+    if (pair && D == 8 && !(impl & 1))
+        return prob_pair_launch(x, w_prob + prob_pair_blob_offset(), xmax, prob, planes, depth, conf, B, D, h, w, true, 0, st);
+    if (!pair && !(impl & 1) && prob_head_fused_supported(D, h, w)) return prob_head_fused_launch(x, w_prob, planes, depth, conf, prob, B, D, h, w, st);
     RCMVS_REQUIRE(prob, "depth_head_fwd: prob is required for D = %d (it doubles as the logit scratch; only the D = 8 form runs without)", D);
-    int rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st, (impl & 2) ? 16 : 0);
+    if (pair) rc = prob_pair_launch(x, w_prob + prob_pair_blob_offset(), xmax, prob, nullptr, nullptr, nullptr, B, D, h, w, false, zc_force, st);
+    else rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st, ((impl & 2) ? 16 : 0) | (zc_force << 8));
     if (rc) return rc;
     const long long hw = (long long)h * w;
-    RCMVS_REQUIRE(D <= 64, "depth_head_fwd: at most 64 depth hypotheses per stage (got %d)", D);
     if (D <= 16)      hipLaunchKernelGGL(softmax_regress_kernel<1>, dim3((unsigned)cdiv(hw, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
     else if (D <= 32) hipLaunchKernelGGL(softmax_regress_kernel<2>, dim3((unsigned)cdiv(hw * 2, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
     else              hipLaunchKernelGGL(softmax_regress_kernel<4>, dim3((unsigned)cdiv(hw * 4, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
@@ -113,9 +125,9 @@ static int depth_head_fwd(const float* x, const float* w_prob, const float* plan
 
 extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
                                     int B, int D, int h, int w, void* stream) {
-    return depth_head_fwd(x, w_prob, planes, depth, conf, prob, B, D, h, w, 0, stream);
+    return depth_head_fwd(x, nullptr, w_prob, planes, depth, conf, prob, B, D, h, w, 0, stream);
 }
-extern "C" int rcmvs_debug_depth_head_fwd(const float* x, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
-                                          int B, int D, int h, int w, int impl, void* stream) {
-    return depth_head_fwd(x, w_prob, planes, depth, conf, prob, B, D, h, w, impl, stream);
+extern "C" int rcmvs_depth_head_scaled_fwd(const float* x, const float* x_absmax, const float* w_prob, const float* planes, float* depth, float* conf,
+                                           float* prob, int B, int D, int h, int w, int impl, void* stream) {
+    return depth_head_fwd(x, x_absmax, w_prob, planes, depth, conf, prob, B, D, h, w, impl, stream);
 }

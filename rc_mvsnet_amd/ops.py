@@ -452,24 +452,26 @@ def fpn_out_folded(lat, up, tables, ysq_absmax=None):
 
 
 # ------------------------------------------------------------------------------- K4
-DEPTH_HEAD_IMPL = 0          # tests / A-B timing: bit 0 = two launches also for D = 8, bit 1 = the generic marching prob conv
+DEPTH_HEAD_IMPL = 0          # tests / A-B timing: bit 0 = two launches also for D = 8, bit 1 = the generic marching prob conv,
+                             # bit 2 = the fp32 form although a bound was given, bits 8-15 = z chunk of the prob conv
 
 
-def depth_head(x8, w_prob_packed, planes, want_prob=False):
+def depth_head(x8, w_prob_packed, planes, want_prob=False, x_absmax=None):
     """x8 (B,D,h,w,8) -> depth (B,h,w), confidence (B,h,w)[, prob (B,D,h,w)].  With D = 8 (the cascade's last stage) the head is one
-    launch that keeps the logits in registers; the probability volume is then stored only when asked for."""
+    launch; the probability volume is then stored only when asked for.  x_absmax (a bound of max|x8|, ops.absmax format or the
+    y_absmax of the layer that produced x8): the prob conv runs on the matrix cores in fp16 pairs (csrc/prob_pair.hip)."""
     B, D, h, w, C = x8.shape
     if C != 8:
         raise _lib.RcmvsError("depth_head: the prob conv takes 8 channels")
+    if x_absmax is not None and w_prob_packed.images != IMG_ALL:
+        raise _lib.RcmvsError("depth_head: the fp16-pair form reads an image that a selectively packed weight does not hold")
     depth = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     conf = torch.empty((B, h, w), device=x8.device, dtype=torch.float32)
     one_launch = D == 8 and not (DEPTH_HEAD_IMPL & 1)
     prob = None if one_launch and not want_prob else torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32)     # logit scratch -> probabilities
-    args = (_chk(x8, "x8"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"), _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w)
-    if DEPTH_HEAD_IMPL:
-        _lib.check(_lib.load().rcmvs_debug_depth_head_fwd(*args, DEPTH_HEAD_IMPL, _stream()), "debug_depth_head_fwd")
-    else:
-        _lib.check(_lib.load().rcmvs_depth_head_fwd(*args, _stream()), "depth_head_fwd")
+    _lib.check(_lib.load().rcmvs_depth_head_scaled_fwd(_chk(x8, "x8"), _opt(x_absmax, "x_absmax"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
+                                                       _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w, DEPTH_HEAD_IMPL, _stream()),
+               "depth_head_scaled_fwd")
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 

@@ -833,6 +833,43 @@ def test_depth_head_forms_are_bit_identical(hip, D, h, w):
     assert torch.equal(outs["noprob"][0], outs[0][0]) and torch.equal(outs["noprob"][1], outs[0][1])
 
 
+@pytest.mark.parametrize("D,h,w,zc", [(8, 12, 16, 0), (8, 21, 70, 0), (48, 16, 24, 0), (32, 9, 130, 0), (32, 9, 45, 5), (16, 8, 33, 3), (7, 10, 31, 2)])
+def test_depth_head_matrix_core_form_vs_fp32_form(hip, D, h, w, zc):
+    """The prob conv on the matrix cores (csrc/prob_pair.hip: M = (kd, kw) partial sums, three rotated weight images, fp16 pairs after a
+    power-of-two pre-scale from the caller's bound) against the exact fp32 head: logits to fp32-chain accuracy on log-normal inputs
+    (three decades of range), so probabilities, depth and confidence agree to rounding; every z chunk length and start phase of the
+    rotation, ragged tiles (widths that are not multiples of 14 or 32), batch 2, the one-launch form (D = 8) and the two-launch form,
+    and a bound that is 8x too loose."""
+    g = torch.Generator().manual_seed(D * 3 + w)
+    x = gpu(torch.randn(2, D, h, w, 8, generator=g) * torch.exp(torch.randn(2, D, h, w, 8, generator=g)))
+    wprob = torch.randn(1, 8, 3, 3, 3, generator=g) * 0.1
+    wp = hip.pack_conv3d_weight(gpu(wprob))
+    planes = gpu(torch.stack((425.0 + 50 * torch.rand(2, h, w, generator=g), 1.0 + 5 * torch.rand(2, h, w, generator=g)), dim=-1))
+    bound = hip.absmax(x)
+    d32, c32, p32 = hip.depth_head(x, wp, planes, want_prob=True)
+    logits64 = torch.nn.functional.conv3d(x.cpu().permute(0, 4, 1, 2, 3).double(), wprob.double(), padding=1).squeeze(1)
+    p64 = torch.softmax(logits64, dim=1)
+    try:
+        hip.DEPTH_HEAD_IMPL = zc << 8
+        for bnd in (bound, bound * 8.0):
+            dh, ch, ph = hip.depth_head(x, wp, planes, want_prob=True, x_absmax=bnd)
+            e_h, e_32 = float((ph.cpu().double() - p64).abs().max()), float((p32.cpu().double() - p64).abs().max())
+            assert e_h <= 2.0 * e_32 + 2e-6, (e_h, e_32)
+            assert float((dh - d32).abs().max()) < 2e-3                          # mm, of ~600
+            fidx = (p64 * torch.arange(D, dtype=torch.float64).view(1, D, 1, 1)).sum(1)
+            safe = (fidx - fidx.round()).abs() > 1e-3
+            assert float((ch.cpu() - c32.cpu()).abs()[safe].max()) < 1e-4
+        if D == 8:
+            d2, c2 = hip.depth_head(x, wp, planes, x_absmax=bound)             # without the probability volume
+            dh, ch, _ = hip.depth_head(x, wp, planes, want_prob=True, x_absmax=bound)
+            assert torch.equal(d2, dh) and torch.equal(c2, ch)
+            hip.DEPTH_HEAD_IMPL = 1                                             # two launches on the same logits: the same bits
+            d3, c3, p3 = hip.depth_head(x, wp, planes, want_prob=True, x_absmax=bound)
+            assert torch.equal(d3, dh) and torch.equal(c3, ch)
+    finally:
+        hip.DEPTH_HEAD_IMPL = 0
+
+
 def test_depth_head_golden(hip):
     g = load_golden("depth_head")
     # feed the golden logits through a 1-hot prob conv: x channel 0 = logits, centre tap weight 1
