@@ -269,6 +269,12 @@ int rcmvs_fpn_out_fused(const float* lat, const float* up, const float* w_inner,
 #define RCMVS_FPN_FOLDED_FLOATS 4744
 int rcmvs_fpn_out_folded(const float* lat, const float* up, const float* tables, float* y, float* ysq_absmax, int N, int H, int W, void* stream);
 /* ysq_absmax (may be NULL): bound vector (RCMVS_ABSMAX_FLOATS floats, zero-filled by the caller) that receives the square of max|y|. */
+/* The same level on the matrix cores, exact (three bf16 pieces per operand, six MFMAs per product; csrc/fpn_folded_mfma.hip):
+ * rcmvs_fpn_folded_mfma_pack turns the RCMVS_FPN_FOLDED_FLOATS tables into an image of rcmvs_fpn_folded_mfma_floats() floats,
+ * rcmvs_fpn_out_folded_mfma takes that image in place of the tables; same arguments and result (to fp32 rounding) otherwise. */
+long long rcmvs_fpn_folded_mfma_floats(void);
+int rcmvs_fpn_folded_mfma_pack(const float* tables, float* image, void* stream);
+int rcmvs_fpn_out_folded_mfma(const float* lat, const float* up, const float* image, float* y, float* ysq_absmax, int N, int H, int W, void* stream);
 
 
 /* ---- K4: prob conv + softmax + soft-argmin + photometric confidence ---------------------- */

@@ -49,6 +49,9 @@ SIGNATURES = {
     "rcmvs_conv1x1_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_fpn_out_fused": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_fpn_out_folded": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "rcmvs_fpn_folded_mfma_floats": [],
+    "rcmvs_fpn_folded_mfma_pack": [_p, _p, _p],
+    "rcmvs_fpn_out_folded_mfma": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "rcmvs_bn_stats": [_p, _p, _ll, _i, _p],
     "rcmvs_bn_finalize": [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "rcmvs_bn_bwd_finalize": [_p, _p, _p, _p, _p, _p, _i, _p],
@@ -89,7 +92,7 @@ SIGNATURES = {
     "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
 }
 _RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll, "rcmvs_nerf_workspace_floats": _ll, "rcmvs_nerf_train_workspace_floats": _ll, "rcmvs_nerf_bwd_workspace_floats": _ll,
-             "rcmvs_packed_weight_floats": _ll,}
+             "rcmvs_packed_weight_floats": _ll, "rcmvs_fpn_folded_mfma_floats": _ll}
 
 _lib = None
 

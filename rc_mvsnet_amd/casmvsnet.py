@@ -270,6 +270,8 @@ class FeatureNet(nn.Module):
                 # equal up to fp32 rounding): the default; RCMVS_FPN_FOLD=0 keeps the bit-identical-to-unfused kernel
                 if plan["fuse_out3"] and os.environ.get("RCMVS_FPN_FOLD", "1") != "0":
                     plan["fold_out3"] = ops.pack_fpn_folded(self.inner2.weight, self.inner2.bias, self.out3.weight)
+                    if os.environ.get("RCMVS_FPN_MFMA", "1") != "0":           # ... on the matrix cores, exact split operands (csrc/fpn_folded_mfma.hip)
+                        plan["fold_out3"] = ops.pack_fpn_folded_mfma(plan["fold_out3"])
             self._plan, self._plan_key = plan, key
         return self._plan
 

@@ -439,15 +439,27 @@ def pack_fpn_folded(w_inner, b_inner, w_out):
     return tab
 
 
+def pack_fpn_folded_mfma(tables):
+    """The tables of pack_fpn_folded as the weight image of the matrix-core form of the level (rcmvs_fpn_folded_mfma_pack: A fragments,
+    three bf16 pieces per weight -- exact)."""
+    if tables.numel() != FPN_FOLDED_FLOATS:
+        raise _lib.RcmvsError("pack_fpn_folded_mfma: expects the tables of pack_fpn_folded")
+    img = torch.empty((_lib.load().rcmvs_fpn_folded_mfma_floats(),), device=tables.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_fpn_folded_mfma_pack(_chk(tables, "tables"), _chk(img, "image"), _stream()), "fpn_folded_mfma_pack")
+    return img
+
+
 def fpn_out_folded(lat, up, tables, ysq_absmax=None):
-    """conv3x3(up2(up) + conv1x1(lat) + bias) with the two convolutions folded (rcmvs_fpn_out_folded): lat (N,H,W,8), up (N,H/2,W/2,32)
-    -> (N,H,W,8).  ysq_absmax: a zero-filled (1024,) bound vector that receives (max|y|)^2."""
+    """conv3x3(up2(up) + conv1x1(lat) + bias) with the two convolutions folded: lat (N,H,W,8), up (N,H/2,W/2,32) -> (N,H,W,8).
+    tables: pack_fpn_folded's fp32 tables (rcmvs_fpn_out_folded: fp32 FMA chains) or pack_fpn_folded_mfma's image
+    (rcmvs_fpn_out_folded_mfma: the matrix cores, exact split operands).  ysq_absmax: a zero-filled (1024,) bound vector that receives (max|y|)^2."""
     N, H, W, CL = lat.shape
-    if CL != 8 or tuple(up.shape) != (N, H // 2, W // 2, 32) or tables.numel() != FPN_FOLDED_FLOATS:
+    mfma = tables.numel() == _lib.load().rcmvs_fpn_folded_mfma_floats()
+    if CL != 8 or tuple(up.shape) != (N, H // 2, W // 2, 32) or not (mfma or tables.numel() == FPN_FOLDED_FLOATS):
         raise _lib.RcmvsError(f"fpn_out_folded: lat {tuple(lat.shape)} / up {tuple(up.shape)} / {tables.numel()} table floats do not fit 8 -> 32 -> 8")
     y = torch.empty((N, H, W, 8), device=lat.device, dtype=torch.float32)
-    _lib.check(_lib.load().rcmvs_fpn_out_folded(_chk(lat, "lat"), _chk(up, "up"), _chk(tables, "tables"), _chk(y, "y"), _opt(ysq_absmax, "ysq_absmax"), N, H, W, _stream()),
-               "fpn_out_folded")
+    fn = _lib.load().rcmvs_fpn_out_folded_mfma if mfma else _lib.load().rcmvs_fpn_out_folded
+    _lib.check(fn(_chk(lat, "lat"), _chk(up, "up"), _chk(tables, "tables"), _chk(y, "y"), _opt(ysq_absmax, "ysq_absmax"), N, H, W, _stream()), "fpn_out_folded")
     return y
 
 

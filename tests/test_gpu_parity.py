@@ -1407,5 +1407,11 @@ def test_fpn_out_folded_matches_the_unfused_path(N, H, W):
     assert float((got.double() - want).abs().max()) < 2e-6 * scale
     two = ops.conv2d(ops.conv2d(lat.to(DEV), ops.pack_conv2d_weight(w_in_t.to(DEV)), None, b_in_t.to(DEV), up_add=up.to(DEV)), ops.pack_conv2d_weight(w_out_t.to(DEV))).cpu()
     assert float((got - two).abs().max()) < 4e-6 * scale
+    # the same level on the matrix cores (csrc/fpn_folded_mfma.hip: exact three-piece bf16 operands, persistent blocks), with its bound output
+    img = ops.pack_fpn_folded_mfma(tab)
+    bound = torch.zeros(ops.ABSMAX_FLOATS, device=DEV)
+    got_m = ops.fpn_out_folded(lat.to(DEV), up.to(DEV), img, ysq_absmax=bound).cpu()
+    assert float((got_m.double() - want).abs().max()) < 2e-6 * scale
+    assert float(bound.max()) == float(got_m.abs().max() ** 2)          # (squared in fp32, as the kernel does)
     with pytest.raises(_lib.RcmvsError):
         ops.fpn_out_folded(lat.to(DEV)[:, :-1], up.to(DEV), tab)
