@@ -3,8 +3,8 @@
 // exact: operands split into three bf16 pieces by truncation, six v_mfma_f32_16x16x32_bf16 per product (the arithmetic of
 // conv3d_x3.hip, NP = 3), no bound needed.  gfx950 only.
 //
-// Why.  The VALU form spends 800 v_pk_fma_f32 per pixel quad on scalar-operand FMAs that issue at half rate (8 clocks): 57 us per
-// scene for 3.1 GFLOP and 94 MB.  As a GEMM per 16 PIXEL PAIRS (x = 2 n + px) of one output row:
+// Why.  The VALU form spends 800 v_pk_fma_f32 per thread (4.7 issue clocks each: 24 us of the chip for the three views) and runs at
+// 57 us per scene for 3.1 GFLOP and 94 MB.  As a GEMM per 16 PIXEL PAIRS (x = 2 n + px) of one output row:
 //   M = (px, co) = 16 rows,  N = 16 pairs,
 //   K = (dy, e, ci): the lateral map's 3 rows x 4 columns 2 n - 1 + e x 8 channels (weight (W3 o W2)[dy][e - px], zero outside 0..2)   3 k-steps
 //     + (ry, e3, cj): `prev`'s 2 rows x 3 columns n - 1 + e3 x 32 channels (weight WA[py][px][ry][e3 - px], zero outside 0..1)         6 k-steps

@@ -2,13 +2,13 @@
 // conv3d_x3.hip (two fp16 pieces per operand after an exact power-of-two pre-scale, v_mfma_f32_16x16x32_f16, three MFMAs per
 // product), for callers that hand over a bound of max|x| -- the B = 1 inference scene.  gfx950 only.
 //
-// Why.  The VALU form (conv3d_lds.hip, prob_conv_march_plain_kernel) is bound by its 108 v_pk_fma_f32 per plane and wave, which
-// issue at half rate with their scalar weight operands (8 clocks: 864 of the ~1400 clocks a plane costs a wave; profiles/
-// r3_prob_conv.txt, r4 notes in DESIGN.md).  One output channel is a poor GEMM (M = 1), so the GEMM here is built differently:
+// Why.  The VALU form (conv3d_lds.hip, prob_conv_march_plain_kernel) needs 108 v_pk_fma_f32 (4.7 issue clocks each), 18 ds_read_b128 and 18
+// scalar weight loads per plane and wave and runs at ~1400 clocks per plane and wave (profiles/r4_prob_pair.txt).
+// One output channel is a poor GEMM (M = 1), so the GEMM here is built differently:
 //   M = (kd, kw)   -- the NINE partial sums  P[kd][kw][h][q] = sum_{kh, c} x[z][h + kh][q][c] W[kd][kh][kw][c]  of an input plane z,
 //                     one per output plane it feeds (kd) and per column shift still to be applied (kw); rows m = 4 g + kw, g = lane group,
 //   N = 16 halo columns q of one row,   K = (kh, c) = 24 of 32.
-// One MFMA triple per (row, 16 columns) and plane: 18 per wave and plane = 288 clocks of the matrix pipe instead of 864 of the VALU.
+// One MFMA triple per (row, 16 columns) and plane: 18 per wave and plane = 288 clocks of the matrix pipe instead of ~510 VALU clocks of packed FMAs.
 // The output is  out[z + 1 - kd][h][w] = sum_kw P[kd][kw][h][w + kw]  (halo column q = w + 1 - 1 + kw): two DPP row shifts and two adds;
 // n-tiles start every 14 columns so that the shifted lanes stay inside a 16-lane row.
 // The three kd of a plane belong to three different output planes.  The weight image exists in three ROTATIONS (plane i of a block

@@ -31,6 +31,10 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, long long* cyc, 
                 if (OP == 5) { asm volatile("v_or_b32 %0, %0, %1" : "+v"(s[i]) : "v"(ms)); }
                 if (OP == 6) { asm volatile("v_sub_u32 %0, %0, %1" : "+v"(s[i]) : "v"(ms)); }
                 if (OP == 7) { asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(a[i]) : "v"(m)); }
+                if (OP == 8) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(m)); }
+                if (OP == 9) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(mask)); }
+                if (OP == 10) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s[i]) : "v"(s[(i + 1) & 7]), "s"(addr)); }
+                if (OP == 11) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s[i]) : "v"(s[(i + 1) & 7]), "v"(ms)); }
             }
         }
     }
@@ -45,16 +49,16 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, long long* cyc, 
 int main() {
     float* out; long long* cyc;
     CK(hipMalloc(&out, 256 * 1024 * 4)); CK(hipMalloc(&cyc, 8));
-    const char* names[] = {"cmp vcc + cndmask vcc", "cmp_e64 sgpr + cndmask_e64", "cndmask vcc (vcc set by s_mov first)", "cndmask_e64 vcc explicit", "v_bfi_b32", "v_or_b32", "v_sub_u32", "v_pk_add_f32 neg"};
+    const char* names[] = {"cmp vcc + cndmask vcc", "cmp_e64 sgpr + cndmask_e64", "cndmask vcc (vcc set by s_mov first)", "cndmask_e64 vcc explicit", "v_bfi_b32", "v_or_b32", "v_sub_u32", "v_pk_add_f32 neg", "v_pk_fma_f32 v,v,v", "v_pk_fma_f32 v,SGPR pair,v", "v_fma_f32 v,SGPR,v", "v_fma_f32 v,v,v"};
     const int iters = 2000;
-    for (int op = 0; op < 8; ++op)
-        for (int wps = 1; wps <= 3; wps += 2) {
+    for (int op = 0; op < 12; ++op)
+        for (int wps = 1; wps <= 4; wps += (wps == 1 ? 2 : 1)) {
             const int threads = 256 * wps;      // one block per CU, wps waves per SIMD
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             auto launch = [&]() {
                 switch (op) {
 #define L(O) case O: hipLaunchKernelGGL(rate_kernel<O>, dim3(256), dim3(threads), 0, 0, out, cyc, iters); break;
-                    L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7)
+                    L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11)
                 }
             };
             launch(); CK(hipDeviceSynchronize());
