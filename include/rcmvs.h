@@ -253,6 +253,10 @@ int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, 
  * (RCMVS_ABSMAX_FLOATS floats) that receives (max |y|)^2 -- the bound of the variance volume built from the map. */
 int rcmvs_conv1x1_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
                       float* y, float* ysq_absmax, int N, int H, int W, int Ci, int Co, int relu, void* stream);
+/* the same layer on the matrix cores, exact (three bf16 pieces per operand, six MFMAs per product): 16 -> 32 and 32 -> 32; equal to
+ * rcmvs_conv1x1_fwd up to fp32 summation order */
+int rcmvs_conv1x1_mfma_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
+                      float* y, float* ysq_absmax, int N, int H, int W, int Ci, int Co, int relu, void* stream);
 /* Last FPN level in one launch: y = conv3x3(up2(up) + conv1x1(lat) + b_inner) without materialising the 32-channel
  * intermediate (models/modules.py:448-462: `intra_feat = F.interpolate(intra_feat) + self.inner2(conv0)`,
  * `self.out3(intra_feat)`).  lat (N,H,W,CL), up (N,H/2,W/2,CM), w_inner packed [1][CL][CM], b_inner (CM), w_out packed

@@ -21,6 +21,7 @@ Execution:
 import os
 
 FP16_PAIR_DEFAULT = True       # inference CostRegNet on the fp16-pair matrix-core form unless RCMVS_FP16_PAIR=0 (the exact bf16 triple)
+ONE_BY_ONE_MFMA = os.environ.get("RCMVS_1X1_MFMA", "1") != "0"  # FeatureNet's 32 -> 32 1x1 output conv (out1) on the matrix cores, exact split operands; 0 = fp32 FMA chains
 HEAD_PAIR = os.environ.get("RCMVS_HEAD_PAIR", "1") != "0"       # ... and the depth head's prob conv (csrc/prob_pair.hip); 0 = fp32 FMA chains there
 DEEP_PAIR = os.environ.get("RCMVS_DEEP_PAIR", "1") != "0"       # ... its deep levels (conv5-7) included (csrc/conv3d_deep.hip); 0 = fp32 MFMAs there
 
@@ -310,8 +311,8 @@ class FeatureNet(nn.Module):
         # there -- the bound of the variance volume built from the map, which the fp16-pair cost regularisation needs -- in its epilogue
         # and returns (map, True); (map, False) = no bound was kept (the caller runs ops.absmax over the map).
         def out1(bound=None, t=c2):
-            if bound is not None and tuple(self.out1.weight.shape) == (32, 32, 1, 1):      # the streaming 1x1 kernel keeps the bound in its epilogue
-                return ops.conv1x1(t, p["out1"], ysq_absmax=bound), True
+            if tuple(self.out1.weight.shape) == (32, 32, 1, 1) and (bound is not None or ONE_BY_ONE_MFMA):      # the 1x1 kernels keep the bound in their epilogue
+                return ops.conv1x1(t, p["out1"], ysq_absmax=bound, mfma=ONE_BY_ONE_MFMA), bound is not None
             return ops.conv2d(t, p["out1"]), False
         out = {"stage1": out1}
         plain = lambda f: (lambda bound=None: (f(), False))
@@ -325,6 +326,8 @@ class FeatureNet(nn.Module):
                 out["stage3"] = plain(lambda t=intra: one(t, "out3"))
             return out if lazy else {k: f()[0] for k, f in out.items()}
         if self.num_stage >= 2:
+            # (the 16 -> 32 lateral merge stays on the fp32 streaming kernel: with K = 16 half of the matrix-core form's lanes carry zeros
+            # and it measured 16.3 against 14.9 us; the 32 -> 32 output conv above: 14.1 -> 7.1 us)
             intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
             if isinstance(p["out2"], tuple):
                 def out2(bound=None, t=intra):

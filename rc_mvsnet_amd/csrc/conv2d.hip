@@ -7,6 +7,7 @@
 // (B*V, h, w, C) are exactly the channels-last maps K1 consumes, so no layout pass is needed.
 // gfx950 only.
 #include "common.h"
+#include "x3_pieces.h"
 
 namespace rcmvs {
 
@@ -299,6 +300,114 @@ static int conv2d_launch_t(const float* x, const float* wp, const float* scale, 
     return launch_status("conv2d");
 }
 
+// ---- 1x1 layers on the matrix cores (round 4), exact: three bf16 pieces per operand by truncation, six v_mfma_f32_16x16x32_bf16 per
+// product (the arithmetic of conv3d_x3.hip, NP = 3).  A 1x1 conv is the one layer whose B fragment needs no staging: lane (n, kq) of a
+// wave owns pixel 16 t + n of n-tile t and loads channels 8 kq .. 8 kq + 7 of it -- exactly its fragment of v_mfma (column n, k = 8 kq + i).
+// M = the 32 output channels (two m-tiles, weight fragments built once per wave from the fp32 [Ci][Co] image and kept in registers),
+// K = Ci (one k-step; Ci = 16: the upper half of K is zero), 12 MFMAs per 16 pixels; the output fragment of a lane is four channels of
+// its pixel: float4 stores, and the epilogue (BatchNorm / bias, nearest x2 up-add, ReLU, squared bound) works on that float4.
+// No LDS, no barrier; a wave walks n-tiles with the next tile's loads in flight.
+template <int CI>
+__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ up, float* __restrict__ y, float* __restrict__ ysq, long long npix, int H, int W, int relu) {
+    constexpr int CO = 32;
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    // weight fragments: row m = co % 16, k = 8 kq + i = input channel
+    x3_u32x4 A[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ci = kq * 8 + i;
+            const float v = ci < CI ? wp[ci * CO + mt * 16 + n] : 0.0f;
+            hb[i] = __float_as_uint(v) & 0xffff0000u;
+            const float r1 = v - __uint_as_float(hb[i]);
+            mb[i] = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mb[i]);
+            lb[i] = __float_as_uint(r2) & 0xffff0000u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            A[mt][0][j] = (hb[2 * j] >> 16) | hb[2 * j + 1];
+            A[mt][1][j] = (mb[2 * j] >> 16) | mb[2 * j + 1];
+            A[mt][2][j] = (lb[2 * j] >> 16) | lb[2 * j + 1];
+        }
+    }
+    const long long ntiles = (npix + 15) / 16, stride = (long long)gridDim.x * 4;
+    const bool kin = kq * 8 < CI;
+    auto fetch = [&](long long tile, x3_f32x4& a, x3_f32x4& b) {
+        const long long p = tile * 16 + n;
+        a = b = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kin && tile < ntiles && p < npix) {
+            a = *reinterpret_cast<const x3_f32x4*>(x + p * CI + kq * 8);
+            b = *reinterpret_cast<const x3_f32x4*>(x + p * CI + kq * 8 + 4);
+        }
+    };
+    float vmax = 0.0f;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    x3_f32x4 xa, xb;
+    fetch(tile, xa, xb);
+    const long long hw = (long long)H * W;
+    for (; tile < ntiles; tile += stride) {
+        x3_u32x2 h0, m0, l0, h1, m1, l1;
+        x3_split4(xa, h0, m0, l0);
+        x3_split4(xb, h1, m1, l1);
+        const x3_u32x4 bq[3] = {(x3_u32x4){h0.x, h0.y, h1.x, h1.y}, (x3_u32x4){m0.x, m0.y, m1.x, m1.y}, (x3_u32x4){l0.x, l0.y, l1.x, l1.y}};
+        fetch(tile + stride, xa, xb);
+        const long long p = tile * 16 + n;
+        const bool live = p < npix;
+        long long upo = 0;
+        if (up && live) {                                                // F.interpolate(intra) + inner(conv): pixel (b, oy, ox) <- up[b, oy / 2, ox / 2]
+            const long long b = p / hw;
+            const int r = (int)(p - b * hw), oy = r / W, ox = r - oy * W;
+            upo = ((b * (H / 2) + oy / 2) * (W / 2) + ox / 2) * CO;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            x3_f32x4 acc[3] = {(x3_f32x4){0.f, 0.f, 0.f, 0.f}, (x3_f32x4){0.f, 0.f, 0.f, 0.f}, (x3_f32x4){0.f, 0.f, 0.f, 0.f}};
+            acc[2] = x3_mfma<3>(A[mt][0], bq[2], acc[2]);
+            acc[1] = x3_mfma<3>(A[mt][0], bq[1], acc[1]);
+            acc[0] = x3_mfma<3>(A[mt][0], bq[0], acc[0]);
+            acc[2] = x3_mfma<3>(A[mt][1], bq[1], acc[2]);
+            acc[1] = x3_mfma<3>(A[mt][1], bq[0], acc[1]);
+            acc[2] = x3_mfma<3>(A[mt][2], bq[0], acc[2]);
+            const int co = mt * 16 + kq * 4;                             // this lane's four output channels of pixel p
+            x3_f32x4 v = acc[0] + (acc[1] + acc[2]);
+            if (scale) v = v * *reinterpret_cast<const x3_f32x4*>(scale + co);
+            if (shift) v = v + *reinterpret_cast<const x3_f32x4*>(shift + co);
+            if (live) {
+                if (up) v = *reinterpret_cast<const x3_f32x4*>(up + upo + co) + v;
+                if (relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
+                *reinterpret_cast<x3_f32x4*>(y + p * CO + co) = v;
+                vmax = x3_absmax4(vmax, v);
+            }
+        }
+    }
+    if (ysq) {
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, k));
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            atomicMax(reinterpret_cast<unsigned int*>(ysq) + (blockIdx.x & 63) * 16, __float_as_uint(m * m));
+        }
+    }
+}
+
+template <int CI>
+static int conv1x1_mfma_launch_t(const float* x, const float* wp, const float* scale, const float* shift, const float* up, float* y, float* ysq,
+                                 int N, int H, int W, int relu, hipStream_t st) {
+    const long long npix = (long long)N * H * W, ntiles = (npix + 15) / 16;
+    const long long blocks = (ntiles + 3) / 4 < 2048 ? (ntiles + 3) / 4 : 2048;          // (a wave walks ~2-4 n-tiles on the FeatureNet maps)
+    hipLaunchKernelGGL(conv1x1_mfma_kernel<CI>, dim3((unsigned)blocks), dim3(256), 0, st, x, wp, scale, shift, up, y, ysq, npix, H, W, relu);
+    return launch_status("conv1x1_mfma");
+}
+
 }  // namespace rcmvs
 
 using namespace rcmvs;
@@ -329,6 +438,17 @@ int rcmvs_conv1x1_fwd(const float* x, const float* w_packed, const float* scale,
     if (Ci == 32 && Co == 32) return conv1x1_launch_t<32, 32>(x, w_packed, scale, shift, up_add, y, ysq_absmax, N, H, W, relu, st);
     if (Ci == 8 && Co == 32) return conv1x1_launch_t<8, 32>(x, w_packed, scale, shift, up_add, y, ysq_absmax, N, H, W, relu, st);
     return fail(-1, "conv1x1_fwd: unsupported layer Ci=%d Co=%d (16 -> 32, 32 -> 32, 8 -> 32)", Ci, Co);
+}
+
+int rcmvs_conv1x1_mfma_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,
+                           float* y, float* ysq_absmax, int N, int H, int W, int Ci, int Co, int relu, void* stream) {
+    RCMVS_REQUIRE(x && w_packed && y, "conv1x1_mfma_fwd: null pointer");
+    RCMVS_REQUIRE(N > 0 && H > 0 && W > 0, "conv1x1_mfma_fwd: bad sizes");
+    RCMVS_REQUIRE(!up_add || (H % 2 == 0 && W % 2 == 0), "conv1x1_mfma_fwd: the up-add merge needs even H and W (got %d x %d)", H, W);
+    hipStream_t st = as_stream(stream);
+    if (Ci == 16 && Co == 32) return conv1x1_mfma_launch_t<16>(x, w_packed, scale, shift, up_add, y, ysq_absmax, N, H, W, relu, st);
+    if (Ci == 32 && Co == 32) return conv1x1_mfma_launch_t<32>(x, w_packed, scale, shift, up_add, y, ysq_absmax, N, H, W, relu, st);
+    return fail(-1, "conv1x1_mfma_fwd: unsupported layer Ci=%d Co=%d (16 -> 32, 32 -> 32)", Ci, Co);
 }
 
 int rcmvs_conv2d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, const float* up_add,

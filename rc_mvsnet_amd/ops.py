@@ -371,9 +371,10 @@ def conv2d(x, w_packed, scale=None, shift=None, up_add=None, stride=1, relu=Fals
     return y
 
 
-def conv1x1(x, w_packed, scale=None, shift=None, up_add=None, relu=False, ysq_absmax=None):
+def conv1x1(x, w_packed, scale=None, shift=None, up_add=None, relu=False, ysq_absmax=None, mfma=False):
     """x (N,H,W,Ci) -> (N,H,W,Co) = [relu](up2(up_add) + conv1x1 * scale + shift) on the streaming 1x1 kernel (what conv2d routes its K = 1
-    layers to); ysq_absmax: a zero-filled (1024,) bound vector that receives (max|y|)^2."""
+    layers to); ysq_absmax: a zero-filled (1024,) bound vector that receives (max|y|)^2.  mfma=True: the same layer on the matrix cores
+    (16 -> 32 and 32 -> 32; exact split operands, equal up to fp32 summation order)."""
     N, H, W, Ci = x.shape
     Co = w_packed.co
     if w_packed.ci != Ci or w_packed.k != 1:
@@ -381,8 +382,9 @@ def conv1x1(x, w_packed, scale=None, shift=None, up_add=None, relu=False, ysq_ab
     if up_add is not None and tuple(up_add.shape) != (N, H // 2, W // 2, Co):
         raise _lib.RcmvsError(f"conv1x1: up_add {tuple(up_add.shape)} does not match half of the output")
     y = torch.empty((N, H, W, Co), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().rcmvs_conv1x1_fwd(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"), _opt(up_add, "up_add"),
-                                             _chk(y, "y"), _opt(ysq_absmax, "ysq_absmax"), N, H, W, Ci, Co, int(relu), _stream()), "conv1x1_fwd")
+    fn = _lib.load().rcmvs_conv1x1_mfma_fwd if mfma else _lib.load().rcmvs_conv1x1_fwd
+    _lib.check(fn(_chk(x, "x"), _chk(w_packed.blob, "w"), _opt(scale, "scale"), _opt(shift, "shift"), _opt(up_add, "up_add"),
+                  _chk(y, "y"), _opt(ysq_absmax, "ysq_absmax"), N, H, W, Ci, Co, int(relu), _stream()), "conv1x1_fwd")
     return y
 
 

@@ -1361,6 +1361,34 @@ def test_first_layer_reads_the_planar_images_itself(hip, N, H, W):
         hip.conv2d_rgb(x[:, :2].contiguous(), w, sc, sh)
 
 
+@pytest.mark.parametrize("Ci,N,H,W,up,relu", [(16, 2, 10, 14, True, False), (32, 1, 6, 22, False, True), (16, 1, 4, 6, False, False), (32, 3, 8, 18, True, True)])
+def test_conv1x1_matrix_core_form(hip, Ci, N, H, W, up, relu):
+    """rcmvs_conv1x1_mfma_fwd -- FeatureNet's 1x1 layers (16 -> 32 lateral merge with the nearest x2 up-add, 32 -> 32 output conv) on the matrix
+    cores with exact three-piece bf16 operands -- against fp64 and against the fp32 FMA-chain kernel: as accurate, ragged n-tiles, BatchNorm /
+    bias / up-add / ReLU epilogue, the squared bound of its output."""
+    g = torch.Generator().manual_seed(Ci + H)
+    x = torch.randn(N, H, W, Ci, generator=g) * torch.exp(torch.randn(N, H, W, Ci, generator=g))
+    w = torch.randn(32, Ci, 1, 1, generator=g) / Ci ** 0.5
+    sc, sh = 0.5 + torch.rand(32, generator=g), 0.1 * torch.randn(32, generator=g)
+    ua = torch.randn(N, H // 2, W // 2, 32, generator=g) if up else None
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double()).permute(0, 2, 3, 1) * sc.double() + sh.double()
+    if up:
+        want = want + ua.double().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    if relu:
+        want = want.clamp_min(0)
+    wp = hip.pack_conv2d_weight(gpu(w))
+    args = (gpu(x), wp, gpu(sc), gpu(sh))
+    bound = torch.zeros(hip.ABSMAX_FLOATS, device=DEV)
+    got = hip.conv1x1(*args, up_add=gpu(ua) if up else None, relu=relu, ysq_absmax=bound, mfma=True)
+    ref32 = hip.conv1x1(*args, up_add=gpu(ua) if up else None, relu=relu)
+    mag = float(want.abs().max())
+    e_m, e_32 = float((got.cpu().double() - want).abs().max()), float((ref32.cpu().double() - want).abs().max())
+    assert e_m <= 2.0 * e_32 + 1e-7 * mag and e_m < 3e-6 * mag, (e_m, e_32, mag)
+    assert float(bound.max()) == float(got.abs().max() ** 2)
+    with pytest.raises(Exception):
+        hip.conv1x1(gpu(x[..., :8].contiguous()), hip.pack_conv2d_weight(gpu(w[:, :8].contiguous())), mfma=True)      # 8 -> 32 has no matrix-core form
+
+
 def test_feature_output_convs_keep_the_variance_bound(hip):
     """FeatureNet's three output convs leave (max|f|)^2 of their maps -- the bound of the variance volume the fp16-pair cost regularisation
     needs -- in the bound vector they are handed, bit-equal to what rcmvs_absmax_fwd(square=1) computes in a pass over the map (the launch
