@@ -295,7 +295,8 @@ int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* plane
  *     convolution left) -> the prob conv runs on the matrix cores in fp16 pairs (csrc/prob_pair.hip; w_prob must be the full blob
  *     of rcmvs_pack_conv3d_weight(Co = 1, Ci = 8)); NULL -> the exact fp32 form, as rcmvs_depth_head_fwd.
  *   impl (0 in production; tests and A/B timing): bit 0 = two launches also for D = 8, bit 1 = the generic (predicated) marching
- *     prob conv instead of the depth head's plain one, bit 2 = the fp32 form although a bound was given, bits 8-15 = z chunk. */
+ *     prob conv instead of the depth head's plain one, bit 2 = the fp32 form although a bound was given, bits 8-15 = z chunk;
+ *     bit 3 (a production flag): prob is scratch only -- the probabilities are not written back (callers that want depth and confidence only). */
 int rcmvs_depth_head_scaled_fwd(const float* x, const float* x_absmax, const float* w_prob, const float* planes,
                                 float* depth, float* conf, float* prob,
                                 int B, int D, int h, int w, int impl, void* stream);

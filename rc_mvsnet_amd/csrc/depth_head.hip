@@ -36,7 +36,9 @@ int prob_head_fused_launch(const float* x, const float* wp, const float* planes,
 // column is read ONCE with all of a lane's loads in flight, max / sum / soft-argmin / window sums are combined across the
 // LP lanes with shuffles, the probabilities are written once.  LP = 1, 2, 4 for D <= 16, 32, 64 -- the 128x160 stage has
 // only 20 k pixels, so spreading a pixel over four lanes is also what fills the machine there.
-template <int LP>
+// KEEP = false: the caller does not want the probability volume (inference: only depth and confidence leave the head) -- the logits are
+// read and nothing is written back.
+template <int LP, bool KEEP = true>
 __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict__ prob, const float* __restrict__ planes,
                                                                float* __restrict__ depth, float* __restrict__ conf, int D, long long hw) {
     constexpr int MAXK = 16;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict_
         const int k = j + i * LP;
         v[i] = v[i] / sum;
         if (k < D) {
-            if (live) col[(long long)k * hw] = v[i];
+            if (KEEP && live) col[(long long)k * hw] = v[i];
             dsum = fmaf(v[i], fmaf((float)k, pl.y, pl.x), dsum);       // (explicit: the one-launch form of conv3d_lds.hip must round alike)
             isum = fmaf(v[i], (float)k, isum);
         }
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256) void softmax_regress_kernel(float* __restrict_
 using namespace rcmvs;
 
 /* impl (tests, A/B): bit 0 = two launches even where the one-launch form exists (D = 8); bit 1 = the generic marching prob conv;
- * bit 2 = the VALU prob conv although a bound was given; bits 8-15 = z chunk of the prob conv (0 = chosen per launch).
+ * bit 2 = the VALU prob conv although a bound was given; bit 3 = `prob` is scratch only (the probabilities are not written back: production
+ * callers that want depth and confidence only); bits 8-15 = z chunk of the prob conv (0 = chosen per launch).
  * xmax: bound of max|x| (ABSMAX slot format) -> the matrix-core prob conv of prob_pair.hip (fp16 pairs); NULL -> the exact VALU form */
 static int depth_head_fwd(const float* x, const float* xmax, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
                           int B, int D, int h, int w, int impl, void* stream) {
@@ -117,9 +120,13 @@ static int depth_head_fwd(const float* x, const float* xmax, const float* w_prob
     else rc = conv3d_lds_launch(x, w_prob, nullptr, nullptr, nullptr, prob, B, D, h, w, 8, 1, 0, st, ((impl & 2) ? 16 : 0) | (zc_force << 8));
     if (rc) return rc;
     const long long hw = (long long)h * w;
-    if (D <= 16)      hipLaunchKernelGGL(softmax_regress_kernel<1>, dim3((unsigned)cdiv(hw, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
-    else if (D <= 32) hipLaunchKernelGGL(softmax_regress_kernel<2>, dim3((unsigned)cdiv(hw * 2, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
-    else              hipLaunchKernelGGL(softmax_regress_kernel<4>, dim3((unsigned)cdiv(hw * 4, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw);
+    const bool keep = !(impl & 8);
+#define RCMVS_SOFTMAX(LP) do { if (keep) hipLaunchKernelGGL((softmax_regress_kernel<LP, true>), dim3((unsigned)cdiv(hw * LP, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw); \
+                               else hipLaunchKernelGGL((softmax_regress_kernel<LP, false>), dim3((unsigned)cdiv(hw * LP, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw); } while (0)
+    if (D <= 16) RCMVS_SOFTMAX(1);
+    else if (D <= 32) RCMVS_SOFTMAX(2);
+    else RCMVS_SOFTMAX(4);
+#undef RCMVS_SOFTMAX
     return launch_status("depth_head_fwd");
 }
 

@@ -484,7 +484,8 @@ def depth_head(x8, w_prob_packed, planes, want_prob=False, x_absmax=None):
     one_launch = D == 8 and not (DEPTH_HEAD_IMPL & 1)
     prob = None if one_launch and not want_prob else torch.empty((B, D, h, w), device=x8.device, dtype=torch.float32)     # logit scratch -> probabilities
     _lib.check(_lib.load().rcmvs_depth_head_scaled_fwd(_chk(x8, "x8"), _opt(x_absmax, "x_absmax"), _chk(w_prob_packed.blob, "w_prob"), _chk(planes, "planes"),
-                                                       _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w, DEPTH_HEAD_IMPL, _stream()),
+                                                       _chk(depth, "depth"), _chk(conf, "conf"), _opt(prob, "prob"), B, D, h, w,
+                                                       DEPTH_HEAD_IMPL | (0 if want_prob else 8), _stream()),
                "depth_head_scaled_fwd")
     return (depth, conf, prob) if want_prob else (depth, conf)
 
