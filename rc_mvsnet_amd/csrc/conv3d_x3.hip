@@ -276,6 +276,7 @@ struct X3Dims {
     int bal;                // 1 = balanced schedule: block r walks steps [T r / n, T (r + 1) / n) of the flattened (batch, tile, z) sequence (see the kernel)
     int dbg;            // phase-ablation mask (0 in the library; X3_ABLATION builds only)
     long long* trace;   // s_memtime stamps of block 0 (nullptr in the library; X3_ABLATION builds only)
+    int place;          // wave placement of the 4 + 4 forms (see the kernel): 0 = one consumer and one producer per SIMD, 1 = consumers on SIMDs 0-1, producers on 2-3
     int ysq;            // ymax receives the SQUARE of max|y| (the bound of a variance volume from the bound of its samples: FeatureNet's output convs)
     int s2d;            // planar kind only: the input is physically (B, D, 2H, 2W, CIN / 4) and is read through a space-to-depth view
                         // (channel (py, px, c) of voxel (y, x) = channel c of pixel (2y + py, 2x + px)): a 5x5 stride-2 layer as a 3x3 one
@@ -346,8 +347,14 @@ __global__ __launch_bounds__(512) void conv3d_x3_kernel(
     int4* const itab_w = reinterpret_cast<int4*>(partbase + 2 * C::PARTB);
     int* const tab_w = reinterpret_cast<int*>(itab_w + dm.itemcap);
     float* const redmax = reinterpret_cast<float*>(tab_w + dm.stepcap);        // 8 floats: the waves' output maxima
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    // Wave placement (dm.place, 4 + 4 forms): hardware wave h runs on SIMD h & 3, and VALU work does not overlap MFMAs issued on the same
+    // SIMD -- not another wave's either.  With roles dealt by hardware id (consumers 0-3, producers 4-7) every SIMD hosts one of each and
+    // a tick is MFMA time PLUS producer time.  place = 1 deals the logical ids so that consumers sit on SIMDs 0 and 1 (two each) and
+    // producers on SIMDs 2 and 3: the MFMA phase takes twice as long and the producers run beside it.
+    const int hwave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((dm.place && C::NCW == 4) ? ((hwave & 1) | ((hwave & 4) >> 1) | ((hwave & 2) << 1)) : hwave);
+    const int tid = wave * 64 + lane;
     const bool producer = wave >= C::NCW;
     const int n = lane & 15, kk = lane >> 4;
     // item order: with a block count that is a multiple of 8 the blocks of one XCD (every 8th block id, MI355X_MICROARCH
@@ -985,6 +992,7 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     const int n_blk = max_blocks > 0 ? max_blocks : n_cu;      // max_blocks: test / tuning hook (few blocks = many items per block)
     X3Dims dm;
     dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d; dm.ysq = ysq; dm.dbg = 0; dm.trace = nullptr;
+    { static const int place_env = [] { const char* e = getenv("RCMVS_X3_PLACE"); return e ? atoi(e) : 0; }(); dm.place = place_env; }
 #if X3_ABLATION
     dm.dbg = x3_ablation_mask;
     dm.trace = x3_trace_buf;
