@@ -326,8 +326,8 @@ class FeatureNet(nn.Module):
                 out["stage3"] = plain(lambda t=intra: one(t, "out3"))
             return out if lazy else {k: f()[0] for k, f in out.items()}
         if self.num_stage >= 2:
-            # (the 16 -> 32 lateral merge stays on the fp32 streaming kernel: with K = 16 half of the matrix-core form's lanes carry zeros
-            # and it measured 16.3 against 14.9 us; the 32 -> 32 output conv above: 14.1 -> 7.1 us)
+            # (the 16 -> 32 lateral merge stays on the fp32 streaming kernel: its matrix-core form -- K = 16, v_mfma_f32_16x16x16_bf16 --
+            # measured 15.7 against 14.9 us: the layer waits for its 55 MB, not for arithmetic; the 32 -> 32 output conv above: 14.1 -> 7.1 us)
             intra = ops.conv2d(c1, p["inner1"][0], None, p["inner1"][1], up_add=c2)
             if isinstance(p["out2"], tuple):
                 def out2(bound=None, t=intra):

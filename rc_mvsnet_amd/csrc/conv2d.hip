@@ -302,9 +302,9 @@ static int conv2d_launch_t(const float* x, const float* wp, const float* scale, 
 
 // ---- 1x1 layers on the matrix cores (round 4), exact: three bf16 pieces per operand by truncation, six v_mfma_f32_16x16x32_bf16 per
 // product (the arithmetic of conv3d_x3.hip, NP = 3).  A 1x1 conv is the one layer whose B fragment needs no staging: lane (n, kq) of a
-// wave owns pixel 16 t + n of n-tile t and loads channels 8 kq .. 8 kq + 7 of it -- exactly its fragment of v_mfma (column n, k = 8 kq + i).
+// wave owns pixel 16 t + n of n-tile t and loads channels 8 kq .. 8 kq + 7 of it (4 kq .. 4 kq + 3 with Ci = 16) -- exactly its fragment of v_mfma (column n).
 // M = the 32 output channels (two m-tiles, weight fragments built once per wave from the fp32 [Ci][Co] image and kept in registers),
-// K = Ci (one k-step; Ci = 16: the upper half of K is zero), 12 MFMAs per 16 pixels; the output fragment of a lane is four channels of
+// K = Ci (one k-step: v_mfma_f32_16x16x32_bf16 for Ci = 32, v_mfma_f32_16x16x16_bf16 -- four channels per lane -- for Ci = 16), 12 MFMAs per 16 pixels; the output fragment of a lane is four channels of
 // its pixel: float4 stores, and the epilogue (BatchNorm / bias, nearest x2 up-add, ReLU, squared bound) works on that float4.
 // No LDS, no barrier; a wave walks n-tiles with the next tile's loads in flight.
 template <int CI>
@@ -312,18 +312,21 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ up, float* __restrict__ y, float* __restrict__ ysq, long long npix, int H, int W, int relu) {
     constexpr int CO = 32;
+    constexpr int KL = CI / 4;                                           // input channels per lane: 8 (K = 32: v_mfma_f32_16x16x32_bf16) or 4 (K = 16: v_mfma_f32_16x16x16_bf16)
+    static_assert(CI == 32 || CI == 16, "one k-step: Ci = 32 or 16");
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int frag_t __attribute__((ext_vector_type(KL / 2)));        // KL bf16
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, kq = lane >> 4;
-    // weight fragments: row m = co % 16, k = 8 kq + i = input channel
-    x3_u32x4 A[2][3];
+    // weight fragments: row m = co % 16, k = KL kq + i = input channel
+    frag_t A[2][3];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        unsigned hb[8], mb[8], lb[8];
+        unsigned hb[KL], mb[KL], lb[KL];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ci = kq * 8 + i;
-            const float v = ci < CI ? wp[ci * CO + mt * 16 + n] : 0.0f;
+        for (int i = 0; i < KL; ++i) {
+            const float v = wp[(kq * KL + i) * CO + mt * 16 + n];
             hb[i] = __float_as_uint(v) & 0xffff0000u;
             const float r1 = v - __uint_as_float(hb[i]);
             mb[i] = __float_as_uint(r1) & 0xffff0000u;
@@ -331,33 +334,40 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(
             lb[i] = __float_as_uint(r2) & 0xffff0000u;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < KL / 2; ++j) {
             A[mt][0][j] = (hb[2 * j] >> 16) | hb[2 * j + 1];
             A[mt][1][j] = (mb[2 * j] >> 16) | mb[2 * j + 1];
             A[mt][2][j] = (lb[2 * j] >> 16) | lb[2 * j + 1];
         }
     }
+    auto mfma = [](frag_t a, frag_t b, x3_f32x4 c) -> x3_f32x4 {
+        if constexpr (KL == 8) return x3_mfma<3>(a, b, c);
+        else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    };
     const long long ntiles = (npix + 15) / 16, stride = (long long)gridDim.x * 4;
-    const bool kin = kq * 8 < CI;
-    auto fetch = [&](long long tile, x3_f32x4& a, x3_f32x4& b) {
+    x3_f32x4 xq[KL / 4];
+    auto fetch = [&](long long tile) {
         const long long p = tile * 16 + n;
-        a = b = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
-        if (kin && tile < ntiles && p < npix) {
-            a = *reinterpret_cast<const x3_f32x4*>(x + p * CI + kq * 8);
-            b = *reinterpret_cast<const x3_f32x4*>(x + p * CI + kq * 8 + 4);
-        }
+        const bool in = tile < ntiles && p < npix;
+#pragma unroll
+        for (int c = 0; c < KL / 4; ++c) xq[c] = in ? *reinterpret_cast<const x3_f32x4*>(x + p * CI + kq * KL + c * 4) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
     };
     float vmax = 0.0f;
     long long tile = (long long)blockIdx.x * 4 + wave;
-    x3_f32x4 xa, xb;
-    fetch(tile, xa, xb);
+    fetch(tile);
     const long long hw = (long long)H * W;
     for (; tile < ntiles; tile += stride) {
-        x3_u32x2 h0, m0, l0, h1, m1, l1;
-        x3_split4(xa, h0, m0, l0);
-        x3_split4(xb, h1, m1, l1);
-        const x3_u32x4 bq[3] = {(x3_u32x4){h0.x, h0.y, h1.x, h1.y}, (x3_u32x4){m0.x, m0.y, m1.x, m1.y}, (x3_u32x4){l0.x, l0.y, l1.x, l1.y}};
-        fetch(tile + stride, xa, xb);
+        frag_t bq[3];
+        {
+            x3_u32x2 h0, m0, l0;
+            x3_split4(xq[0], h0, m0, l0);
+            if constexpr (KL == 8) {
+                x3_u32x2 h1, m1, l1;
+                x3_split4(xq[KL / 4 - 1], h1, m1, l1);
+                bq[0] = (frag_t){h0.x, h0.y, h1.x, h1.y}; bq[1] = (frag_t){m0.x, m0.y, m1.x, m1.y}; bq[2] = (frag_t){l0.x, l0.y, l1.x, l1.y};
+            } else { bq[0] = (frag_t){h0.x, h0.y}; bq[1] = (frag_t){m0.x, m0.y}; bq[2] = (frag_t){l0.x, l0.y}; }
+        }
+        fetch(tile + stride);
         const long long p = tile * 16 + n;
         const bool live = p < npix;
         long long upo = 0;
@@ -369,12 +379,12 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             x3_f32x4 acc[3] = {(x3_f32x4){0.f, 0.f, 0.f, 0.f}, (x3_f32x4){0.f, 0.f, 0.f, 0.f}, (x3_f32x4){0.f, 0.f, 0.f, 0.f}};
-            acc[2] = x3_mfma<3>(A[mt][0], bq[2], acc[2]);
-            acc[1] = x3_mfma<3>(A[mt][0], bq[1], acc[1]);
-            acc[0] = x3_mfma<3>(A[mt][0], bq[0], acc[0]);
-            acc[2] = x3_mfma<3>(A[mt][1], bq[1], acc[2]);
-            acc[1] = x3_mfma<3>(A[mt][1], bq[0], acc[1]);
-            acc[2] = x3_mfma<3>(A[mt][2], bq[0], acc[2]);
+            acc[2] = mfma(A[mt][0], bq[2], acc[2]);
+            acc[1] = mfma(A[mt][0], bq[1], acc[1]);
+            acc[0] = mfma(A[mt][0], bq[0], acc[0]);
+            acc[2] = mfma(A[mt][1], bq[1], acc[2]);
+            acc[1] = mfma(A[mt][1], bq[0], acc[1]);
+            acc[2] = mfma(A[mt][2], bq[0], acc[2]);
             const int co = mt * 16 + kq * 4;                             // this lane's four output channels of pixel p
             x3_f32x4 v = acc[0] + (acc[1] + acc[2]);
             if (scale) v = v * *reinterpret_cast<const x3_f32x4*>(scale + co);

@@ -269,6 +269,31 @@ inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16_emu(emu_v8bf a, emu_v8bf 
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16_emu((a), (b), (c), (x), (y), (z))
+// v_mfma_f32_16x16x16_bf16 (the "_1k" form): lane l holds the four bf16 A[l % 16][4 (l / 16) + i] and B[4 (l / 16) + i][l % 16]; D as above
+typedef short emu_v4s __attribute__((ext_vector_type(4)));
+inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x16bf16_1k_emu(emu_v4s a, emu_v4s b, emu_v4f c, int, int, int) {
+    struct H4 { unsigned short h[4]; } ha, hb;
+    std::memcpy(ha.h, &a, 8);
+    std::memcpy(hb.h, &b, 8);
+    const auto wa = ::shim::exchange(ha);
+    const int j = wa.lane % 16, g = wa.lane / 16;
+    H4 xa[4][4];
+    for (int r = 0; r < 4; ++r)
+        for (int kq = 0; kq < 4; ++kq) xa[r][kq] = ::shim::lane_value(wa, 4 * g + r + 16 * kq, H4{});
+    const auto wb = ::shim::exchange(hb);
+    auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float v; std::memcpy(&v, &u, 4); return v; };
+    emu_v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        float s = 0.0f;
+        for (int kq = 0; kq < 4; ++kq) {
+            const H4 y = ::shim::lane_value(wb, j + 16 * kq, H4{});
+            for (int e = 0; e < 4; ++e) s += f(xa[r][kq].h[e]) * f(y.h[e]);
+        }
+        d[r] = c[r] + s;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k_emu((a), (b), (c), (x), (y), (z))
 // v_mfma_f32_16x16x32_f16: the same fragment layout with fp16 elements (products of two fp16 are exact in fp32)
 typedef _Float16 emu_v8h __attribute__((ext_vector_type(8)));
 inline emu_v4f __builtin_amdgcn_mfma_f32_16x16x32_f16_emu(emu_v8h a, emu_v8h b, emu_v4f c, int, int, int) {
