@@ -343,6 +343,9 @@ long long rcmvs_nerf_workspace_floats(long long M);
 int rcmvs_pack_nerf_weights(const float* const* wb, float* blob, void* stream);
 int rcmvs_nerf_mlp_fwd(const float* ndc, float* feat, int ldf, const float* dirs, const float* w2c_ref,
                        const float* weights, float* workspace, float* raw, int N, int S, void* stream);
+/* Renderer_ours.forward(x) / RenderNet.forward(x) called on their own (models/render_models.py:192-220,538-565): the rows of x are already
+ * [embedded point (63) | point feature (20) | view direction (3)] (x (M, ldx >= 86)); feat32 = scratch (M, 32); raw (M, 4) = [rgb, sigma]. */
+int rcmvs_nerf_mlp_embedded_fwd(const float* x, int ldx, const float* weights, float* workspace, float* feat32, float* raw, long long M, void* stream);
 
 /* NeRF MLP in training (autograd of Renderer_ours.forward, models/render_models.py:192-220, called through
  * run_network_mvs, models/renderer.py:42-63; replaces the 11 nn.Linear forward/backward pairs of the reference).

@@ -83,6 +83,7 @@ SIGNATURES = {
     "rcmvs_gu_sample_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "rcmvs_point_feats_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_nerf_mlp_fwd": [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p],
+    "rcmvs_nerf_mlp_embedded_fwd": [_p, _i, _p, _p, _p, _p, _ll, _p],
     "rcmvs_nerf_mlp_train_fwd": [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p],
     "rcmvs_nerf_mlp_bwd": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "rcmvs_nerf_train_workspace_floats": [_ll],

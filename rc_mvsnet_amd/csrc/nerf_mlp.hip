@@ -96,6 +96,24 @@ __global__ __launch_bounds__(256) void mlp_embed_rows_kernel(const float* __rest
     for (int c = nfeat; c < ldf; ++c) feat[(long long)m * ldf + c] = 0.0f;
 }
 
+// stand-alone forward of the MLP (Renderer_ours.forward(x), models/render_models.py:192-220): x rows are already
+// [embedded point (63) | point feature (20) | view direction (3)]; they are copied into the workspace layout of the fused forward
+__global__ __launch_bounds__(256) void mlp_scatter_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ feat, float* __restrict__ ws,
+                                                                long long M, int ldf, int row, int xs_off, int xv_off) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* xr = x + m * ldx;
+    float* xs = ws + m * row + xs_off;
+    for (int c = 0; c < 63; ++c) xs[c] = xr[c];
+    xs[63] = 0.0f;
+    float* fr = feat + m * ldf;
+    for (int c = 0; c < 20; ++c) fr[c] = xr[63 + c];
+    for (int c = 20; c < ldf; ++c) fr[c] = 0.0f;
+    float* xv = ws + m * row + xv_off;
+    xv[128] = xr[83]; xv[129] = xr[84]; xv[130] = xr[85];
+    for (int c = 131; c < 144; ++c) xv[c] = 0.0f;
+}
+
 // Y[m][ycol + co] = act((X[m][:Kp] . W[co][:] + b[co]) * RM[m][co])
 template <int MT, int ACT, bool ROWMUL>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ wimg,
@@ -432,15 +450,23 @@ struct MlpRowLayout { int row, xs, bias, h[4], h5, xv, hv; };
 static const MlpRowLayout kInferLayout = {WS_ROW, WS_XS, WS_BIAS, {WS_HA, WS_HB, WS_HA, WS_HB}, WS_HA, WS_XV, WS_HV};
 static const MlpRowLayout kTrainLayout = {TW_ROW, TW_XS, TW_BIAS, {TW_H0, TW_H1, TW_H2, TW_H3}, TW_H5, TW_XV, TW_HV};
 
+static int nerf_chain(const MlpRowLayout& lay, float* feat, int ldf, const float* weights, float* ws, float* raw, int M, hipStream_t st);
+
 static int nerf_forward(const MlpRowLayout& lay, const float* ndc, float* feat, int ldf, const float* dirs, const float* w2c_ref,
                         const float* weights, float* ws, float* raw, int N, int S, hipStream_t st) {
     const int M = N * S;
-    const float* L[11];
-    long long off = 0;
-    for (int i = 0; i < 11; ++i) { L[i] = weights + off; off += mlp_layer_floats(kLayers[i].cout, kLayers[i].kp); }
     hipLaunchKernelGGL(mlp_embed_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ndc, dirs, w2c_ref, feat, ws, M, S, ldf, 20, lay.row, lay.xs, lay.xv);
     int rc = launch_status("nerf embed");
     if (rc) return rc;
+    return nerf_chain(lay, feat, ldf, weights, ws, raw, M, st);
+}
+
+// the eleven layers on rows whose inputs (X0, feat, dir) are in place
+static int nerf_chain(const MlpRowLayout& lay, float* feat, int ldf, const float* weights, float* ws, float* raw, int M, hipStream_t st) {
+    const float* L[11];
+    long long off = 0;
+    for (int i = 0; i < 11; ++i) { L[i] = weights + off; off += mlp_layer_floats(kLayers[i].cout, kLayers[i].kp); }
+    int rc;
     const int R = lay.row;
     float *XS = ws + lay.xs, *BI = ws + lay.bias, *XV = ws + lay.xv, *HV = ws + lay.hv, *H5 = ws + lay.h5;
     float* H[4] = {ws + lay.h[0], ws + lay.h[1], ws + lay.h[2], ws + lay.h[3]};
@@ -465,6 +491,18 @@ int rcmvs_nerf_mlp_fwd(const float* ndc, float* feat, int ldf, const float* dirs
     RCMVS_REQUIRE(ndc && feat && dirs && w2c_ref && weights && workspace && raw, "nerf_mlp_fwd: null pointer");
     RCMVS_REQUIRE(N > 0 && S > 0 && ldf == 32, "nerf_mlp_fwd: feat must have a row stride of 32 floats (20 used)");
     return nerf_forward(kInferLayout, ndc, feat, ldf, dirs, w2c_ref, weights, workspace, raw, N, S, as_stream(stream));
+}
+
+/* Renderer_ours.forward(x) on its own: x (M, ldx >= 86) rows = [embedded point 63 | feature 20 | view direction 3] -> raw (M, 4) = [rgb, sigma].
+ * feat32: scratch (M, 32); workspace: rcmvs_nerf_workspace_floats(M) floats. */
+int rcmvs_nerf_mlp_embedded_fwd(const float* x, int ldx, const float* weights, float* workspace, float* feat32, float* raw, long long M, void* stream) {
+    RCMVS_REQUIRE(x && weights && workspace && feat32 && raw, "nerf_mlp_embedded_fwd: null pointer");
+    RCMVS_REQUIRE(M > 0 && M < (1LL << 31) / WS_ROW && ldx >= 86, "nerf_mlp_embedded_fwd: bad sizes (M = %lld, ldx = %d)", M, ldx);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(mlp_scatter_rows_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, x, ldx, feat32, workspace, M, 32, kInferLayout.row, kInferLayout.xs, kInferLayout.xv);
+    int rc = launch_status("nerf scatter");
+    if (rc) return rc;
+    return nerf_chain(kInferLayout, feat32, 32, weights, workspace, raw, (int)M, st);
 }
 
 long long rcmvs_nerf_train_workspace_floats(long long M) { return M * TW_ROW; }

@@ -558,6 +558,20 @@ def nerf_mlp(ndc, feat, dirs, w2c_ref, blob):
     return raw
 
 
+def nerf_mlp_embedded(x, blob):
+    """Renderer_ours.forward on its own: x (M, 86) rows [embedded point 63 | feature 20 | view direction 3] -> raw (M, 4) = [rgb, sigma]."""
+    lib = _lib.load()
+    M, ldx = x.shape
+    if ldx != 86:
+        raise _lib.RcmvsError(f"nerf_mlp_embedded: rows of 63 + 20 + 3 = 86 columns expected (got {ldx})")
+    ws = torch.empty((lib.rcmvs_nerf_workspace_floats(M),), device=x.device, dtype=torch.float32)
+    feat = torch.empty((M, 32), device=x.device, dtype=torch.float32)
+    raw = torch.empty((M, 4), device=x.device, dtype=torch.float32)
+    _lib.check(lib.rcmvs_nerf_mlp_embedded_fwd(_chk(x, "x"), ldx, _chk(blob, "weights"), _chk(ws, "workspace"), _chk(feat, "feat"), _chk(raw, "raw"), M, _stream()),
+               "nerf_mlp_embedded_fwd")
+    return raw
+
+
 def composite(raw, z):
     """raw (N,S,4), z (N,S) -> rgb (N,3), depth (N), weights (N,S), alpha (N,S)."""
     N, S = z.shape

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .casmvsnet import _block3d, _bn_fold, _hip_inference, _hip_training, _holder_only, _unsupported
+from .casmvsnet import RcmvsError, _block3d, _bn_fold, _hip_inference, _hip_training, _holder_only, _unsupported
 
 N_RAYS = 1024                               # hard-coded in the reference (render_consist_net.py:68)
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -202,8 +202,45 @@ class Renderer_ours(nn.Module):
                 nn.init.kaiming_normal_(m.weight.data)
                 nn.init.zeros_(m.bias.data)
 
+        self._blob = None
+        self._blob_key = None
+
+    def hip_blob(self):
+        """The eleven layers as one packed MFMA weight blob (rebuilt when a parameter changes)."""
+        named = {"pts_bias": self.pts_bias, "alpha_linear": self.alpha_linear, "feature_linear": self.feature_linear,
+                 "views_linears.0": self.views_linears[0], "rgb_linear": self.rgb_linear}
+        for i in range(6):
+            named[f"pts_linears.{i}"] = self.pts_linears[i]
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in named.values())
+        if self._blob is None or key != self._blob_key:
+            self._blob = ops.pack_nerf_weights({k: (m.weight, m.bias) for k, m in named.items()})
+            self._blob_key = key
+        return self._blob
+
+    def _mvs_form(self):
+        return (self.use_viewdirs and self.D == 6 and self.W == 128 and self.in_ch_pts == 63 and self.in_ch_feat == 20 and self.in_ch_views == 3
+                and list(self.skips) == [4])
+
     def forward(self, x):
-        _holder_only(self)       # the eleven layers run as one MFMA chain: ops.nerf_mlp / train_ops.nerf_mlp_train
+        """models/render_models.py:192-220 on its own: x (..., 63 + 20 + 3) = [embedded point | point feature | view direction] ->
+        (..., 4) = [rgb, sigma].  Inference only (inside the rendering branch the layers run fused with the embedding and, in
+        training, through train_ops.nerf_mlp_train); the form create_nerf_mvs builds (D = 6, W = 128, 63 / 20 / 3 columns)."""
+        if not self._mvs_form():
+            raise RcmvsError("Renderer_ours.forward: only the configuration of create_nerf_mvs runs on the HIP kernels "
+                             "(D=6, W=128, input_ch=63, input_ch_feat=20, input_ch_views=3, skips=[4], use_viewdirs=True)")
+        if not _hip_inference(self, x):
+            _unsupported(self, x)
+        if x.shape[-1] != 86:
+            raise RcmvsError(f"Renderer_ours.forward: rows of 63 + 20 + 3 = 86 columns expected (got {x.shape[-1]})")
+        raw = ops.nerf_mlp_embedded(x.reshape(-1, 86).contiguous().float(), self.hip_blob())
+        return raw.reshape(*x.shape[:-1], 4)
+
+    def forward_alpha(self, x):
+        """models/render_models.py:175-190: sigma only, from rows without the view direction (..., 63 + 20) -> (..., 1)."""
+        if x.shape[-1] != 83:
+            raise RcmvsError(f"Renderer_ours.forward_alpha: rows of 63 + 20 = 83 columns expected (got {x.shape[-1]})")
+        xv = torch.cat((x, torch.zeros(*x.shape[:-1], 3, device=x.device, dtype=x.dtype)), dim=-1)      # sigma does not depend on the direction
+        return self.forward(xv)[..., 3:4]
 
 
 class RenderNet(nn.Module):
@@ -216,23 +253,15 @@ class RenderNet(nn.Module):
         self.in_ch_pts, self.in_ch_views, self.in_ch_feat = input_ch_pts, input_ch_views, input_ch_feat
         self.nerf = Renderer_ours(D=D, W=W, input_ch_feat=input_ch_feat, input_ch=input_ch_pts, output_ch=4, skips=skips,
                                   input_ch_views=input_ch_views, use_viewdirs=True)
-        self._blob = None
-        self._blob_key = None
 
     def hip_blob(self):
-        n = self.nerf
-        named = {"pts_bias": n.pts_bias, "alpha_linear": n.alpha_linear, "feature_linear": n.feature_linear,
-                 "views_linears.0": n.views_linears[0], "rgb_linear": n.rgb_linear}
-        for i in range(6):
-            named[f"pts_linears.{i}"] = n.pts_linears[i]
-        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in named.values())
-        if self._blob is None or key != self._blob_key:
-            self._blob = ops.pack_nerf_weights({k: (m.weight, m.bias) for k, m in named.items()})
-            self._blob_key = key
-        return self._blob
+        return self.nerf.hip_blob()
+
+    def forward_alpha(self, x):
+        return self.nerf.forward_alpha(x)
 
     def forward(self, x):
-        _holder_only(self)
+        return self.nerf(x)
 
 
 class Rendering_Consistency_Net(nn.Module):

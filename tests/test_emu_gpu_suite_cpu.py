@@ -66,7 +66,7 @@ FAST = {
          "test_fpn_out_fused_is_bit_identical", "test_fpn_out_folded_matches_the_unfused_path", "test_conv1x1_matrix_core_form", "test_feature_output_convs_keep_the_variance_bound", "test_first_layer_reads_the_planar_images_itself", "test_standalone_blocks_vs_reference_golden",
          "test_deconv2d_fuse_and_unet_pyramid_vs_reference_golden", "test_standalone_conv3d_block_trains_like_torch",
          "test_depthnet_on_its_own_vs_reference_golden", "test_execution_plans_follow_their_parameters"],
-    GR: ["test_resize_planes", "test_gu_sampler_vs_oracle", "test_nerf_mlp_vs_oracle", "test_composite_vs_oracle"],
+    GR: ["test_resize_planes", "test_gu_sampler_vs_oracle", "test_nerf_mlp_vs_oracle", "test_rendernet_forward_on_its_own_vs_reference_golden", "test_composite_vs_oracle"],
     GT: ["test_prob_depth_head_backward", "test_prob_conv_weight_gradient_marching_kernel", "test_conv3d_weight_gradient_cout8_paired_columns",
          "test_selective_weight_pack_matches_full_blob_and_is_checked", "test_packed_weight_reuse_follows_the_parameter_version", "test_pack_cache_follows_data_writes_of_a_legacy_optimizer_and_dies_with_its_parameter", "test_batchnorm_and_wgrad_scratch_survive_an_aborted_call",
          "test_fused_batchnorm_forms_equal_the_two_launch_forms", "test_weight_gradient_finish_permutes_and_clears"],

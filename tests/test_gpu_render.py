@@ -129,6 +129,33 @@ def test_nerf_mlp_vs_oracle(hip):
     assert rel_err(raw, ref) < 5e-5
 
 
+def test_rendernet_forward_on_its_own_vs_reference_golden(hip):
+    """RenderNet.forward / Renderer_ours.forward / forward_alpha called directly (models/render_models.py:175-220,538-565) on rows that are
+    already [embedded point | point feature | view direction]: against the reference's own `network_fn` on the same weights
+    (tests/golden/nerf_mlp.npz), batch shape kept; the module explains itself on a foreign configuration, with gradients, off the device."""
+    from rc_mvsnet_amd import synthetic
+    from rc_mvsnet_amd.render_consist_net import RenderNet, Renderer_ours
+    g = load_golden("nerf_mlp")
+    net = RenderNet(D=6, W=128, input_ch_pts=63, input_ch_views=3, input_ch_feat=20, skips=[4], net_type="v0")
+    net.load_state_dict({k[len("network_fn."):]: v for k, v in synthetic.render_state_dict(1).items() if k.startswith("network_fn.")}, strict=True)
+    net = net.to(DEV).eval()
+    x = gpu(g["x"])
+    with torch.no_grad():
+        out = net(x)
+        alpha = net.forward_alpha(x[..., :83])
+        out2 = net.nerf(x.reshape(-1, 86))
+    assert out.shape == (64, 16, 4) and alpha.shape == (64, 16, 1)
+    assert rel_err(out.cpu(), g["out"]) < 5e-5
+    assert torch.equal(alpha[..., 0], out[..., 3]) and torch.equal(out2.reshape(64, 16, 4), out)
+    with pytest.raises(Exception, match="no_grad|train|GPU"):
+        net(x)                                                           # eval mode with autograd on
+    with torch.no_grad():
+        with pytest.raises(Exception, match="86"):
+            net(x[..., :80])
+        with pytest.raises(Exception, match="create_nerf_mvs"):
+            Renderer_ours(D=8, W=256, use_viewdirs=True).to(DEV).eval()(x)
+
+
 def test_composite_vs_oracle(hip):
     from oracle import render as orr
     gen = torch.Generator().manual_seed(2)
