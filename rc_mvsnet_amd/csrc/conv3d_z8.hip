@@ -1,0 +1,274 @@
+// conv0 of the cost regularisation (3x3x3, stride 1, Cin = 8 / 16 -> Cout = 8; models/modules.py:472) for a B = 1 inference scene, fp16-pair
+// arithmetic (conv3d_x3.hip, NP = 2: the SAME weight image and fragment maps) -- without the producer / consumer split.  gfx950 only.
+//
+// Why.  The tick trace of the split kernel (profiles/r3_x3_tick_trace.txt) reads: consumer MFMAs end at 1 374 of a
+// 3 593-clock tick; the producer wave that shares the SIMD then needs ~2 000 clocks for 45 VALU instructions, 6 LDS stores and 12 load
+// requests -- its work is tiny, but VALU work does not overlap MFMAs issued on the same SIMD and a lone wave has nothing to hide its own
+// latencies behind: a tick is MFMA time PLUS a latency chain.  Here all eight waves are alike: each owns one n-tile (16 columns x 2 rows,
+// or 32 columns x 1 row for Cin = 8) of an 8 x 32 output tile and the whole K range (weights register-stationary: 9 / 18 k-steps x two
+// pieces), each stages its share of the next input plane (split into fp16 pieces on the way into a four-slot LDS ring), one barrier per
+// output plane.  A SIMD hosts two such waves: while one waits for LDS or memory the other issues MFMAs.
+// Work is a STREAM of planes: a block takes a contiguous range of the flattened (tile, z) steps; an item (tile, z range of n planes) needs
+// n + 2 input planes = n + 2 ticks, the first two of which only stage (the ring, the register queue and the loads run on across item
+// boundaries: no latency is exposed when the block moves to its next tile).  Tick t: park stream plane t + 1 (requested two ticks
+// earlier), request stream plane t + 3, compute the output plane whose three input planes are stream planes t - 2 .. t.
+#include "common.h"
+#include "x3_pieces.h"
+
+namespace rcmvs {
+
+template <int CIN>
+struct Z8 {
+    static constexpr bool XT = CIN == 8;             // M = (shift along x, co) for Cin = 8, (shift along y, co) for Cin = 16 (the x3 image's maps)
+    static constexpr int TY = 8, TX = 32;
+    static constexpr int VB = CIN * 2;               // bytes per voxel per piece plane
+    static constexpr int Q4 = CIN / 4;               // float4 per voxel
+    static constexpr int PPS = 32 / CIN;             // tap positions per k-step
+    static constexpr int QC = XT ? 4 : 3, PPKD = 12;
+    static constexpr int SPK = PPKD / PPS;           // k-steps per plane
+    static constexpr int KSTEPS = 3 * SPK;
+    static constexpr int TYP = TY + 2, TXP = TX + 2;
+    static constexpr int ROWB = TXP * VB, PLB = TYP * ROWB, SLB = 2 * PLB;
+    static constexpr int NSLOT = 4;
+    static constexpr int NLD = (TYP * TXP * Q4 + 511) / 512;
+    static constexpr int CS = XT ? 2 : 1;
+    static constexpr int LDS = NSLOT * SLB + 64;
+    static_assert(CIN == 8 || CIN == 16, "conv0 of stages 3 and 2");
+};
+
+struct Z8Dims {
+    int B, D, H, W;
+    int tiles_x, ntiles;          // tile grid of one batch element
+    int relu;
+};
+
+// cursor over the block's stream: item = (tile index over batch x tile grid, first plane zb, planes nz), i = tick of the item (0 .. nz + 1)
+struct Z8Cursor {
+    long long g, hi;              // next step of the flattened (tile, z) sequence this cursor has not entered yet / end of the block's range
+    int tile, zb, nz, i;
+    bool valid;
+};
+__device__ __forceinline__ void z8_next_item(Z8Cursor& c, int D) {
+    c.valid = c.g < c.hi;
+    if (!c.valid) return;
+    c.tile = (int)(c.g / D);
+    c.zb = (int)(c.g % D);
+    const long long left = c.hi - c.g;
+    c.nz = (int)(left < D - c.zb ? left : D - c.zb);
+    c.i = 0;
+    c.g += c.nz;
+}
+__device__ __forceinline__ void z8_advance(Z8Cursor& c, int D) {
+    if (!c.valid) return;
+    if (++c.i == c.nz + 2) z8_next_item(c, D);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(512) void conv3d_z8_kernel(
+    const float* __restrict__ x, const x3_u32x4* __restrict__ wimg, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ y, Z8Dims dm, const float* __restrict__ xmax, float* __restrict__ ymax) {
+    using C = Z8<CIN>;
+    constexpr int KSTEPS = C::KSTEPS, NLD = C::NLD, OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) x3_byte smem[];
+    float* const redmax = reinterpret_cast<float*>(smem + C::NSLOT * C::SLB);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kk = lane >> 4;
+    // ---- the block's share of the step sequence (neighbouring ranges on one XCD: block ids b, b + 8, ... share an L2)
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int r = ((nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
+    const long long T = (long long)dm.B * dm.ntiles * dm.D;
+    const long long lo = T * r / nblk, hi = T * (r + 1) / nblk;
+    if (hi <= lo) return;
+
+    // ---- scales, weights (register-stationary), this lane's B-fragment offsets inside a slice
+    float bound = xmax[lane * 16];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) bound = fmaxf(bound, __shfl_xor(bound, m));
+    float xinv;
+    const float xs_scale = x3_pow2_scale(bound, xinv);
+    const float unscale = xinv * reinterpret_cast<const float*>(wimg)[1];
+    x3_u32x4 wr[KSTEPS][2];
+    int boff[KSTEPS];
+    const int toff = C::XT ? wave * C::ROWB : (wave >> 1) * 2 * C::ROWB + (wave & 1) * 16 * C::VB;      // this wave's n-tile
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wr[j][p] = wimg[1 + (j * 2 + p) * 64 + lane];
+        const int js = j % C::SPK;
+        int q = js * C::PPS + kk / (4 / C::PPS);
+        const int ci0 = (kk % (4 / C::PPS)) * 8;
+        if (q >= C::PPKD) q = 0;
+        boff[j] = toff + (q / C::QC) * C::ROWB + (q % C::QC + n * C::CS) * C::VB + ci0 * 2;
+    }
+    const int co0 = (kk & 1) * 4;
+    const x3_f32x4 sc = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
+    const x3_f32x4 sh = shift ? *reinterpret_cast<const x3_f32x4*>(shift + co0) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
+    // this lane's output voxel inside the tile
+    const int oyl = C::XT ? wave : 2 * (wave >> 1) + (kk >> 1), oxl = C::XT ? 2 * n + (kk >> 1) : (wave & 1) * 16 + n;
+
+    // ---- staging shares of a plane: element e = (halo voxel, float4 of its channels)
+    int grel[NLD], loff[NLD], hyx[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * 512, v = e / C::Q4, c4 = e % C::Q4;
+        const int hy = v / C::TXP, hx = v % C::TXP;
+        const bool has = e < C::TYP * C::TXP * C::Q4;
+        grel[i] = ((hy * dm.W + hx) * CIN + c4 * 4) * 4;
+        loff[i] = has ? hy * C::ROWB + hx * C::VB + c4 * 8 : -1;
+        hyx[i] = has ? (hy << 16) | hx : -1;
+    }
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)((long long)dm.B * dm.D * dm.H * dm.W * CIN * 4), 0x00020000);
+    const int zstride = dm.H * dm.W * CIN * 4;
+
+    // fetch side: the item whose planes are being requested
+    Z8Cursor fc;
+    fc.g = lo; fc.hi = hi;
+    z8_next_item(fc, dm.D);
+    int goff[NLD];
+    int f_tile = -1;
+    auto fetch = [&](x3_f32x4 (&q)[NLD]) {        // request the plane under the fetch cursor (zeros past the end of the stream), advance it
+        bool zin = false;
+        int zoff = 0;
+        if (fc.valid) {
+            if (fc.tile != f_tile) {
+                f_tile = fc.tile;
+                const int b = fc.tile / dm.ntiles, t = fc.tile % dm.ntiles;
+                const int y0 = (t / dm.tiles_x) * C::TY, x0 = (t % dm.tiles_x) * C::TX;
+                const int base = (((b * dm.D) * dm.H + (y0 - 1)) * dm.W + (x0 - 1)) * CIN * 4;
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int gy = y0 - 1 + (hyx[i] >> 16), gx = x0 - 1 + (hyx[i] & 0xffff);
+                    goff[i] = (hyx[i] >= 0 && gy >= 0 && gy < dm.H && gx >= 0 && gx < dm.W) ? base + grel[i] : OOB;
+                }
+            }
+            const int z = fc.zb - 1 + fc.i;
+            zin = z >= 0 && z < dm.D;
+            zoff = zin ? z * zstride : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) q[i] = __builtin_bit_cast(x3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, zin ? goff[i] : OOB, zoff, 0));
+        z8_advance(fc, dm.D);
+    };
+    auto stash = [&](const x3_f32x4 (&q)[NLD], int slot) {
+        x3_byte* sb = smem + slot * C::SLB;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            x3_u32x2 h, l;
+            x3_split4h(q[i] * xs_scale, h, l);
+            if (loff[i] >= 0) {
+                *reinterpret_cast<x3_u32x2*>(sb + loff[i]) = h;
+                *reinterpret_cast<x3_u32x2*>(sb + C::PLB + loff[i]) = l;
+            }
+        }
+    };
+
+    // compute side
+    Z8Cursor cc;
+    cc.g = lo; cc.hi = hi;
+    z8_next_item(cc, dm.D);
+    int ob = OOB;                 // byte offset of this lane's float4 of the current output plane
+    const int ostep = dm.H * dm.W * 8 * 4;
+    float vmax = 0.0f;
+    x3_f32x4 pq[2][NLD];
+    // stream planes 0 and 1 now, plane 0 parked before the first tick, plane 2 requested
+    fetch(pq[0]);
+    fetch(pq[1]);
+    stash(pq[0], 0);
+    fetch(pq[0]);
+    __syncthreads();
+    auto tick = [&](int t, x3_f32x4 (&q)[NLD]) {          // q = the register set of stream plane t + 1
+        stash(q, (t + 1) & 3);
+        fetch(q);                                          // stream plane t + 3
+        if (cc.valid && cc.i >= 2) {
+            if (cc.i == 2) {                               // first output plane of the item: where this lane's voxels go
+                const int b = cc.tile / dm.ntiles, tl = cc.tile % dm.ntiles;
+                const int oy = (tl / dm.tiles_x) * C::TY + oyl, ox = (tl % dm.tiles_x) * C::TX + oxl;
+                ob = (oy < dm.H && ox < dm.W) ? (((((b * dm.D) + cc.zb) * dm.H + oy) * dm.W + ox) * 8 + co0) * 4 : OOB;
+            }
+            x3_f32x4 acc0 = (x3_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            int sbase[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sbase[k] = ((t - 2 + k) & 3) * C::SLB;
+#pragma unroll
+            for (int j = 0; j < KSTEPS; ++j) {
+                const x3_byte* pb = smem + sbase[j / C::SPK] + boff[j];
+                const x3_u32x4 bh = *reinterpret_cast<const x3_u32x4*>(pb);
+                const x3_u32x4 bl = *reinterpret_cast<const x3_u32x4*>(pb + C::PLB);
+                acc0 = x3_mfma<2>(wr[j][0], bh, acc0);
+                acc1 = x3_mfma<2>(wr[j][0], bl, acc1);
+                acc1 = x3_mfma<2>(wr[j][1], bh, acc1);
+            }
+            x3_f32x4 v = (acc0 + acc1) * sc + sh;
+            if (dm.relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
+            if (ob != OOB) {
+                *reinterpret_cast<x3_f32x4*>(reinterpret_cast<x3_byte*>(y) + ob) = v;
+                vmax = x3_absmax4(vmax, v);
+                ob += ostep;
+            }
+        }
+        z8_advance(cc, dm.D);
+        __syncthreads();
+    };
+    for (int t = 0; cc.valid; t += 2) {
+        tick(t, pq[1]);
+        if (cc.valid) tick(t + 1, pq[0]);
+    }
+    if (ymax) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+        if (lane == 0) redmax[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = redmax[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, redmax[i]);
+            atomicMax(reinterpret_cast<unsigned int*>(ymax) + (blockIdx.x & 63) * 16, __float_as_uint(m));
+        }
+    }
+}
+
+bool conv3d_z8_supported(int Ci, int Co, int kind) { return kind == 0 && Co == 8 && (Ci == 8 || Ci == 16); }
+
+template <int CIN>
+static int z8_launch_t(const float* x, const float* wimg, const float* scale, const float* shift, float* y, const Z8Dims& dm, int n_cu, int dev,
+                       const float* xmax, float* ymax, hipStream_t st) {
+    using C = Z8<CIN>;
+    constexpr int MAXDEV = 64;
+    static bool raised[MAXDEV];
+    if (C::LDS > 64 * 1024 && !raised[dev]) {
+        if (hipFuncSetAttribute((const void*)conv3d_z8_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+            return fail(-1, "conv3d_z8: cannot raise the dynamic LDS limit to %d bytes", C::LDS);
+        raised[dev] = true;
+    }
+    const long long T = (long long)dm.B * dm.ntiles * dm.D;
+    const int blocks = (int)(T < n_cu ? T : n_cu);
+    hipLaunchKernelGGL((conv3d_z8_kernel<CIN>), dim3(blocks), dim3(512), C::LDS, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, y, dm, xmax, ymax);
+    return launch_status("conv3d_z8");
+}
+
+// x (B, D, H, W, Ci) -> y (B, D, H, W, 8); wimg = the x3h image of the pair (conv3d_x3h_pack); xmax required, ymax optional
+int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, const float* shift, float* y,
+                     int B, int D, int H, int W, int Ci, int relu, hipStream_t st, int max_blocks, const float* xmax, float* ymax) {
+    if (!xmax) return fail(-1, "conv3d_z8: the fp16-pair form needs a bound of max|x|");
+    if ((long long)B * D * H * W * (Ci > 8 ? Ci : 8) * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_z8: tensor too large for 32-bit offsets");
+    constexpr int MAXDEV = 64;
+    static int cu_of[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return fail(-1, "conv3d_z8: cannot query the device");
+    if (cu_of[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(-1, "conv3d_z8: cannot query the device");
+        cu_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    Z8Dims dm;
+    dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu;
+    dm.tiles_x = (W + 31) / 32;
+    dm.ntiles = dm.tiles_x * ((H + 7) / 8);
+    const int n_blk = max_blocks > 0 ? max_blocks : cu_of[dev];
+    if (Ci == 8) return z8_launch_t<8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
+    if (Ci == 16) return z8_launch_t<16>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
+    return fail(-1, "conv3d_z8: unsupported Ci=%d", Ci);
+}
+
+}  // namespace rcmvs
