@@ -4,8 +4,8 @@
 // Why.  The tick trace of the split kernel (profiles/r3_x3_tick_trace.txt) reads: consumer MFMAs end at 1 374 of a
 // 3 593-clock tick; the producer wave that shares the SIMD then needs ~2 000 clocks for 45 VALU instructions, 6 LDS stores and 12 load
 // requests -- its work is tiny, but VALU work does not overlap MFMAs issued on the same SIMD and a lone wave has nothing to hide its own
-// latencies behind: a tick is MFMA time PLUS a latency chain.  Here all eight waves are alike: each owns one n-tile (16 columns x 2 rows,
-// or 32 columns x 1 row for Cin = 8) of an 8 x 32 output tile and the whole K range (weights register-stationary: 9 / 18 k-steps x two
+// latencies behind: a tick is MFMA time PLUS a latency chain.  Here all eight waves are alike: each owns one n-tile (16 columns x 2 rows) of
+// an 8 x 32 output tile (Cin = 8: two n-tiles of 32 columns x 1 row of a 16 x 32 tile) and the whole K range (weights register-stationary: 9 / 18 k-steps x two
 // pieces), each stages its share of the next input plane (split into fp16 pieces on the way into a four-slot LDS ring), one barrier per
 // output plane.  A SIMD hosts two such waves: while one waits for LDS or memory the other issues MFMAs.
 // Work is a STREAM of planes: a block takes a contiguous range of the flattened (tile, z) steps; an item (tile, z range of n planes) needs
@@ -20,7 +20,8 @@ namespace rcmvs {
 template <int CIN>
 struct Z8 {
     static constexpr bool XT = CIN == 8;             // M = (shift along x, co) for Cin = 8, (shift along y, co) for Cin = 16 (the x3 image's maps)
-    static constexpr int TY = 8, TX = 32;
+    static constexpr int NTW = XT ? 2 : 1;           // n-tiles per wave (Cin = 8: two -- its 9 k-steps leave the registers, and a tick of 27 MFMAs per wave was mostly barrier)
+    static constexpr int TY = 8 * NTW, TX = 32;
     static constexpr int VB = CIN * 2;               // bytes per voxel per piece plane
     static constexpr int Q4 = CIN / 4;               // float4 per voxel
     static constexpr int PPS = 32 / CIN;             // tap positions per k-step
@@ -105,18 +106,17 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     const x3_f32x4 sc = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
     const x3_f32x4 sh = shift ? *reinterpret_cast<const x3_f32x4*>(shift + co0) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
     // this lane's output voxel inside the tile
-    const int oyl = C::XT ? wave : 2 * (wave >> 1) + (kk >> 1), oxl = C::XT ? 2 * n + (kk >> 1) : (wave & 1) * 16 + n;
+    const int oyl = C::XT ? wave : 2 * (wave >> 1) + (kk >> 1), oxl = C::XT ? 2 * n + (kk >> 1) : (wave & 1) * 16 + n;      // (n-tile i of the wave: 8 i rows further down)
 
     // ---- staging shares of a plane: element e = (halo voxel, float4 of its channels)
-    int grel[NLD], loff[NLD], hyx[NLD];
+    int loff[NLD], hyx[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + i * 512, v = e / C::Q4, c4 = e % C::Q4;
         const int hy = v / C::TXP, hx = v % C::TXP;
         const bool has = e < C::TYP * C::TXP * C::Q4;
-        grel[i] = ((hy * dm.W + hx) * CIN + c4 * 4) * 4;
         loff[i] = has ? hy * C::ROWB + hx * C::VB + c4 * 8 : -1;
-        hyx[i] = has ? (hy << 16) | hx : -1;
+        hyx[i] = has ? (hy << 20) | (hx << 8) | c4 : -1;
     }
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)((long long)dm.B * dm.D * dm.H * dm.W * CIN * 4), 0x00020000);
     const int zstride = dm.H * dm.W * CIN * 4;
@@ -138,8 +138,9 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
                 const int base = (((b * dm.D) * dm.H + (y0 - 1)) * dm.W + (x0 - 1)) * CIN * 4;
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
-                    const int gy = y0 - 1 + (hyx[i] >> 16), gx = x0 - 1 + (hyx[i] & 0xffff);
-                    goff[i] = (hyx[i] >= 0 && gy >= 0 && gy < dm.H && gx >= 0 && gx < dm.W) ? base + grel[i] : OOB;
+                    const int hy = hyx[i] >> 20, hx = (hyx[i] >> 8) & 0xfff, c4 = hyx[i] & 0xff;
+                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                    goff[i] = (hyx[i] >= 0 && gy >= 0 && gy < dm.H && gx >= 0 && gx < dm.W) ? base + ((hy * dm.W + hx) * CIN + c4 * 4) * 4 : OOB;
                 }
             }
             const int z = fc.zb - 1 + fc.i;
@@ -167,7 +168,9 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     Z8Cursor cc;
     cc.g = lo; cc.hi = hi;
     z8_next_item(cc, dm.D);
-    int ob = OOB;                 // byte offset of this lane's float4 of the current output plane
+    int ob[C::NTW];               // byte offset of this lane's float4 of the current output plane, per n-tile of the wave
+#pragma unroll
+    for (int i = 0; i < C::NTW; ++i) ob[i] = OOB;
     const int ostep = dm.H * dm.W * 8 * 4;
     float vmax = 0.0f;
     x3_f32x4 pq[2][NLD];
@@ -183,28 +186,52 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
         if (cc.valid && cc.i >= 2) {
             if (cc.i == 2) {                               // first output plane of the item: where this lane's voxels go
                 const int b = cc.tile / dm.ntiles, tl = cc.tile % dm.ntiles;
-                const int oy = (tl / dm.tiles_x) * C::TY + oyl, ox = (tl % dm.tiles_x) * C::TX + oxl;
-                ob = (oy < dm.H && ox < dm.W) ? (((((b * dm.D) + cc.zb) * dm.H + oy) * dm.W + ox) * 8 + co0) * 4 : OOB;
+#pragma unroll
+                for (int i = 0; i < C::NTW; ++i) {
+                    const int oy = (tl / dm.tiles_x) * C::TY + oyl + 8 * i, ox = (tl % dm.tiles_x) * C::TX + oxl;
+                    ob[i] = (oy < dm.H && ox < dm.W) ? (((((b * dm.D) + cc.zb) * dm.H + oy) * dm.W + ox) * 8 + co0) * 4 : OOB;
+                }
             }
-            x3_f32x4 acc0 = (x3_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            // three independent accumulators per n-tile (hh, hl, lh: no MFMA waits for the one before it), B fragments read one k-step ahead
+            x3_f32x4 acc[C::NTW][3];
+#pragma unroll
+            for (int i = 0; i < C::NTW; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[i][c] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
             int sbase[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) sbase[k] = ((t - 2 + k) & 3) * C::SLB;
+            x3_u32x4 bq[2][C::NTW][2];
+            auto read_b = [&](int buf, int j) {
+#pragma unroll
+                for (int i = 0; i < C::NTW; ++i) {
+                    const x3_byte* pb = smem + sbase[j / C::SPK] + boff[j] + i * 8 * C::ROWB;
+                    bq[buf][i][0] = *reinterpret_cast<const x3_u32x4*>(pb);
+                    bq[buf][i][1] = *reinterpret_cast<const x3_u32x4*>(pb + C::PLB);
+                }
+            };
+            read_b(0, 0);
 #pragma unroll
             for (int j = 0; j < KSTEPS; ++j) {
-                const x3_byte* pb = smem + sbase[j / C::SPK] + boff[j];
-                const x3_u32x4 bh = *reinterpret_cast<const x3_u32x4*>(pb);
-                const x3_u32x4 bl = *reinterpret_cast<const x3_u32x4*>(pb + C::PLB);
-                acc0 = x3_mfma<2>(wr[j][0], bh, acc0);
-                acc1 = x3_mfma<2>(wr[j][0], bl, acc1);
-                acc1 = x3_mfma<2>(wr[j][1], bh, acc1);
+                if (j + 1 < KSTEPS) read_b((j + 1) & 1, j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < C::NTW; ++i) acc[i][0] = x3_mfma<2>(wr[j][0], bq[j & 1][i][0], acc[i][0]);
+#pragma unroll
+                for (int i = 0; i < C::NTW; ++i) acc[i][1] = x3_mfma<2>(wr[j][0], bq[j & 1][i][1], acc[i][1]);
+#pragma unroll
+                for (int i = 0; i < C::NTW; ++i) acc[i][2] = x3_mfma<2>(wr[j][1], bq[j & 1][i][0], acc[i][2]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            x3_f32x4 v = (acc0 + acc1) * sc + sh;
-            if (dm.relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
-            if (ob != OOB) {
-                *reinterpret_cast<x3_f32x4*>(reinterpret_cast<x3_byte*>(y) + ob) = v;
-                vmax = x3_absmax4(vmax, v);
-                ob += ostep;
+#pragma unroll
+            for (int i = 0; i < C::NTW; ++i) {
+                x3_f32x4 v = (acc[i][0] + (acc[i][1] + acc[i][2])) * sc + sh;
+                if (dm.relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
+                if (ob[i] != OOB) {
+                    *reinterpret_cast<x3_f32x4*>(reinterpret_cast<x3_byte*>(y) + ob[i]) = v;
+                    vmax = x3_absmax4(vmax, v);
+                    ob[i] += ostep;
+                }
             }
         }
         z8_advance(cc, dm.D);
@@ -263,8 +290,9 @@ int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, cons
     }
     Z8Dims dm;
     dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu;
+    const int ty = Ci == 8 ? Z8<8>::TY : Z8<16>::TY;
     dm.tiles_x = (W + 31) / 32;
-    dm.ntiles = dm.tiles_x * ((H + 7) / 8);
+    dm.ntiles = dm.tiles_x * ((H + ty - 1) / ty);
     const int n_blk = max_blocks > 0 ? max_blocks : cu_of[dev];
     if (Ci == 8) return z8_launch_t<8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
     if (Ci == 16) return z8_launch_t<16>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
