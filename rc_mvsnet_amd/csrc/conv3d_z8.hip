@@ -12,6 +12,9 @@
 // n + 2 input planes = n + 2 ticks, the first two of which only stage (the ring, the register queue and the loads run on across item
 // boundaries: no latency is exposed when the block moves to its next tile).  Tick t: park stream plane t + 1 (requested two ticks
 // earlier), request stream plane t + 3, compute the output plane whose three input planes are stream planes t - 2 .. t.
+// (Cin = 32 -> 8, stage 1: its 36 k-steps do not fit one wave's registers; the form with wave = (n-tile, K half), 4 x 32 tiles and the halves
+// meeting through LDS one tick later was built and measured: 96 - 100 us against 89 for the split kernel -- 17 - 25 spilled registers, 128 voxels per
+// barrier -- and removed.)
 #include "common.h"
 #include "x3_pieces.h"
 
