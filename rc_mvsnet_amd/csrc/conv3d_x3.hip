@@ -847,10 +847,10 @@ int conv3d_deep_pack(const float* w, float* img, int Co, int Ci, int kind, int t
 int conv3d_deep_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
                        int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, const float* xmax, float* ymax);
 
-// conv3d_z8.hip: conv0 of stages 2 / 3 (Cin = 16 / 8 -> 8, stride 1, no skip tensor) without the producer / consumer split; same image
+// conv3d_z8.hip: conv0 of stages 2 / 3 (Cin = 16 / 8 -> 8) and conv2 (16 -> 16), stride 1, no skip tensor, without the producer / consumer split; same image
 bool conv3d_z8_supported(int Ci, int Co, int kind);
 int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, const float* shift, float* y,
-                     int B, int D, int H, int W, int Ci, int relu, hipStream_t st, int max_blocks, const float* xmax, float* ymax);
+                     int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int max_blocks, const float* xmax, float* ymax);
 
 bool conv3d_x3h_supported(int Ci, int Co, int kind) {
     if (conv3d_deep_supported(Ci, Co, kind)) return true;
@@ -977,7 +977,7 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     {
         static const int z8_env = [] { const char* e = getenv("RCMVS_Z8"); return e ? atoi(e) : 1; }();
         if (z8_env && xmax && !res && !s2d && conv3d_z8_supported(Ci, Co, kind))
-            return conv3d_z8_launch(x, wimg, scale, shift, y, B, D, H, W, Ci, relu, st, max_blocks, xmax, ymax);
+            return conv3d_z8_launch(x, wimg, scale, shift, y, B, D, H, W, Ci, Co, relu, st, max_blocks, xmax, ymax);
     }
     const int ysq = (s2d >> 1) & 1;            // `s2d` carries two flags: bit 0 = space-to-depth view of the input, bit 1 = square the output bound
     s2d &= 1;

@@ -20,16 +20,20 @@
 
 namespace rcmvs {
 
-template <int CIN>
+template <int CIN, int COUT>
 struct Z8 {
-    static constexpr bool XT = CIN == 8;             // M = (shift along x, co) for Cin = 8, (shift along y, co) for Cin = 16 (the x3 image's maps)
-    static constexpr int NTW = XT ? 2 : 1;           // n-tiles per wave (Cin = 8: two -- its 9 k-steps leave the registers, and a tick of 27 MFMAs per wave was mostly barrier)
-    static constexpr int TY = 8 * NTW, TX = 32;
+    // fragment maps of the x3 image: Cout = 8 fills the 16 rows of an m-tile with two output positions -- M = (shift along x, co) for Cin = 8
+    // ("XT": an n-tile is 32 columns of one row), (shift along y, co) for Cin = 16 ("YT": 16 columns of two rows); Cout = 16: M = co ("PL": 16 columns of one row)
+    static constexpr bool XT = COUT == 8 && CIN == 8, YT = COUT == 8 && CIN == 16, PL = COUT == 16;
+    static constexpr int NTW = YT ? 1 : 2;           // n-tiles per wave (two where the weights leave the registers: a tick of 27 - 45 MFMAs per wave is mostly barrier)
+    static constexpr int NTT = 8 * NTW;              // n-tiles per tick
+    static constexpr int TY = PL ? NTT / 2 : NTT, TX = 32;      // XT: a row per n-tile; YT: row pairs, two side by side; PL: rows, two side by side
+    static constexpr int RSTEP = PL ? 4 : 8;         // tile rows between the two n-tiles of a wave
     static constexpr int VB = CIN * 2;               // bytes per voxel per piece plane
     static constexpr int Q4 = CIN / 4;               // float4 per voxel
     static constexpr int PPS = 32 / CIN;             // tap positions per k-step
-    static constexpr int QC = XT ? 4 : 3, PPKD = 12;
-    static constexpr int SPK = PPKD / PPS;           // k-steps per plane
+    static constexpr int QR = YT ? 4 : 3, QC = XT ? 4 : 3, PPKD = QR * QC;
+    static constexpr int SPK = (PPKD + PPS - 1) / PPS;      // k-steps per plane
     static constexpr int KSTEPS = 3 * SPK;
     static constexpr int TYP = TY + 2, TXP = TX + 2;
     static constexpr int ROWB = TXP * VB, PLB = TYP * ROWB, SLB = 2 * PLB;
@@ -37,7 +41,7 @@ struct Z8 {
     static constexpr int NLD = (TYP * TXP * Q4 + 511) / 512;
     static constexpr int CS = XT ? 2 : 1;
     static constexpr int LDS = NSLOT * SLB + 64;
-    static_assert(CIN == 8 || CIN == 16, "conv0 of stages 3 and 2");
+    static_assert((COUT == 8 && (CIN == 8 || CIN == 16)) || (COUT == 16 && CIN == 16), "conv0 of stages 3 and 2, conv2");
 };
 
 struct Z8Dims {
@@ -67,11 +71,11 @@ __device__ __forceinline__ void z8_advance(Z8Cursor& c, int D) {
     if (++c.i == c.nz + 2) z8_next_item(c, D);
 }
 
-template <int CIN>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     const float* __restrict__ x, const x3_u32x4* __restrict__ wimg, const float* __restrict__ scale, const float* __restrict__ shift,
     float* __restrict__ y, Z8Dims dm, const float* __restrict__ xmax, float* __restrict__ ymax) {
-    using C = Z8<CIN>;
+    using C = Z8<CIN, COUT>;
     constexpr int KSTEPS = C::KSTEPS, NLD = C::NLD, OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) x3_byte smem[];
     float* const redmax = reinterpret_cast<float*>(smem + C::NSLOT * C::SLB);
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     const float unscale = xinv * reinterpret_cast<const float*>(wimg)[1];
     x3_u32x4 wr[KSTEPS][2];
     int boff[KSTEPS];
-    const int toff = C::XT ? wave * C::ROWB : (wave >> 1) * 2 * C::ROWB + (wave & 1) * 16 * C::VB;      // this wave's n-tile
+    const int toff = C::XT ? wave * C::ROWB : (wave >> 1) * (C::YT ? 2 : 1) * C::ROWB + (wave & 1) * 16 * C::VB;      // this wave's (first) n-tile
 #pragma unroll
     for (int j = 0; j < KSTEPS; ++j) {
 #pragma unroll
@@ -102,14 +106,14 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
         const int js = j % C::SPK;
         int q = js * C::PPS + kk / (4 / C::PPS);
         const int ci0 = (kk % (4 / C::PPS)) * 8;
-        if (q >= C::PPKD) q = 0;
+        if (q >= C::PPKD) q = 0;                       // (padding slot of the last k-step of a plane: its weights are zero)
         boff[j] = toff + (q / C::QC) * C::ROWB + (q % C::QC + n * C::CS) * C::VB + ci0 * 2;
     }
-    const int co0 = (kk & 1) * 4;
+    const int co0 = C::PL ? kk * 4 : (kk & 1) * 4;
     const x3_f32x4 sc = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
     const x3_f32x4 sh = shift ? *reinterpret_cast<const x3_f32x4*>(shift + co0) : (x3_f32x4){0.f, 0.f, 0.f, 0.f};
     // this lane's output voxel inside the tile
-    const int oyl = C::XT ? wave : 2 * (wave >> 1) + (kk >> 1), oxl = C::XT ? 2 * n + (kk >> 1) : (wave & 1) * 16 + n;      // (n-tile i of the wave: 8 i rows further down)
+    const int oyl = C::XT ? wave : (C::YT ? 2 * (wave >> 1) + (kk >> 1) : (wave >> 1)), oxl = C::XT ? 2 * n + (kk >> 1) : (wave & 1) * 16 + n;      // (n-tile i of the wave: RSTEP i rows further down)
 
     // ---- staging shares of a plane: element e = (halo voxel, float4 of its channels)
     int loff[NLD], hyx[NLD];
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     int ob[C::NTW];               // byte offset of this lane's float4 of the current output plane, per n-tile of the wave
 #pragma unroll
     for (int i = 0; i < C::NTW; ++i) ob[i] = OOB;
-    const int ostep = dm.H * dm.W * 8 * 4;
+    const int ostep = dm.H * dm.W * COUT * 4;
     float vmax = 0.0f;
     x3_f32x4 pq[2][NLD];
     // stream planes 0 and 1 now, plane 0 parked before the first tick, plane 2 requested
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
                 const int b = cc.tile / dm.ntiles, tl = cc.tile % dm.ntiles;
 #pragma unroll
                 for (int i = 0; i < C::NTW; ++i) {
-                    const int oy = (tl / dm.tiles_x) * C::TY + oyl + 8 * i, ox = (tl % dm.tiles_x) * C::TX + oxl;
-                    ob[i] = (oy < dm.H && ox < dm.W) ? (((((b * dm.D) + cc.zb) * dm.H + oy) * dm.W + ox) * 8 + co0) * 4 : OOB;
+                    const int oy = (tl / dm.tiles_x) * C::TY + oyl + C::RSTEP * i, ox = (tl % dm.tiles_x) * C::TX + oxl;
+                    ob[i] = (oy < dm.H && ox < dm.W) ? (((((b * dm.D) + cc.zb) * dm.H + oy) * dm.W + ox) * COUT + co0) * 4 : OOB;
                 }
             }
             // three independent accumulators per n-tile (hh, hl, lh: no MFMA waits for the one before it), B fragments read one k-step ahead
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
             auto read_b = [&](int buf, int j) {
 #pragma unroll
                 for (int i = 0; i < C::NTW; ++i) {
-                    const x3_byte* pb = smem + sbase[j / C::SPK] + boff[j] + i * 8 * C::ROWB;
+                    const x3_byte* pb = smem + sbase[j / C::SPK] + boff[j] + i * C::RSTEP * C::ROWB;
                     bq[buf][i][0] = *reinterpret_cast<const x3_u32x4*>(pb);
                     bq[buf][i][1] = *reinterpret_cast<const x3_u32x4*>(pb + C::PLB);
                 }
@@ -258,30 +262,30 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     }
 }
 
-bool conv3d_z8_supported(int Ci, int Co, int kind) { return kind == 0 && Co == 8 && (Ci == 8 || Ci == 16); }
+bool conv3d_z8_supported(int Ci, int Co, int kind) { return kind == 0 && ((Co == 8 && (Ci == 8 || Ci == 16)) || (Co == 16 && Ci == 16)); }
 
-template <int CIN>
+template <int CIN, int COUT>
 static int z8_launch_t(const float* x, const float* wimg, const float* scale, const float* shift, float* y, const Z8Dims& dm, int n_cu, int dev,
                        const float* xmax, float* ymax, hipStream_t st) {
-    using C = Z8<CIN>;
+    using C = Z8<CIN, COUT>;
     constexpr int MAXDEV = 64;
     static bool raised[MAXDEV];
     if (C::LDS > 64 * 1024 && !raised[dev]) {
-        if (hipFuncSetAttribute((const void*)conv3d_z8_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv3d_z8_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
             return fail(-1, "conv3d_z8: cannot raise the dynamic LDS limit to %d bytes", C::LDS);
         raised[dev] = true;
     }
     const long long T = (long long)dm.B * dm.ntiles * dm.D;
     const int blocks = (int)(T < n_cu ? T : n_cu);
-    hipLaunchKernelGGL((conv3d_z8_kernel<CIN>), dim3(blocks), dim3(512), C::LDS, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, y, dm, xmax, ymax);
+    hipLaunchKernelGGL((conv3d_z8_kernel<CIN, COUT>), dim3(blocks), dim3(512), C::LDS, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, y, dm, xmax, ymax);
     return launch_status("conv3d_z8");
 }
 
-// x (B, D, H, W, Ci) -> y (B, D, H, W, 8); wimg = the x3h image of the pair (conv3d_x3h_pack); xmax required, ymax optional
+// x (B, D, H, W, Ci) -> y (B, D, H, W, Co); wimg = the x3h image of the pair (conv3d_x3h_pack); xmax required, ymax optional
 int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, const float* shift, float* y,
-                     int B, int D, int H, int W, int Ci, int relu, hipStream_t st, int max_blocks, const float* xmax, float* ymax) {
+                     int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int max_blocks, const float* xmax, float* ymax) {
     if (!xmax) return fail(-1, "conv3d_z8: the fp16-pair form needs a bound of max|x|");
-    if ((long long)B * D * H * W * (Ci > 8 ? Ci : 8) * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_z8: tensor too large for 32-bit offsets");
+    if ((long long)B * D * H * W * (Ci > Co ? Ci : Co) * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_z8: tensor too large for 32-bit offsets");
     constexpr int MAXDEV = 64;
     static int cu_of[MAXDEV];
     int dev = 0;
@@ -293,13 +297,14 @@ int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, cons
     }
     Z8Dims dm;
     dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu;
-    const int ty = Ci == 8 ? Z8<8>::TY : Z8<16>::TY;
+    const int ty = Co == 16 ? Z8<16, 16>::TY : (Ci == 8 ? Z8<8, 8>::TY : Z8<16, 8>::TY);
     dm.tiles_x = (W + 31) / 32;
     dm.ntiles = dm.tiles_x * ((H + ty - 1) / ty);
     const int n_blk = max_blocks > 0 ? max_blocks : cu_of[dev];
-    if (Ci == 8) return z8_launch_t<8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
-    if (Ci == 16) return z8_launch_t<16>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
-    return fail(-1, "conv3d_z8: unsupported Ci=%d", Ci);
+    if (Ci == 8 && Co == 8) return z8_launch_t<8, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
+    if (Ci == 16 && Co == 8) return z8_launch_t<16, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
+    if (Ci == 16 && Co == 16) return z8_launch_t<16, 16>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
+    return fail(-1, "conv3d_z8: unsupported Ci=%d Co=%d", Ci, Co);
 }
 
 }  // namespace rcmvs
