@@ -976,8 +976,10 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     if (xmax && conv3d_deep_supported(Ci, Co, kind)) return conv3d_deep_launch(x, wimg, scale, shift, res, y, B, D, H, W, Ci, Co, kind, relu, st, xmax, ymax);
     {
         static const int z8_env = [] { const char* e = getenv("RCMVS_Z8"); return e ? atoi(e) : 1; }();
-        if (z8_env && xmax && !res && !s2d && conv3d_z8_supported(Ci, Co, kind))
-            return conv3d_z8_launch(x, wimg, scale, shift, y, B, D, H, W, Ci, Co, relu, st, max_blocks, xmax, ymax);
+        if (z8_env && xmax && !res && !s2d && conv3d_z8_supported(Ci, Co, kind)) {
+            const int rc = conv3d_z8_launch(x, wimg, scale, shift, y, B, D, H, W, Ci, Co, relu, st, max_blocks, xmax, ymax);
+            if (rc != 1) return rc;        // (1 = not taken: volumes with more than 64 k steps per block stay on the split kernel)
+        }
     }
     const int ysq = (s2d >> 1) & 1;            // `s2d` carries two flags: bit 0 = space-to-depth view of the input, bit 1 = square the output bound
     s2d &= 1;

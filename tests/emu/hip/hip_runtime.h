@@ -326,6 +326,7 @@ inline unsigned __builtin_amdgcn_perm_emu(unsigned s0, unsigned s1, unsigned sel
     return r;
 }
 #define __builtin_amdgcn_perm(a, b, s) __builtin_amdgcn_perm_emu((a), (b), (s))
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 
