@@ -15,9 +15,9 @@
 // Measured on the way (16 -> 8 at 32 x 256 x 320; profiles/r4_z8.txt): three planes read per output plane instead of rolling accumulators
 // 74.3 us (LDS bandwidth is not the bound); a cursor object instead of the closed-form stream plan 72.2; with every memory, LDS and MFMA
 // instruction switched off 36.9 -- the skeleton of a tick (split arithmetic, epilogue, barrier) is half of it.
-// (Cin = 32 -> 8, stage 1: its 36 k-steps do not fit one wave's registers; the form with wave = (n-tile, K half), 4 x 32 tiles and the halves
-// meeting through LDS one tick later was built and measured: 96 - 100 us against 89 for the split kernel -- 17 - 25 spilled registers, 128 voxels per
-// barrier -- and removed.)
+// Cin = 32 -> 8 (stage 1): 36 k-steps x two pieces are 288 registers, so the LOW pieces of the weights live in LDS (36 KB, one ds_read_b128
+// per use), a plane's loads fly one tick instead of two and the B fragments are not read ahead: 89 -> 77 us with 15 spilled registers left.
+// (A first form with wave = (n-tile, K half), 4 x 32 tiles and the halves meeting through LDS one tick later measured 96 - 100 us: removed.)
 #include "common.h"
 #include "x3_pieces.h"
 
@@ -27,7 +27,8 @@ template <int CIN, int COUT>
 struct Z8 {
     // fragment maps of the x3 image: Cout = 8 fills the 16 rows of an m-tile with two output positions -- M = (shift along x, co) for Cin = 8
     // ("XT": an n-tile is 32 columns of one row), (shift along y, co) for Cin = 16 ("YT": 16 columns of two rows); Cout = 16: M = co ("PL": 16 columns of one row)
-    static constexpr bool XT = COUT == 8 && CIN == 8, YT = COUT == 8 && CIN == 16, PL = COUT == 16;
+    static constexpr bool XT = COUT == 8 && CIN == 8, YT = COUT == 8 && CIN >= 16, PL = COUT == 16;
+    static constexpr bool ALO = CIN == 32;           // Cin = 32: 36 k-steps x two pieces are 288 registers -- the low pieces of the weights live in LDS (36 KB, read per use)
     static constexpr int NTW = YT ? 1 : 2;           // n-tiles per wave (two where the weights leave the registers: a tick of 27 - 45 MFMAs per wave is mostly barrier)
     static constexpr int NTT = 8 * NTW;              // n-tiles per tick
     static constexpr int TY = PL ? NTT / 2 : NTT, TX = 32;      // XT: a row per n-tile; YT: row pairs, two side by side; PL: rows, two side by side
@@ -43,9 +44,14 @@ struct Z8 {
     static constexpr int NSLOT = 2;                  // the plane being read + the one being parked
     static constexpr int NLD = (TYP * TXP * Q4 + 511) / 512;
     static constexpr int CS = XT ? 2 : 1;
-    static constexpr int LDS = NSLOT * SLB + 64;
-    static_assert((COUT == 8 && (CIN == 8 || CIN == 16)) || (COUT == 16 && CIN == 16), "conv0 of stages 3 and 2, conv2");
+    static constexpr int ALOB = ALO ? KSTEPS * 1024 : 0;
+    static constexpr int LDS = NSLOT * SLB + ALOB + 64;
+    static_assert((COUT == 8 && (CIN == 8 || CIN == 16 || CIN == 32)) || (COUT == 16 && CIN == 16), "conv0 of stages 3, 2 and 1, conv2");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
 };
+
+// voxel-internal byte swizzle of the Cin = 32 layout (64-byte voxels: lanes n, n + 4 of a ds_read_b128 lane group would collide; conv3d_x3.hip)
+template <int CIN> __device__ __forceinline__ int z8_swz(int hc) { return CIN == 32 ? ((hc >> 2) & 1) * 32 : 0; }
 
 struct Z8Dims {
     int B, D, H, W;
@@ -75,7 +81,8 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     using C = Z8<CIN, COUT>;
     constexpr int KSTEPS = C::KSTEPS, NLD = C::NLD, OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) x3_byte smem[];
-    float* const redmax = reinterpret_cast<float*>(smem + C::NSLOT * C::SLB);
+    x3_byte* const alo = smem + C::NSLOT * C::SLB;              // (Cin = 32) low pieces of the weight fragments, [k-step][lane][16 B]
+    float* const redmax = reinterpret_cast<float*>(alo + C::ALOB);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kk = lane >> 4;
@@ -105,20 +112,22 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     float xinv;
     const float xs_scale = x3_pow2_scale(bound, xinv);
     const float unscale = xinv * reinterpret_cast<const float*>(wimg)[1];
-    x3_u32x4 wr[KSTEPS][2];
+    x3_u32x4 wr[KSTEPS][C::ALO ? 1 : 2];
     int boff[C::SPK];              // (the same for the three kd weight sets of a plane)
     const int toff = C::XT ? wave * C::ROWB : (wave >> 1) * (C::YT ? 2 : 1) * C::ROWB + (wave & 1) * 16 * C::VB;      // this wave's (first) n-tile
 #pragma unroll
     for (int j = 0; j < KSTEPS; ++j) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) wr[j][p] = wimg[1 + (j * 2 + p) * 64 + lane];
+        for (int p = 0; p < (C::ALO ? 1 : 2); ++p) wr[j][p] = wimg[1 + (j * 2 + p) * 64 + lane];
+        if (C::ALO && wave == (j & 7)) *reinterpret_cast<x3_u32x4*>(alo + (j * 64 + lane) * 16) = wimg[1 + (j * 2 + 1) * 64 + lane];      // (visible after the barrier in front of the first tick)
     }
 #pragma unroll
     for (int js = 0; js < C::SPK; ++js) {
         int q = js * C::PPS + kk / (4 / C::PPS);
         const int ci0 = (kk % (4 / C::PPS)) * 8;
         if (q >= C::PPKD) q = 0;                       // (padding slot of the last k-step of a plane: its weights are zero)
-        boff[js] = toff + (q / C::QC) * C::ROWB + (q % C::QC + n * C::CS) * C::VB + ci0 * 2;
+        const int hc = q % C::QC + n * C::CS;          // halo column of this lane's voxel (tile column offsets are multiples of 16: same swizzle)
+        boff[js] = toff + (q / C::QC) * C::ROWB + hc * C::VB + ((ci0 * 2) ^ z8_swz<CIN>(hc));
     }
     const int co0 = C::PL ? kk * 4 : (kk & 1) * 4;
     const x3_f32x4 sc = (scale ? *reinterpret_cast<const x3_f32x4*>(scale + co0) : (x3_f32x4){1.f, 1.f, 1.f, 1.f}) * unscale;
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
         const int e = tid + i * 512, v = e / C::Q4, c4 = e % C::Q4;
         const int hy = v / C::TXP, hx = v % C::TXP;
         const bool has = e < C::TYP * C::TXP * C::Q4;
-        loff[i] = has ? hy * C::ROWB + hx * C::VB + c4 * 8 : -1;
+        loff[i] = has ? hy * C::ROWB + hx * C::VB + ((c4 * 8) ^ z8_swz<CIN>(hx)) : -1;
         hyx[i] = has ? (hy << 20) | (hx << 8) | c4 : -1;
     }
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)((long long)dm.B * dm.D * dm.H * dm.W * CIN * 4), 0x00020000);
@@ -187,12 +196,13 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     for (int i = 0; i < C::NTW; ++i) ob[i] = OOB;
     const int ostep = dm.H * dm.W * COUT * 4;
     float vmax = 0.0f;
-    x3_f32x4 pq[2][NLD];
+    constexpr int QD = C::ALO ? 1 : 2;                   // ticks of flight of a plane's loads (Cin = 32: one register set is all there is room for)
+    x3_f32x4 pq[QD][NLD];
     // stream planes 0 and 1 now, plane 0 parked before the first tick, plane 2 requested
     fetch(pq[0], 0);
-    fetch(pq[1], 1);
+    if constexpr (QD == 2) fetch(pq[1], 1);
     stash(pq[0], 0);
-    fetch(pq[0], 2);
+    fetch(pq[0], QD);
     __syncthreads();
     // Rolling accumulators (as in the depth head's marching conv): the fragments of input plane i are read from LDS ONCE and feed all three
     // kd weight sets -- acc[.][kd] holds output plane i - kd of the item; after plane i output i - 2 is complete, the sets move up.
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     x3_f32x4 acc[C::NTW][3];
     auto tick = [&](int t, x3_f32x4 (&q)[NLD]) {          // q = the register set of stream plane t + 1
         stash(q, (t + 1) & 1);
-        fetch(q, t + 3);
+        fetch(q, t + 1 + QD);
         int ctile, ip, czb, cnz;                           // ip = plane of the item (0 .. nz + 1): input plane zb - 1 + ip
         z8_entry(pl, dm.D, t, ctile, ip, czb, cnz);        // (t < nticks: the loop's own bound)
         {
@@ -222,7 +232,8 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
             }
             // (an input plane feeds output planes ip - kd; those outside 0 .. nz - 1 are computed too and never stored: no branches in the MFMA stream)
             const x3_byte* sb = smem + (t & 1) * C::SLB;
-            x3_u32x4 bq[2][C::NTW][2];
+            constexpr int NBQ = C::ALO ? 1 : 2;            // (Cin = 32: no registers for reading a k-step ahead)
+            x3_u32x4 bq[NBQ][C::NTW][2];
             auto read_b = [&](int buf, int js) {
 #pragma unroll
                 for (int i = 0; i < C::NTW; ++i) {
@@ -231,19 +242,23 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
                     bq[buf][i][1] = *reinterpret_cast<const x3_u32x4*>(pb + C::PLB);
                 }
             };
-            read_b(0, 0);
+            if (NBQ == 2) read_b(0, 0);
 #pragma unroll
             for (int js = 0; js < C::SPK; ++js) {
-                if (js + 1 < C::SPK) read_b((js + 1) & 1, js + 1);
+                if (NBQ == 1) read_b(0, js);
+                else if (js + 1 < C::SPK) read_b((js + 1) & 1, js + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {              // product hh, hl, lh
 #pragma unroll
                     for (int kd = 0; kd < 3; ++kd) {
                         const int j = kd * C::SPK + js;
+                        x3_u32x4 a;
+                        if constexpr (C::ALO) a = p == 2 ? *reinterpret_cast<const x3_u32x4*>(alo + (j * 64 + lane) * 16) : wr[j][0];
+                        else a = wr[j][p == 2 ? 1 : 0];
 #pragma unroll
                         for (int i = 0; i < C::NTW; ++i)
-                            acc[i][kd] = x3_mfma<2>(wr[j][p == 2 ? 1 : 0], bq[js & 1][i][p == 1 ? 1 : 0], acc[i][kd]);
+                            acc[i][kd] = x3_mfma<2>(a, bq[js & (NBQ - 1)][i][p == 1 ? 1 : 0], acc[i][kd]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
         __syncthreads();
     };
     for (int t = 0; t < pl.nticks; t += 2) {
-        tick(t, pq[1]);
+        tick(t, pq[QD - 1]);
         if (t + 1 < pl.nticks) tick(t + 1, pq[0]);
     }
     if (ymax) {
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
 }
 
 // (16 -> 16, conv2, runs on this kernel too -- the plain M = co map is in the template -- but does not gain: 24.4 against 24.2 us; it stays on the split kernel)
-bool conv3d_z8_supported(int Ci, int Co, int kind) { return kind == 0 && Co == 8 && (Ci == 8 || Ci == 16); }
+bool conv3d_z8_supported(int Ci, int Co, int kind) { return kind == 0 && Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32); }
 
 template <int CIN, int COUT>
 static int z8_launch_t(const float* x, const float* wimg, const float* scale, const float* shift, float* y, const Z8Dims& dm, int n_cu, int dev,
@@ -320,7 +335,7 @@ int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, cons
     }
     Z8Dims dm;
     dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu;
-    const int ty = Co == 16 ? Z8<16, 16>::TY : (Ci == 8 ? Z8<8, 8>::TY : Z8<16, 8>::TY);
+    const int ty = Co == 16 ? Z8<16, 16>::TY : (Ci == 8 ? Z8<8, 8>::TY : Z8<16, 8>::TY);      // (32 -> 8: as 16 -> 8)
     dm.tiles_x = (W + 31) / 32;
     dm.ntiles = dm.tiles_x * ((H + ty - 1) / ty);
     const int n_blk = max_blocks > 0 ? max_blocks : cu_of[dev];
@@ -328,6 +343,7 @@ int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, cons
         return 1;        // too many steps per block for the 16-bit stream arithmetic: not taken (conv3d_x3_launch goes on to the split kernel)
     if (Ci == 8 && Co == 8) return z8_launch_t<8, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
     if (Ci == 16 && Co == 8) return z8_launch_t<16, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
+    if (Ci == 32 && Co == 8) return z8_launch_t<32, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
     if (Ci == 16 && Co == 16) return z8_launch_t<16, 16>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
     return fail(-1, "conv3d_z8: unsupported Ci=%d Co=%d", Ci, Co);
 }
