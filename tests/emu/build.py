@@ -56,10 +56,19 @@ def build_cached(out_dir=None):
     """Build into tests/emu/_build (git-ignored) unless the library there is newer than every source."""
     out_dir = out_dir or os.path.join(HERE, "_build")
     lib = os.path.join(out_dir, "librcmvs_emu.so")
-    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(p) for p in sources()):
+    def fresh():
+        return os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(p) for p in sources())
+
+    if fresh():
         return lib
     os.makedirs(out_dir, exist_ok=True)
-    return build(out_dir)
+    import fcntl
+    with open(os.path.join(out_dir, ".lock"), "w") as lock:          # two test processes may find the library stale at the same moment
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return lib if fresh() else build(out_dir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":

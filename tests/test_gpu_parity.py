@@ -1220,11 +1220,14 @@ def test_tanks_and_temples_shape(hip):
     assert torch.equal(out["depth"], out2["depth"])
 
 
-@pytest.mark.parametrize("C,V,D,h,w,with_noref", [(8, 3, 4, 16, 20, True), (16, 3, 8, 24, 40, False), (32, 5, 6, 12, 24, True),
-                                                  (8, 2, 3, 7, 9, True)])
-def test_warp_variance_backward_vs_oracle_autograd(hip, C, V, D, h, w, with_noref):
+@pytest.mark.parametrize("C,V,D,h,w,with_noref,smooth", [(8, 3, 4, 16, 20, True, False), (16, 3, 8, 24, 40, False, False), (32, 5, 6, 12, 24, True, False),
+                                                         (8, 2, 3, 7, 9, True, False), (8, 3, 6, 16, 40, True, True), (16, 4, 5, 12, 36, False, True),
+                                                         (32, 3, 9, 10, 33, True, True)])
+def test_warp_variance_backward_vs_oracle_autograd(hip, C, V, D, h, w, with_noref, smooth):
     """K1 backward (rcmvs_warp_variance_bwd through ops.WarpVarianceFn) against torch autograd through the
-    oracle's op-by-op restatement of homo_warping + variance (oracle/warp.py), float64 on the CPU."""
+    oracle's op-by-op restatement of homo_warping + variance (oracle/warp.py), float64 on the CPU.  smooth: hypothesis planes that
+    vary slowly over the image, so that the tiles take the window form of the kernel (per-pixel random depths send them to the
+    run-length form; the right half of the smooth cases is noisy, so both forms and their hand-over are in one launch)."""
     from rc_mvsnet_amd import synthetic
     from oracle import warp as ow
     gen = torch.Generator().manual_seed(C + V)
@@ -1234,6 +1237,11 @@ def test_warp_variance_backward_vs_oracle_autograd(hip, C, V, D, h, w, with_nore
     feats = [torch.randn(1, C, h, w, generator=gen) for _ in range(V)]
     imgs = torch.rand(1, V, 3, h, w, generator=gen)
     depth = (450.0 + 80.0 * torch.rand(1, 1, h, w, generator=gen)) + 12.0 * torch.arange(D).view(1, D, 1, 1)
+    if smooth:
+        yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        base = 500.0 + 0.8 * xx + 0.5 * yy + 3.0 * torch.sin(xx / 5.0)
+        base[:, w - w // 3:] += 40.0 * torch.rand(h, w // 3, generator=gen)
+        depth = base.view(1, 1, h, w) + 2.5 * torch.arange(D).view(1, D, 1, 1)
     planes = torch.stack((depth[:, 0], depth[:, 1] - depth[:, 0]), dim=-1).contiguous()
     depth = planes[..., 0].unsqueeze(1) + torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) * planes[..., 1].unsqueeze(1)
     gvar = torch.randn(1, D, h, w, C, generator=gen)
@@ -1272,6 +1280,35 @@ def test_warp_variance_backward_vs_oracle_autograd(hip, C, V, D, h, w, with_nore
     err = rel_err(got, ref_grads)
     print(f"K1 bwd C={C} V={V}: rel err {err:.2e}")
     assert err < 2e-5
+
+
+@pytest.mark.parametrize("C,scale,D", [(32, 4, 9), (16, 2, 6), (8, 1, 8)])
+def test_warp_variance_backward_window_form_vs_run_length_form(hip, C, scale, D):
+    """The two forms of K1 backward on one input whose left half has smooth hypothesis planes (tiles that fit the LDS windows) and whose
+    right half has per-pixel random ones (tiles left to the run-length kernel): the shipped launch pair (variant 0) against the
+    run-length kernel alone (variant 4), and the gradient of the reference view -- which carries no atomics -- bit for bit.
+    Includes a source view without parallax (its taps do not move between planes) and one batch element more than one."""
+    from rc_mvsnet_amd import ops, synthetic
+    V, H, W = 4, 128, 256
+    h, w = H // scale, W // scale
+    proj = synthetic.proj_matrices(2, V, H, W)["stage%d" % {4: 1, 2: 2, 1: 3}[scale]].clone()
+    proj[:, 3] = proj[:, 0]                                          # third source view = the reference camera
+    rot, trans = ops.compose_homography(gpu(proj))
+    g = torch.Generator().manual_seed(C)
+    feats = gpu(torch.randn(2, V, h, w, C, generator=g))
+    d0 = torch.full((2, h, w), 600.0) + 0.3 * torch.arange(w, dtype=torch.float32).view(1, 1, w)
+    d0[:, :, w // 2:] += 30.0 * torch.rand(2, h, w - w // 2, generator=g)
+    planes = gpu(torch.stack((d0, torch.full((2, h, w), 2.65 * scale)), dim=-1).contiguous())
+    gvar = gpu(torch.randn(2, D, h, w, C, generator=g))
+    gnr = gpu(torch.randn(2, D, h, w, C, generator=g))
+    a = ops.warp_variance_bwd(feats, rot, trans, planes, gvar, gnr)
+    b = ops.warp_variance_bwd(feats, rot, trans, planes, gvar, gnr, variant=4)
+    assert torch.equal(a[:, 0], b[:, 0])
+    err = float((a - b).abs().max() / b.abs().max())
+    moved = float(((a - b).abs() > 0)[:, 1:, :, : w // 2 - 40 // scale].float().mean())
+    print(f"K1 bwd window vs run-length C={C}: rel diff {err:.1e}, {moved:.2f} of the smooth half's elements differ in the last bits")
+    assert err < 1e-6
+    assert moved > 0.05                                              # the window form did take the smooth tiles
 
 
 def test_cascade_batch_two_equals_two_singles(hip, monkeypatch):
