@@ -32,23 +32,18 @@ struct K1Geom {
     int w, h;
 };
 
-// one (pixel, plane, view), first half: the sampling position in pixels (ix, iy).  k1_chain = k1_position + k1_corner; the window
-// form of the backward keeps (ix, iy) in its tap table and runs the second half again, which reproduces the forward's bits.
-__device__ __forceinline__ void k1_position(float rx, float ry, float rz, float t0, float t1, float t2, float d,
-                                            const K1Geom& g, float& ix, float& iy) {
+// one (pixel, plane, view): integer coordinates of the north-west tap (-4 for non-finite positions) + masked weights.
+// Shared by every K1 kernel so that all of them sample at bit-identical positions.
+__device__ __forceinline__ void k1_chain(float rx, float ry, float rz, float t0, float t1, float t2, float d,
+                                         const K1Geom& g, int& xi, int& yi, v4f& wt) {
 #pragma clang fp contract(off)
     const float px = rx * d + t0, py = ry * d + t1, pz = rz * d + t2;
     const float rpz = rcp_nr(pz);
     const float u = div_c<2>(px, pz, rpz), vv = div_c<2>(py, pz, rpz);
     const float gx = div_c<1>(u, g.half_w, g.r_half_w) - 1.0f;
     const float gy = div_c<1>(vv, g.half_h, g.r_half_h) - 1.0f;
-    ix = ((gx + 1.0f) * 0.5f) * g.wm1;
-    iy = ((gy + 1.0f) * 0.5f) * g.hm1;
-}
-
-// second half: integer coordinates of the north-west tap (-4 for non-finite positions) + masked weights
-__device__ __forceinline__ void k1_corner(float ix, float iy, const K1Geom& g, int& xi, int& yi, v4f& wt) {
-#pragma clang fp contract(off)
+    const float ix = ((gx + 1.0f) * 0.5f) * g.wm1;
+    const float iy = ((gy + 1.0f) * 0.5f) * g.hm1;
     const float x0 = floorf(ix), y0 = floorf(iy);
     const float wx1 = ix - x0, wx0 = (x0 + 1.0f) - ix;
     const float wy1 = iy - y0, wy0 = (y0 + 1.0f) - iy;
@@ -64,39 +59,16 @@ __device__ __forceinline__ void k1_corner(float ix, float iy, const K1Geom& g, i
     wt.w = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
 }
 
-// one (pixel, plane, view): integer coordinates of the north-west tap (-4 for non-finite positions) + masked weights.
-// Shared by every K1 kernel so that all of them sample at bit-identical positions.
-__device__ __forceinline__ void k1_chain(float rx, float ry, float rz, float t0, float t1, float t2, float d,
-                                         const K1Geom& g, int& xi, int& yi, v4f& wt) {
-    float ix, iy;
-    k1_position(rx, ry, rz, t0, t1, t2, d, g, ix, iy);
-    k1_corner(ix, iy, g, xi, yi, wt);
-}
-
-// byte offsets of the four taps of a north-west corner (xi, yi): clamped in-bounds, view row base included
-template <int C>
-__device__ __forceinline__ void k1_offsets(int xi, int yi, const K1Geom& g, int vrow, v4i& o) {
-    const int xc0 = min(max(xi, 0), g.w - 1), xc1 = min(max(xi + 1, 0), g.w - 1);
-    const int row0 = min(max(yi, 0), g.h - 1) * g.w + vrow, row1 = min(max(yi + 1, 0), g.h - 1) * g.w + vrow;
-    o.x = (row0 + xc0) * (C * 4); o.y = (row0 + xc1) * (C * 4);
-    o.z = (row1 + xc0) * (C * 4); o.w = (row1 + xc1) * (C * 4);
-}
-
-// the same with the texel size in bytes as a run-time value
-__device__ __forceinline__ void k1_offsets_rt(int xi, int yi, const K1Geom& g, int vrow, int texel_bytes, v4i& o) {
-    const int xc0 = min(max(xi, 0), g.w - 1), xc1 = min(max(xi + 1, 0), g.w - 1);
-    const int row0 = min(max(yi, 0), g.h - 1) * g.w + vrow, row1 = min(max(yi + 1, 0), g.h - 1) * g.w + vrow;
-    o.x = (row0 + xc0) * texel_bytes; o.y = (row0 + xc1) * texel_bytes;
-    o.z = (row1 + xc0) * texel_bytes; o.w = (row1 + xc1) * texel_bytes;
-}
-
 // offsets (bytes, clamped in-bounds, view row base included) + weights
 template <int C>
 __device__ __forceinline__ void k1_tap(float rx, float ry, float rz, float t0, float t1, float t2, float d,
                                        const K1Geom& g, int vrow, v4i& o, v4f& wt) {
     int xi, yi;
     k1_chain(rx, ry, rz, t0, t1, t2, d, g, xi, yi, wt);
-    k1_offsets<C>(xi, yi, g, vrow, o);
+    const int xc0 = min(max(xi, 0), g.w - 1), xc1 = min(max(xi + 1, 0), g.w - 1);
+    const int row0 = min(max(yi, 0), g.h - 1) * g.w + vrow, row1 = min(max(yi + 1, 0), g.h - 1) * g.w + vrow;
+    o.x = (row0 + xc0) * (C * 4); o.y = (row0 + xc1) * (C * 4);
+    o.z = (row1 + xc0) * (C * 4); o.w = (row1 + xc1) * (C * 4);
 }
 
 // min / max over the wave with DPP row shifts + four readlanes (no LDS traffic, no atomics); result is wave-uniform
