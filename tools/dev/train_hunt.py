@@ -38,11 +38,12 @@ def main():
         if dt is None: dt = getattr(e, "self_cuda_time_total", 0)
         if not dt: continue
         site = next((s for s in (e.stack or []) if "rc_mvsnet_amd" in s or "bench.py" in s), "?")
-        key = (e.name, site.strip()[-90:])
+        shp = str([tuple(x) for x in (e.input_shapes or []) if x])[:70]
+        key = (e.name, site.strip()[-70:] + " " + shp)
         a = agg.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += dt
     tot = sum(v[1] for v in agg.values())
     print(f"ATen ops with device time in one iteration: {sum(v[0] for v in agg.values())} calls, {tot / 1e3:.2f} ms")
-    for (name, site), (n, dt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    for (name, site), (n, dt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
         print(f"{dt:8.1f} us x{n:4d} {name:24s} {site}")
 
 
