@@ -1,5 +1,5 @@
-// The deep levels of the 3-D U-Nets (conv5 32->64 stride 2, conv6 64->64, conv7 64->32 transposed; models/modules.py:470-501 in the
-// reference) on the fp16-pair matrix-core arithmetic of conv3d_x3.hip (two fp16 pieces per operand after an exact power-of-two
+// The deep levels of the 3-D U-Nets (conv5 32->64 stride 2, conv6 64->64, conv7 64->32 transposed, and conv4 32->32 / conv9 32->16 transposed one level up;
+// models/modules.py:470-501 in the reference) on the fp16-pair matrix-core arithmetic of conv3d_x3.hip (two fp16 pieces per operand after an exact power-of-two
 // pre-scale, three v_mfma_f32_16x16x32_f16 per product), for callers that hand over a bound of max|x|.  gfx950 only.
 //
 // Why a kernel of their own.  These volumes are tiny (a DTU scene: 1 920 - 5 120 cells of 64 channels) and the weight tensors are
@@ -44,7 +44,10 @@ __host__ __device__ inline void dp_class_tap(int p, int i, int& kd, int& kh, int
 
 template <int CIN, int COUT, int KIND>
 struct Deep {
-    static constexpr int TH = 4, TW = 8, NT = 2;        // cell tile: 4 x 8 cells of one (b, d) plane; n-tile t = rows 2t, 2t + 1
+    // cell tile: 4 x 8 cells of one (b, d) plane, n-tile t = rows 2t, 2t + 1.  (NT = 4, 8 x 8 cells, for the 32 -> 32 layer -- 8x the cells, a quarter of
+    // the weights -- measured 9.0 / 20.9 us per launch against 8.9 / 17.3: the weight stream is not its bound, the block count is its latency hiding)
+    static constexpr int NT = 2;
+    static constexpr int TH = 2 * NT, TW = 8;
     static constexpr int MT = COUT / 16;
     static constexpr int HALVES = CIN / 32;             // k-steps (K = 32 input channels) per tap
     static constexpr int HD = KIND == DP_T2 ? 2 : 3;
@@ -58,10 +61,11 @@ struct Deep {
     static constexpr int UNITS = NVOX * (CIN / 8);      // 8-channel units of the halo (32 B in, 16 + 16 B out)
     static constexpr int NLD = (UNITS + 511) / 512;
     static constexpr int PF = KIND == DP_T2 ? 6 : 8;    // k-steps of weight prefetch per ring (8 registers per step)
-    static constexpr int PARTB = KIND == DP_T2 ? 0 : MT * NT * 1024;
+    static constexpr int KP = KIND == DP_T2 ? 1 : 8 / MT;      // convolutions: wave = (m-tile, one of KP parts of the K range); the parts meet through LDS
+    static constexpr int PARTB = KIND == DP_T2 ? 0 : (KP - 1) * MT * NT * 1024;
     static constexpr int LDS = 2 * PLANE + PARTB + 64;
     static constexpr long long IMG_HALFS = 8 + (long long)KSTEPS * 2 * MT * 512;
-    static_assert(CIN % 32 == 0 && COUT % 16 == 0 && (KIND == DP_T2 ? MT == 2 : MT == 4), "wave layout");
+    static_assert(CIN % 32 == 0 && COUT % 16 == 0 && (KIND == DP_T2 ? (MT == 2 || MT == 1) : (MT == 4 || MT == 2)), "wave layout");
 };
 
 // ---- weight image: a 16-byte header {s_w, 1 / s_w, 0, 0}, then [k-step][piece][m-tile][lane][8 fp16]: the A fragment of
@@ -105,7 +109,7 @@ struct DeepDims {
 
 // Work of a wave: up to three SEGMENTS, each one (m-tile, contiguous k-step range, output parity class) with its own accumulators,
 // finished (or handed over) before the next one starts.
-//   convolutions: one segment = (m-tile wave & 3, K half wave >> 2); the halves meet through LDS.
+//   convolutions: one segment = (m-tile wave % MT, K part wave / MT: halves for 64 output channels, quarters for 32); the parts meet through LDS.
 //   transposed:   (class, m-tile) pairs dealt so that the two waves of every SIMD get 13 - 14 tap-tiles (taps per class 8 4 4 4 2 2 2 1):
 //                 waves 0 1: class 7; 2 3: classes 3, 1, 0; 4 5: classes 5, 2; 6 7: classes 6, 4; m-tile = wave & 1.
 __device__ __forceinline__ int dp_t2_segments(int wave, int (&cls)[3]) {
@@ -145,8 +149,10 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
     // two kd choices of an odd class the one that reads plane dg + 1 first) they are a prefix (first plane below the volume) and / or
     // a suffix (last plane above it) of a segment's range.
     int seg_cls[3] = {0, 0, 0}, nseg = 1, mt0;
-    if constexpr (KIND == DP_T2) { nseg = dp_t2_segments(wave, seg_cls); mt0 = wave & 1; }
-    else mt0 = wave & 3;
+    if constexpr (KIND == DP_T2 && MT == 1) { seg_cls[0] = wave; mt0 = 0; }                 // 16 output channels: a wave per parity class (1 - 8 taps: the MFMAs are nothing here)
+    else if constexpr (KIND == DP_T2) { nseg = dp_t2_segments(wave, seg_cls); mt0 = wave & 1; }
+    else mt0 = wave % MT;
+    const int kp = KIND == DP_T2 ? 0 : wave / MT;                    // which part of the K range (convolutions)
     auto seg_range = [&](int sg, int& j0, int& nsteps) {
         if constexpr (KIND == DP_T2) {
             const int cls = seg_cls[sg], nt = dp_ntaps(cls);
@@ -154,9 +160,9 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
             j0 = (dp_first(cls) + (drop ? nt / 2 : 0)) * HALVES;
             nsteps = (drop ? nt / 2 : nt) * HALVES;
         } else {
-            const int lo = (zd0 < 0 ? 9 : 0) * HALVES, hi = (zd0 + 2 >= dm.D ? 18 : 27) * HALVES, mid = lo + (hi - lo + 1) / 2;
-            j0 = wave < 4 ? lo : mid;
-            nsteps = wave < 4 ? mid - lo : hi - mid;
+            const int lo = (zd0 < 0 ? 9 : 0) * HALVES, hi = (zd0 + 2 >= dm.D ? 18 : 27) * HALVES, per = (hi - lo + C::KP - 1) / C::KP;
+            j0 = min(lo + kp * per, hi);
+            nsteps = min(per, hi - j0);                              // (>= 1: a range holds 9 steps at least)
         }
     };
     // byte offset of step j's tap inside a piece plane
@@ -307,15 +313,17 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
         for (int t = 0; t < NT; ++t) tot[t] = acc[t][0] + (acc[t][1] + acc[t][2]);
         bool finisher = true;
         if constexpr (KIND != DP_T2) {
-            finisher = wave < 4;
+            finisher = kp == 0;
             if (!finisher) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) *reinterpret_cast<x3_f32x4*>(part + ((mt0 * NT + t) * 64 + lane) * 16) = tot[t];
+                for (int t = 0; t < NT; ++t) *reinterpret_cast<x3_f32x4*>(part + ((((kp - 1) * MT + mt0) * NT + t) * 64 + lane) * 16) = tot[t];
             }
             __syncthreads();
             if (finisher) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) tot[t] += *reinterpret_cast<const x3_f32x4*>(part + ((mt0 * NT + t) * 64 + lane) * 16);
+                for (int q = 0; q < C::KP - 1; ++q)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) tot[t] += *reinterpret_cast<const x3_f32x4*>(part + (((q * MT + mt0) * NT + t) * 64 + lane) * 16);
             }
         }
         if (finisher) {
@@ -355,9 +363,19 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-#define RCMVS_DEEP_LIST(X) X(32, 64, DP_S2) X(64, 64, DP_S1) X(64, 32, DP_T2)
+// (32 -> 32 stride 1 = conv4, one level up: 15 - 41 k cells; the z-marching kernel, whose blocks have 2 - 12 planes to march over, took 14.7 / 20.7 us
+// per launch, this one 8.9 / 17.3: -13 us per scene, +1 % in bench.py on one box; 32 -> 16 transposed = conv9: 17.4 / 25.1 -> 8.8 / 18.5 us, +2 %)
+#define RCMVS_DEEP_LIST(X) X(32, 64, DP_S2) X(64, 64, DP_S1) X(64, 32, DP_T2) X(32, 32, DP_S1) X(32, 16, DP_T2)
 
 bool conv3d_deep_supported(int Ci, int Co, int kind) {
+    if (Ci == 32 && Co == 16) {                    // RCMVS_DEEP9=0: conv9 (32 -> 16 transposed) stays on the z-marching kernel (A/B)
+        static const bool on = [] { const char* e = getenv("RCMVS_DEEP9"); return !e || e[0] != '0'; }();
+        if (!on) return false;
+    }
+    if (Ci == 32 && Co == 32) {                    // RCMVS_DEEP4=0: conv4 stays on the z-marching kernel (A/B; read once: pack and launch must agree)
+        static const bool on = [] { const char* e = getenv("RCMVS_DEEP4"); return !e || e[0] != '0'; }();
+        if (!on) return false;
+    }
 #define DP_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return true;
     RCMVS_DEEP_LIST(DP_CASE)
 #undef DP_CASE
@@ -384,7 +402,7 @@ int conv3d_deep_pack(const float* w, float* img, int Co, int Ci, int kind, int t
 
 template <int CI, int CO, int K>
 static int deep_launch_t(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
-                         const DeepDims& dm, int dev, const float* xmax, float* ymax, hipStream_t st) {
+                         const DeepDims& dm_in, int dev, const float* xmax, float* ymax, hipStream_t st) {
     using C = Deep<CI, CO, K>;
     constexpr int MAXDEV = 64;
     static bool raised[MAXDEV];                    // per device: dynamic-LDS limit of this instantiation (benign race: same value)
@@ -393,6 +411,8 @@ static int deep_launch_t(const float* x, const float* wimg, const float* scale, 
             return fail(-1, "conv3d_deep: cannot raise the dynamic LDS limit to %d bytes", C::LDS);
         raised[dev] = true;
     }
+    DeepDims dm = dm_in;
+    dm.tiles_h = (dm.Hg + C::TH - 1) / C::TH; dm.tiles_w = (dm.Wg + C::TW - 1) / C::TW;
     const long long blocks = (long long)dm.B * dm.Dg * dm.tiles_h * dm.tiles_w;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return fail(-1, "conv3d_deep: bad grid");
     hipLaunchKernelGGL((conv3d_deep_kernel<CI, CO, K>), dim3((unsigned)blocks), dim3(512), C::LDS, st, x, reinterpret_cast<const x3_u32x4*>(wimg),
@@ -412,7 +432,7 @@ int conv3d_deep_launch(const float* x, const float* wimg, const float* scale, co
         dm.Dg = dm.Do; dm.Hg = dm.Ho; dm.Wg = dm.Wo;
     }
     if ((long long)B * D * H * W * Ci * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_deep: input tensor too large for 32-bit offsets");
-    dm.tiles_h = (dm.Hg + 3) / 4; dm.tiles_w = (dm.Wg + 7) / 8;
+    dm.tiles_h = dm.tiles_w = 0;                   // (per instantiation: deep_launch_t)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(-1, "conv3d_deep: cannot query the device");
 #define DP_CASE(CI, CO, K) if (Ci == CI && Co == CO && kind == K) return deep_launch_t<CI, CO, K>(x, wimg, scale, shift, res, y, dm, dev, xmax, ymax, st);

@@ -312,13 +312,13 @@ def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
 @pytest.mark.parametrize("shape", [(2, 5, 11, 21), (1, 9, 37, 70), (1, 1, 13, 9)])
 def test_conv3d_x3h_vs_fp64(hip, Ci, Co, kind, shape):
     """The fp16-pair form of the matrix-core kernels (csrc/conv3d_x3.hip, NP = 2, and the deep-level tile kernels of csrc/conv3d_deep.hip
-    -- 32->64 stride 2, 64->64, 64->32 transposed; the one-plane shape drops their out-of-volume taps: two fp16 pieces per operand after a power-of-two
+    -- 32->64 stride 2, 64->64, 64->32 transposed, 32->32; the one-plane shape drops their out-of-volume taps: two fp16 pieces per operand after a power-of-two
     pre-scale taken from the caller's bound of max|x|, three MFMAs per product) against an fp64 convolution: as close as the fp32
     FMA-chain kernels are, on log-normal inputs (three decades of dynamic range), ragged tiles, z chunks, batch 2, the full
     epilogue.  The bound it returns (y_absmax) is max|y| exactly; a bound that is 16x too loose changes nothing measurable; and
     the result does not depend on the magnitude of the tensor (inputs scaled by 2^40: exactly the scaled output)."""
-    deep = (Ci, Co, kind) in ((32, 64, "s2"), (64, 64, "s1"), (64, 32, "t2"))      # csrc/conv3d_deep.hip
-    if DEV == "cpu" and (shape[2] > 30 or (Ci, Co, kind) not in ((8, 8, "s1"), (16, 8, "s1"), (8, 16, "s2"), (16, 8, "t2"), (32, 64, "s2"), (64, 64, "s1"), (64, 32, "t2"))
+    deep = (Ci, Co, kind) in ((32, 64, "s2"), (64, 64, "s1"), (64, 32, "t2"), (32, 32, "s1"), (32, 16, "t2"))      # csrc/conv3d_deep.hip
+    if DEV == "cpu" and (shape[2] > 30 or (Ci, Co, kind) not in ((8, 8, "s1"), (16, 8, "s1"), (8, 16, "s2"), (16, 8, "t2"), (32, 64, "s2"), (64, 64, "s1"), (64, 32, "t2"), (32, 32, "s1"), (32, 16, "t2"))
                          or (deep and Ci == 64 and shape[0] == 2)) \
             and os.environ.get("RCMVS_EMU_FULL", "0") != "1":
         pytest.skip("up to a minute on the kernel emulation: RCMVS_EMU_FULL=1 (always run on the GPU)")
