@@ -1,4 +1,4 @@
-// The deep levels of the 3-D U-Nets (conv5 32->64 stride 2, conv6 64->64, conv7 64->32 transposed, and conv4 32->32 / conv9 32->16 transposed one level up;
+// The deep levels of the 3-D U-Nets (conv5 32->64 stride 2, conv6 64->64, conv7 64->32 transposed, and conv3 16->32 stride 2 / conv4 32->32 / conv9 32->16 transposed one level up;
 // models/modules.py:470-501 in the reference) on the fp16-pair matrix-core arithmetic of conv3d_x3.hip (two fp16 pieces per operand after an exact power-of-two
 // pre-scale, three v_mfma_f32_16x16x32_f16 per product), for callers that hand over a bound of max|x|.  gfx950 only.
 //
@@ -49,7 +49,8 @@ struct Deep {
     static constexpr int NT = 2;
     static constexpr int TH = 2 * NT, TW = 8;
     static constexpr int MT = COUT / 16;
-    static constexpr int HALVES = CIN / 32;             // k-steps (K = 32 input channels) per tap
+    static constexpr int HALVES = CIN >= 32 ? CIN / 32 : 1;      // k-steps (K = 32 input channels) per tap
+    static constexpr int TPS = CIN >= 32 ? 1 : 32 / CIN;         // taps per k-step (Cin = 16: a k-step is two taps x 16 channels; the 28th tap is a zero)
     static constexpr int HD = KIND == DP_T2 ? 2 : 3;
     static constexpr int HH = KIND == DP_S1 ? TH + 2 : (KIND == DP_S2 ? 2 * TH + 1 : TH + 1);
     static constexpr int HW = KIND == DP_S1 ? TW + 2 : (KIND == DP_S2 ? 2 * TW + 1 : TW + 1);
@@ -57,7 +58,7 @@ struct Deep {
     static constexpr int NVOX = HD * HH * HW;
     static constexpr int VS = CIN * 2 + 16;             // bytes of a voxel in a piece plane
     static constexpr int PLANE = NVOX * VS;
-    static constexpr int KSTEPS = 27 * HALVES;
+    static constexpr int KSTEPS = (27 + TPS - 1) / TPS * HALVES;
     static constexpr int UNITS = NVOX * (CIN / 8);      // 8-channel units of the halo (32 B in, 16 + 16 B out)
     static constexpr int NLD = (UNITS + 511) / 512;
     static constexpr int PF = KIND == DP_T2 ? 6 : 8;    // k-steps of weight prefetch per ring (8 registers per step)
@@ -65,7 +66,7 @@ struct Deep {
     static constexpr int PARTB = KIND == DP_T2 ? 0 : (KP - 1) * MT * NT * 1024;
     static constexpr int LDS = 2 * PLANE + PARTB + 64;
     static constexpr long long IMG_HALFS = 8 + (long long)KSTEPS * 2 * MT * 512;
-    static_assert(CIN % 32 == 0 && COUT % 16 == 0 && (KIND == DP_T2 ? (MT == 2 || MT == 1) : (MT == 4 || MT == 2)), "wave layout");
+    static_assert((CIN % 32 == 0 || (CIN == 16 && KIND != DP_T2)) && COUT % 16 == 0 && (KIND == DP_T2 ? (MT == 2 || MT == 1) : (MT == 4 || MT == 2)), "wave layout");
 };
 
 // ---- weight image: a 16-byte header {s_w, 1 / s_w, 0, 0}, then [k-step][piece][m-tile][lane][8 fp16]: the A fragment of
@@ -87,9 +88,11 @@ __global__ void deep_pack_kernel(const float* __restrict__ w, unsigned short* __
         dp_class_tap(p, jj / C::HALVES, kd, kh, kw);
         tap = (kd * 3 + kh) * 3 + kw;
         half = jj % C::HALVES;
-    } else { tap = j / C::HALVES; half = j % C::HALVES; }
-    const int ci = half * 32 + kq * 8 + e;
-    const float v = transposed ? w[((long long)ci * COUT + co) * 27 + (transposed == 2 ? 26 - tap : tap)] : w[((long long)co * CIN + ci) * 27 + tap];
+    } else if (C::TPS == 2) { tap = 2 * j + (kq >> 1); half = 0; }
+    else { tap = j / C::HALVES; half = j % C::HALVES; }
+    const int ci = C::TPS == 2 ? (kq & 1) * 8 + e : half * 32 + kq * 8 + e;
+    float v = 0.0f;
+    if (tap < 27) v = transposed ? w[((long long)ci * COUT + co) * 27 + (transposed == 2 ? 26 - tap : tap)] : w[((long long)co * CIN + ci) * 27 + tap];
     const float sw = wsc[0];
     if (t == 0) { float* hdr = reinterpret_cast<float*>(img); hdr[0] = sw; hdr[1] = wsc[1]; hdr[2] = 0.0f; hdr[3] = 0.0f; }
     const float vs = v * sw;                                       // exact (power of two)
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
             j0 = (dp_first(cls) + (drop ? nt / 2 : 0)) * HALVES;
             nsteps = (drop ? nt / 2 : nt) * HALVES;
         } else {
-            const int lo = (zd0 < 0 ? 9 : 0) * HALVES, hi = (zd0 + 2 >= dm.D ? 18 : 27) * HALVES, per = (hi - lo + C::KP - 1) / C::KP;
+            // (two taps per step: a step that straddles the boundary is kept -- its dropped tap reads the halo's zeros)
+            const int lo = (zd0 < 0 ? 9 : 0) * HALVES / C::TPS, hi = ((zd0 + 2 >= dm.D ? 18 : 27) * HALVES + C::TPS - 1) / C::TPS, per = (hi - lo + C::KP - 1) / C::KP;
             j0 = min(lo + kp * per, hi);
             nsteps = min(per, hi - j0);                              // (>= 1: a range holds 9 steps at least)
         }
@@ -176,6 +180,8 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
         } else { const int tp = j / HALVES; od = tp / 9; oh = (tp / 3) % 3; ow = tp % 3; }
         return ((od * C::HH + oh) * C::HW + ow) * VS + half * 64;
     };
+    // (two taps per step: offset of tap tp, the zero 28th one mapped to the 27th)
+    auto tap_offset_of = [&](int tp) -> int { tp = min(tp, 26); return (((tp / 9) * C::HH + (tp / 3) % 3) * C::HW + tp % 3) * VS; };
 
     // ---- weights: A fragments straight from the image (L2), a ring of PF k-steps
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<x3_u32x4*>(wimg + 1), (short)0, (int)(C::KSTEPS * 2 * MT * 1024), 0x00020000);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
     static_assert(PF % 2 == 0, "the B double buffer alternates with the step parity");
     int bb[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bb[t] = (((2 * t + (n >> 3)) * C::CS) * C::HW + (n & 7) * C::CS) * VS + kq * 16;
+    for (int t = 0; t < NT; ++t) bb[t] = (((2 * t + (n >> 3)) * C::CS) * C::HW + (n & 7) * C::CS) * VS + (C::TPS == 2 ? (kq & 1) : kq) * 16;
     float vmax = 0.0f;
 #pragma unroll
     for (int sg = 0; sg < (KIND == DP_T2 ? 3 : 1); ++sg) {           // (unrolled: the ring of a segment is a compile-time choice)
@@ -258,9 +264,12 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[t][c] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
         x3_u32x4 bq[2][NT][2];
-        const int entv = tap_offset(cls, j0 + min(lane, nsteps - 1));         // lane jj: the tap offset of step jj (past the end: the last step's)
+        const int jl = j0 + min(lane, nsteps - 1);
+        const int entv = C::TPS == 2 ? tap_offset_of(2 * jl) : tap_offset(cls, jl);      // lane jj: the tap offset of step jj (past the end: the last step's)
+        const int entv2 = C::TPS == 2 ? tap_offset_of(2 * jl + 1) : 0;                   // ... and of the step's second tap (lanes kq = 2, 3 read that one)
         auto read_b = [&](int buf, int jj) {
-            const int boff = __builtin_amdgcn_readlane(entv, jj);
+            int boff = __builtin_amdgcn_readlane(entv, jj);
+            if constexpr (C::TPS == 2) { const int b2 = __builtin_amdgcn_readlane(entv2, jj); boff = (kq >> 1) ? b2 : boff; }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 bq[buf][t][0] = *reinterpret_cast<const x3_u32x4*>(smem + bb[t] + boff);
@@ -364,10 +373,15 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 // (32 -> 32 stride 1 = conv4, one level up: 15 - 41 k cells; the z-marching kernel, whose blocks have 2 - 12 planes to march over, took 14.7 / 20.7 us
-// per launch, this one 8.9 / 17.3: -13 us per scene, +1 % in bench.py on one box; 32 -> 16 transposed = conv9: 17.4 / 25.1 -> 8.8 / 18.5 us, +2 %)
-#define RCMVS_DEEP_LIST(X) X(32, 64, DP_S2) X(64, 64, DP_S1) X(64, 32, DP_T2) X(32, 32, DP_S1) X(32, 16, DP_T2)
+// per launch, this one 8.9 / 17.3: -13 us per scene, +1 % in bench.py on one box; 32 -> 16 transposed = conv9: 17.4 / 25.1 -> 8.8 / 18.5 us, +2 %;
+// 16 -> 32 stride 2 = conv3, a k-step of two taps x 16 channels: 11.6 / 16.7 -> 7.9 / 15.2 us, +0.6 %)
+#define RCMVS_DEEP_LIST(X) X(32, 64, DP_S2) X(64, 64, DP_S1) X(64, 32, DP_T2) X(32, 32, DP_S1) X(32, 16, DP_T2) X(16, 32, DP_S2)
 
 bool conv3d_deep_supported(int Ci, int Co, int kind) {
+    if (Ci == 16 && Co == 32) {                    // RCMVS_DEEP3=0: conv3 (16 -> 32 stride 2) stays on the z-marching kernel (A/B)
+        static const bool on = [] { const char* e = getenv("RCMVS_DEEP3"); return !e || e[0] != '0'; }();
+        if (!on) return false;
+    }
     if (Ci == 32 && Co == 16) {                    // RCMVS_DEEP9=0: conv9 (32 -> 16 transposed) stays on the z-marching kernel (A/B)
         static const bool on = [] { const char* e = getenv("RCMVS_DEEP9"); return !e || e[0] != '0'; }();
         if (!on) return false;
