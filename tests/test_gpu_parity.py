@@ -307,6 +307,19 @@ def test_conv3d_x3_strided_vs_fp64(hip, Ci, Co, kind, shape):
         assert e_x3 <= 2.0 * e_32 + 1e-7 * mag and e_x3 < 3e-6 * mag, (i, e_x3, e_32, mag)
 
 
+def test_conv3d_x3h_marching_forms_of_the_layers_that_moved_to_the_tile_kernel(hip):
+    """conv3 / conv4 / conv9 (16->32 stride 2, 32->32, 32->16 transposed) run on the tile-owning kernel of csrc/conv3d_deep.hip since the end of
+    round 4; RCMVS_DEEP3 / 4 / 9 = 0 send them back to the plane-marching fp16-pair kernels of csrc/conv3d_x3.hip.  The switches are read once per
+    process, so the same parity cases run once more in a child process with the three switches off."""
+    import subprocess, sys
+    if DEV == "cpu":
+        pytest.skip("GPU only: a child pytest process on the kernel emulation would take minutes")
+    env = dict(os.environ, RCMVS_DEEP3="0", RCMVS_DEEP4="0", RCMVS_DEEP9="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "test_conv3d_x3h_vs_fp64 and (32-32-s1 or 32-16-t2 or 16-32-s2)"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("Ci,Co,kind", [(8, 8, "s1"), (16, 8, "s1"), (32, 8, "s1"), (16, 16, "s1"), (32, 32, "s1"), (8, 16, "s2"), (16, 32, "s2"),
                                         (16, 8, "t2"), (32, 16, "t2"), (32, 64, "s2"), (64, 64, "s1"), (64, 32, "t2")])
 @pytest.mark.parametrize("shape", [(2, 5, 11, 21), (1, 9, 37, 70), (1, 1, 13, 9)])
