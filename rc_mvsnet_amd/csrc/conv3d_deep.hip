@@ -45,7 +45,8 @@ __host__ __device__ inline void dp_class_tap(int p, int i, int& kd, int& kh, int
 template <int CIN, int COUT, int KIND>
 struct Deep {
     // cell tile: 4 x 8 cells of one (b, d) plane, n-tile t = rows 2t, 2t + 1.  (NT = 4, 8 x 8 cells, for the 32 -> 32 layer -- 8x the cells, a quarter of
-    // the weights -- measured 9.0 / 20.9 us per launch against 8.9 / 17.3: the weight stream is not its bound, the block count is its latency hiding)
+    // the weights -- measured 9.0 / 20.9 us per launch against 8.9 / 17.3, and NT = 1, 2 x 8 cells, 11.9 / 24.7: 32 cells is the sweet spot between the
+    // blocks in flight and the halo overhead; a persistent form with register-stationary weights measured 22.4: DESIGN.md section 8)
     static constexpr int NT = 2;
     static constexpr int TH = 2 * NT, TW = 8;
     static constexpr int MT = COUT / 16;
