@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 102          /* 0.1.2 -- 102: rcmvs_depth_head_fwd accepts prob == NULL for D = 8; 101: rcmvs_bn_stats writes 2C + 1 doubles (the row count joined the sums: one SyncBatchNorm message);
+#define RCMVS_VERSION 103          /* 0.1.3 -- 103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5, 6;
+                                      rcmvs_compose_homography_stages gained (zero, zero_n) before its stream argument in 102 (not listed then).  102: rcmvs_depth_head_fwd accepts prob == NULL for D = 8; 101: rcmvs_bn_stats writes 2C + 1 doubles (the row count joined the sums: one SyncBatchNorm message);
                                       rcmvs_debug_warp_variance_fwd takes variants 0-3 only.  A caller built against 100 must be rebuilt: check
                                       rcmvs_version() >= the RCMVS_VERSION it was compiled with. */
 #define RCMVS_MAX_SRC_VIEWS 10     /* V-1 */
@@ -73,10 +74,28 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
 
 /* Test / profiling twin of rcmvs_warp_variance_fwd with an explicit code variant (stateless, re-entrant): 0 = the production
  * kernel, 1 = production with FMA-contracted blend (<= 2e-7 relative), 2 = reference-order kernel (one full coordinate chain per
- * lane, compiler IEEE division -- the kernel the production one is held bit-identical to), 3 = store-only ablation. */
+ * lane, compiler IEEE division -- the kernel the production one is held bit-identical to), 3 = store-only ablation,
+ * 5 / 6 = the LDS-window form (V = 3 only; see rcmvs_debug_warp_variance_win_fwd). */
 int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                                   const float* planes, float* var,
                                   int B, int V, int C, int D, int h, int w, int variant, void* stream);
+
+/* rcmvs_warp_variance_fwd with a hint about the plane table.  RCMVS_K1_UNIFORM_PLANES: the hypothesis planes are the same (or nearly
+ * the same) for every pixel -- stage 1 of the cascade (models/modules.py:549-566) -- so the 2x2 footprints of a tile over a chunk of planes
+ * fit a small source window: with two source views the kernel stages that window in LDS and takes the taps from there (csrc/k1_win.h;
+ * tiles whose footprints do not fit fall back to gathers one by one, so the hint never changes results beyond the kernel's FMA-level
+ * tolerance, ~4e-7 of the value range, only the speed).  hint 0 = rcmvs_warp_variance_fwd. */
+#define RCMVS_K1_UNIFORM_PLANES 1
+int rcmvs_warp_variance_hint_fwd(const float* feats, const float* rot, const float* trans,
+                                 const float* planes, float* var,
+                                 int B, int V, int C, int D, int h, int w, int hint, void* stream);
+
+/* The window-form kernel (csrc/k1_win.h) with its tile statistics: variant 5 = source windows loaded
+ * ahead of the coordinate phase, 6 = after the fit test.  stats (device pointer, two unsigned, caller-zeroed, NULL = none):
+ * stats[0] += thread blocks launched, stats[1] += blocks whose tile took the LDS-window path. */
+int rcmvs_debug_warp_variance_win_fwd(const float* feats, const float* rot, const float* trans,
+                                      const float* planes, float* var,
+                                      int B, int V, int C, int D, int h, int w, int variant, unsigned* stats, void* stream);
 
 /* train-variant extra (models/casmvsnet.py:59,82,89-101): volume_feature_no_ref, NCDHW like
  * the reference returns it: out (B, 3(V-1)+C, D, h, w) = warped RGB of each source view

@@ -29,6 +29,8 @@ SIGNATURES = {
     "rcmvs_hypothesis_planes": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_warp_variance_hint_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_debug_warp_variance_win_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     "rcmvs_absmax_fwd": [_p, _ll, _i, _p, _p],
     "rcmvs_conv3d_scaled_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_deconv3d_scaled_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

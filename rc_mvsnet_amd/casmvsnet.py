@@ -782,7 +782,8 @@ class _CascadeBase(nn.Module):
             else:
                 rot, trans = rots[s], transs[s]
             planes = ops.hypothesis_planes(depth, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
-            var = ops.warp_variance(f_cl, rot, trans, planes, D)
+            # stage 1 sweeps the same planes at every pixel (models/modules.py:549-566): K1 can stage its source windows in LDS
+            var = ops.warp_variance(f_cl, rot, trans, planes, D, uniform_planes=depth is None)
             cr = self._cr(s)
             # The cost regularisation runs on the two-piece fp16 form of the matrix-core kernels (half the MFMAs of the exact bf16
             # triple; RCMVS_FP16_PAIR=0 selects the exact form).  It needs a bound of max|var|: var = E[f^2] - E[f]^2 <= max f^2, from

@@ -32,18 +32,27 @@ struct K1Geom {
     int w, h;
 };
 
-// one (pixel, plane, view): integer coordinates of the north-west tap (-4 for non-finite positions) + masked weights.
-// Shared by every K1 kernel so that all of them sample at bit-identical positions.
-__device__ __forceinline__ void k1_chain(float rx, float ry, float rz, float t0, float t1, float t2, float d,
-                                         const K1Geom& g, int& xi, int& yi, v4f& wt) {
+// one (pixel, plane, view): the sampling position in source pixels, in the reference's operation order (models/modules.py:326-333
+// and grid_sample's align_corners un-normalisation), every division correctly rounded.  The position is what decides the tap pair,
+// so every K1 kernel -- forward, backward, gather or window path -- takes it from here and samples at bit-identical positions.
+__device__ __forceinline__ void k1_position(float rx, float ry, float rz, float t0, float t1, float t2, float d,
+                                            const K1Geom& g, float& ix, float& iy) {
 #pragma clang fp contract(off)
     const float px = rx * d + t0, py = ry * d + t1, pz = rz * d + t2;
     const float rpz = rcp_nr(pz);
     const float u = div_c<2>(px, pz, rpz), vv = div_c<2>(py, pz, rpz);
     const float gx = div_c<1>(u, g.half_w, g.r_half_w) - 1.0f;
     const float gy = div_c<1>(vv, g.half_h, g.r_half_h) - 1.0f;
-    const float ix = ((gx + 1.0f) * 0.5f) * g.wm1;
-    const float iy = ((gy + 1.0f) * 0.5f) * g.hm1;
+    ix = ((gx + 1.0f) * 0.5f) * g.wm1;
+    iy = ((gy + 1.0f) * 0.5f) * g.hm1;
+}
+
+// integer coordinates of the north-west tap (-4 for non-finite positions) + masked weights
+__device__ __forceinline__ void k1_chain(float rx, float ry, float rz, float t0, float t1, float t2, float d,
+                                         const K1Geom& g, int& xi, int& yi, v4f& wt) {
+#pragma clang fp contract(off)
+    float ix, iy;
+    k1_position(rx, ry, rz, t0, t1, t2, d, g, ix, iy);
     const float x0 = floorf(ix), y0 = floorf(iy);
     const float wx1 = ix - x0, wx0 = (x0 + 1.0f) - ix;
     const float wy1 = iy - y0, wy0 = (y0 + 1.0f) - iy;
@@ -57,6 +66,28 @@ __device__ __forceinline__ void k1_chain(float rx, float ry, float rz, float t0,
     wt.y = (vx1 && vy0) ? wx1 * wy0 : 0.0f;
     wt.z = (vx0 && vy1) ? wx0 * wy1 : 0.0f;
     wt.w = (vx1 && vy1) ? wx1 * wy1 : 0.0f;
+}
+
+// The same taps in FIXED-PATTERN form: the 2x2 footprint is moved inside the image -- (xc, yc) in [0, w-2] x [0, h-2] is its
+// north-west corner -- and the four weights follow the texels: a footprint that hangs over a border by one texel keeps its inside
+// taps' weights on the texels they belong to and gives the two texels it never had a weight of zero; a footprint wholly outside, or
+// a non-finite position, gets four zeros (live = false: it may be pointed anywhere).  The four texels are then always
+// base, base + 1 texel, base + 1 row, base + 1 row + 1 texel: one offset per record, the other three are immediates of the load.
+// The products are the ones k1_chain forms (same operands, same roundings).
+__device__ __forceinline__ void k1_tap_fixed(float ix, float iy, const K1Geom& g, int& xc, int& yc, v4f& wt, bool& live) {
+#pragma clang fp contract(off)
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float wx1 = ix - x0, wx0 = (x0 + 1.0f) - ix;
+    const float wy1 = iy - y0, wy0 = (y0 + 1.0f) - iy;
+    const bool fin = (fabsf(ix) < 16777216.0f) && (fabsf(iy) < 16777216.0f);
+    const int xi = fin ? (int)x0 : -4, yi = fin ? (int)y0 : -4;
+    const bool inx = (unsigned)xi < (unsigned)(g.w - 1), iny = (unsigned)yi < (unsigned)(g.h - 1);
+    const float xa = inx ? wx0 : (xi == -1 ? wx1 : 0.0f), xb = inx ? wx1 : (xi == g.w - 1 ? wx0 : 0.0f);
+    const float ya = iny ? wy0 : (yi == -1 ? wy1 : 0.0f), yb = iny ? wy1 : (yi == g.h - 1 ? wy0 : 0.0f);
+    xc = min(max(xi, 0), g.w - 2);
+    yc = min(max(yi, 0), g.h - 2);
+    live = ((unsigned)(xi + 1) < (unsigned)(g.w + 1)) && ((unsigned)(yi + 1) < (unsigned)(g.h + 1));
+    wt.x = xa * ya; wt.y = xb * ya; wt.z = xa * yb; wt.w = xb * yb;
 }
 
 // offsets (bytes, clamped in-bounds, view row base included) + weights

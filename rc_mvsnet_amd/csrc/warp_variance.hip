@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "common.h"
 #include "k1_taps.h"
+#include "k1_win.h"
 
 namespace rcmvs {
 
@@ -481,16 +482,28 @@ using namespace rcmvs;
 
 extern "C" {
 
-// variant: 0 = production (exact arithmetic), 1 = production with FMA-contracted blend, 2 = reference-order kernel (one full
-// coordinate chain per lane, compiler IEEE division: what variant 0 is held bit-identical to), 3 = store-only ablation
+// variant: 0 = production gather kernel (exact arithmetic), 1 = the same with FMA-contracted blend, 2 = reference-order kernel (one full
+// coordinate chain per lane, compiler IEEE division: what variant 0 is held bit-identical to), 3 = store-only ablation,
+// 5 / 6 = the LDS-window form (k1_win.h; what rcmvs_warp_variance_hint_fwd launches for pixel-invariant planes is 5)
 static int k1_launch(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
-                     int B, int V, int C, int D, int h, int w, int variant, hipStream_t st) {
+                     int B, int V, int C, int D, int h, int w, int variant, hipStream_t st, unsigned* stats = nullptr) {
     RCMVS_REQUIRE(feats && rot && trans && planes && var, "warp_variance_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
     RCMVS_REQUIRE((long long)h * w * C < (1LL << 31), "warp_variance_fwd: feature map too large for 32-bit offsets");
-    RCMVS_REQUIRE(variant >= 0 && variant <= 3, "warp_variance_fwd: unknown variant %d", variant);
+    RCMVS_REQUIRE((variant >= 0 && variant <= 3) || variant == 5 || variant == 6, "warp_variance_fwd: unknown variant %d", variant);
     RCMVS_REQUIRE(C == 8 || C == 16 || C == 32, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+    if (variant >= 5) {
+        // window form (k1_win.h): 5 = source windows loaded ahead of the coordinate phase, 6 = after the fit test
+        RCMVS_REQUIRE(V == 3, "warp_variance_fwd: the window form is built for two source views (got V=%d)", V);
+        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
+#define RCMVS_K1WIN(CC, DD, PP, RR) (variant == 5 ? k1_win_launch_one<CC, DD, 2, PP, RR, 1>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st) : \
+                                                    k1_win_launch_one<CC, DD, 2, PP, RR, 2>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st))
+        if (C == 32) return RCMVS_K1WIN(32, 4, 16, 8);
+        if (C == 16) return RCMVS_K1WIN(16, 4, 32, 8);
+        return RCMVS_K1WIN(8, 4, 64, 8);
+#undef RCMVS_K1WIN
+    }
     if (variant <= 1) {
         const bool fastm = variant == 1;
         const int LPP = C / 4, PIX = 256 / LPP;
@@ -550,10 +563,25 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
     return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, 0, as_stream(stream));
 }
 
+int rcmvs_warp_variance_hint_fwd(const float* feats, const float* rot, const float* trans,
+                                 const float* planes, float* var,
+                                 int B, int V, int C, int D, int h, int w, int hint, void* stream) {
+    // pixel-invariant hypothesis planes + two source views: the LDS-window form (stage 1 of the cascade: 33 us against 40 at config 2)
+    const bool window = (hint & RCMVS_K1_UNIFORM_PLANES) && V == 3 && (long long)V * h * w * C * 4 < 0x7fffffffLL;
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, window ? 5 : 0, as_stream(stream));
+}
+
 int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                                   const float* planes, float* var,
                                   int B, int V, int C, int D, int h, int w, int variant, void* stream) {
     return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, variant, as_stream(stream));
+}
+
+int rcmvs_debug_warp_variance_win_fwd(const float* feats, const float* rot, const float* trans,
+                                      const float* planes, float* var,
+                                      int B, int V, int C, int D, int h, int w, int variant, unsigned* stats, void* stream) {
+    RCMVS_REQUIRE(variant == 5 || variant == 6, "debug_warp_variance_win_fwd: variant must be 5 or 6 (got %d)", variant);
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, variant, as_stream(stream), stats);
 }
 
 int rcmvs_warp_noref_fwd(const float* feats, const float* imgs, const float* rot, const float* trans,

@@ -14,6 +14,7 @@ from . import _lib
 # bench.py sets this to a list to have every K1 launch bracketed by HIP events recorded on the
 # launch stream (torch's current stream); None = no instrumentation.
 K1_EVENTS = None
+K1_UNIFORM_PLANES = 1          # RCMVS_K1_UNIFORM_PLANES (include/rcmvs.h)
 # same for the 3-D convolutions: list of (event0, event1, key) with key = (kind, B, D, H, W, Ci, Co), kind 's1' | 's2' | 't2'
 CONV_EVENTS = None
 
@@ -103,37 +104,42 @@ def absmax(x, square=False, out=None):
     return out
 
 
-def warp_variance(feats, rot, trans, planes, ndepth, variant=0):
-    """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C).  variant != 0: the test / profiling code variants of
-    rcmvs_debug_warp_variance_fwd (1 FMA blend, 2 reference-order kernel, 3 store-only)."""
+def warp_variance(feats, rot, trans, planes, ndepth, variant=0, uniform_planes=False):
+    """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C).  uniform_planes: the caller's hint that the plane table is the same for every
+    pixel (stage 1 of the cascade): with two source views the kernel then stages the tiles' source windows in LDS (csrc/k1_win.h;
+    same results within ~4e-7 of the value range, per-tile fallback).  variant != 0: the test / profiling code variants of
+    rcmvs_debug_warp_variance_fwd (1 FMA blend, 2 reference-order kernel, 3 store-only, 5 / 6 window form)."""
     B, V, h, w, C = feats.shape
     var = torch.empty((B, ndepth, h, w, C), device=feats.device, dtype=torch.float32)
-    ev = None
-    if K1_EVENTS is not None and not variant:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     if variant:
         _lib.check(_lib.load().rcmvs_debug_warp_variance_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
                                                              _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, int(variant),
                                                              _stream()), "debug_warp_variance_fwd")
         return var
-    _lib.check(_lib.load().rcmvs_warp_variance_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
-                                                   _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, _stream()),
-               "warp_variance_fwd")
+    ev = None
+    if K1_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _lib.check(_lib.load().rcmvs_warp_variance_hint_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                        _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w,
+                                                        K1_UNIFORM_PLANES if uniform_planes else 0, _stream()),
+               "warp_variance_hint_fwd")
     if ev is not None:
         ev[1].record()
         K1_EVENTS.append(ev)
     return var
 
 
-def warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first):
-    """feats (B,V,h,w,C), imgs (B,V,h,w,3) -> (B, 3(V-1)+C, D, h, w) in the reference's NCDHW."""
+def warp_variance_win(feats, rot, trans, planes, ndepth, variant=5):
+    """The window-form K1 kernel with its tile statistics -> (variance volume, blocks launched, blocks on the LDS-window path)."""
     B, V, h, w, C = feats.shape
-    out = torch.empty((B, 3 * (V - 1) + C, ndepth, h, w), device=feats.device, dtype=torch.float32)
-    _lib.check(_lib.load().rcmvs_warp_noref_fwd(_chk(feats, "feats"), _chk(imgs, "imgs"), _chk(rot, "rot"), _chk(trans, "trans"),
-                                                _chk(planes, "planes"), _chk(out, "out"), B, V, C, ndepth, h, w,
-                                                int(bool(square_first)), _stream()), "warp_noref_fwd")
-    return out
+    var = torch.empty((B, ndepth, h, w, C), device=feats.device, dtype=torch.float32)
+    stats = torch.zeros(2, device=feats.device, dtype=torch.int32)
+    _lib.check(_lib.load().rcmvs_debug_warp_variance_win_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                                 _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, int(variant),
+                                                                 _chk(stats, "stats", torch.int32), _stream()), "debug_warp_variance_win_fwd")
+    n = stats.cpu()
+    return var, int(n[0]), int(n[1])
 
 
 def warp_variance_bwd(feats, rot, trans, planes, grad_var, grad_noref=None, variant=0):

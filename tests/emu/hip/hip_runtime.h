@@ -204,6 +204,7 @@ inline int __lane_id() { return ::shim::me().lin % ::shim::WAVE; }
 #define __builtin_amdgcn_ds_bpermute(a, s) __builtin_amdgcn_ds_bpermute_emu((a), (s))
 // scheduling / counters: no effect on results
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_memrealtime() (0ull)        // timing is not modelled
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -89,6 +89,40 @@ def test_k1_variants_on_emulated_kernels(C, D, h, w, V, emu):
     assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("C,D,h,w,smooth", [(32, 8, 20, 37, True), (16, 7, 33, 50, True), (8, 12, 24, 96, True), (32, 5, 9, 13, False),
+                                            (16, 8, 6, 70, False), (8, 4, 5, 3, False)])
+def test_k1_window_form_on_emulated_kernels(C, D, h, w, smooth, emu):
+    """K1, LDS-window form (csrc/k1_win.h; two source views): windows loaded ahead of the coordinate phase (5, what the
+    uniform-planes hint launches) and after the fit test (6) against the reference-order kernel -- identical sampling positions, FMA
+    blend -- on plane tables whose tiles fit the windows (smooth: the window path must really run) and on rough ones (per-tile
+    fallback to gathers, ragged edges, D not a multiple of the plane chunk, images smaller than a tile)."""
+    from rc_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(C + h)
+    B, V = 2, 3
+    feats = torch.randn(B, V, h, w, C, generator=g)
+    pm = synthetic.proj_matrices(B, V, h * 4, w * 4)["stage1"]
+    rot, trans = ops.compose_homography(pm)
+    if smooth:
+        planes = torch.stack((500.0 + 3.0 * torch.rand(B, h, w, generator=g), torch.full((B, h, w), 5.0)), dim=-1).contiguous()
+    else:
+        planes = torch.stack((300.0 + 600.0 * torch.rand(B, h, w, generator=g), 2.0 + 40.0 * torch.rand(B, h, w, generator=g)), dim=-1).contiguous()
+    vref = ops.warp_variance(feats, rot, trans, planes, D, variant=2)
+    tol = 2e-6 * max(1.0, float(vref.abs().max()))
+    for var in (5, 6):
+        v, blocks, on_window = ops.warp_variance_win(feats, rot, trans, planes, D, variant=var)
+        assert float((v - vref).abs().max()) <= tol, var
+        assert blocks > 0 and (on_window == blocks if smooth else on_window <= blocks), (var, blocks, on_window)
+        assert torch.equal(v, ops.warp_variance(feats, rot, trans, planes, D, variant=var))
+    hinted = ops.warp_variance(feats, rot, trans, planes, D, uniform_planes=True)
+    assert torch.equal(hinted, ops.warp_variance(feats, rot, trans, planes, D, variant=5))
+    assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), ops.warp_variance(feats, rot, trans, planes, D, variant=0))
+    with pytest.raises(Exception):
+        ops.warp_variance(feats[:, :2].contiguous(), rot[:, :1].contiguous(), trans[:, :1].contiguous(), planes, D, variant=5)   # V = 2: not built
+    # ... but the hint itself is only a hint: other view counts take the gather kernel
+    v2 = ops.warp_variance(feats[:, :2].contiguous(), rot[:, :1].contiguous(), trans[:, :1].contiguous(), planes, D, uniform_planes=True)
+    assert torch.equal(v2, ops.warp_variance(feats[:, :2].contiguous(), rot[:, :1].contiguous(), trans[:, :1].contiguous(), planes, D))
+
+
 def test_results_do_not_depend_on_the_thread_schedule(emu):
     """Missing-barrier detector: between synchronisation points the emulation may run a block's threads in any order; ascending,
     descending and wave-reversed schedules must give bit-identical results for kernels without float atomics (the whole inference

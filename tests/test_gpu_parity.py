@@ -175,6 +175,48 @@ def test_warp_variance_variants_agree(hip):
         hip.warp_variance(feats, rot, trans, planes, D, variant=9)
 
 
+def test_warp_variance_window_form(hip):
+    """K1 with the tiles' source windows staged in LDS (csrc/k1_win.h; what the uniform-planes hint of stage 1 launches): same sampling
+    positions as the reference-order kernel, FMA-contracted blend -> <= 2e-6 of the value range; on the config-2 stage-1 shape with the
+    cascade's own plane table (pixel-invariant) nearly every tile must take the window path, on rough plane tables tiles fall back one
+    by one; the hint changes nothing for view counts the window form is not built for."""
+    from rc_mvsnet_amd import synthetic
+    # (a) config-2 stage shapes, stage-1 style planes
+    for (C, D, h, w, stage) in ((32, 48, 128, 160, "stage1"), (16, 32, 256, 320, "stage2"), (8, 8, 512, 640, "stage3")):
+        g = torch.Generator().manual_seed(C)
+        feats = gpu(torch.randn(1, 3, h, w, C, generator=g))
+        rot, trans = hip.compose_homography(gpu(synthetic.proj_matrices(1, 3, 512, 640)[stage]))
+        planes = hip.hypothesis_planes(None, gpu(synthetic.depth_values(1)), (512, 640), 512 // h, D, 4 if C == 32 else 1)
+        vref = hip.warp_variance(feats, rot, trans, planes, D, variant=2)
+        tol = 2e-6 * max(1.0, float(vref.abs().max()))
+        for var in (5, 6):
+            v, blocks, on_window = hip.warp_variance_win(feats, rot, trans, planes, D, variant=var)
+            err = float((v - vref).abs().max())
+            print(f"K1 window form C={C} variant {var}: {on_window} of {blocks} tiles on the window path, max |d| {err:.2e} (tol {tol:.2e})")
+            assert err <= tol
+            if C == 32:
+                assert on_window >= 0.9 * blocks
+        assert torch.equal(hip.warp_variance(feats, rot, trans, planes, D, uniform_planes=True), hip.warp_variance(feats, rot, trans, planes, D, variant=5))
+    # (b) rough plane tables, ragged sizes, two items
+    for (C, D, h, w) in ((32, 16, 20, 37), (16, 7, 33, 50), (8, 12, 64, 96), (32, 5, 9, 13), (8, 4, 5, 3)):
+        g = torch.Generator().manual_seed(C + h)
+        feats = gpu(torch.randn(2, 3, h, w, C, generator=g))
+        rot, trans = hip.compose_homography(gpu(synthetic.proj_matrices(2, 3, h * 4, w * 4)["stage1"]))
+        planes = gpu(torch.stack((300.0 + 600.0 * torch.rand(2, h, w, generator=g), 2.0 + 40.0 * torch.rand(2, h, w, generator=g)), dim=-1))
+        vref = hip.warp_variance(feats, rot, trans, planes, D, variant=2)
+        for var in (5, 6):
+            v, blocks, on_window = hip.warp_variance_win(feats, rot, trans, planes, D, variant=var)
+            assert float((v - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), (C, var)
+            assert 0 < blocks and on_window <= blocks
+    # (c) the hint is only a hint
+    feats = gpu(torch.randn(1, 5, 12, 20, 32))
+    rot, trans = hip.compose_homography(gpu(synthetic.proj_matrices(1, 5, 48, 80)["stage1"]))
+    planes = gpu(torch.stack((torch.full((1, 12, 20), 500.0), torch.full((1, 12, 20), 5.0)), dim=-1))
+    assert torch.equal(hip.warp_variance(feats, rot, trans, planes, 8, uniform_planes=True), hip.warp_variance(feats, rot, trans, planes, 8))
+    with pytest.raises(Exception):
+        hip.warp_variance(feats, rot, trans, planes, 8, variant=5)
+
+
 # ------------------------------------------------------------------------------------------ K2/K3
 @pytest.mark.parametrize("Ci,Co,mode", [(8, 16, "s2"), (16, 16, "s1"), (16, 32, "s2"), (32, 32, "s1"), (32, 64, "s2"),
                                         (64, 64, "s1"), (64, 32, "t2"), (32, 16, "t2")])

@@ -8,11 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.a
 sys.path.insert(0, ROOT)
 from rc_mvsnet_amd import synthetic
 from oracle import cascade, warp
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+GAIN = float(os.environ.get("K1_GAIN", "20"))        # 20 = the bench scene, 1 = its smooth-head twin
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data" if GAIN == 20 else "data_smooth")
 os.makedirs(OUT, exist_ok=True)
 V = int(os.environ.get("K1_V", "3"))
 imgs, proj, dv = synthetic.cascade_inputs(1, V, 512, 640, 0)
-sd = synthetic.cascade_state_dict(0)
+sd = synthetic.cascade_state_dict(0, prob_gain=GAIN)
 with torch.no_grad():
     out, aux = cascade.forward_eval(imgs, proj, dv, sd, impl="aten", return_aux=True)
 for s, sc in ((1, 4), (2, 2), (3, 1)):

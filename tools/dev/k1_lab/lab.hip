@@ -18,6 +18,7 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace rcmvs
 
 #include "lab_kernels.h"
+#include "lab_win.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -52,6 +53,9 @@ int main(int argc, char** argv) {
         std::vector<float> rot((V - 1) * 9), trans((V - 1) * 3);
         for (int v = 0; v < V - 1; ++v) { memcpy(&rot[v * 9], &rt[v * 12], 36); memcpy(&trans[v * 3], &rt[v * 12 + 9], 12); }
         float *d_f, *d_r, *d_t, *d_p, *d_o;
+        unsigned* d_st;
+        const size_t nst = 8 * 8 * 16384;             // room for the per-block timelines of variants 70+
+        CK(hipMalloc(&d_st, nst));
         CK(hipMalloc(&d_f, nf * 4)); CK(hipMalloc(&d_r, rot.size() * 4)); CK(hipMalloc(&d_t, trans.size() * 4));
         CK(hipMalloc(&d_p, planes.size() * 4)); CK(hipMalloc(&d_o, nv * 4));
         CK(hipMemcpy(d_f, feats.data(), nf * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_r, rot.data(), rot.size() * 4, hipMemcpyHostToDevice));
@@ -63,17 +67,29 @@ int main(int argc, char** argv) {
         const double nbytes = 4.0 * ((double)(V - 1) * C * h * w + (double)C * h * w + (double)D * h * w + (double)C * D * h * w);
         for (size_t vi = 0; vi < variants.size(); ++vi) {
             const int v = variants[vi];
+            unsigned* stp = d_st;           // statistics in the verification run only: 10^4 same-address atomics cost ~20 ns each
             auto run = [&]() -> int {
                 if (v < 20) return rcmvs_debug_warp_variance_fwd(d_f, d_r, d_t, d_p, d_o, 1, V, C, D, h, w, v, nullptr);
+                if (v >= 40) return lab_win_launch(v, d_f, d_r, d_t, d_p, d_o, 1, V, C, D, h, w, stp, nullptr);
                 return lab_launch(v, d_f, d_r, d_t, d_p, d_o, 1, V, C, D, h, w, nullptr);
             };
             CK(hipMemset(d_o, 0xff, nv * 4));
+            CK(hipMemset(d_st, 0, nst));
             int rc = run();
             if (rc) { printf("C=%2d variant %3d: launch failed: %s\n", C, v, rcmvs::err_buf()); continue; }
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(out.data(), d_o, nv * 4, hipMemcpyDeviceToHost));
             size_t bad = 0, first = 0;
-            for (size_t i = 0; i < nv; ++i) if (memcmp(&out[i], &ref[i], 4)) { if (!bad) first = i; ++bad; }
+            double maxd = 0, maxr = 0;
+            unsigned hst[2] = {0, 0};
+            CK(hipMemcpy(hst, d_st, 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nv; ++i) {
+                if (memcmp(&out[i], &ref[i], 4)) { if (!bad) first = i; ++bad; }
+                const double dd = fabs((double)out[i] - (double)ref[i]);
+                if (!(dd <= maxd)) maxd = dd;               // NaN-propagating
+                if (fabs((double)ref[i]) > maxr) maxr = fabs((double)ref[i]);
+            }
+            stp = nullptr;
             for (int i = 0; i < 3; ++i) run();
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -87,7 +103,8 @@ int main(int argc, char** argv) {
             const double us = ms * 1e3 / R;
             tot[vi] += us;
             printf("S%d C=%2d D=%2d %dx%d variant %3d: %8.1f us %8.1f GB/s  %s", s + 1, C, D, h, w, v, us, nbytes / us / 1e3, bad ? "MISMATCH" : "bit-identical");
-            if (bad) printf(" (%zu of %zu words, first at %zu: %g vs %g)", bad, nv, first, out[first], ref[first]);
+            if (bad) printf(" (%zu of %zu words, first at %zu: %g vs %g; max |d| %.3g = %.2e of max |ref|)", bad, nv, first, out[first], ref[first], maxd, maxd / maxr);
+            if (hst[0]) printf("  [window path: %u of %u blocks]", hst[1], hst[0]);
             printf("\n");
             fflush(stdout);
         }
