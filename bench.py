@@ -12,7 +12,10 @@ streams of scenes with no data-path collective ("weak" scaling): value = N*K / m
 The JSON line also carries
   roofline      the fused warp+variance kernel (K1): algorithmic bytes of its three per-scene
                 launches (137.6 + 194.0 + 125.8 MB) / their HIP-event durations
-                recorded on the launch stream inside the timed region, vs the 8 TB/s HBM peak;
+                recorded on the launch stream in a separate pass over the same scenes right after the timed region
+                (6 event records per scene would sit inside `value` otherwise), vs the 8 TB/s HBM peak;
+                `roofline.smooth_scene` = the same kernel on the same scene with prob.weight x1 (depth maps of stages 2 / 3
+                that are not noise: the gathers a trained network produces);
   roofline_conv the 3-D convolutions that run on the matrix cores at fp32 accuracy (csrc/conv3d_x3.hip: operands split into two
                 fp16 pieces after an exact power-of-two pre-scale -- the default for a B = 1 scene -- or into three bf16 pieces):
                 algorithmic flops of every such launch of a scene / HIP-event durations from a separate untimed pass, vs the
@@ -21,8 +24,6 @@ The JSON line also carries
   train_step    a short timing of the config-3 training iteration (5 iterations after 2 warm-ups; --no-train-step skips it);
   two_procs_per_gpu      N = 1 only, a side pass after the timed region, never `value`: `bench.py --procs-per-gpu 2` run as a child -- two worker
                 processes on the GPU, whole scenes each (--no-side-pass skips it);
-  two_scenes_in_flight   only with --in-flight-side-pass: 96 scenes with two in flight in ONE process (2 HIP streams, one hipGraph per
-                (stream, scene)), every output compared bit for bit with the one-stream run (experimental, rc_mvsnet_amd/scene_pipeline.py);
   timed_rounds  when K steps take less than 0.5 s the barrier-bracketed region of exactly K steps is repeated and the MEDIAN round is
                 reported (`value`, `ms_per_step`, `timed_region_s`), so that a short --steps still keeps the GPU busy for half a second;
   cpu_baseline  the oracle's ATen op graph (= the reference's CPU path) timed on the host cores
@@ -53,8 +54,6 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s achievable)
 H, W, V = 512, 640, 3
 NDEPTHS, RATIOS = (48, 32, 8), (4, 2, 1)
-STREAMS_DEFAULT = 1              # HIP streams the cascade workload issues independent scenes on (--streams).  EXPERIMENTAL above 1 (rc_mvsnet_amd/
-                                 # scene_pipeline.py): the stage-3 corruption of round 3 is fixed at its first wrong op, its cause is not understood
 FEAT_C = (32, 16, 8)
 
 
@@ -199,53 +198,6 @@ def timed_region(world, dev, warmup, steps, step):
         dist.barrier()
         dist.destroy_process_group()
     return elapsed, rounds
-
-
-def two_scenes_in_flight(make_model, model, scenes, steps, nstreams=2):
-    """Side figure of the cascade workload: `steps` scenes with `nstreams` of them in flight -- one model replica and one HIP stream per
-    slot, one captured hipGraph per (stream, scene) over the resident inputs, replayed round-robin; a scene is still one whole
-    CascadeMVSNet_eval.forward at batch 1.  Every (stream, scene) output is compared bit for bit with the one-stream eager output.
-    Round 3 (profiles/r3_two_streams.txt): this mode used to corrupt stage-3 outputs in 7 % of the scenes; the first wrong op was always
-    the hypothesis-planes kernel reading a stale piece of the previous stage's depth map, fixed by agent-scope loads there (0 of ~7000
-    scenes since).  The cause of the staleness is not understood, so this is reported beside the headline, not as it."""
-    import torch
-    keys = ("depth", "photometric_confidence")
-    with torch.no_grad():
-        want = []
-        for sc in scenes:
-            o = model(*sc)
-            want.append({k: o[k].clone() for k in keys})
-        torch.cuda.synchronize()
-        models = [make_model() for _ in range(nstreams)]
-        streams = [torch.cuda.Stream() for _ in range(nstreams)]
-        graphs, outs = {}, {}
-        for k in range(nstreams):
-            with torch.cuda.stream(streams[k]):
-                for sc in scenes:                             # plans, packed weights, allocator warm-up on the capture stream
-                    models[k](*sc)
-            streams[k].synchronize()
-            for j, sc in enumerate(scenes):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=streams[k]):
-                    o = models[k](*sc)
-                graphs[(k, j)], outs[(k, j)] = g, {key: o[key] for key in keys}
-        torch.cuda.synchronize()
-        order = [(i % nstreams, (i // nstreams) % len(scenes)) for i in range(steps)]
-        for k, j in order[:4 * nstreams]:
-            with torch.cuda.stream(streams[k]):
-                graphs[(k, j)].replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k, j in order:
-            with torch.cuda.stream(streams[k]):
-                graphs[(k, j)].replay()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        same = all(torch.equal(outs[kj][key], want[kj[1]][key]) for kj in set(order) for key in keys)
-    return {"value": round(steps / dt, 3), "unit": "ref-scenes/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
-            "streams": nstreams, "mode": "one hipGraph per (stream, scene), replayed round-robin over resident inputs",
-            "outputs_identical_to_single_stream": bool(same),
-            "note": "side pass after the timed region, NOT `value`: experimental mode (rc_mvsnet_amd/scene_pipeline.py)"}
 
 
 def two_procs_side_pass(steps):
@@ -496,12 +448,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the short config-3 training-iteration timing appended to the default line")
-    ap.add_argument("--no-side-pass", action="store_true", help="skip the side passes of the cascade workload (N = 1): two worker processes on the GPU, "
-                                                                "and (with --in-flight-side-pass) two scenes in flight on two HIP streams")
-    ap.add_argument("--in-flight-side-pass", action="store_true", help="also run the experimental two-scenes-in-flight side pass (two HIP streams in one process)")
-    ap.add_argument("--streams", type=int, default=STREAMS_DEFAULT,
-                    help="cascade workload, EXPERIMENTAL above 1: independent scenes issued round-robin on this many HIP streams (one model replica "
-                         "per stream); the line then carries `outputs_identical_to_single_stream` from a self-check after the timed region")
+    ap.add_argument("--no-side-pass", action="store_true", help="skip the side pass of the cascade workload (N = 1): two worker processes on the GPU")
     ap.add_argument("--cpu-scenes", type=int, default=5, help="scenes timed on the CPU baseline after 2 warm-ups (bounded sample, BASELINE.md section 3)")
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.procs_per_gpu < 1:
@@ -520,13 +467,17 @@ def main(argv=None):
     if args.workload == "stub":
         dev = torch.device("cpu")
         if world > 1:
-            import torch.distributed as dist
-            dist.init_process_group(backend="gloo")
+            from rc_mvsnet_amd.sharding import init_process_group
+            dist = init_process_group("gloo")
         result = bench_stub(args, rank, world, dev)
         if result is not None:
             print(json.dumps(result), flush=True)
         return
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback): torch.cuda.is_available() is False")
+    if args.gpus > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s) "
+                         f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = {os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', 'unset'))})")
     from rc_mvsnet_amd.sharding import device_index as _device_index
     device_index = _device_index(local_rank, args.procs_per_gpu)           # ranks g*P .. g*P+P-1 share GPU g
     torch.cuda.set_device(device_index)
@@ -535,7 +486,8 @@ def main(argv=None):
         import torch.distributed as dist
         # RCCL needs one device per rank: with several processes per GPU the rendezvous (barrier, max-time reduction -- there is no data-path
         # collective in the cascade workload) goes over gloo instead
-        dist.init_process_group(backend="nccl" if args.procs_per_gpu == 1 else "gloo")
+        from rc_mvsnet_amd.sharding import init_process_group
+        dist = init_process_group("nccl" if args.procs_per_gpu == 1 else "gloo")
         assert dist.get_world_size() == world
     if args.procs_per_gpu > 1 and args.workload != "cascade":
         raise SystemExit("bench.py: --procs-per-gpu applies to the cascade workload (independent items); training ranks own one GPU each")
@@ -552,16 +504,13 @@ def main(argv=None):
         return
 
     sd = synthetic.cascade_state_dict(0)
-    nstreams = max(1, int(args.streams))
-    from rc_mvsnet_amd.scene_pipeline import ScenePipeline
 
-    def make_model():                                        # one replica per stream (3.7 MB of weights): a model's activation-bound buffer is not re-entrant
+    def make_model(state):
         m = CascadeMVSNet_eval(ndepths=list(NDEPTHS), depth_interals_ratio=list(RATIOS))
-        m.load_state_dict(sd, strict=True)
+        m.load_state_dict(state, strict=True)
         return m.to(dev).eval()
 
-    pipe = ScenePipeline(make_model, nstreams, dev, wait_inputs=False, experimental=nstreams > 1)      # the scenes are resident and synchronised before the timed region
-    model = pipe.models[0]
+    model = make_model(sd)
 
     # a few distinct scenes resident in HBM; rank r starts at a different one
     scenes = []
@@ -569,73 +518,48 @@ def main(argv=None):
         imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, seed)
         scenes.append((imgs.to(dev), {k: v.to(dev) for k, v in pm.items()}, dv.to(dev)))
 
-    def step(i):
-        # Reference views are independent: with S > 1 streams consecutive scenes are issued on different HIP streams, so one scene's
-        # latency-bound phases (the deep U-Net levels: ~40 launches of 10-30 us on a fraction of the CUs) overlap the other's
-        # full-GPU kernels.  Every scene is still one CascadeMVSNet_eval.forward at batch 1.
-        imgs, pm, dv = scenes[(i + rank) % len(scenes)]
-        return pipe(imgs, pm, dv)[0]
+    def step(i):                                              # one CascadeMVSNet_eval.forward at batch 1 on the current stream
+        return model(*scenes[(i + rank) % len(scenes)])
 
     cdev = dev if args.procs_per_gpu == 1 else torch.device("cpu")      # where the rendezvous tensors live (RCCL / gloo)
     with torch.no_grad():
         for i in range(args.warmup):
             out = step(i)
         torch.cuda.synchronize()
-        ops.K1_EVENTS = []                                  # HIP events around every K1 launch of the timed rounds
         elapsed, own, rounds = timed_rounds(world, cdev, args.steps, step, torch.cuda.synchronize)
-    events, ops.K1_EVENTS = ops.K1_EVENTS, None
-    # second, UNTIMED pass with HIP events around every 3-D convolution launch (80 event records per scene would perturb `value`)
-    conv_events = []
+    # second, UNTIMED pass over the same scenes with HIP events (torch's current stream = the launch stream) around every K1 launch and
+    # every 3-D convolution launch: ~90 event records per scene would perturb `value` inside the timed region
+    events, conv_events, smooth_events = [], [], []
+    nprobe = min(10, args.steps)
     if rank == 0:
         with torch.no_grad():
-            ops.CONV_EVENTS = conv_events
-            for i in range(min(10, args.steps)):             # (on ONE stream whatever --streams says: per-launch durations of a scene alone)
-                imgs, pm, dv = scenes[(i + rank) % len(scenes)]
-                model(imgs, pm, dv)
+            ops.K1_EVENTS, ops.CONV_EVENTS = events, conv_events
+            for i in range(nprobe):
+                step(i)
             torch.cuda.synchronize()
-            ops.CONV_EVENTS = None
-    # with S > 1 streams the in-region K1 events bracket launches that SHARE the GPU with the other stream's kernels; a third, single-stream
-    # pass gives the kernel's own durations (`roofline.frac_single_stream`) and the one-scene-at-a-time rate (`single_stream`)
-    alone_events, single = [], None
-    if rank == 0 and nstreams > 1:
-        with torch.no_grad():
-            n1 = min(100, args.steps)
-            for i in range(5):
-                model(*scenes[i % len(scenes)])
-            torch.cuda.synchronize()
-            ops.K1_EVENTS = alone_events
-            t1 = time.perf_counter()
-            for i in range(n1):
-                model(*scenes[(i + rank) % len(scenes)])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter() - t1
-            ops.K1_EVENTS = None
-            single = {"value": round(n1 / t1, 3), "ms_per_step": round(t1 / n1 * 1e3, 4), "steps": n1,
-                      "note": "the same scenes issued one at a time on one stream (K1 events recorded in this pass too)"}
-            # self-check of the multi-stream mode: the same scenes again on the streams, against the one-stream outputs, bit for bit
-            want = [model(*s)["depth"].clone() for s in scenes]
-            torch.cuda.synchronize()
-            got = [pipe(*scenes[i % len(scenes)])[0]["depth"] for i in range(4 * len(scenes))]
-            pipe.synchronize()
-            single["outputs_identical_to_single_stream"] = bool(all(torch.equal(o, want[i % len(scenes)]) for i, o in enumerate(got)))
+            ops.K1_EVENTS = ops.CONV_EVENTS = None
+            # the smooth-head twin of the scene (prob.weight x1 instead of BASELINE.md's x20): K1 on depth maps that are not noise
+            if world == 1:
+                sd1 = synthetic.cascade_state_dict(0, prob_gain=1.0)
+                model1 = make_model(sd1)
+                for i in range(3):
+                    model1(*scenes[i % len(scenes)])
+                torch.cuda.synchronize()
+                ops.K1_EVENTS = smooth_events
+                for i in range(nprobe):
+                    model1(*scenes[i % len(scenes)])
+                torch.cuda.synchronize()
+                ops.K1_EVENTS = None
 
-    # SIDE PASSES (N = 1, one process, one stream in the timed region; never `value`).
-    #  two_procs_per_gpu: the same workload as `python bench.py --procs-per-gpu 2` in a child -- two worker processes on this GPU, each issuing
-    #      whole scenes on its own queue from its own address space: the safe way of keeping two scenes in flight (the item list is sharded
-    #      over the processes like over GPUs: rc_mvsnet_amd/sharding.py, eval_driver --procs-per-gpu);
-    #  two_scenes_in_flight (--in-flight-side-pass): two HIP streams in ONE process, hipGraph replay, outputs compared bit for bit with the
-    #      one-stream run; experimental, see rc_mvsnet_amd/scene_pipeline.py for its status.
-    two_procs = in_flight = None
-    if rank == 0 and world == 1 and nstreams == 1 and not args.no_side_pass:
+    # SIDE PASS (N = 1, one process; never `value`).  two_procs_per_gpu: the same workload as `python bench.py --procs-per-gpu 2` in a
+    # child -- two worker processes on this GPU, each issuing whole scenes on its own queue from its own address space (the item list is
+    # sharded over the processes like over GPUs: rc_mvsnet_amd/sharding.py, eval_driver --procs-per-gpu)
+    two_procs = None
+    if rank == 0 and world == 1 and not args.no_side_pass:
         try:
             two_procs = two_procs_side_pass(min(300, max(20, args.steps)))
         except Exception as e:                               # never at the expense of the headline line
             two_procs = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if args.in_flight_side_pass:
-            try:
-                in_flight = two_scenes_in_flight(make_model, model, scenes, min(96, max(8, args.steps)))      # (short: its launches share the rocprof averages of this command)
-            except Exception as e:
-                in_flight = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     rank_rates = None
     if world > 1:
@@ -649,35 +573,43 @@ def main(argv=None):
     if rank != 0:
         return
 
-    # ---- roofline of K1 from the events recorded inside the timed region -------------------
-    k1_ms = [e0.elapsed_time(e1) for (e0, e1) in events]
+    # ---- roofline of K1 from the events of the probe pass -------------------------------------
     nstage = len(NDEPTHS)
-    per_stage_ms = [sum(k1_ms[s::nstage]) / max(1, len(k1_ms[s::nstage])) for s in range(nstage)]
     bytes_stage = k1_algorithmic_bytes()
-    tot_ms = sum(per_stage_ms)
-    achieved = sum(bytes_stage) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-    traffic = None                      # HBM bytes per scene from the committed PMC profile (FETCH_SIZE x2 + WRITE_SIZE)
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r4_k1_traffic.json")))["bytes_per_scene"]
-    except Exception:
-        pass
-    roofline = {"bound": "hbm", "kernel": "rcmvs::warp_variance_tp_kernel (K1, 3 launches per scene)",
+
+    def k1_summary(evs):
+        ms = [e0.elapsed_time(e1) for (e0, e1) in evs]
+        per_stage = [sum(ms[s::nstage]) / max(1, len(ms[s::nstage])) for s in range(nstage)]
+        tot = sum(per_stage)
+        ach = sum(bytes_stage) / (tot * 1e-3) / 1e9 if tot > 0 else 0.0
+        return per_stage, ach
+
+    per_stage_ms, achieved = k1_summary(events)
+    traffic, traffic_file = None, None  # HBM bytes per scene from the committed PMC profile (FETCH_SIZE x2 + WRITE_SIZE)
+    for name in ("r5_k1_traffic.json", "r4_k1_traffic.json"):
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["bytes_per_scene"]
+            traffic_file = name
+            break
+        except Exception:
+            pass
+    roofline = {"bound": "hbm", "kernel": "K1, 3 launches per scene: rcmvs::warp_variance_win_kernel (stage 1: pixel-invariant planes, source windows "
+                                          "in LDS) + rcmvs::warp_variance_tp_kernel (stages 2, 3: gathers)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r4_k1_traffic.json -- rocprofv3 PMC passes over this command line in an earlier visit of the round "
-                                  "(tools/visits/r4_k1_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE per launch, summed over the 3 launches of a scene); "
+                "traffic_source": f"profiles/{traffic_file} -- rocprofv3 PMC passes over this command line in an earlier visit "
+                                  "(FETCH_SIZE x2 + WRITE_SIZE per launch, summed over the 3 launches of a scene); "
                                   "a committed measurement, NOT taken in this run (a profiler cannot wrap its own process)",
                 "algorithmic_bytes_per_scene": sum(bytes_stage),
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
-                "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)]}
-    if alone_events:
-        a_ms = [e0.elapsed_time(e1) for (e0, e1) in alone_events]
-        a_stage = [sum(a_ms[s::nstage]) / max(1, len(a_ms[s::nstage])) for s in range(nstage)]
-        roofline["frac_single_stream"] = round(sum(bytes_stage) / (sum(a_stage) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        roofline["per_stage_us_single_stream"] = [round(m * 1e3, 2) for m in a_stage]
-        roofline["note"] = (f"`frac` / `per_stage_us`: HIP events inside the timed region, where {nstreams} streams overlap independent scenes -- a K1 launch "
-                            "shares the GPU with the other stream's kernels for part of its duration; `frac_single_stream`: the same events in a separate "
-                            "single-stream pass = the kernel on its own")
+                "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)],
+                "timing": f"HIP events on the launch stream around every K1 launch, separate untimed pass of {nprobe} scenes right after the timed region"}
+    if smooth_events:
+        sm_ms, sm_ach = k1_summary(smooth_events)
+        roofline["smooth_scene"] = {"frac": round(sm_ach / HBM_PEAK_GBS, 4), "achieved": round(sm_ach, 1),
+                                    "per_stage_us": [round(m * 1e3, 2) for m in sm_ms],
+                                    "note": "same inputs and weights with prob.weight x1 instead of BASELINE.md's x20: stage-2 / 3 depth maps that are not "
+                                            "noise, i.e. the gather locality of a trained network (the x20 scene's neighbouring pixels sample +-20 px apart)"}
 
     roofline_conv = conv_roofline(conv_events, min(10, args.steps))
 
@@ -699,18 +631,14 @@ def main(argv=None):
                                "D=(48,32,8), batch 1 per GPU, fp32, random-init seeded weights",
                    "views": V, "height": H, "width": W, "ndepths": list(NDEPTHS),
                    "parallelism": f"scene-per-gpu x{args.gpus}" + (f", {args.procs_per_gpu} worker processes per GPU" if args.procs_per_gpu > 1 else ""),
-                   "ranks": world, "procs_per_gpu": args.procs_per_gpu, "streams_per_gpu": nstreams},
+                   "ranks": world, "procs_per_gpu": args.procs_per_gpu,
+                   "rccl_ranks": world if (world > 1 and args.procs_per_gpu == 1) else 0},
         "roofline": roofline,
         "roofline_conv": roofline_conv,
     }
     result.update(rounds_fields(rounds))
     if two_procs is not None:
         result["two_procs_per_gpu"] = two_procs
-    if in_flight is not None:
-        result["two_scenes_in_flight"] = in_flight
-    if single is not None:
-        result["outputs_identical_to_single_stream"] = single.pop("outputs_identical_to_single_stream")
-        result["single_stream"] = single
     if rank_rates:
         result["per_rank_scenes_per_s"] = {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2), "ranks": world}
 
@@ -749,13 +677,9 @@ def main(argv=None):
                             "note": "BASELINE.md's seeded weights scale prob.weight x20: a chaotic soft-argmin in which single-ulp logit "
                                     "differences move isolated pixels by millimetres; 'smooth_head' is the same scene with prob.weight x1"}
         # the same scene with a well-conditioned (trained-like) probability head: HIP vs the CPU op graph
-        sd1 = synthetic.cascade_state_dict(0, prob_gain=1.0)
-        m1 = CascadeMVSNet_eval(ndepths=list(NDEPTHS), depth_interals_ratio=list(RATIOS))
-        m1.load_state_dict(sd1, strict=True)
-        m1 = m1.to(dev).eval()
         with torch.no_grad():
             ref1 = cascade.forward_eval(imgs, pm, dv, sd1, NDEPTHS, RATIOS, impl="aten")
-            hip1 = m1(*scenes[0])
+            hip1 = model1(*scenes[0])
         d1 = (hip1["depth"].cpu() - ref1["depth"]).abs()
         result["parity"]["smooth_head"] = {"depth_l1_over_range": float(d1.mean()) / rng, "depth_max_abs_mm": float(d1.max()),
                                            "frac_pixels_over_0.1mm": float((d1 > 0.1).float().mean())}
@@ -765,6 +689,7 @@ def main(argv=None):
         try:
             from rc_mvsnet_amd import train_step as ts
             del model, scenes
+            model1 = None
             torch.cuda.empty_cache()
             tm, tn, topt = ts.build(dev, seed=0)
             ti, tp, td, tb = ts.synthetic_sample(dev, H=H, W=W, V=4, seed=0)

@@ -299,7 +299,9 @@ class FeatureNet(nn.Module):
             w, sc, sh, stride = p[n]
             return ops.conv2d(t, w, sc, sh, stride=stride, relu=True)
 
-        if len(p["conv0.0"]) == 4 and p["conv0.0"][0].ci == 4 and not ops._CONV_IMPL:
+        w00 = p["conv0.0"][0] if len(p["conv0.0"]) == 4 else None
+        # the planar first layer is built for the reference's 3 -> 8, k = 3, stride 1 (base_channels = 8); other widths take the NHWC4 path
+        if w00 is not None and w00.ci == 4 and w00.co == 8 and w00.k == 3 and p["conv0.0"][3] == 1 and not ops._CONV_IMPL:
             w, sc, sh, _ = p["conv0.0"]                              # the first layer reads the planar images itself (no NHWC4 pass)
             c00 = ops.conv2d_rgb(x.contiguous().float(), w, sc, sh, relu=True)
         else:

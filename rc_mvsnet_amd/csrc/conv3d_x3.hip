@@ -933,7 +933,7 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
         const long long spb = (T + n_blk - 1) / n_blk + 1;                   // steps of the longest block
         const long long ipb = (spb + dm.Dt - 1) / dm.Dt + 1;                 // item starts of a block, at most
         const long long cost_bal = 2 * spb + (C::NKD > 1 ? 3 : 0) * ipb;
-        if (T < 0x7fffffffLL && spb < 32768 && (mode == 1 || (mode == 2 && cost_bal < best))) {
+        if (T < 0x7fffffffLL && spb < 32768 && dm.Dt < 32768 && (mode == 1 || (mode == 2 && cost_bal < best))) {      // the step table packs z into 15 bits
             dm.bal = 1;
             dm.itemcap = (int)((ipb + 1 + 3) & ~3LL);
             dm.stepcap = (int)((spb + 2 + 3) & ~3LL);

@@ -6,10 +6,10 @@
 // (buffer_load ... lds, no VGPR round trip) -- and takes the taps from LDS (ds_read_b128: ~4x the L1's bandwidth).
 //
 // Structure of a block (256 threads, tile = PIX pixels x DKB planes, NVT source views):
-//   origin   every thread evaluates the SAME cheap approximate position of the tile's centre pixel at the chunk's middle plane
-//            (uniform operands -> uniform result, no exchange): the window of view v is WR rows x WP texels around it.
-//            MODE 1 issues the window loads here, so they fly while phase A computes.  A wave-load is one scalar address
-//            (view, row, segment) plus lane * 16: no vector arithmetic.
+//   origin   wave 0 evaluates a cheap approximate position of the tile's centre pixel at the chunk's middle plane and hands it to the
+//            block through LDS (one early barrier): the window of view v is WR rows x WP texels around it.
+//            MODE 1 issues the window loads here, so they fly while phase A computes.  A wave-load is one scalar row offset
+//            plus a per-lane column offset computed once per chunk: one vector add per load.
 //   phase A  one thread per (pixel, plane, view): exact position (k1_position), fixed-pattern taps (k1_tap_fixed), record =
 //            four weights + the texel offset twice: in the feature map (gather path) and in the window.  A record "fits" if
 //            its 2x2 footprint lies inside the window (records with four zero weights always fit).  The block takes the window
@@ -43,8 +43,8 @@ struct K1Win {
     static constexpr int OFF_W = 0;                         // v4f weights[NREC]
     static constexpr int OFF_G = OFF_W + NREC * 16;         // int  feature-map byte offset[NREC]
     static constexpr int OFF_L = OFF_G + NREC * 4;          // int  window byte offset[NREC]
-    static constexpr int OFF_F = OFF_L + NREC * 4;          // int  fit flags[4] (+ pad to 1 KiB alignment of the window)
-    static constexpr int OFF_WIN = (OFF_F + 16 + 1023) / 1024 * 1024;
+    static constexpr int OFF_F = OFF_L + NREC * 4;          // int  fit flags[4], then the window origins (x, y per view; + pad to 1 KiB)
+    static constexpr int OFF_WIN = (OFF_F + 16 + 8 * NVT + 1023) / 1024 * 1024;
     static constexpr int LDS_BYTES = OFF_WIN + NVT * WBYTES;
     static_assert(NREC % 256 == 0, "records must divide over the threads");
     static_assert(WBYTES % 1024 == 0 && LPV % 4 == 0, "the window loads of a view must divide over the four waves");
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void warp_variance_win_kernel(
     int* rec_g = reinterpret_cast<int*>(lds + W::OFF_G);
     int* rec_l = reinterpret_cast<int*>(lds + W::OFF_L);
     int* fitf = reinterpret_cast<int*>(lds + W::OFF_F);
+    int* orgf = fitf + 4;
     char* win = lds + W::OFF_WIN;
     const int b = blockIdx.z;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -108,23 +109,27 @@ __global__ __launch_bounds__(256) void warp_variance_win_kernel(
         int ox[NVT], oy[NVT];
         auto fill = [&]() {
             const int rw = (4 % W::SEG == 0) ? swave / W::SEG : 0, sw = (4 % W::SEG == 0) ? swave % W::SEG : 0;
+            // The byte offset of a wave-load is uniform (view, row, origin column + segment) + lane * 16 and may be NEGATIVE left of the
+            // first row: a huge unsigned offset, which the descriptor's size turns into zeros (texels no record points at).  It all goes
+            // into the VECTOR offset (one v_add with a scalar): the hardware adds the instruction's scalar offset zero-extended, so a
+            // negative value there reads far outside the buffer (round 5: wrong results on 5x3 images; the emulation models it now).
 #pragma unroll
             for (int j = 0; j < W::NLD / 4; ++j) {
                 const int va = j / (W::LPV / 4), jj = j % (W::LPV / 4);   // compile-time: wave s takes loads s, s + 4, ... of every view
-                int r, c0;
-                if (4 % W::SEG == 0) { r = rw + (4 / W::SEG) * jj; c0 = sw * W::TPW; }
+                int r, c0 = 0;
+                if (4 % W::SEG == 0) r = rw + (4 / W::SEG) * jj;
                 else { const int l = swave + 4 * jj; r = l / W::SEG; c0 = (l % W::SEG) * W::TPW; }
                 const int L = va * W::LPV + swave + 4 * jj;         // wave-uniform load id = 1 KiB slot of the window
-                // rows outside the image are never referenced (records point at clamped, in-image footprints): bring a valid
-                // row instead, so that the scalar offset never runs below the buffer; columns past either end of a row wrap
-                // into the neighbouring rows (unreferenced as well) or past the end of the buffer, where the descriptor's size
-                // returns zero
+                // rows outside the image are never referenced (records point at clamped, in-image footprints): bring a valid row
                 const int yy = min(max(oy[va] + r, 0), h - 1);
-                const int soff = (((va + 1) * h + yy) * w + ox[va] + c0) * TEXB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, win + L * 1024, 16, lane * 16, soff, 0, 0);
+                const int off = (((va + 1) * h + yy) * w + ox[va] + c0 + ((4 % W::SEG == 0) ? sw * W::TPW : 0)) * TEXB;      // scalar, any sign
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, win + L * 1024, 16, lane * 16 + off, 0, 0, 0);
             }
         };
-        {
+        // The origin must be ONE value for the whole block: the window rows are loaded by all four waves and every record is tested
+        // against it.  Wave 0 computes it and hands it over through LDS, so that the block agrees by construction (four waves each
+        // deriving it from their own loads of rot / trans / planes would agree only as long as those loads return the same bytes).
+        if (swave == 0) {
             const float dmid = plc.x + ((float)k0 + 0.5f * (float)(DKB - 1)) * plc.y;
 #pragma unroll
             for (int va = 0; va < NVT; ++va) {
@@ -136,11 +141,16 @@ __global__ __launch_bounds__(256) void warp_variance_win_kernel(
                 const float cy = fmaf(fmaf(r[3], fxc, fmaf(r[4], fyc, r[5])), dmid, t[1]) * rp;
                 // centre the window on the footprint of the tile's centre: clamp so that the int conversion is defined
                 const float cxc = fminf(fmaxf(cx, -65536.0f), 65536.0f), cyc = fminf(fmaxf(cy, -65536.0f), 65536.0f);
-                ox[va] = __builtin_amdgcn_readfirstlane((int)floorf(cxc) - (WP / 2 - 1));
-                oy[va] = __builtin_amdgcn_readfirstlane((int)floorf(cyc) - (WR / 2 - 1));
+                if (lane == 0) { orgf[2 * va] = (int)floorf(cxc) - (WP / 2 - 1); orgf[2 * va + 1] = (int)floorf(cyc) - (WR / 2 - 1); }
             }
-            if (MODE == 1) fill();
         }
+        __syncthreads();
+#pragma unroll
+        for (int va = 0; va < NVT; ++va) {
+            ox[va] = __builtin_amdgcn_readfirstlane(orgf[2 * va]);
+            oy[va] = __builtin_amdgcn_readfirstlane(orgf[2 * va + 1]);
+        }
+        if (MODE == 1) fill();
 
         // ---------------- phase A: one record per (pixel, plane, view)
         bool all_fit = true;

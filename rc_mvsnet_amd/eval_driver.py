@@ -147,8 +147,15 @@ def main(argv=None):
 
     from .casmvsnet import CascadeMVSNet_eval
     rank, local, world = rank_env()
-    device = torch.device("cuda", device_index(local, args.procs_per_gpu)) if torch.cuda.is_available() else torch.device("cpu")
-    if device.type == "cuda":
+    if world != nproc:
+        raise SystemExit(f"eval_driver: --gpus {args.gpus} x --procs-per-gpu {args.procs_per_gpu} = {nproc} ranks, but WORLD_SIZE={world} "
+                         f"(launch torch.distributed.run with --nproc-per-node {nproc}, or drop WORLD_SIZE and let the driver start them)")
+    device = torch.device("cpu")
+    if torch.cuda.is_available():
+        index = device_index(local, args.procs_per_gpu)
+        if index >= torch.cuda.device_count():
+            raise SystemExit(f"eval_driver: local rank {local} maps to GPU {index}, but this node shows {torch.cuda.device_count()} GPU(s)")
+        device = torch.device("cuda", index)
         torch.cuda.set_device(device)
     model = CascadeMVSNet_eval(ndepths=[int(n) for n in args.ndepths.split(",")],
                                depth_interals_ratio=[float(r) for r in args.depth_inter_r.split(",")])

@@ -142,6 +142,16 @@ def warp_variance_win(feats, rot, trans, planes, ndepth, variant=5):
     return var, int(n[0]), int(n[1])
 
 
+def warp_noref(feats, imgs, rot, trans, planes, ndepth, square_first):
+    """feats (B,V,h,w,C), imgs (B,V,h,w,3) -> (B, 3(V-1)+C, D, h, w) in the reference's NCDHW."""
+    B, V, h, w, C = feats.shape
+    out = torch.empty((B, 3 * (V - 1) + C, ndepth, h, w), device=feats.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_warp_noref_fwd(_chk(feats, "feats"), _chk(imgs, "imgs"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                _chk(planes, "planes"), _chk(out, "out"), B, V, C, ndepth, h, w,
+                                                int(bool(square_first)), _stream()), "warp_noref_fwd")
+    return out
+
+
 def warp_variance_bwd(feats, rot, trans, planes, grad_var, grad_noref=None, variant=0):
     """d loss / d feats (B,V,h,w,C) from d loss / d var (and, optionally, d loss / d no-ref variance), both
     (B,D,h,w,C) channels-last."""

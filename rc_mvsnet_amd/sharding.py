@@ -50,12 +50,29 @@ def free_port():
         return sk.getsockname()[1]
 
 
+RENDEZVOUS_TIMEOUT_S = 120      # init_process_group timeout of the drivers (bench.py, eval_driver): fail readably instead of hanging for 30 minutes
+
+
+def init_process_group(backend):
+    """torch.distributed.init_process_group with the drivers' timeout; a failed rendezvous names the backend and the rank."""
+    import datetime
+    import torch.distributed as dist
+    try:
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
+    except Exception as e:
+        raise SystemExit(f"rank {os.environ.get('RANK', '?')} of {os.environ.get('WORLD_SIZE', '?')}: {backend} rendezvous on "
+                         f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')} failed within {RENDEZVOUS_TIMEOUT_S} s: "
+                         f"{type(e).__name__}: {e}")
+    return dist
+
+
 def launch_ranks(target, nproc, argv, module=False):
     """Start ``nproc`` ranks of ``target`` (a script path, or a module name with ``module=True``) on this node under
     torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), and return the launcher's exit code."""
     env = clean_env()
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver supports dmabuf IPC only (RCCL, tensor sharing)
     env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("NCCL_DEBUG", "WARN")                     # a first contact with N > 1 GPUs should say WHY a rendezvous failed
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port())]
     cmd += (["-m", target] if module else [os.path.abspath(target)]) + list(argv)

@@ -342,13 +342,13 @@ typedef unsigned emu_v2u __attribute__((ext_vector_type(2)));
 // raw buffer loads return 0 for out-of-range offsets; "range" can only be emulated when the caller passes a real size: the
 // kernels here pass 0x7fffffff and steer invalid lanes to offsets >= 0x80000000, which the unsigned compare below catches
 inline emu_v4u __builtin_amdgcn_raw_buffer_load_b128_emu(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
-    const unsigned off = (unsigned)voffset + (unsigned)soffset;
+    const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned long long)(unsigned)soffset;      // scalar offset: zero-extended, no wrap
     emu_v4u v = {0u, 0u, 0u, 0u};
     if (off < r.num_records && off + 16u <= r.num_records) std::memcpy(&v, r.base + off, 16);
     return v;
 }
 inline emu_v2u __builtin_amdgcn_raw_buffer_load_b64_emu(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
-    const unsigned off = (unsigned)voffset + (unsigned)soffset;
+    const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned long long)(unsigned)soffset;      // scalar offset: zero-extended, no wrap
     emu_v2u v = {0u, 0u};
     if (off < r.num_records && off + 8u <= r.num_records) std::memcpy(&v, r.base + off, 8);
     return v;
@@ -370,7 +370,10 @@ inline void __builtin_amdgcn_raw_buffer_store_b32_emu(unsigned v, __amdgpu_buffe
 // buffer_load ... lds (direct-to-LDS DMA): lane i of the wave writes `size` bytes at ldsptr + i * size.  Emulated synchronously,
 // which is what the data looks like once the s_waitcnt vmcnt(0) + barrier that must follow on hardware have passed.
 inline void __builtin_amdgcn_raw_ptr_buffer_load_lds_emu(__amdgpu_buffer_rsrc_t r, void* ldsptr, int size, int voffset, int soffset, int offset, int) {
-    const unsigned off = (unsigned)voffset + (unsigned)soffset + (unsigned)offset;
+    // the hardware adds the SCALAR offset zero-extended (MI355X, round 5: a negative soffset read far outside the buffer instead of
+    // wrapping): modelled as "anything but a small non-negative scalar offset is a bug"
+    if (soffset < 0) { std::fprintf(stderr, "emu: buffer_load ... lds with a negative scalar offset (%d)\n", soffset); std::abort(); }
+    const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned long long)(unsigned)offset + (unsigned long long)(unsigned)soffset;
     char* dst = reinterpret_cast<char*>(ldsptr) + (size_t)(::shim::me().lin % ::shim::WAVE) * size;
     if (off < r.num_records && off + (unsigned)size <= r.num_records) std::memcpy(dst, r.base + off, size);
     else std::memset(dst, 0, size);

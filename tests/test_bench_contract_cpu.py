@@ -24,13 +24,12 @@ def test_k1_algorithmic_bytes_are_the_survey_figures(bench):
     per_stage = bench.k1_algorithmic_bytes()
     assert [round(b / 1e6, 1) for b in per_stage] == [137.6, 194.0, 125.8]
     assert sum(per_stage) == 457441280
-    assert bench.STREAMS_DEFAULT == 1                                                # more streams are experimental (scene_pipeline.py)
 
 
 def test_command_line_parses_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--streams", "--no-side-pass", "--no-cpu-baseline", "--procs-per-gpu"):
+    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--no-side-pass", "--no-cpu-baseline", "--procs-per-gpu"):
         assert flag in out.stdout
 
 
@@ -56,8 +55,9 @@ def test_bench_starts_its_own_ranks(gpus, ppg):
     assert b["n_gpus"] == gpus and b["config"]["ranks"] == gpus * ppg and b["config"]["procs_per_gpu"] == ppg
     assert b["steps"] == 40 and b["warmup"] == 3 and b["scaling"] == "weak" and b["higher_is_better"] is True
     assert abs(b["value"] * b["ms_per_step"] * 1e-3 - gpus * ppg) < 1e-2 * gpus * ppg                 # value = ranks * K / median round
-    # a 40-step round of the stub is far below 0.5 s: the region is repeated in rounds of exactly K steps, the median is reported
-    assert 1 < b["timed_rounds"] <= 64 and b["round_s_min_max"][0] <= b["timed_region_s"] <= b["round_s_min_max"][1]
+    # a 40-step round of the stub is far below 0.5 s on an idle box: the region is then repeated in rounds of exactly K steps and the
+    # median is reported (how many rounds fit depends on the machine's load: only the bookkeeping is asserted)
+    assert 1 <= b["timed_rounds"] <= 64 and b["round_s_min_max"][0] <= b["timed_region_s"] <= b["round_s_min_max"][1]
     assert b["steps_run_by_rank0"] == 3 + 40 * b["timed_rounds"]
 
 
@@ -98,6 +98,4 @@ def test_committed_closing_line_meets_the_contract():
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_scene"] < 1.2     # nothing re-read from HBM
     c = b["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    side = b.get("two_scenes_in_flight")
-    if side is not None and "error" not in side:
-        assert side["outputs_identical_to_single_stream"] is True and side["value"] > 0
+

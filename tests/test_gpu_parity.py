@@ -1066,60 +1066,33 @@ def test_cascade_fp16_pair_form_vs_reference_golden(hip, monkeypatch, name, l1_t
         assert float(d2.mean()) / rng < 2e-6
 
 
-def test_scene_pipeline_one_stream_is_the_plain_loop(hip):
-    """rc_mvsnet_amd.scene_pipeline with ONE stream (the supported mode; more streams are experimental, see its docstring) is the plain loop."""
-    from rc_mvsnet_amd import synthetic
-    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
-    from rc_mvsnet_amd.scene_pipeline import ScenePipeline
-
-    def make():
-        m = CascadeMVSNet_eval(ndepths=[16, 8, 8], depth_interals_ratio=[4, 2, 1])
-        m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
-        return m.to(DEV).eval()
-
-    i, p, d = synthetic.cascade_inputs(1, 3, 64, 96, 3)
-    scene = (gpu(i), {k: gpu(v) for k, v in p.items()}, gpu(d))
-    with torch.no_grad():
-        want = make()(*scene)["depth"]
-        out, stream = ScenePipeline(make, 1, DEV)(*scene)
-    assert stream is None and torch.equal(out["depth"], want)
+C2_MARGIN_L1 = 7.5e-5          # depth L1 / range of cascade_c2 must stay below this (north_star's tolerance: 1e-4)
+C2_MARGIN_STABLE = 0.88        # ... and this share of its pixels within 0.05 mm of the reference (measured 0.8906 in round 5, minus 1 %)
 
 
-def test_two_scenes_in_flight_match_the_one_stream_run(hip):
-    """Regression test of round 3's two-stream defect (profiles/r3_two_streams.txt): 24 full-size config-2 scenes on two HIP streams, every
-    stage's outputs bit-identical to the one-stream run.  Before the hypothesis-planes kernel read the previous stage's depth map at
-    agent scope, ~7 % of such scenes had wrong stage-3 outputs (the probability that 24 scenes all passed was ~17 %)."""
-    import warnings
-    from rc_mvsnet_amd import synthetic
-    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
-    from rc_mvsnet_amd.scene_pipeline import ScenePipeline
+def test_cascade_c2_parity_margin_is_pinned(hip, monkeypatch):
+    """The headline scene (prob.weight x20, a chaotic soft-argmin) sits at ~6.5e-5 of the depth range from the fp32
+    reference, with 1e-4 allowed: every arithmetic shortcut spends from that margin.  This test is the ceiling: it fails when the
+    default configuration passes 7.5e-5 or loses more than 1 % of its stable pixels, and prints what each shortcut costs (the same scene
+    with one switch set back to the exact form at a time), so that the next change shows what it spent."""
+    from rc_mvsnet_amd import casmvsnet
 
-    def make():
-        m = CascadeMVSNet_eval(ndepths=[48, 32, 8], depth_interals_ratio=[4, 2, 1])
-        m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
-        return m.to(DEV).eval()
+    def measure():
+        g, out, rng = _run_cascade("cascade_c2")
+        dd = (out["depth"].cpu() - g["depth"]).abs()
+        return float(dd.mean()) / rng, float((dd < 0.05).float().mean())
 
-    scenes = []
-    for seed in range(4):
-        i, p, d = synthetic.cascade_inputs(1, 3, 512, 640, seed)
-        scenes.append((gpu(i), {k: gpu(v) for k, v in p.items()}, gpu(d)))
-    keys = [("depth",), ("photometric_confidence",), ("stage1", "depth"), ("stage2", "depth")]
-    pick = lambda o, k: o[k[0]] if len(k) == 1 else o[k[0]][k[1]]
-    with torch.no_grad(), warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        one = make()
-        want = [[pick(one(*s), k).clone() for k in keys] for s in scenes]
-        with pytest.raises(RuntimeError, match="experimental"):
-            ScenePipeline(make, 2, DEV)                                  # the mode needs an explicit opt-in
-        pipe = ScenePipeline(make, 2, DEV, experimental=True)
-        for i in range(2):
-            pipe(*scenes[i])                                 # plans and packed weights of both replicas
-        pipe.synchronize()
-        got = [pipe(*scenes[i % 4])[0] for i in range(24)]
-        pipe.synchronize()
-    for i, o in enumerate(got):
-        for k, w in zip(keys, want[i % 4]):
-            assert torch.equal(pick(o, k), w), f"scene {i} (stream {i % 2}): {'/'.join(k)} differs from the one-stream run"
+    err, stable = measure()
+    print(f"cascade_c2 default: depth L1 / range {err:.3e}, stable pixels {stable:.4f}  (ceilings {C2_MARGIN_L1:.1e} / {C2_MARGIN_STABLE})")
+    for label, setter in (("RCMVS_FP16_PAIR=0 (exact bf16 triple in the cost regularisation)", lambda mp: mp.setenv("RCMVS_FP16_PAIR", "0")),
+                          ("DEEP_PAIR off (fp32 MFMAs at the deep levels)", lambda mp: mp.setattr(casmvsnet, "DEEP_PAIR", False)),
+                          ("HEAD_PAIR off (fp32 prob conv)", lambda mp: mp.setattr(casmvsnet, "HEAD_PAIR", False))):
+        with monkeypatch.context() as mp:
+            setter(mp)
+            e1, s1 = measure()
+        print(f"    {label}: {e1:.3e}, {s1:.4f}")
+    assert err <= C2_MARGIN_L1
+    assert stable >= C2_MARGIN_STABLE
 
 
 def test_reference_fp32_homography_depends_on_the_backend(hip):

@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from rc_mvsnet_amd import _lib, synthetic
 from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
-from rc_mvsnet_amd.scene_pipeline import ScenePipeline
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from scene_pipeline import ScenePipeline
 if os.environ.get('RCMVS_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['RCMVS_LIB'])       # a library variant (A/B of a kernel change)
 _lib.load()
 dev = "cuda:0"
