@@ -594,7 +594,8 @@ def main(argv=None):
         except Exception:
             pass
     roofline = {"bound": "hbm", "kernel": "K1, 3 launches per scene: rcmvs::warp_variance_win_kernel (stage 1: pixel-invariant planes, source windows "
-                                          "in LDS) + rcmvs::warp_variance_tp_kernel (stages 2, 3: gathers)",
+                                          "in LDS), warp_variance_tp_kernel (stage 2: two-phase gathers), warp_variance_pp_kernel (stage 3: "
+                                          "plane-pipelined gathers)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": f"profiles/{traffic_file} -- rocprofv3 PMC passes over this command line in an earlier visit "

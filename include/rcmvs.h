@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 103          /* 0.1.3 -- 103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5, 6;
+#define RCMVS_VERSION 103          /* 0.1.3 -- 103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5-7; rcmvs_warp_variance_fwd is FMA-contracted for V = 3, C = 8;
                                       rcmvs_compose_homography_stages gained (zero, zero_n) before its stream argument in 102 (not listed then).  102: rcmvs_depth_head_fwd accepts prob == NULL for D = 8; 101: rcmvs_bn_stats writes 2C + 1 doubles (the row count joined the sums: one SyncBatchNorm message);
                                       rcmvs_debug_warp_variance_fwd takes variants 0-3 only.  A caller built against 100 must be rebuilt: check
                                       rcmvs_version() >= the RCMVS_VERSION it was compiled with. */
@@ -75,7 +75,8 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
 /* Test / profiling twin of rcmvs_warp_variance_fwd with an explicit code variant (stateless, re-entrant): 0 = the production
  * kernel, 1 = production with FMA-contracted blend (<= 2e-7 relative), 2 = reference-order kernel (one full coordinate chain per
  * lane, compiler IEEE division -- the kernel the production one is held bit-identical to), 3 = store-only ablation,
- * 5 / 6 = the LDS-window form (V = 3 only; see rcmvs_debug_warp_variance_win_fwd). */
+ * 5 / 6 = the LDS-window form, 7 = the plane-pipelined gather form (both V = 3 only, same sampling positions as 2, FMA-contracted blend:
+ * <= 2e-6 of the value range from 2).  rcmvs_warp_variance_fwd itself runs 7 for V = 3, C = 8 and 0 otherwise. */
 int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                                   const float* planes, float* var,
                                   int B, int V, int C, int D, int h, int w, int variant, void* stream);

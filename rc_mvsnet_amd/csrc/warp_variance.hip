@@ -19,6 +19,7 @@
 #include "common.h"
 #include "k1_taps.h"
 #include "k1_win.h"
+#include "k1_pp.h"
 
 namespace rcmvs {
 
@@ -482,17 +483,25 @@ using namespace rcmvs;
 
 extern "C" {
 
-// variant: 0 = production gather kernel (exact arithmetic), 1 = the same with FMA-contracted blend, 2 = reference-order kernel (one full
+// variant: 0 = two-phase gather kernel (exact arithmetic), 1 = the same with FMA-contracted blend, 2 = reference-order kernel (one full
 // coordinate chain per lane, compiler IEEE division: what variant 0 is held bit-identical to), 3 = store-only ablation,
-// 5 / 6 = the LDS-window form (k1_win.h; what rcmvs_warp_variance_hint_fwd launches for pixel-invariant planes is 5)
+// 5 / 6 = the LDS-window form (k1_win.h), 7 = the plane-pipelined gather form (k1_pp.h); k1_production_variant() picks 0, 5 or 7
 static int k1_launch(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
                      int B, int V, int C, int D, int h, int w, int variant, hipStream_t st, unsigned* stats = nullptr) {
     RCMVS_REQUIRE(feats && rot && trans && planes && var, "warp_variance_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
     RCMVS_REQUIRE((long long)h * w * C < (1LL << 31), "warp_variance_fwd: feature map too large for 32-bit offsets");
-    RCMVS_REQUIRE((variant >= 0 && variant <= 3) || variant == 5 || variant == 6, "warp_variance_fwd: unknown variant %d", variant);
+    RCMVS_REQUIRE((variant >= 0 && variant <= 3) || (variant >= 5 && variant <= 7), "warp_variance_fwd: unknown variant %d", variant);
     RCMVS_REQUIRE(C == 8 || C == 16 || C == 32, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
+    if (variant == 7) {
+        // plane-pipelined gather form (k1_pp.h)
+        RCMVS_REQUIRE(V == 3, "warp_variance_fwd: the plane-pipelined form is built for two source views (got V=%d)", V);
+        RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
+        if (C == 32) return k1_pp_launch_one<32, 8, 2>(feats, rot, trans, planes, var, B, V, D, h, w, st);
+        if (C == 16) return k1_pp_launch_one<16, 8, 2>(feats, rot, trans, planes, var, B, V, D, h, w, st);
+        return k1_pp_launch_one<8, 8, 2>(feats, rot, trans, planes, var, B, V, D, h, w, st);
+    }
     if (variant >= 5) {
         // window form (k1_win.h): 5 = source windows loaded ahead of the coordinate phase, 6 = after the fit test
         RCMVS_REQUIRE(V == 3, "warp_variance_fwd: the window form is built for two source views (got V=%d)", V);
@@ -557,18 +566,26 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
     return launch_status("warp_variance_fwd");
 }
 
+// which kernel a production call takes: per-pixel planes with two source views at C = 8 (stage 3 of config 2) run the plane-pipelined
+// gather form (37.6 us against 40.8, profiles/r5_k1_window.txt), everything else the two-phase gather kernel; pixel-invariant planes
+// (the caller's hint) with two source views run the LDS-window form
+static int k1_production_variant(int V, int C, int h, int w, int hint) {
+    const bool small = (long long)V * h * w * C * 4 < 0x7fffffffLL;
+    if (V == 3 && small && (hint & RCMVS_K1_UNIFORM_PLANES)) return 5;
+    if (V == 3 && small && C == 8) return 7;
+    return 0;
+}
+
 int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                             const float* planes, float* var,
                             int B, int V, int C, int D, int h, int w, void* stream) {
-    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, 0, as_stream(stream));
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, k1_production_variant(V, C, h, w, 0), as_stream(stream));
 }
 
 int rcmvs_warp_variance_hint_fwd(const float* feats, const float* rot, const float* trans,
                                  const float* planes, float* var,
                                  int B, int V, int C, int D, int h, int w, int hint, void* stream) {
-    // pixel-invariant hypothesis planes + two source views: the LDS-window form (stage 1 of the cascade: 33 us against 40 at config 2)
-    const bool window = (hint & RCMVS_K1_UNIFORM_PLANES) && V == 3 && (long long)V * h * w * C * 4 < 0x7fffffffLL;
-    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, window ? 5 : 0, as_stream(stream));
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, k1_production_variant(V, C, h, w, hint), as_stream(stream));
 }
 
 int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,

@@ -104,14 +104,15 @@ def absmax(x, square=False, out=None):
     return out
 
 
-def warp_variance(feats, rot, trans, planes, ndepth, variant=0, uniform_planes=False):
+def warp_variance(feats, rot, trans, planes, ndepth, variant=None, uniform_planes=False):
     """feats (B,V,h,w,C) -> variance volume (B,D,h,w,C).  uniform_planes: the caller's hint that the plane table is the same for every
     pixel (stage 1 of the cascade): with two source views the kernel then stages the tiles' source windows in LDS (csrc/k1_win.h;
-    same results within ~4e-7 of the value range, per-tile fallback).  variant != 0: the test / profiling code variants of
-    rcmvs_debug_warp_variance_fwd (1 FMA blend, 2 reference-order kernel, 3 store-only, 5 / 6 window form)."""
+    same results within ~4e-7 of the value range, per-tile fallback).  variant (None = the production call): the test / profiling code
+    variants of rcmvs_debug_warp_variance_fwd (0 two-phase exact kernel, 1 its FMA build, 2 reference-order kernel, 3 store-only,
+    5 / 6 window form, 7 plane-pipelined gather form)."""
     B, V, h, w, C = feats.shape
     var = torch.empty((B, ndepth, h, w, C), device=feats.device, dtype=torch.float32)
-    if variant:
+    if variant is not None:
         _lib.check(_lib.load().rcmvs_debug_warp_variance_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
                                                              _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, int(variant),
                                                              _stream()), "debug_warp_variance_fwd")

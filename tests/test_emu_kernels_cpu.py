@@ -108,6 +108,7 @@ def test_k1_window_form_on_emulated_kernels(C, D, h, w, smooth, emu):
         planes = torch.stack((300.0 + 600.0 * torch.rand(B, h, w, generator=g), 2.0 + 40.0 * torch.rand(B, h, w, generator=g)), dim=-1).contiguous()
     vref = ops.warp_variance(feats, rot, trans, planes, D, variant=2)
     tol = 2e-6 * max(1.0, float(vref.abs().max()))
+    assert float((ops.warp_variance(feats, rot, trans, planes, D, variant=7) - vref).abs().max()) <= tol      # plane-pipelined gather form
     for var in (5, 6):
         v, blocks, on_window = ops.warp_variance_win(feats, rot, trans, planes, D, variant=var)
         assert float((v - vref).abs().max()) <= tol, var
@@ -115,7 +116,7 @@ def test_k1_window_form_on_emulated_kernels(C, D, h, w, smooth, emu):
         assert torch.equal(v, ops.warp_variance(feats, rot, trans, planes, D, variant=var))
     hinted = ops.warp_variance(feats, rot, trans, planes, D, uniform_planes=True)
     assert torch.equal(hinted, ops.warp_variance(feats, rot, trans, planes, D, variant=5))
-    assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), ops.warp_variance(feats, rot, trans, planes, D, variant=0))
+    assert torch.equal(ops.warp_variance(feats, rot, trans, planes, D), ops.warp_variance(feats, rot, trans, planes, D, variant=7 if C == 8 else 0))
     with pytest.raises(Exception):
         ops.warp_variance(feats[:, :2].contiguous(), rot[:, :1].contiguous(), trans[:, :1].contiguous(), planes, D, variant=5)   # V = 2: not built
     # ... but the hint itself is only a hint: other view counts take the gather kernel
