@@ -351,15 +351,12 @@ def bench_train_step(args, rank, world, dev):
     """BASELINE configs[2] (N = 1) / configs[3] (N > 1, one sample per GPU, RCCL gradient exchange).  Step = one training
     iteration (rc_mvsnet_amd/train_step.py = train_rcmvsnet.py:279-312,330-446) on synthetic inputs resident in HBM."""
     import torch.distributed as dist
-    from rc_mvsnet_amd import ops, train_step as ts, parallel
+    from rc_mvsnet_amd import ops, train_step as ts
     Vt = 4
     model, model_nerf, opt = ts.build(dev, seed=0)
     sync = None
     if world > 1:
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)                   # train_rcmvsnet.py:524-525
-        model_nerf = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model_nerf)
-        opt = torch.optim.Adam(list(model.parameters()) + list(model_nerf.parameters()), lr=1e-4, betas=(0.9, 0.999))
-        sync = parallel.GradSync([model, model_nerf])
+        (model, model_nerf), opt, sync = ts.make_data_parallel([model, model_nerf])     # SyncBatchNorm + one Adam + GradSync (train_rcmvsnet.py:524-525)
     imgs, proj, dv, batch = ts.synthetic_sample(dev, H=H, W=W, V=Vt, seed=rank)
     last = {}
 

@@ -242,7 +242,7 @@ class FeatureNet(nn.Module):
                     w3[:, :, 1] = w.detach()
                     plan[n] = ("mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
                     continue
-                if tuple(w.shape) in ((32, 16, 5, 5), (16, 8, 5, 5)) and m.stride == 2 and os.environ.get("RCMVS_S2D", "1") != "0":
+                if tuple(w.shape) in ((32, 16, 5, 5), (16, 8, 5, 5)) and m.stride == 2:
                     # 5x5 stride 2 (12 % VALU busy on the scalar-weight kernel): space-to-depth turns it into a 4C -> Co 3x3
                     # stride-1 layer (tap k = 2t + parity; the k = 5 taps are zero) for the planar split-bf16 matrix-core kernel,
                     # which reads the space-to-depth view straight from the un-rearranged map (ops.conv2d_s2d)
@@ -265,11 +265,10 @@ class FeatureNet(nn.Module):
             if self.num_stage == 3 and not unet:
                 plan["inner2"] = (ops.pack_conv2d_weight(self.inner2.weight), self.inner2.bias.detach().float().contiguous())
                 plan["out3"] = ops.pack_conv2d_weight(self.out3.weight)
-                plan["fuse_out3"] = (os.environ.get("RCMVS_FPN_FUSE", "1") != "0" and tuple(self.inner2.weight.shape[:2]) == (32, 8)
-                                     and tuple(self.out3.weight.shape[:2]) == (8, 32))
+                plan["fuse_out3"] = tuple(self.inner2.weight.shape[:2]) == (32, 8) and tuple(self.out3.weight.shape[:2]) == (8, 32)
                 # the same level with the 1x1 lateral conv folded into the 3x3 output conv (1600 instead of 2628 multiply-adds per pixel;
-                # equal up to fp32 rounding): the default; RCMVS_FPN_FOLD=0 keeps the bit-identical-to-unfused kernel
-                if plan["fuse_out3"] and os.environ.get("RCMVS_FPN_FOLD", "1") != "0":
+                # equal up to fp32 rounding; ops.fpn_out_fused is the bit-identical-to-unfused kernel, kept under test)
+                if plan["fuse_out3"]:
                     plan["fold_out3"] = ops.pack_fpn_folded(self.inner2.weight, self.inner2.bias, self.out3.weight)
                     if os.environ.get("RCMVS_FPN_MFMA", "1") != "0":           # ... on the matrix cores, exact split operands (csrc/fpn_folded_mfma.hip)
                         plan["fold_out3"] = ops.pack_fpn_folded_mfma(plan["fold_out3"])

@@ -270,9 +270,9 @@ static inline unsigned grid_for(long long work_items) {
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 // the two reductions end with one fp64 atomic per channel and BLOCK on the same 2C words: same-address atomics serialise (~90 per
-// microsecond), so their grid is capped lower than the element-wise kernels' (developer hook RCMVS_BN_RED_GRID for the sweep)
+// microsecond), so their grid is capped lower than the element-wise kernels'
 static inline unsigned grid_for_reduce(long long work_items) {
-    static const long long cap = [] { const char* e = getenv("RCMVS_BN_RED_GRID"); const int v = e ? atoi(e) : 0; return (long long)(v > 0 ? v : 256); }();      // (sweep: profiles/r3_bn_reduce_grid.txt)
+    constexpr long long cap = 256;      // (sweep: profiles/r3_bn_reduce_grid.txt)
     long long g = cdiv(work_items, (long long)BN_BLOCK);
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }

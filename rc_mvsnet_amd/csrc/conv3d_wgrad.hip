@@ -431,7 +431,7 @@ static int wgrad_launch(const float* x, const float* dy, float* dw, const WgradD
     using Cfg = WgradCfg<CI, CO, STRIDE>;
     const int rows = dm.B * dm.Do * dm.Ho;
     int gx = (rows + WG_WAVES - 1) / WG_WAVES;
-    static const int gx_cap = [] { const char* e = getenv("RCMVS_WGRAD_GX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();      // (developer sweep hook)
+    constexpr int gx_cap = 1024;
     if (gx > gx_cap) gx = gx_cap;
     if (dm.D == 1 && STRIDE == 1) {
         // few rows (one-plane volumes): split each row into chunks of >= 64 cells until there are ~512 waves (more waves cost

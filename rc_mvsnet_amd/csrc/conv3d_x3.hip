@@ -927,8 +927,7 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
     // chunked split (cost in half steps: steps + 1.5 per item start, a block of a balanced launch starts ceil(steps / Dt) + 1 items at most)
     dm.bal = 0;
     {
-        static int mode = -1;                                               // RCMVS_X3_BALANCE=0 / 1: off / forced (A/B); default: by the model
-        if (mode < 0) { const char* e = getenv("RCMVS_X3_BALANCE"); mode = e ? (e[0] == '0' ? 0 : 1) : 2; }
+        constexpr int mode = 2;                                             // by the cost model (0 / 1 = off / forced were A/B settings, tools/dev/x3_balance_ab.py)
         const long long T = (long long)dm.B * dm.ntiles * dm.Dt;
         const long long spb = (T + n_blk - 1) / n_blk + 1;                   // steps of the longest block
         const long long ipb = (spb + dm.Dt - 1) / dm.Dt + 1;                 // item starts of a block, at most
@@ -974,12 +973,9 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
                      int B, int D, int H, int W, int Ci, int Co, int kind, int relu, hipStream_t st, int max_blocks, int s2d,
                      const float* xmax, float* ymax) {
     if (xmax && conv3d_deep_supported(Ci, Co, kind)) return conv3d_deep_launch(x, wimg, scale, shift, res, y, B, D, H, W, Ci, Co, kind, relu, st, xmax, ymax);
-    {
-        static const int z8_env = [] { const char* e = getenv("RCMVS_Z8"); return e ? atoi(e) : 1; }();
-        if (z8_env && xmax && !res && !s2d && conv3d_z8_supported(Ci, Co, kind)) {
-            const int rc = conv3d_z8_launch(x, wimg, scale, shift, y, B, D, H, W, Ci, Co, relu, st, max_blocks, xmax, ymax);
-            if (rc != 1) return rc;        // (1 = not taken: volumes with more than 64 k steps per block stay on the split kernel)
-        }
+    if (xmax && !res && !s2d && conv3d_z8_supported(Ci, Co, kind)) {
+        const int rc = conv3d_z8_launch(x, wimg, scale, shift, y, B, D, H, W, Ci, Co, relu, st, max_blocks, xmax, ymax);
+        if (rc != 1) return rc;        // (1 = not taken: volumes with more than 64 k steps per block stay on the split kernel)
     }
     const int ysq = (s2d >> 1) & 1;            // `s2d` carries two flags: bit 0 = space-to-depth view of the input, bit 1 = square the output bound
     s2d &= 1;
@@ -1004,7 +1000,7 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     const int n_blk = max_blocks > 0 ? max_blocks : n_cu;      // max_blocks: test / tuning hook (few blocks = many items per block)
     X3Dims dm;
     dm.B = B; dm.D = D; dm.H = H; dm.W = W; dm.relu = relu; dm.s2d = s2d; dm.ysq = ysq; dm.dbg = 0; dm.trace = nullptr;
-    { static const int place_env = [] { const char* e = getenv("RCMVS_X3_PLACE"); return e ? atoi(e) : 0; }(); dm.place = place_env; }
+    dm.place = 0;
 #if X3_ABLATION
     dm.dbg = x3_ablation_mask;
     dm.trace = x3_trace_buf;

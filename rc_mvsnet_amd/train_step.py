@@ -35,6 +35,17 @@ def build(device, ndepths=(48, 32, 8), n_samples=128, seed=0):
     return model, model_nerf, opt
 
 
+def make_data_parallel(modules, lr=1e-4):
+    """The data-parallel form of a training setup (BASELINE configs[3]; train_rcmvsnet.py:524-525,565-578): every BatchNorm becomes a
+    SyncBatchNorm, ONE Adam over all parameters (the converted modules own new parameter objects), and a parallel.GradSync that averages
+    all gradients in one reduce-scatter + all-gather message.  Needs an initialised process group.  -> (modules, optimizer, grad_sync);
+    used by `bench.py --workload train_step --gpus N` and by tests/test_multiproc_cpu.py over gloo."""
+    from . import parallel
+    modules = [torch.nn.SyncBatchNorm.convert_sync_batchnorm(m) for m in modules]
+    opt = torch.optim.Adam([p for m in modules for p in m.parameters()], lr=lr, betas=(0.9, 0.999))
+    return modules, opt, parallel.GradSync(modules)
+
+
 def synthetic_sample(device, H=512, W=640, V=4, seed=0):
     imgs, pm, dv = synthetic.cascade_inputs(1, V, H, W, seed)
     batch = synthetic.render_batch(V, H, W, seed)

@@ -167,12 +167,13 @@ def _syncbn_worker(rank, world, port, q):
     local = (blk.conv.weight.grad.numpy().copy(), blk.bn.weight.grad.numpy().copy())
     # ... and one data-parallel optimizer step on top (config 4: SyncBatchNorm + GradSync + Adam): the gradients of the two ranks are
     # averaged through the flat buffer (copied in: they were produced before the buffer existed), every rank takes the same step
-    from rc_mvsnet_amd.parallel import GradSync
+    # (through train_step.make_data_parallel: the setup `bench.py --workload train_step --gpus N` runs on the real node)
+    from rc_mvsnet_amd import train_step as ts
     grads = [p.grad.clone() for p in blk.parameters()]
-    sync = GradSync([blk])
+    (blk2,), opt, sync = ts.make_data_parallel([blk], lr=1e-3)
+    assert blk2 is blk                            # already converted: convert_sync_batchnorm returns the module itself
     for p, gcopy in zip(blk.parameters(), grads):
         p.grad.copy_(gcopy)
-    opt = torch.optim.Adam(blk.parameters(), lr=1e-3)
     sync.sync()
     opt.step()
     q.put((rank, z.detach().numpy(), x.grad.numpy(), local[0], local[1],
