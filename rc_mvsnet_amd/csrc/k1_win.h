@@ -278,9 +278,15 @@ static int k1_win_launch_one(const float* feats, const float* rot, const float* 
     dim3 grid(txp * typ, (D + DKB - 1) / DKB, B);
     const size_t lds = (size_t)W::LDS_BYTES;
     auto kern = warp_variance_win_kernel<C, DKB, NVT, WP, WR, MODE>;
-    if (lds > 48 * 1024) {
-        static bool done = false;      // per instantiation
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    if (lds > 48 * 1024) {             // (the debug geometries of C = 8; the production launch of stage 1 needs 39 KB)
+        static bool raised[64];        // per instantiation and device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !raised[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return fail(-1, "warp_variance_fwd (window form): cannot raise the dynamic LDS limit to %zu bytes", lds);
+            raised[dev] = true;
+        }
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, stats);
     return launch_status("warp_variance_fwd (window form)");
