@@ -55,6 +55,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s ac
 H, W, V = 512, 640, 3
 NDEPTHS, RATIOS = (48, 32, 8), (4, 2, 1)
 FEAT_C = (32, 16, 8)
+SCENE_ALGORITHMIC_BYTES = 457441280 + 1870000000 + 49900000 + 300000000      # K1, 3-D CNN (ideal activations), depth head, FeatureNet
 
 
 def host_threads():
@@ -633,6 +634,13 @@ def main(argv=None):
                    "rccl_ranks": world if (world > 1 and args.procs_per_gpu == 1) else 0},
         "roofline": roofline,
         "roofline_conv": roofline_conv,
+        # the scene as a whole against HBM: what every layer must move at least (K1 + the 3-D CNN's ideal activation traffic + the
+        # depth head + FeatureNet's maps) over the wall time of a step -- the honest summary next to the
+        # per-kernel objects: the scene is bound by its kernels' tick structures and launch latencies, not by a pipe
+        "roofline_scene": {"bound": "hbm", "algorithmic_bytes_per_scene": SCENE_ALGORITHMIC_BYTES,
+                           "achieved": round(SCENE_ALGORITHMIC_BYTES / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(SCENE_ALGORITHMIC_BYTES / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                           "parts_MB": {"k1": 457.4, "cnn3d_ideal_activations": 1870.0, "depth_head": 49.9, "feature_net": 300.0}},
     }
     result.update(rounds_fields(rounds))
     if two_procs is not None:

@@ -124,6 +124,39 @@ def test_k1_window_form_on_emulated_kernels(C, D, h, w, smooth, emu):
     assert torch.equal(v2, ops.warp_variance(feats[:, :2].contiguous(), rot[:, :1].contiguous(), trans[:, :1].contiguous(), planes, D))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_k1_forms_on_random_shapes_and_plane_tables(seed, emu):
+    """Seeded fuzz of the three-view K1 forms (window 5 / 6, plane-pipelined 7) against the reference-order kernel: ragged image sizes down to
+    2 x 2, 1-19 planes, 1-3 batch items, and plane tables that are smooth, rough, uniform, or cross z = 0 (taps dropped, non-finite
+    positions): same values to 2e-6 of the range and the same finite / non-finite pattern."""
+    import random
+    from rc_mvsnet_amd import ops
+    rnd = random.Random(seed)
+    for n in range(10):
+        C, B, D = rnd.choice([8, 16, 32]), rnd.choice([1, 1, 2, 3]), rnd.randint(1, 19)
+        h, w = rnd.randint(2, 40), rnd.randint(2, 90)
+        g = torch.Generator().manual_seed(1000 * seed + n)
+        feats = torch.randn(B, 3, h, w, C, generator=g)
+        rot, trans = ops.compose_homography(synthetic.proj_matrices(B, 3, h * 4, w * 4)["stage1"])
+        mode = rnd.choice(["smooth", "rough", "uniform", "behind"])
+        if mode == "smooth":
+            planes = torch.stack((500.0 + 30.0 * torch.rand(B, h, w, generator=g), torch.full((B, h, w), 5.0)), -1)
+        elif mode == "uniform":
+            planes = torch.stack((torch.full((B, h, w), 430.0), torch.full((B, h, w), 10.6)), -1)
+        elif mode == "behind":
+            planes = torch.stack((-200.0 + 400.0 * torch.rand(B, h, w, generator=g), 40.0 * torch.randn(B, h, w, generator=g)), -1)
+        else:
+            planes = torch.stack((300.0 + 600.0 * torch.rand(B, h, w, generator=g), 2.0 + 40.0 * torch.rand(B, h, w, generator=g)), -1)
+        planes = planes.contiguous()
+        vref = ops.warp_variance(feats, rot, trans, planes, D, variant=2)
+        fin = torch.isfinite(vref)
+        tol = 2e-6 * max(1.0, float(vref[fin].abs().max()) if bool(fin.any()) else 1.0)
+        for var in (5, 6, 7):
+            v = ops.warp_variance(feats, rot, trans, planes, D, variant=var)
+            assert torch.equal(torch.isfinite(v), fin), (C, B, D, h, w, mode, var)
+            assert float((torch.nan_to_num(v) - torch.nan_to_num(vref)).abs().max()) <= tol, (C, B, D, h, w, mode, var)
+
+
 def test_results_do_not_depend_on_the_thread_schedule(emu):
     """Missing-barrier detector: between synchronisation points the emulation may run a block's threads in any order; ascending,
     descending and wave-reversed schedules must give bit-identical results for kernels without float atomics (the whole inference
