@@ -603,6 +603,15 @@ def main(argv=None):
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)],
                 "timing": f"HIP events on the launch stream around every K1 launch, separate untimed pass of {nprobe} scenes right after the timed region"}
+    try:        # the window path depends on the geometry only (homographies, plane table): count stage 1's tiles on it with blank feature maps
+        with torch.no_grad():
+            imgs0, pm0, dv0 = scenes[0]
+            rot1, trans1 = ops.compose_homography(pm0["stage1"].contiguous().float())
+            planes1 = ops.hypothesis_planes(None, dv0, (H, W), 4, NDEPTHS[0], RATIOS[0])
+            _, tiles, on_window = ops.warp_variance_win(torch.zeros(1, V, H // 4, W // 4, FEAT_C[0], device=dev), rot1, trans1, planes1, NDEPTHS[0], variant=5)
+        roofline["stage1_window_path"] = {"tiles": tiles, "on_lds_windows": on_window, "fallback_to_gathers": tiles - on_window}
+    except Exception as e:
+        roofline["stage1_window_path"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if smooth_events:
         sm_ms, sm_ach = k1_summary(smooth_events)
         roofline["smooth_scene"] = {"frac": round(sm_ach / HBM_PEAK_GBS, 4), "achieved": round(sm_ach, 1),
