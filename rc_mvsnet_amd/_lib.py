@@ -9,6 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librcmvs_hip.so")
+REQUIRED_VERSION = 104      # RCMVS_VERSION of include/rcmvs.h this binding was written against (104: the hint bits of rcmvs_warp_variance_hint_fwd)
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rcmvs.h")
 
@@ -152,8 +153,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, ctypes.c_int)
-    if lib.rcmvs_version() < 102:          # 102: depth head without a probability buffer for D = 8 (include/rcmvs.h)
-        raise RcmvsError("librcmvs_hip.so is older than this package")
+    if lib.rcmvs_version() < REQUIRED_VERSION:
+        raise RcmvsError(f"librcmvs_hip.so (version {lib.rcmvs_version()}) is older than this package needs ({REQUIRED_VERSION}): rebuild it")
     _lib = lib
     return lib
 

@@ -18,7 +18,11 @@
 
 namespace rcmvs {
 
-template <int C, int DKB, int NVT>
+// View counts (round 6): NVT = 2 / 3 / 4 / 6 source views (V = 3 DTU bench, 4 training, 5 DTU evaluation, 7 Tanks and Temples).  The gathers of
+// a plane are issued in groups of NG views (all of them up to four; 3 + 3 for six: two full tap sets of six views exceed the register
+// file); the views are accumulated in ascending order whatever the grouping.  Chains per plane that do not tile the block (C = 8 with
+// three views: 384; C = 16 / 32 with three or six: 192 / 96) leave the surplus threads of the record phase idle.
+template <int C, int DKB, int NVT, int NG = (NVT <= 4 ? NVT : 3)>
 __global__ __launch_bounds__(256) void warp_variance_pp_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x) {
@@ -26,7 +30,8 @@ __global__ __launch_bounds__(256) void warp_variance_pp_kernel(
     constexpr int CPP = PIX * NVT;                       // chains (= records) per plane
     constexpr int NCH = (CPP + 255) / 256;               // chains per thread and plane when every thread works on every plane
     constexpr int GROUPS = (CPP < 256) ? 256 / CPP : 1;  // thread groups that take the planes in turn otherwise
-    static_assert(CPP % 256 == 0 || 256 % CPP == 0, "chains per plane must tile the block");
+    constexpr int NGRP = NVT / NG;
+    static_assert(NVT % NG == 0, "view groups must divide the view count");
     __shared__ __attribute__((aligned(16))) v4f rec_w[2][CPP];
     __shared__ int rec_g[2][CPP];
     const int b = blockIdx.z;
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256) void warp_variance_pp_kernel(
     const int pa = threadIdx.x % PIX;
     const int xa = min(tx0 + pa % TW, w - 1), ya = min(ty0 + pa / TW, h - 1);
     const float2 pla = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ya * w + xa];
-    const int grp = threadIdx.x / CPP;                   // (0 when CPP >= 256)
+    const int grp = threadIdx.x / CPP;                   // (0 when CPP >= 256; >= GROUPS: a surplus thread of the record phase)
     float rx[NCH], ry[NCH], rz[NCH], t0[NCH], t1[NCH], t2[NCH];
     {
 #pragma clang fp contract(off)
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void warp_variance_pp_kernel(
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = (threadIdx.x % CPP) + 256 * j;
-            const int va = c / PIX;
+            const int va = min(c / PIX, NVT - 1);                // (surplus chains of a ragged plane: any valid view, never stored)
             const float* r = rotb + va * 9;
             const float* t = trb + va * 3;
             rx[j] = (r[0] * fxa + r[1] * fya) + r[2];
@@ -65,11 +70,12 @@ __global__ __launch_bounds__(256) void warp_variance_pp_kernel(
         }
     }
     auto records = [&](int k, int buf) {                 // the records of plane k0 + k -> rec_*[buf]
-        if (GROUPS > 1 && (k % GROUPS) != grp) return;
+        if (CPP < 256 && (k % GROUPS) != grp) return;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
 #pragma clang fp contract(off)
             const int c = (threadIdx.x % CPP) + 256 * j;
+            if (CPP % 256 != 0 && CPP > 256 && c >= CPP) continue;
             const int va = c / PIX;
             const float d = pla.x + (float)(k0 + k) * pla.y;
             float ix, iy;
@@ -98,35 +104,39 @@ __global__ __launch_bounds__(256) void warp_variance_pp_kernel(
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < DKB; ++k) {
-        v4f tp[NVT][4], wt[NVT];
-        if (inside) {
+        v4f a = ref, a2 = ref2;
 #pragma unroll
-            for (int va = 0; va < NVT; ++va) {
-                const int o = rec_g[k & 1][va * PIX + p] + q4b;
-                wt[va] = rec_w[k & 1][va * PIX + p];
-                tp[va][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
-                tp[va][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + TEXB, 0, 0));
-                tp[va][2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, pitch, 0));
-                tp[va][3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + TEXB, pitch, 0));
+        for (int gi = 0; gi < NGRP; ++gi) {
+            v4f tp[NG][4], wt[NG];
+            if (inside) {
+#pragma unroll
+                for (int vg = 0; vg < NG; ++vg) {
+                    const int va = gi * NG + vg;
+                    const int o = rec_g[k & 1][va * PIX + p] + q4b;
+                    wt[vg] = rec_w[k & 1][va * PIX + p];
+                    tp[vg][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
+                    tp[vg][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + TEXB, 0, 0));
+                    tp[vg][2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, pitch, 0));
+                    tp[vg][3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + TEXB, pitch, 0));
+                }
+            }
+            if (gi == 0 && k + 1 < DKB) records(k + 1, (k + 1) & 1);    // ... while the gathers fly
+            if (inside) {
+#pragma unroll
+                for (int vg = 0; vg < NG; ++vg) {
+                    v4f val = tp[vg][0] * wt[vg].x;
+                    val = __builtin_elementwise_fma(tp[vg][1], (v4f){wt[vg].y, wt[vg].y, wt[vg].y, wt[vg].y}, val);
+                    val = __builtin_elementwise_fma(tp[vg][2], (v4f){wt[vg].z, wt[vg].z, wt[vg].z, wt[vg].z}, val);
+                    val = __builtin_elementwise_fma(tp[vg][3], (v4f){wt[vg].w, wt[vg].w, wt[vg].w, wt[vg].w}, val);
+                    a = a + val;
+                    a2 = __builtin_elementwise_fma(val, val, a2);
+                }
             }
         }
-        if (k + 1 < DKB) records(k + 1, (k + 1) & 1);    // ... while the gathers fly
-        if (inside) {
-            v4f a = ref, a2 = ref2;
-#pragma unroll
-            for (int va = 0; va < NVT; ++va) {
-                v4f val = tp[va][0] * wt[va].x;
-                val = __builtin_elementwise_fma(tp[va][1], (v4f){wt[va].y, wt[va].y, wt[va].y, wt[va].y}, val);
-                val = __builtin_elementwise_fma(tp[va][2], (v4f){wt[va].z, wt[va].z, wt[va].z, wt[va].z}, val);
-                val = __builtin_elementwise_fma(tp[va][3], (v4f){wt[va].w, wt[va].w, wt[va].w, wt[va].w}, val);
-                a = a + val;
-                a2 = __builtin_elementwise_fma(val, val, a2);
-            }
-            if (k0 + k < D) {
-                const v4f m = a * rV;
-                const v4f o = __builtin_elementwise_fma(a2, (v4f){rV, rV, rV, rV}, -(m * m));
-                __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(ob + k * pstride));
-            }
+        if (inside && k0 + k < D) {
+            const v4f m = a * rV;
+            const v4f o = __builtin_elementwise_fma(a2, (v4f){rV, rV, rV, rV}, -(m * m));
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(ob + k * pstride));
         }
         if (k + 1 < DKB) __syncthreads();
     }

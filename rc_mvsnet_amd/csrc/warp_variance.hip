@@ -496,22 +496,32 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
     RCMVS_REQUIRE(C == 8 || C == 16 || C == 32, "warp_variance_fwd: C must be 8, 16 or 32 (got %d)", C);
     if (variant == 7) {
         // plane-pipelined gather form (k1_pp.h)
-        RCMVS_REQUIRE(V == 3, "warp_variance_fwd: the plane-pipelined form is built for two source views (got V=%d)", V);
+        const int nsrc = V - 1;
+        RCMVS_REQUIRE(nsrc == 2 || nsrc == 3 || nsrc == 4 || nsrc == 6, "warp_variance_fwd: the plane-pipelined form is built for 2, 3, 4 or 6 source views (got V=%d)", V);
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-        if (C == 32) return k1_pp_launch_one<32, 8, 2>(feats, rot, trans, planes, var, B, V, D, h, w, st);
-        if (C == 16) return k1_pp_launch_one<16, 8, 2>(feats, rot, trans, planes, var, B, V, D, h, w, st);
-        return k1_pp_launch_one<8, 8, 2>(feats, rot, trans, planes, var, B, V, D, h, w, st);
+#define RCMVS_K1PP(NN) do { \
+            if (C == 32) return k1_pp_launch_one<32, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st); \
+            if (C == 16) return k1_pp_launch_one<16, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st); \
+            return k1_pp_launch_one<8, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st); } while (0)
+        if (nsrc == 2) RCMVS_K1PP(2);
+        if (nsrc == 3) RCMVS_K1PP(3);
+        if (nsrc == 4) RCMVS_K1PP(4);
+        RCMVS_K1PP(6);
+#undef RCMVS_K1PP
     }
     if (variant >= 5) {
         // window form (k1_win.h): 5 = source windows loaded ahead of the coordinate phase, 6 = after the fit test
-        RCMVS_REQUIRE(V == 3, "warp_variance_fwd: the window form is built for two source views (got V=%d)", V);
+        // V = 3: the one-group kernel; any other view count: the same kernel walking the views two at a time (MULTI; the tile
+        // statistics then count (tile, view group) pairs)
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-#define RCMVS_K1WIN(CC, DD, PP, RR) (variant == 5 ? k1_win_launch_one<CC, DD, 2, PP, RR, 1>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st) : \
-                                                    k1_win_launch_one<CC, DD, 2, PP, RR, 2>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st))
+#define RCMVS_K1WIN_M(CC, DD, PP, RR, MM) (variant == 5 ? k1_win_launch_one<CC, DD, 2, PP, RR, 1, MM>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st) : \
+                                                          k1_win_launch_one<CC, DD, 2, PP, RR, 2, MM>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st))
+#define RCMVS_K1WIN(CC, DD, PP, RR) (V == 3 ? RCMVS_K1WIN_M(CC, DD, PP, RR, false) : RCMVS_K1WIN_M(CC, DD, PP, RR, true))
         if (C == 32) return RCMVS_K1WIN(32, 4, 16, 8);
         if (C == 16) return RCMVS_K1WIN(16, 4, 32, 8);
         return RCMVS_K1WIN(8, 4, 64, 8);
 #undef RCMVS_K1WIN
+#undef RCMVS_K1WIN_M
     }
     if (variant <= 1) {
         const bool fastm = variant == 1;
@@ -566,20 +576,22 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
     return launch_status("warp_variance_fwd");
 }
 
-// which kernel a production call takes: per-pixel planes with two source views at C = 8 (stage 3 of config 2) run the plane-pipelined
-// gather form (37.6 us against 40.8, profiles/r5_k1_window.txt), everything else the two-phase gather kernel; pixel-invariant planes
-// (the caller's hint) with two source views run the LDS-window form
+// which kernel a call takes.  No hint: the exact two-phase gather kernel (bit-identical to the reference-order kernel) -- the plain ABI entry.
+// RCMVS_K1_UNIFORM_PLANES (pixel-invariant planes: stage 1 of the cascade): the LDS-window form, any view count.  RCMVS_K1_FAST_BLEND (the
+// caller accepts FMA-contracted blends): per-pixel planes at C = 8 run the plane-pipelined gather form for 2, 3, 4 or 6 source views
+// (two views, stage 3 of config 2: 37.6 us against 40.8, profiles/r5_k1_window.txt; the other view counts: profiles/r6_k1_views.txt).
 static int k1_production_variant(int V, int C, int h, int w, int hint) {
     const bool small = (long long)V * h * w * C * 4 < 0x7fffffffLL;
-    if (V == 3 && small && (hint & RCMVS_K1_UNIFORM_PLANES)) return 5;
-    if (V == 3 && small && C == 8) return 7;
+    const int nsrc = V - 1;
+    if (small && (hint & RCMVS_K1_UNIFORM_PLANES)) return 5;
+    if (small && (hint & RCMVS_K1_FAST_BLEND) && C == 8 && (nsrc == 2 || nsrc == 3 || nsrc == 4 || nsrc == 6)) return 7;
     return 0;
 }
 
 int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                             const float* planes, float* var,
                             int B, int V, int C, int D, int h, int w, void* stream) {
-    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, k1_production_variant(V, C, h, w, 0), as_stream(stream));
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, 0, as_stream(stream));
 }
 
 int rcmvs_warp_variance_hint_fwd(const float* feats, const float* rot, const float* trans,

@@ -6,6 +6,7 @@ library call on the current stream.  Layout convention inside the library is cha
 (maps (B,h,w,C), volumes (B,D,h,w,C)).
 """
 import ctypes
+import os
 
 import torch
 
@@ -15,12 +16,34 @@ from . import _lib
 # launch stream (torch's current stream); None = no instrumentation.
 K1_EVENTS = None
 K1_UNIFORM_PLANES = 1          # RCMVS_K1_UNIFORM_PLANES (include/rcmvs.h)
+K1_FAST_BLEND = 2              # RCMVS_K1_FAST_BLEND: the FMA-contracted forms (<= 2e-6 of the value range from the exact kernel)
 # same for the 3-D convolutions: list of (event0, event1, key) with key = (kind, B, D, H, W, Ci, Co), kind 's1' | 's2' | 't2'
 CONV_EVENTS = None
 
 
+# One HIP stream per device and process.  With kernels of one process in flight on two hardware queues of an MI355X, a consumer kernel can
+# read STALE 64-byte granules of a tensor its predecessor on the same stream has just rewritten completely (profiles/r6_two_streams.txt: seen by
+# an ATen copy kernel as well as by ours, any producer / consumer pair, gone with GPU_MAX_HW_QUEUES=1 or AMD_SERIALIZE_KERNEL=3) -- wrong numbers,
+# no error.  So the binding remembers the first stream it launched on per device and refuses a second one; two worker PROCESSES per GPU
+# (sharding.py) are the supported overlap.  GPU_MAX_HW_QUEUES=1 (all streams of the process share one hardware queue) lifts the refusal.
+_FIRST_STREAM = {}
+
+
+def _multi_stream_allowed():
+    return os.environ.get("GPU_MAX_HW_QUEUES") == "1" or os.environ.get("RCMVS_ALLOW_MULTI_STREAM") == "1"
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.current_stream()
+    key = st.device_index
+    first = _FIRST_STREAM.setdefault(key, st.cuda_stream)
+    if first != st.cuda_stream and not _multi_stream_allowed():
+        raise _lib.RcmvsError(
+            f"rc_mvsnet_amd launches on ONE HIP stream per device and process: cuda:{key} started on stream {first:#x}, this call is on "
+            f"{st.cuda_stream:#x}.  Two hardware queues of one process give silently wrong results on this platform "
+            "(profiles/r6_two_streams.txt); use one stream, or one worker process per stream (rc_mvsnet_amd.sharding), or run the "
+            "process with GPU_MAX_HW_QUEUES=1.")
+    return ctypes.c_void_p(st.cuda_stream)
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -123,7 +146,7 @@ def warp_variance(feats, rot, trans, planes, ndepth, variant=None, uniform_plane
         ev[0].record()
     _lib.check(_lib.load().rcmvs_warp_variance_hint_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
                                                         _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w,
-                                                        K1_UNIFORM_PLANES if uniform_planes else 0, _stream()),
+                                                        K1_FAST_BLEND | (K1_UNIFORM_PLANES if uniform_planes else 0), _stream()),
                "warp_variance_hint_fwd")
     if ev is not None:
         ev[1].record()

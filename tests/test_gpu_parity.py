@@ -89,11 +89,21 @@ def _k1_case(B, V, C, D, h, w, seed):
     return feats, pm, torch.stack((d0, dl), dim=-1)
 
 
-@pytest.mark.parametrize("B,V,C,D,h,w", [(1, 3, 32, 8, 16, 20), (2, 3, 16, 16, 24, 40), (1, 5, 8, 8, 32, 48),
-                                         (1, 2, 32, 5, 9, 13), (1, 7, 8, 12, 10, 70)])
-def test_warp_variance_vs_oracle(hip, B, V, C, D, h, w):
+@pytest.mark.parametrize("B,V,C,D,h,w,uniform", [(1, 3, 32, 8, 16, 20, False), (2, 3, 16, 16, 24, 40, False), (1, 5, 8, 8, 32, 48, False),
+                                                 (1, 2, 32, 5, 9, 13, False), (1, 7, 8, 12, 10, 70, False),
+                                                 # the production kernels of the headline configuration, each against the oracle directly: V = 3, C = 8 with
+                                                 # per-pixel planes -> the plane-pipelined form (csrc/k1_pp.h); pixel-invariant planes + the caller's hint -> the
+                                                 # LDS-window form (csrc/k1_win.h); and the same two forms at the view counts the reference's workflows use
+                                                 # (4 training, 5 DTU evaluation, 7 Tanks and Temples)
+                                                 (1, 3, 8, 8, 32, 48, False), (1, 3, 32, 8, 16, 20, True), (1, 3, 16, 12, 24, 40, True), (2, 3, 8, 8, 32, 48, True),
+                                                 (1, 4, 8, 8, 20, 48, False), (1, 5, 16, 8, 24, 40, False), (1, 7, 32, 8, 12, 24, False), (1, 7, 8, 16, 16, 64, False),
+                                                 (1, 4, 32, 8, 16, 20, True), (1, 5, 32, 12, 16, 24, True), (1, 7, 32, 8, 12, 20, True), (1, 2, 16, 4, 12, 36, True),
+                                                 (2, 5, 8, 4, 8, 70, True)])
+def test_warp_variance_vs_oracle(hip, B, V, C, D, h, w, uniform):
     from oracle import warp
     feats, pm, planes = _k1_case(B, V, C, D, h, w, 3)
+    if uniform:                 # stage 1 of the cascade: the same planes at every pixel (models/modules.py:549-566)
+        planes = planes[:, :1, :1].expand(B, h, w, 2).contiguous()
     k = torch.arange(D, dtype=torch.float32).reshape(1, D, 1, 1)
     samples = planes[..., 0].unsqueeze(1) + k * planes[..., 1].unsqueeze(1)
     # the oracle composes the homography in fp32 LU; feed the kernel the SAME rot/trans so that the
@@ -103,10 +113,13 @@ def test_warp_variance_vs_oracle(hip, B, V, C, D, h, w):
     trans = torch.stack(transs, dim=1)
     ref = warp.variance_volume(feats, pm, samples)                       # (B,C,D,h,w)
     f_cl = torch.stack([f.permute(0, 2, 3, 1) for f in feats], dim=1)    # (B,V,h,w,C)
-    var = hip.warp_variance(gpu(f_cl), gpu(rot), gpu(trans), gpu(planes), D).cpu().permute(0, 4, 1, 2, 3)
+    var = hip.warp_variance(gpu(f_cl), gpu(rot), gpu(trans), gpu(planes), D, uniform_planes=uniform).cpu().permute(0, 4, 1, 2, 3)
     diff = (var - ref).abs()
     print(f"K1 max|d|={float(diff.max()):.3e} exact={float((diff == 0).float().mean()):.4f}")
     assert float(diff.max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    if uniform:                 # ... and the window kernel really ran: the hinted call is the window form's debug variant, bit for bit
+        v5 = hip.warp_variance(gpu(f_cl), gpu(rot), gpu(trans), gpu(planes), D, variant=5).cpu().permute(0, 4, 1, 2, 3)
+        assert torch.equal(v5, var)
 
 
 def test_warp_variance_golden_fixture(hip):
@@ -173,9 +186,14 @@ def test_warp_variance_variants_agree(hip):
         print(f"K1 C={C} D={D} V={V}: two-phase kernel vs reference-order bit-identical {exact:.6f}; FMA build max rel {err1:.2e}; production call {errp:.2e}")
         assert torch.equal(v0, vref)
         assert err1 < 2e-6 and errp < 2e-6
-        if V == 3:
+        tol = 2e-6 * max(1.0, float(vref.abs().max()))
+        if V - 1 in (2, 3, 4, 6):           # plane-pipelined gather form: 2, 3, 4 or 6 source views
             v7 = hip.warp_variance(feats, rot, trans, planes, D, variant=7)
-            assert float((v7 - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max()))
+            assert float((v7 - vref).abs().max()) <= tol, ("pp", C, V)
+        for var in (5, 6):                   # window form: any view count (two at a time; rough planes: most tiles fall back one by one)
+            v5, blocks, on_window = hip.warp_variance_win(feats, rot, trans, planes, D, variant=var)
+            assert float((v5 - vref).abs().max()) <= tol, ("win", var, C, V)
+            assert 0 < blocks and on_window <= blocks
     with pytest.raises(Exception):
         hip.warp_variance(feats, rot, trans, planes, D, variant=9)
 
@@ -213,13 +231,19 @@ def test_warp_variance_window_form(hip):
             v, blocks, on_window = hip.warp_variance_win(feats, rot, trans, planes, D, variant=var)
             assert float((v - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max())), (C, var)
             assert 0 < blocks and on_window <= blocks
-    # (c) the hint is only a hint
-    feats = gpu(torch.randn(1, 5, 12, 20, 32))
-    rot, trans = hip.compose_homography(gpu(synthetic.proj_matrices(1, 5, 48, 80)["stage1"]))
-    planes = gpu(torch.stack((torch.full((1, 12, 20), 500.0), torch.full((1, 12, 20), 5.0)), dim=-1))
-    assert torch.equal(hip.warp_variance(feats, rot, trans, planes, 8, uniform_planes=True), hip.warp_variance(feats, rot, trans, planes, 8))
-    with pytest.raises(Exception):
-        hip.warp_variance(feats, rot, trans, planes, 8, variant=5)
+    # (c) other view counts (round 6: the views two at a time, sums carried in registers): the hinted call runs the window form, nearly every
+    # tile of a pixel-invariant table on the window path for every view group, same tolerance; the hint is only a hint for rough tables
+    for V in (2, 4, 5, 7):
+        g = torch.Generator().manual_seed(V)
+        feats = gpu(torch.randn(1, V, 32, 40, 32, generator=g))
+        rot, trans = hip.compose_homography(gpu(synthetic.proj_matrices(1, V, 128, 160)["stage1"]))
+        planes = gpu(torch.stack((torch.full((1, 32, 40), 500.0), torch.full((1, 32, 40), 5.0)), dim=-1))
+        vref = hip.warp_variance(feats, rot, trans, planes, 8, variant=2)
+        v, blocks, on_window = hip.warp_variance_win(feats, rot, trans, planes, 8, variant=5)
+        print(f"K1 window form V={V}: {on_window} of {blocks} (tile, view group) pairs on the window path")
+        assert blocks == 5 * 8 * 2 * ((V - 1 + 1) // 2) and on_window >= 0.8 * blocks
+        assert float((v - vref).abs().max()) <= 2e-6 * max(1.0, float(vref.abs().max()))
+        assert torch.equal(hip.warp_variance(feats, rot, trans, planes, 8, uniform_planes=True), v)
 
 
 # ------------------------------------------------------------------------------------------ K2/K3

@@ -181,3 +181,27 @@ def test_eval_driver_two_worker_processes_per_gpu_write_the_same_files(tmp_path)
     assert len(names) == 12                                              # 6 items x (depth_est, confidence)
     for n in names:
         assert open(os.path.join(one, n), "rb").read() == open(os.path.join(two, n), "rb").read(), n
+
+
+def test_a_second_stream_is_refused(monkeypatch):
+    """Two hardware queues of one process give silently wrong results on this platform (profiles/r6_two_streams.txt), and the boundary's
+    contract is "the CURRENT stream": the binding remembers the first stream per device and raises on a second one instead of returning wrong
+    numbers; GPU_MAX_HW_QUEUES=1 (one hardware queue for the process: the mode in which the hazard does not occur) or the developer override
+    lift the refusal."""
+    from rc_mvsnet_amd import _lib, ops
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.delenv("RCMVS_ALLOW_MULTI_STREAM", raising=False)
+    x = torch.randn(4, 8, 16, 16, device="cuda")
+    first = ops.absmax(x)                                # (the process's stream so far: whatever the earlier tests of this process ran on)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        if ops._FIRST_STREAM[x.device.index] != side.cuda_stream:
+            with pytest.raises(_lib.RcmvsError, match="ONE HIP stream"):
+                ops.absmax(x)
+        monkeypatch.setenv("RCMVS_ALLOW_MULTI_STREAM", "1")
+        again = ops.absmax(x)
+    side.synchronize()
+    assert torch.equal(first, again)
+    monkeypatch.delenv("RCMVS_ALLOW_MULTI_STREAM")
+    assert torch.equal(ops.absmax(x), first)             # the first stream keeps working

@@ -11,6 +11,7 @@
 Prints the indices of the corrupted scenes per round and the wall time per scene."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("RCMVS_ALLOW_MULTI_STREAM", "1")      # (ops._stream() refuses a second stream otherwise: this script studies exactly that)
 import torch
 from rc_mvsnet_amd import _lib, synthetic
 from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval

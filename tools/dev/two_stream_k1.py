@@ -2,6 +2,7 @@
 24 config-2 scenes alternately on two HIP streams (one replica each) against the one-stream outputs, with the stage-1 hint on and off."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("RCMVS_ALLOW_MULTI_STREAM", "1")      # (ops._stream() refuses a second stream otherwise: this script studies exactly that)
 import torch
 from rc_mvsnet_amd import _lib, ops, synthetic
 from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval

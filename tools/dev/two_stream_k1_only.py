@@ -3,6 +3,7 @@ fresh feature block (an elementwise kernel on that stream; the allocator reuses 
 keep max |difference| on the GPU.  Both must agree to ~4e-7 of the value range whatever the other stream is doing."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("RCMVS_ALLOW_MULTI_STREAM", "1")      # (ops._stream() refuses a second stream otherwise: this script studies exactly that)
 import torch
 from rc_mvsnet_amd import _lib, ops, synthetic
 _lib.load()
