@@ -56,6 +56,42 @@ H, W, V = 512, 640, 3
 NDEPTHS, RATIOS = (48, 32, 8), (4, 2, 1)
 FEAT_C = (32, 16, 8)
 SCENE_ALGORITHMIC_BYTES = 457441280 + 1870000000 + 49900000 + 300000000      # K1, 3-D CNN (ideal activations), depth head, FeatureNet
+SCENE_PARTS_MB = {"k1": 457.4, "cnn3d_ideal_activations": 1870.0, "depth_head": 49.9, "feature_net": 300.0}
+
+# --shape: the cascade workload at the shapes the reference's own workflows run (the default is BASELINE configs[1], the one `metric` is quoted on)
+SHAPES = {
+    "dtu_bench": {"V": 3, "H": 512, "W": 640, "ndepths": (48, 32, 8), "steps": 600,
+                  "workload": "BASELINE configs[1]: CascadeMVSNet_eval.forward, DTU-shaped 3 views 512x640, D=(48,32,8), batch 1 per GPU, fp32, random-init seeded weights",
+                  "metric": "ref-scenes/sec (DTU 3-view 512x640, D=48/32/8)"},
+    "dtu_eval": {"V": 5, "H": 1184, "W": 1600, "ndepths": (48, 32, 8), "steps": 60,
+                 "workload": "the reference's DTU evaluation shape (eval_rcmvsnet_dtu.py:49-51: 5 views, 1184x1600, D=(48,32,8)): CascadeMVSNet_eval.forward, "
+                             "batch 1 per GPU, fp32, random-init seeded weights",
+                 "metric": "ref-scenes/sec (DTU evaluation shape, 5-view 1184x1600, D=48/32/8)"},
+    "tanks": {"V": 7, "H": 1056, "W": 1920, "ndepths": (64, 32, 8), "steps": 40,
+              "workload": "BASELINE configs[4], one GPU's share (eval_rcmvsnet_tanks.py:47,53-55: Tanks and Temples intermediate, 7 views, 1056x1920, D=(64,32,8)): "
+                          "CascadeMVSNet_eval.forward, batch 1 per GPU, fp32, random-init seeded weights",
+              "metric": "ref-scenes/sec (Tanks and Temples shape, 7-view 1056x1920, D=64/32/8)"},
+}
+
+
+def set_shape(name):
+    """Switch the module's workload constants to SHAPES[name]; the scene's algorithmic bytes follow SURVEY.md 8d's per-layer formulas."""
+    global H, W, V, NDEPTHS, SCENE_ALGORITHMIC_BYTES, SCENE_PARTS_MB
+    sh = SHAPES[name]
+    H, W, V, NDEPTHS = sh["H"], sh["W"], sh["V"], tuple(sh["ndepths"])
+    if name == "dtu_bench":
+        return
+    k1 = sum(k1_algorithmic_bytes())
+    cnn = head = 0
+    for s_, (D, C) in enumerate(zip(NDEPTHS, FEAT_C)):
+        n = D * (H // (4 >> s_)) * (W // (4 >> s_))
+        # every layer of the 3-D U-Net reads its input once and writes its output once (the transposed layers also read their skip tensor),
+        # channels 8 / 16 / 32 / 64 at 1 / 1/8 / 1/64 / 1/512 of the voxels; + the prob conv's read of the 8-channel volume
+        cnn += 4 * (n * (C + 8) + n * 10 + n * 4 + n * 2.5 + n * 1 + n * 0.625 + n * 0.25 + n * 1.125 + n * 4.5 + n * 18 + n * 8)
+        head += 4 * 2 * n
+    fnet = int(300e6 * (V * H * W) / (3 * 512 * 640))
+    SCENE_ALGORITHMIC_BYTES = int(k1 + cnn + head + fnet)
+    SCENE_PARTS_MB = {"k1": round(k1 / 1e6, 1), "cnn3d_ideal_activations": round(cnn / 1e6, 1), "depth_head": round(head / 1e6, 1), "feature_net": round(fnet / 1e6, 1)}
 
 
 def host_threads():
@@ -147,7 +183,9 @@ def k1_algorithmic_bytes():
 
 
 MIN_TIMED_S = 0.5               # a timed region shorter than this is repeated in rounds (each exactly K steps) and the median round reported
-MAX_ROUNDS = 64
+MIN_TIMED_S_SHORT = 6.0         # ... and with --steps < 100 (the driver's --steps 20 is ~23 ms of cascade forwards) rounds are repeated for 6 s, so that a
+                                # utilisation sampler with a 5-second period sees a busy GPU (BENCH_r05.gpu_busy had 0 of 5 samples active)
+MAX_ROUNDS = 4000
 
 
 def timed_rounds(world, dev, steps, step, sync):
@@ -176,7 +214,7 @@ def timed_rounds(world, dev, steps, step, sync):
             elapsed = float(t.item())
         rounds.append(elapsed)
         owns.append(own)
-        if sum(rounds) >= MIN_TIMED_S or len(rounds) >= MAX_ROUNDS:
+        if sum(rounds) >= (MIN_TIMED_S_SHORT if (steps < 100 and dev.type == "cuda") else MIN_TIMED_S) or len(rounds) >= MAX_ROUNDS:
             break
     order = sorted(range(len(rounds)), key=lambda i: rounds[i])
     mid = order[len(order) // 2]
@@ -442,7 +480,11 @@ def main(argv=None):
     ap.add_argument("--procs-per-gpu", type=int, default=1,
                     help="worker processes per GPU (cascade workload): independent (scene, view) items need no collective, so P processes on one "
                          "GPU overlap each other's latency-bound phases like HIP streams would, without sharing an address space")
-    ap.add_argument("--steps", type=int, default=600, help="timed steps (default: ~1 s of cascade forwards)")
+    ap.add_argument("--shape", default="dtu_bench", choices=sorted(SHAPES),
+                    help="cascade workload: dtu_bench = BASELINE configs[1] (the metric's configuration, default); dtu_eval = the reference's DTU evaluation shape "
+                         "(5 views, 1184x1600); tanks = configs[4]'s single-GPU workload (7 views, 1056x1920, D=64/32/8).  The other shapes print a full line "
+                         "(roofline with that shape's algorithmic bytes, parity against the oracle on a down-scaled twin) without the CPU timing / side passes.")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: ~1 s of cascade forwards: 600 at the default shape)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the short config-3 training-iteration timing appended to the default line")
@@ -451,6 +493,14 @@ def main(argv=None):
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.procs_per_gpu < 1:
         ap.error("--gpus and --procs-per-gpu must be >= 1")
+    default_steps = args.steps is None
+    if default_steps:
+        args.steps = SHAPES[args.shape]["steps"] if args.workload == "cascade" else 600
+    if args.shape != "dtu_bench":
+        if args.workload != "cascade":
+            ap.error("--shape applies to the cascade workload")
+        set_shape(args.shape)
+        args.no_train_step = args.no_side_pass = True          # appendices of the headline configuration only
     nproc = args.gpus * args.procs_per_gpu
     if "WORLD_SIZE" not in os.environ and nproc > 1:
         from rc_mvsnet_amd.sharding import launch_ranks
@@ -494,7 +544,7 @@ def main(argv=None):
     from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
     _lib.load()
     if args.workload != "cascade":
-        if args.workload == "train_step" and args.steps == 600 and args.warmup == 20:
+        if args.workload == "train_step" and default_steps and args.warmup == 20:
             args.steps, args.warmup = 10, 3                       # an iteration is ~80 ms: the defaults of the cascade workload are overkill
         result = {"unsup_loss": bench_unsup_loss, "fusion": bench_fusion, "train_step": bench_train_step}[args.workload](args, rank, world, dev)
         if result is not None:
@@ -537,6 +587,7 @@ def main(argv=None):
             torch.cuda.synchronize()
             ops.K1_EVENTS = ops.CONV_EVENTS = None
             # the smooth-head twin of the scene (prob.weight x1 instead of BASELINE.md's x20): K1 on depth maps that are not noise
+            sd1 = model1 = None
             if world == 1:
                 sd1 = synthetic.cascade_state_dict(0, prob_gain=1.0)
                 model1 = make_model(sd1)
@@ -591,9 +642,12 @@ def main(argv=None):
             break
         except Exception:
             pass
-    roofline = {"bound": "hbm", "kernel": "K1, 3 launches per scene: rcmvs::warp_variance_win_kernel (stage 1: pixel-invariant planes, source windows "
-                                          "in LDS), warp_variance_tp_kernel (stage 2: two-phase gathers), warp_variance_pp_kernel (stage 3: "
-                                          "plane-pipelined gathers)",
+    k1_kernels = {3: "rcmvs::warp_variance_win_kernel (stage 1: pixel-invariant planes, source windows in LDS), warp_variance_tp_kernel (stage 2: two-phase "
+                     "gathers), warp_variance_pp_kernel (stage 3: plane-pipelined gathers)",
+                  5: "rcmvs::warp_variance_pp_kernel (stages 1 and 3: plane-pipelined gathers, four source views), warp_variance_tp_kernel (stage 2: two-phase "
+                     "gathers, FMA build)",
+                  7: "rcmvs::warp_variance_pp_kernel (plane-pipelined gathers, six source views in two groups of three)"}
+    roofline = {"bound": "hbm", "kernel": "K1, 3 launches per scene: " + k1_kernels[V],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": f"profiles/{traffic_file} -- rocprofv3 PMC passes over this command line in an earlier visit "
@@ -604,6 +658,8 @@ def main(argv=None):
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)],
                 "timing": f"HIP events on the launch stream around every K1 launch, separate untimed pass of {nprobe} scenes right after the timed region"}
     try:        # the window path depends on the geometry only (homographies, plane table): count stage 1's tiles on it with blank feature maps
+        if V != 3:
+            raise RuntimeError("stage 1 runs the plane-pipelined gather form at this view count (profiles/r6_k1_views.txt)")
         with torch.no_grad():
             imgs0, pm0, dv0 = scenes[0]
             rot1, trans1 = ops.compose_homography(pm0["stage1"].contiguous().float())
@@ -622,7 +678,7 @@ def main(argv=None):
     roofline_conv = conv_roofline(conv_events, min(10, args.steps))
 
     result = {
-        "metric": "ref-scenes/sec (DTU 3-view 512x640, D=48/32/8)",
+        "metric": SHAPES[args.shape]["metric"],
         "value": round(world * args.steps / elapsed, 3),
         "unit": "ref-scenes/s",
         "n_gpus": args.gpus,
@@ -635,8 +691,7 @@ def main(argv=None):
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: CascadeMVSNet_eval.forward, DTU-shaped 3 views 512x640, "
-                               "D=(48,32,8), batch 1 per GPU, fp32, random-init seeded weights",
+        "config": {"workload": SHAPES[args.shape]["workload"], "shape": args.shape,
                    "views": V, "height": H, "width": W, "ndepths": list(NDEPTHS),
                    "parallelism": f"scene-per-gpu x{args.gpus}" + (f", {args.procs_per_gpu} worker processes per GPU" if args.procs_per_gpu > 1 else ""),
                    "ranks": world, "procs_per_gpu": args.procs_per_gpu,
@@ -649,7 +704,7 @@ def main(argv=None):
         "roofline_scene": {"bound": "hbm", "algorithmic_bytes_per_scene": SCENE_ALGORITHMIC_BYTES,
                            "achieved": round(SCENE_ALGORITHMIC_BYTES / (elapsed / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(SCENE_ALGORITHMIC_BYTES / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                           "parts_MB": {"k1": 457.4, "cnn3d_ideal_activations": 1870.0, "depth_head": 49.9, "feature_net": 300.0}},
+                           "parts_MB": SCENE_PARTS_MB},
     }
     result.update(rounds_fields(rounds))
     if two_procs is not None:
@@ -657,8 +712,28 @@ def main(argv=None):
     if rank_rates:
         result["per_rank_scenes_per_s"] = {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2), "ranks": world}
 
+    # ---- the other shapes: no CPU timing at full size (a 1184x1600 five-view scene is minutes of PyTorch-CPU per pass: stated, not measured);
+    # parity of the same kernels against the oracle on a DOWN-SCALED TWIN (same view count, same depth counts, 160x192)
+    if world == 1 and args.shape != "dtu_bench" and not args.no_cpu_baseline:
+        from oracle import cascade
+        torch.set_num_threads(host_threads())
+        th, tw = 160, 192
+        imgs, pm, dv = synthetic.cascade_inputs(1, V, th, tw, 0)
+        with torch.no_grad():
+            c0 = time.perf_counter()
+            ref = cascade.forward_eval(imgs, pm, dv, sd, NDEPTHS, RATIOS, impl="aten")
+            twin_s = time.perf_counter() - c0
+            hip = model(imgs.to(dev), {k: v.to(dev) for k, v in pm.items()}, dv.to(dev))
+        rng = float(dv[0, -1] - dv[0, 0])
+        dd = (hip["depth"].cpu() - ref["depth"]).abs()
+        result["cpu_baseline"] = None
+        result["cpu_baseline_note"] = (f"not timed at {H}x{W} (minutes of PyTorch-CPU per scene); the oracle's ATen op graph took {twin_s:.2f} s for the "
+                                       f"{th}x{tw} twin on {host_threads()} threads")
+        result["parity"] = {"depth_l1_over_range": float(dd.mean()) / rng, "depth_l1_mm": float(dd.mean()), "depth_max_abs_mm": float(dd.max()),
+                            "tolerance": 1e-4, "on": f"down-scaled twin: {V} views {th}x{tw}, D={list(NDEPTHS)}, same seeded weights (prob.weight x20), "
+                                                     "HIP path vs oracle impl='aten'"}
     # ---- CPU baseline (oracle, ATen op graph of the reference) + parity on the same inputs -----
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and args.shape == "dtu_bench" and not args.no_cpu_baseline:
         from oracle import cascade
         nthreads = host_threads()
         torch.set_num_threads(nthreads)

@@ -27,8 +27,8 @@ extern "C" {
 #endif
 
 #define RCMVS_VERSION 104          /* 0.1.4 -- 104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
-                                      the FMA-contracted forms are opted into with RCMVS_K1_FAST_BLEND of rcmvs_warp_variance_hint_fwd; the window form (hint
-                                      RCMVS_K1_UNIFORM_PLANES, variants 5 / 6) takes any view count, the plane-pipelined form (variant 7) 2, 3, 4 or 6 source views.
+                                      the FMA-contracted forms are opted into with RCMVS_K1_FAST_BLEND of rcmvs_warp_variance_hint_fwd; the plane-pipelined form
+                                      (variant 7) takes 2, 3, 4 or 6 source views.
                                       103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5-7; rcmvs_warp_variance_fwd is FMA-contracted for V = 3, C = 8;
                                       rcmvs_compose_homography_stages gained (zero, zero_n) before its stream argument in 102 (not listed then).  102: rcmvs_depth_head_fwd accepts prob == NULL for D = 8; 101: rcmvs_bn_stats writes 2C + 1 doubles (the row count joined the sums: one SyncBatchNorm message);
                                       rcmvs_debug_warp_variance_fwd takes variants 0-3 only.  A caller built against 100 must be rebuilt: check
@@ -78,7 +78,7 @@ int rcmvs_warp_variance_fwd(const float* feats, const float* rot, const float* t
 /* Test / profiling twin of rcmvs_warp_variance_fwd with an explicit code variant (stateless, re-entrant): 0 = the production
  * kernel, 1 = production with FMA-contracted blend (<= 2e-7 relative), 2 = reference-order kernel (one full coordinate chain per
  * lane, compiler IEEE division -- the kernel the production one is held bit-identical to), 3 = store-only ablation,
- * 5 / 6 = the LDS-window form (any V: the source views two at a time), 7 = the plane-pipelined gather form (V - 1 in {2, 3, 4, 6});
+ * 5 / 6 = the LDS-window form (V = 3 only), 7 = the plane-pipelined gather form (V - 1 in {2, 3, 4, 6});
  * both: same sampling positions as 2, FMA-contracted blend: <= 2e-6 of the value range from 2.  rcmvs_warp_variance_fwd itself runs 0. */
 int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,
                                   const float* planes, float* var,
@@ -88,10 +88,11 @@ int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const fl
  * the same) for every pixel -- stage 1 of the cascade (models/modules.py:549-566) -- so the 2x2 footprints of a tile over a chunk of planes
  * fit a small source window: with two source views the kernel stages that window in LDS and takes the taps from there (csrc/k1_win.h;
  * tiles whose footprints do not fit fall back to gathers one by one, so the hint never changes results beyond the kernel's FMA-level
- * tolerance, ~4e-7 of the value range, only the speed; other view counts: the views two at a time, plane sums carried in registers).
+ * tolerance, ~4e-7 of the value range, only the speed; other view counts ignore this bit).  It takes effect together with RCMVS_K1_FAST_BLEND.
  * RCMVS_K1_FAST_BLEND: the caller accepts FMA-contracted blend / variance arithmetic (same sampling positions, results within 2e-6 of the value
- * range of rcmvs_warp_variance_fwd's): per-pixel plane tables may then run the plane-pipelined gather form (csrc/k1_pp.h) where it is the faster
- * kernel.  hint 0 = rcmvs_warp_variance_fwd (the exact two-phase kernel, bit-identical to the reference's operation order). */
+ * range of rcmvs_warp_variance_fwd's): the call then runs the fastest kernel measured for its view count and channel count (the window form,
+ * the plane-pipelined gather form csrc/k1_pp.h, or the FMA build of the two-phase kernel; the table is in csrc/warp_variance.hip).
+ * hint 0 = rcmvs_warp_variance_fwd (the exact two-phase kernel, bit-identical to the reference's operation order). */
 #define RCMVS_K1_UNIFORM_PLANES 1
 #define RCMVS_K1_FAST_BLEND 2
 int rcmvs_warp_variance_hint_fwd(const float* feats, const float* rot, const float* trans,

@@ -21,10 +21,10 @@
 // multiplication by 1/V: results differ from the reference-order kernel by a few 1e-7 of the value range (tests bound it).
 // MODE 1 = window loads issued ahead of phase A (the production form for pixel-invariant hypothesis planes: stage 1 of the cascade),
 // MODE 2 = issued after the fit test (no wasted loads on tiles that fall back).  Measurements: profiles/r5_k1_window.txt.
-// MULTI (round 6): any number of source views, NVT at a time.  The block walks the views in groups of NVT (a ragged last group runs
-// with fewer), each group with its own origins, windows, records and vote -- LDS stays at the size of one group whatever V is -- and
-// carries the plane sums of its DKB planes in registers from group to group; the views are accumulated in ascending order, so the
-// result does not depend on the grouping.  MULTI = false is the one-group kernel of round 5 (V - 1 == NVT), unchanged.
+// Two source views only.  Round 6 built the any-view-count form (the views two at a time, each group with its own origins, windows, records
+// and vote, the plane sums carried in registers: 168 VGPRs, three blocks per CU) and timed it at the reference's other view counts
+// (profiles/r6_k1_views.txt): V = 4 73 us against 59 for the plane-pipelined gather form, V = 5 at 296 x 400 547 against 383 (38 % of the
+// (tile, group) pairs fit the 16 x 8 window at that resolution), V = 7 1 118 against 721 -- it lost everywhere and was removed.
 #pragma once
 #include <atomic>
 #include "k1_taps.h"
@@ -56,8 +56,8 @@ struct K1Win {
     static_assert(WP % TPW == 0, "a wave-load must stay inside one window row");
 };
 
-template <int C, int DKB, int NVT, int WP, int WR, int MODE, bool MULTI = false>
-__global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
+template <int C, int DKB, int NVT, int WP, int WR, int MODE>
+__global__ __launch_bounds__(256) void warp_variance_win_kernel(
     const float* __restrict__ feats, const float* __restrict__ rot, const float* __restrict__ trans,
     const float* __restrict__ planes, float* __restrict__ var, int V, int D, int h, int w, int tiles_x, unsigned* __restrict__ stats) {
     using W = K1Win<C, DKB, NVT, WP, WR>;
@@ -107,17 +107,9 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
     plc = reinterpret_cast<const float2*>(planes)[(long long)b * hw + ycen * w + xcen];
 
     struct Taps { v4f t[NVT][4]; v4f w[NVT]; };
-    const int k0 = blockIdx.y * DKB;
-    const int nsrc = MULTI ? V - 1 : NVT;
-    v4f s[MULTI ? DKB : 1], sq[MULTI ? DKB : 1];           // (MULTI) plane sums carried from view group to view group, stored after the last one
-    if (MULTI) {
-#pragma unroll
-        for (int k = 0; k < DKB; ++k) { s[k] = ref; sq[k] = ref2; }
-    }
 
-    for (int v0 = 0; v0 < nsrc; v0 += NVT) {
-        const int nv = MULTI ? min(NVT, nsrc - v0) : NVT;   // views of this group (uniform)
-        if (MULTI && v0 > 0) __syncthreads();               // the previous group's records and windows have been read
+    {
+        const int k0 = blockIdx.y * DKB;
         // ---------------- window origins (uniform) and, MODE 1, the window loads
         int ox[NVT], oy[NVT];
         auto fill = [&]() {
@@ -135,9 +127,7 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
                 const int L = va * W::LPV + swave + 4 * jj;         // wave-uniform load id = 1 KiB slot of the window
                 // rows outside the image are never referenced (records point at clamped, in-image footprints): bring a valid row
                 const int yy = min(max(oy[va] + r, 0), h - 1);
-                // (MULTI, a view past the end of a ragged group: the last view's rows again -- finite values under that view's zero weights)
-                const int vrow = MULTI ? min(v0 + va, nsrc - 1) + 1 : va + 1;
-                const int off = ((vrow * h + yy) * w + ox[va] + c0 + ((4 % W::SEG == 0) ? sw * W::TPW : 0)) * TEXB;      // scalar, any sign
+                const int off = (((va + 1) * h + yy) * w + ox[va] + c0 + ((4 % W::SEG == 0) ? sw * W::TPW : 0)) * TEXB;      // scalar, any sign
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, win + L * 1024, 16, lane * 16 + off, 0, 0, 0);
             }
         };
@@ -148,9 +138,8 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
             const float dmid = plc.x + ((float)k0 + 0.5f * (float)(DKB - 1)) * plc.y;
 #pragma unroll
             for (int va = 0; va < NVT; ++va) {
-                const int vv = MULTI ? min(v0 + va, nsrc - 1) : va;
-                const float* r = rotb + vv * 9;
-                const float* t = trb + vv * 3;
+                const float* r = rotb + va * 9;
+                const float* t = trb + va * 3;
                 const float pz = fmaf(fmaf(r[6], fxc, fmaf(r[7], fyc, r[8])), dmid, t[2]);
                 const float rp = __builtin_amdgcn_rcpf(pz);
                 const float cx = fmaf(fmaf(r[0], fxc, fmaf(r[1], fyc, r[2])), dmid, t[0]) * rp;
@@ -175,10 +164,8 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
 #pragma clang fp contract(off)
             const int c = threadIdx.x + 256 * j;
             const int ka = (c / PIX) % DKB, va = c / (PIX * DKB);
-            const bool dead = MULTI && va >= nv;                 // a view past the end of a ragged group: the last view again, with zero weights
-            const int vv = dead ? nsrc - 1 : v0 + va;
-            const float* r = rotb + vv * 9;
-            const float* t = trb + vv * 3;
+            const float* r = rotb + va * 9;
+            const float* t = trb + va * 3;
             const float rx = (r[0] * fxa + r[1] * fya) + r[2];
             const float ry = (r[3] * fxa + r[4] * fya) + r[5];
             const float rz = (r[6] * fxa + r[7] * fya) + r[8];
@@ -189,9 +176,8 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
             v4f wt;
             bool live;
             k1_tap_fixed(ix, iy, g, xc, yc, wt, live);
-            if (dead) wt = (v4f){0.f, 0.f, 0.f, 0.f};
             rec_w[c] = wt;
-            rec_g[c] = (((vv + 1) * h + yc) * w + xc) * TEXB;
+            rec_g[c] = (((va + 1) * h + yc) * w + xc) * TEXB;
             {
                 int oxv = ox[0], oyv = oy[0];
 #pragma unroll
@@ -199,7 +185,7 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
                 const int lx = xc - oxv, ly = yc - oyv;
                 const bool fits = ((unsigned)lx < (unsigned)(WP - 1)) && ((unsigned)ly < (unsigned)(WR - 1));
                 rec_l[c] = va * W::WBYTES + ((live && fits) ? (ly * WP + lx) * TEXB : 0);
-                all_fit = all_fit && (fits || !live || dead);
+                all_fit = all_fit && (fits || !live);
             }
         }
         bool use_win = false;
@@ -224,7 +210,6 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
         if (inside) {
             auto blend_store = [&](const Taps& f, int k) {
                 v4f a = ref, a2 = ref2;
-                if (MULTI) { a = s[MULTI ? k : 0]; a2 = sq[MULTI ? k : 0]; }
 #pragma unroll
                 for (int va = 0; va < NVT; ++va) {
                     const v4f wt = f.w[va];
@@ -234,11 +219,6 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
                     val = __builtin_elementwise_fma(f.t[va][3], (v4f){wt.w, wt.w, wt.w, wt.w}, val);
                     a = a + val;
                     a2 = __builtin_elementwise_fma(val, val, a2);
-                }
-                if (MULTI) {                                     // (no store ends the plane here: keep the scheduler from pulling every plane's taps to the front -- 240 VGPRs)
-                    s[MULTI ? k : 0] = a; sq[MULTI ? k : 0] = a2;
-                    __builtin_amdgcn_sched_barrier(0);
-                    return;
                 }
                 if (k0 + k < D) {
                     const v4f m = a * rV;
@@ -292,27 +272,17 @@ __global__ __launch_bounds__(256, MULTI ? 3 : 1) void warp_variance_win_kernel(
             }
         }
     }
-    if (MULTI && inside) {
-#pragma unroll
-        for (int k = 0; k < DKB; ++k) {
-            if (k0 + k < D) {
-                const v4f m = s[k] * rV;
-                const v4f o = __builtin_elementwise_fma(sq[k], (v4f){rV, rV, rV, rV}, -(m * m));
-                __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(ob + (k0 + k) * pstride));
-            }
-        }
-    }
 }
 
 // host side: launch one instantiation
-template <int C, int DKB, int NVT, int WP, int WR, int MODE, bool MULTI = false>
+template <int C, int DKB, int NVT, int WP, int WR, int MODE>
 static int k1_win_launch_one(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
                              int B, int V, int D, int h, int w, unsigned* stats, hipStream_t st) {
     using W = K1Win<C, DKB, NVT, WP, WR>;
     const int txp = (w + W::TW - 1) / W::TW, typ = (h + W::TH - 1) / W::TH;
     dim3 grid(txp * typ, (D + DKB - 1) / DKB, B);
     const size_t lds = (size_t)W::LDS_BYTES;
-    auto kern = warp_variance_win_kernel<C, DKB, NVT, WP, WR, MODE, MULTI>;
+    auto kern = warp_variance_win_kernel<C, DKB, NVT, WP, WR, MODE>;
     if (lds > 48 * 1024) {             // (the debug geometries of C = 8; the production launch of stage 1 needs 39 KB)
         static std::atomic<bool> raised[64];        // per instantiation and device
         int dev = 0;

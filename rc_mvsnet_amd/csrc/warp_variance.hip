@@ -511,17 +511,14 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
     }
     if (variant >= 5) {
         // window form (k1_win.h): 5 = source windows loaded ahead of the coordinate phase, 6 = after the fit test
-        // V = 3: the one-group kernel; any other view count: the same kernel walking the views two at a time (MULTI; the tile
-        // statistics then count (tile, view group) pairs)
+        RCMVS_REQUIRE(V == 3, "warp_variance_fwd: the window form is built for two source views (got V=%d)", V);
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-#define RCMVS_K1WIN_M(CC, DD, PP, RR, MM) (variant == 5 ? k1_win_launch_one<CC, DD, 2, PP, RR, 1, MM>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st) : \
-                                                          k1_win_launch_one<CC, DD, 2, PP, RR, 2, MM>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st))
-#define RCMVS_K1WIN(CC, DD, PP, RR) (V == 3 ? RCMVS_K1WIN_M(CC, DD, PP, RR, false) : RCMVS_K1WIN_M(CC, DD, PP, RR, true))
+#define RCMVS_K1WIN(CC, DD, PP, RR) (variant == 5 ? k1_win_launch_one<CC, DD, 2, PP, RR, 1>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st) : \
+                                                    k1_win_launch_one<CC, DD, 2, PP, RR, 2>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st))
         if (C == 32) return RCMVS_K1WIN(32, 4, 16, 8);
         if (C == 16) return RCMVS_K1WIN(16, 4, 32, 8);
         return RCMVS_K1WIN(8, 4, 64, 8);
 #undef RCMVS_K1WIN
-#undef RCMVS_K1WIN_M
     }
     if (variant <= 1) {
         const bool fastm = variant == 1;
@@ -577,14 +574,22 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
 }
 
 // which kernel a call takes.  No hint: the exact two-phase gather kernel (bit-identical to the reference-order kernel) -- the plain ABI entry.
-// RCMVS_K1_UNIFORM_PLANES (pixel-invariant planes: stage 1 of the cascade): the LDS-window form, any view count.  RCMVS_K1_FAST_BLEND (the
-// caller accepts FMA-contracted blends): per-pixel planes at C = 8 run the plane-pipelined gather form for 2, 3, 4 or 6 source views
-// (two views, stage 3 of config 2: 37.6 us against 40.8, profiles/r5_k1_window.txt; the other view counts: profiles/r6_k1_views.txt).
+// RCMVS_K1_FAST_BLEND (the caller accepts FMA-contracted blends, <= 2e-6 of the value range) opens the faster forms, chosen by measurement
+// on the stage shapes of each view count (us per launch, profiles/r6_k1_views.txt; 0 two-phase, 1 its FMA build, 5 window, 7 plane-pipelined):
+//   2 source views (DTU bench, 512 x 640)   stage 1 with RCMVS_K1_UNIFORM_PLANES: 5 (38.8 against 41.0 / 52.0 for 0 / 7); C = 8: 7 (50.4 against 52.7); else 0
+//   3 (training)                            7 everywhere, stage 1 included (59 / 74 / 48 against 78 / 173 / 64 for 0: the run-time-view kernel)
+//   4 (DTU evaluation, 1184 x 1600)         7 (stage 1 383 against 450, stage 3 379 against 487 on smooth tables); per-pixel C = 16: 1 (527 / 942 smooth / rough
+//                                           against 529 / 1 138 for 7 and 614 / 941 for 0)
+//   6 (Tanks and Temples, 1056 x 1920)      7 (721 / 767 / 537 against 1 263 / 1 203 / 983)
+// other view counts: 0 (its run-time-view form).
 static int k1_production_variant(int V, int C, int h, int w, int hint) {
     const bool small = (long long)V * h * w * C * 4 < 0x7fffffffLL;
     const int nsrc = V - 1;
-    if (small && (hint & RCMVS_K1_UNIFORM_PLANES)) return 5;
-    if (small && (hint & RCMVS_K1_FAST_BLEND) && C == 8 && (nsrc == 2 || nsrc == 3 || nsrc == 4 || nsrc == 6)) return 7;
+    if (!small || !(hint & RCMVS_K1_FAST_BLEND)) return 0;
+    const bool uniform = (hint & RCMVS_K1_UNIFORM_PLANES) != 0;
+    if (nsrc == 2) return uniform ? 5 : (C == 8 ? 7 : 0);
+    if (nsrc == 3 || nsrc == 6) return 7;
+    if (nsrc == 4) return (C == 16 && !uniform) ? 1 : 7;
     return 0;
 }
 

@@ -57,7 +57,7 @@ def test_bench_starts_its_own_ranks(gpus, ppg):
     assert abs(b["value"] * b["ms_per_step"] * 1e-3 - gpus * ppg) < 1e-2 * gpus * ppg                 # value = ranks * K / median round
     # a 40-step round of the stub is far below 0.5 s on an idle box: the region is then repeated in rounds of exactly K steps and the
     # median is reported (how many rounds fit depends on the machine's load: only the bookkeeping is asserted)
-    assert 1 <= b["timed_rounds"] <= 64 and b["round_s_min_max"][0] <= b["timed_region_s"] <= b["round_s_min_max"][1]
+    assert 1 <= b["timed_rounds"] <= 4000 and b["round_s_min_max"][0] <= b["timed_region_s"] <= b["round_s_min_max"][1]
     assert b["steps_run_by_rank0"] == 3 + 40 * b["timed_rounds"]
 
 
