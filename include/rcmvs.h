@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 104          /* 0.1.4 -- 104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
+#define RCMVS_VERSION 105          /* 0.1.5 -- 105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd.  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
                                       the FMA-contracted forms are opted into with RCMVS_K1_FAST_BLEND of rcmvs_warp_variance_hint_fwd; the plane-pipelined form
                                       (variant 7) takes 2, 3, 4 or 6 source views.
                                       103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5-7; rcmvs_warp_variance_fwd is FMA-contracted for V = 3, C = 8;
@@ -202,6 +202,22 @@ int rcmvs_absmax_fwd(const float* x, long long n, int square, float* amax, void*
 int rcmvs_conv3d_scaled_fwd(const float* x, const float* x_absmax, const float* w_packed, const float* scale, const float* shift,
                             const float* residual, float* y, float* y_absmax,
                             int B, int D, int H, int W, int Ci, int Co, int stride, int relu, int impl, void* stream);
+/* The last transposed layer of the 3-D U-Net and the prob conv in ONE pass (csrc/conv11_prob.hip): replaces
+ *   x = conv0 + self.conv11(x);  x = self.prob(x)        (models/modules.py:497-500; Deconv3d 16 -> 8 + BatchNorm + ReLU, Conv3d 8 -> 1 without bias)
+ * for a B = 1 inference scene, fp16-pair arithmetic -- the 8-channel full-resolution volume between the two layers never reaches memory.
+ *   t (B,Dt,Ht,Wt,16) with t_absmax (bound of max|t|, RCMVS_ABSMAX_FLOATS slot format);  w11_packed = rcmvs_pack_conv3d_weight(Co = 8, Ci = 16,
+ *   transposed = 1);  scale / shift: the folded BatchNorm of conv11 (8 floats each);  res (B,2Dt,2Ht,2Wt,8) = conv0's output with res_absmax;
+ *   coef: two device floats {c1, c2} with max|conv11 output before the skip| <= c1 max|t| + c2 (c1 = max_co |scale_co| max over the 8 output parity
+ *   classes of sum_{ci, taps of the class} |w|, c2 = max_co |shift_co|): the scale of the intermediate volume's fp16 pieces comes from
+ *   max|res| + c1 max|t| + c2;  wprob_packed = rcmvs_pack_conv3d_weight(Co = 1, Ci = 8);  logits (B,2Dt,2Ht,2Wt): what rcmvs_softmax_head_fwd takes.
+ *   With 2 Dt = 8 planes (the cascade's last stage) the whole head fits the launch: depth != NULL (then planes (B,2Ht,2Wt,2) and conf too) ->
+ *   softmax, soft-argmin and the confidence window finish in the same kernel (the arithmetic of rcmvs_softmax_head_fwd); logits may then be NULL.
+ *   zchunk: output planes per block (even; 0 = chosen per launch).  Results: within the fp16-pair tolerance of the two-launch form
+ *   (rcmvs_deconv3d_scaled_fwd + the prob conv of rcmvs_depth_head_scaled_fwd); tests/test_gpu_parity.py::test_conv11_prob_*. */
+int rcmvs_conv11_prob_fwd(const float* t, const float* t_absmax, const float* w11_packed, const float* scale, const float* shift,
+                          const float* res, const float* res_absmax, const float* coef, const float* wprob_packed, float* logits,
+                          const float* planes, float* depth, float* conf,
+                          int B, int Dt, int Ht, int Wt, int zchunk, void* stream);
 int rcmvs_deconv3d_scaled_fwd(const float* x, const float* x_absmax, const float* w_packed, const float* scale, const float* shift,
                               const float* residual, float* y, float* y_absmax,
                               int B, int D, int H, int W, int Ci, int Co, int relu, int impl, void* stream);
@@ -328,6 +344,9 @@ int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* plane
 int rcmvs_depth_head_scaled_fwd(const float* x, const float* x_absmax, const float* w_prob, const float* planes,
                                 float* depth, float* conf, float* prob,
                                 int B, int D, int h, int w, int impl, void* stream);
+/* The head's second half on its own (F.softmax, depth_regression, the confidence gather: models/casmvsnet.py:293-309) for producers that leave
+ * the logits themselves (rcmvs_conv11_prob_fwd): prob (B,D,h,w) holds the logits on entry and, with keep != 0, the probabilities on return. */
+int rcmvs_softmax_head_fwd(float* prob, const float* planes, float* depth, float* conf, int B, int D, int h, int w, int keep, void* stream);
 
 /* ---- rendering-consistency branch --------------------------------------------------------- */
 /* F.interpolate(size=[Do,h,w], trilinear, align_corners=True) along the plane axis only

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librcmvs_hip.so")
-REQUIRED_VERSION = 104      # RCMVS_VERSION of include/rcmvs.h this binding was written against (104: the hint bits of rcmvs_warp_variance_hint_fwd)
+REQUIRED_VERSION = 105      # RCMVS_VERSION of include/rcmvs.h this binding was written against (105: rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd)
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rcmvs.h")
 
@@ -35,6 +35,8 @@ SIGNATURES = {
     "rcmvs_absmax_fwd": [_p, _ll, _i, _p, _p],
     "rcmvs_conv3d_scaled_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_deconv3d_scaled_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_conv11_prob_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "rcmvs_softmax_head_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "rcmvs_conv2d_s2d_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_warp_variance_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -23,6 +23,9 @@ import os
 FP16_PAIR_DEFAULT = True       # inference CostRegNet on the fp16-pair matrix-core form unless RCMVS_FP16_PAIR=0 (the exact bf16 triple)
 ONE_BY_ONE_MFMA = os.environ.get("RCMVS_1X1_MFMA", "1") != "0"  # FeatureNet's 32 -> 32 1x1 output conv (out1) on the matrix cores, exact split operands; 0 = fp32 FMA chains
 HEAD_PAIR = os.environ.get("RCMVS_HEAD_PAIR", "1") != "0"       # ... and the depth head's prob conv (csrc/prob_pair.hip); 0 = fp32 FMA chains there
+# the last transposed layer + the prob conv (+ the head, D = 8) in one pass (csrc/conv11_prob.hip): 1 = at the cascade's last stage (D = 8: 50 against 70 us on
+# a DTU scene; at the other stages the two launches are as fast, profiles/r6_conv11_prob.txt), 2 = at every stage, 0 = never (the 8-channel volume in memory)
+CONV11_PROB = int(os.environ.get("RCMVS_CONV11_PROB", "1"))
 DEEP_PAIR = os.environ.get("RCMVS_DEEP_PAIR", "1") != "0"       # ... its deep levels (conv5-7) included (csrc/conv3d_deep.hip); 0 = fp32 MFMAs there
 
 import torch
@@ -543,11 +546,30 @@ class CostRegNet(nn.Module):
                 s, b = _bn_fold(m.bn)
                 plan[n] = (w, s, b)
             plan["prob"] = ops.pack_conv3d_weight(self.prob.weight)
+            plan["conv11_coef"] = self._conv11_bound_coef(plan["conv11"][1], plan["conv11"][2])
             self._plan, self._plan_key = plan, key
         return self._plan
 
-    def features_cl(self, x, x_absmax=None, plan=None):
-        """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8).
+    def _conv11_bound_coef(self, scale, shift):
+        """{c1, c2} of ops.conv11_prob: max|relu(bn(conv11(t)))| <= c1 max|t| + c2.  An output voxel of parity class (pd, ph, pw) sums the taps
+        k = 1 (parity 0) or k in {0, 2} (parity 1) per axis over the 16 input channels: c1 = max_co |scale_co| x (the largest of the eight class-wise
+        L1 norms of the weights), c2 = max_co |shift_co|; computed on the device, no sync, x (1 + 2^-10) against the rounding of the sums."""
+        w = self.conv11.conv.weight.detach().float().abs().sum(0)          # ConvTranspose3d weight (Ci, Co, 3, 3, 3) -> (Co, 3, 3, 3)
+        taps = ([1], [0, 2])
+        l1 = None
+        for pd in range(2):
+            for ph in range(2):
+                for pw in range(2):
+                    v = w[:, taps[pd]][:, :, taps[ph]][:, :, :, taps[pw]].sum((1, 2, 3))
+                    l1 = v if l1 is None else torch.maximum(l1, v)
+        c1 = (scale.abs() * l1).max() * (1.0 + 2.0 ** -10)
+        c2 = shift.abs().max() * (1.0 + 2.0 ** -10)
+        return torch.stack((c1, c2)).float().contiguous()
+
+    def features_cl(self, x, x_absmax=None, plan=None, logits=False, planes=None):
+        """x (B,D,h,w,C) channels-last -> the 8-channel volume fed to ``prob`` (B,D,h,w,8); logits=True (fp16-pair form only): -> the prob conv's
+        output (B,D,h,w) instead, the last transposed layer and the prob conv fused; with `planes` (B,h,w,2) as well: (depth, confidence), the head included
+        (one launch for D = 8, the logits + ops.softmax_head otherwise).
         x_absmax: None = the exact three-piece bf16 form of the matrix-core kernels; or a (BOUND_ROWS, ops.ABSMAX_FLOATS) tensor whose row 0
         is a bound of max|x| (ops.absmax format; the cascade derives it from the feature maps) and whose other rows are ZERO: the
         layers then run on the fp16-pair form (half the matrix-pipe work) and every layer leaves the bound of its output in the
@@ -557,6 +579,8 @@ class CostRegNet(nn.Module):
             raise RcmvsError(f"CostRegNet: volume {D}x{h}x{w} must be divisible by 8 in every axis "
                              "(three stride-2 levels with skip connections, models/modules.py:492-499)")
         p = self.hip_plan() if plan is None else plan          # (the cascade validates a stage's plan once and hands it in)
+        if logits and (x_absmax is None or B != 1):
+            raise RcmvsError("CostRegNet.features_cl(logits=True): the fused conv11 + prob pass is the fp16-pair form of a B = 1 scene")
         if x_absmax is None:
             conv0 = ops.conv3d(x, *p["conv0"], relu=True)
             conv2 = ops.conv3d(ops.conv3d(conv0, *p["conv1"], stride=2, relu=True), *p["conv2"], relu=True)
@@ -581,6 +605,8 @@ class CostRegNet(nn.Module):
             t = ops.conv3d(ops.conv3d(conv4, *p["conv5"], stride=2, relu=True), *p["conv6"], relu=True)
             t = ops.deconv3d(t, *p["conv7"], residual=conv4, relu=True, y_absmax=b[5])
         t = ops.deconv3d(t, *p["conv9"], residual=conv2, relu=True, x_absmax=b[5], y_absmax=b[4])
+        if logits:                  # conv11 + prob in one pass: the 8-channel volume never reaches memory (csrc/conv11_prob.hip); with `planes`: the head too
+            return ops.conv11_prob(t, b[4], p["conv11"][0], p["conv11"][1], p["conv11"][2], conv0, b[0], p["conv11_coef"], p["prob"], planes=planes)
         return ops.deconv3d(t, *p["conv11"], residual=conv0, relu=True, x_absmax=b[4], y_absmax=b[9])      # (the depth head's bound)
 
     def features_cl_train(self, x):
@@ -795,9 +821,13 @@ class _CascadeBase(nn.Module):
                 if not bound_kept:                                   # (test hooks, pyramids whose output conv keeps no bound)
                     ops.absmax(f_cl, square=True, out=vmax[0])
             plan = cr.hip_plan()
-            x8 = cr.features_cl(var, vmax, plan)
-            # ... and so does the depth head (prob conv on the matrix cores, csrc/prob_pair.hip; RCMVS_HEAD_PAIR=0: the fp32 form)
-            depth, conf = ops.depth_head(x8, plan["prob"], planes, x_absmax=vmax[CostRegNet.BOUND_ROWS - 1] if vmax is not None and HEAD_PAIR else None)
+            if vmax is not None and HEAD_PAIR and (CONV11_PROB == 2 or (CONV11_PROB == 1 and D == 8)):
+                # conv11 + prob conv in one pass (csrc/conv11_prob.hip), then softmax / soft-argmin / confidence over the logits
+                depth, conf = cr.features_cl(var, vmax, plan, logits=True, planes=planes)
+            else:
+                x8 = cr.features_cl(var, vmax, plan)
+                # ... and so does the depth head (prob conv on the matrix cores, csrc/prob_pair.hip; RCMVS_HEAD_PAIR=0: the fp32 form)
+                depth, conf = ops.depth_head(x8, plan["prob"], planes, x_absmax=vmax[CostRegNet.BOUND_ROWS - 1] if vmax is not None and HEAD_PAIR else None)
             out = {"depth": depth, "photometric_confidence": conf}
             if self.TRAIN_VARIANT:
                 small = F.interpolate(imgs.reshape(B * V, 3, H, W), (h, w), mode="bilinear", align_corners=False)

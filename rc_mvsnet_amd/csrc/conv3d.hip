@@ -182,6 +182,11 @@ int prob_pair_pack(const float* w, float* img, const float* wsc, hipStream_t st)
 static inline bool has_prob_pair(int Ci, int Co) { return Ci == 8 && Co == 1; }
 static inline long long prob_pair_image_offset(int Ci, int Co) { return x3h_image_offset(Ci, Co, X3_NKINDS) + 4; }
 long long prob_pair_blob_offset() { return prob_pair_image_offset(8, 1); }           // (for depth_head.hip)
+// conv11_prob.hip: the last transposed layer (16 -> 8) and the prob conv in one pass
+bool conv11_prob_supported(int Dt, int Ht, int Wt);
+int conv11_prob_launch(const float* t, const float* w11img, const float* scale, const float* shift, const float* res, const float* wprobimg,
+                       const float* tmax, const float* rmax, const float* coef, float* y, int B, int Dt, int Ht, int Wt, int zc_force, hipStream_t st,
+                       const float* planes, float* depth, float* conf);
 
 }  // namespace rcmvs
 
@@ -373,6 +378,19 @@ int rcmvs_deconv3d_scaled_fwd(const float* x, const float* x_absmax, const float
                               const float* residual, float* y, float* y_absmax,
                               int B, int D, int H, int W, int Ci, int Co, int relu, int impl, void* stream) {
     return deconv3d_dispatch(x, w_packed, scale, shift, residual, y, B, D, H, W, Ci, Co, relu, stream, ConvImpl(impl), x_absmax, y_absmax);
+}
+
+int rcmvs_conv11_prob_fwd(const float* t, const float* t_absmax, const float* w11_packed, const float* scale, const float* shift,
+                          const float* res, const float* res_absmax, const float* coef, const float* wprob_packed, float* logits,
+                          const float* planes, float* depth, float* conf,
+                          int B, int Dt, int Ht, int Wt, int zchunk, void* stream) {
+    RCMVS_REQUIRE(t && t_absmax && w11_packed && scale && shift && res && res_absmax && coef && wprob_packed && (logits || depth), "conv11_prob_fwd: null pointer");
+    RCMVS_REQUIRE(!depth || (planes && conf && Dt == 4), "conv11_prob_fwd: the one-launch head (depth != NULL) needs planes, conf and 2 Dt = 8 planes");
+    RCMVS_REQUIRE(B > 0 && Dt > 0 && Ht > 0 && Wt > 0, "conv11_prob_fwd: bad sizes");
+    RCMVS_REQUIRE(zchunk >= 0 && zchunk % 2 == 0, "conv11_prob_fwd: the z chunk must be even (got %d)", zchunk);
+    RCMVS_REQUIRE(conv11_prob_supported(Dt, Ht, Wt), "conv11_prob_fwd: volume %dx%dx%d too large for 32-bit offsets", Dt, Ht, Wt);
+    return conv11_prob_launch(t, w11_packed + x3h_image_offset(16, 8, CONV_T2), scale, shift, res, wprob_packed + prob_pair_image_offset(8, 1),
+                              t_absmax, res_absmax, coef, logits, B, Dt, Ht, Wt, zchunk, as_stream(stream), planes, depth, conf);
 }
 
 int rcmvs_deconv3d_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,

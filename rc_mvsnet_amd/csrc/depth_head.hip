@@ -130,6 +130,23 @@ static int depth_head_fwd(const float* x, const float* xmax, const float* w_prob
     return launch_status("depth_head_fwd");
 }
 
+/* the second launch of the head on its own: logits (B, D, h, w) -> probabilities in place (keep != 0), depth, confidence.  For producers that
+ * leave the logits themselves (rcmvs_conv11_prob_fwd). */
+extern "C" int rcmvs_softmax_head_fwd(float* prob, const float* planes, float* depth, float* conf, int B, int D, int h, int w, int keep, void* stream) {
+    RCMVS_REQUIRE(prob && planes && depth && conf, "softmax_head_fwd: null pointer");
+    RCMVS_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "softmax_head_fwd: bad sizes");
+    RCMVS_REQUIRE(D <= 64, "softmax_head_fwd: at most 64 depth hypotheses per stage (got %d)", D);
+    hipStream_t st = as_stream(stream);
+    const long long hw = (long long)h * w;
+#define RCMVS_SOFTMAX(LP) do { if (keep) hipLaunchKernelGGL((softmax_regress_kernel<LP, true>), dim3((unsigned)cdiv(hw * LP, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw); \
+                               else hipLaunchKernelGGL((softmax_regress_kernel<LP, false>), dim3((unsigned)cdiv(hw * LP, 256), B), dim3(256), 0, st, prob, planes, depth, conf, D, hw); } while (0)
+    if (D <= 16) RCMVS_SOFTMAX(1);
+    else if (D <= 32) RCMVS_SOFTMAX(2);
+    else RCMVS_SOFTMAX(4);
+#undef RCMVS_SOFTMAX
+    return launch_status("softmax_head_fwd");
+}
+
 extern "C" int rcmvs_depth_head_fwd(const float* x, const float* w_prob, const float* planes, float* depth, float* conf, float* prob,
                                     int B, int D, int h, int w, void* stream) {
     return depth_head_fwd(x, nullptr, w_prob, planes, depth, conf, prob, B, D, h, w, 0, stream);

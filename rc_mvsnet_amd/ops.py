@@ -530,6 +530,44 @@ def depth_head(x8, w_prob_packed, planes, want_prob=False, x_absmax=None):
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 
+def conv11_prob(t, t_absmax, w11_packed, scale, shift, res, res_absmax, coef, w_prob_packed, zchunk=0, planes=None):
+    """The last transposed layer (16 -> 8, BatchNorm, ReLU, + skip `res`) and the prob conv in one pass (csrc/conv11_prob.hip):
+    t (B,Dt,Ht,Wt,16), res (B,2Dt,2Ht,2Wt,8) -> logits (B,2Dt,2Ht,2Wt).  coef: (2,) device floats {c1, c2} (include/rcmvs.h).
+    planes (B,2Ht,2Wt,2) with 2 Dt = 8: the whole head in the launch -> (depth, conf) instead of the logits."""
+    B, Dt, Ht, Wt, C = t.shape
+    if C != 16 or tuple(res.shape) != (B, 2 * Dt, 2 * Ht, 2 * Wt, 8):
+        raise _lib.RcmvsError(f"conv11_prob: t {tuple(t.shape)} / res {tuple(res.shape)} are not (B,Dt,Ht,Wt,16) / (B,2Dt,2Ht,2Wt,8)")
+    if w11_packed.images != IMG_ALL or w_prob_packed.images != IMG_ALL:
+        raise _lib.RcmvsError("conv11_prob: needs the full weight blobs (a selectively packed weight does not hold the fp16-pair images)")
+    fused = planes is not None and Dt == 4
+    logits = depth = conf = None
+    if fused:
+        depth = torch.empty((B, 2 * Ht, 2 * Wt), device=t.device, dtype=torch.float32)
+        conf = torch.empty((B, 2 * Ht, 2 * Wt), device=t.device, dtype=torch.float32)
+    else:
+        logits = torch.empty((B, 2 * Dt, 2 * Ht, 2 * Wt), device=t.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_conv11_prob_fwd(_chk(t, "t"), _chk(t_absmax, "t_absmax"), _chk(w11_packed.blob, "w11"), _chk(scale, "scale"),
+                                                 _chk(shift, "shift"), _chk(res, "res"), _chk(res_absmax, "res_absmax"), _chk(coef, "coef"),
+                                                 _chk(w_prob_packed.blob, "w_prob"), _opt(logits, "logits"), _opt(planes if fused else None, "planes"),
+                                                 _opt(depth, "depth"), _opt(conf, "conf"), B, Dt, Ht, Wt, int(zchunk), _stream()),
+               "conv11_prob_fwd")
+    if fused:
+        return depth, conf
+    if planes is not None:
+        return softmax_head(logits, planes)
+    return logits
+
+
+def softmax_head(logits, planes, keep_prob=False):
+    """logits (B,D,h,w) -> depth (B,h,w), confidence (B,h,w); keep_prob: the logits tensor holds the probabilities afterwards."""
+    B, D, h, w = logits.shape
+    depth = torch.empty((B, h, w), device=logits.device, dtype=torch.float32)
+    conf = torch.empty((B, h, w), device=logits.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_softmax_head_fwd(_chk(logits, "logits"), _chk(planes, "planes"), _chk(depth, "depth"), _chk(conf, "conf"),
+                                                  B, D, h, w, int(bool(keep_prob)), _stream()), "softmax_head_fwd")
+    return depth, conf
+
+
 # ------------------------------------------------------------------------------- rendering branch
 def resize_planes(x, out_planes, pad_channels_to=None):
     """x (B,C,D,h,w) NCDHW -> (B,out_planes,h,w,Cp) channels-last, trilinear along D, align_corners=True."""

@@ -464,6 +464,62 @@ def test_conv3d_x3h_vs_fp64(hip, Ci, Co, kind, shape):
     assert torch.equal(y_big, y_h * big)
 
 
+@pytest.mark.parametrize("shape,zchunk", [((4, 6, 14), 0), ((4, 6, 14), 4), ((2, 13, 31), 0), ((1, 3, 5), 0), ((5, 7, 16), 2), ((6, 20, 30), 6), ((12, 32, 40), 0)])
+def test_conv11_prob_vs_fp64(hip, shape, zchunk):
+    """conv11 + prob in one pass (csrc/conv11_prob.hip: x = conv0 + relu(bn(deconv(t))), logits = prob(x), models/modules.py:497-500; the
+    8-channel volume between the two layers never reaches memory) against an fp64 evaluation of the two layers, next to the two-launch form
+    it replaces (fp16-pair transposed conv + the fp32 prob conv) and the all-fp32 kernels: ragged tiles (the 12 x 28 tile does not divide the
+    sizes), z chunks with their halo steps, one-plane-pair volumes, log-normal inputs.  The derived bound of the intermediate volume
+    (CostRegNet._conv11_bound_coef) really is a bound."""
+    if DEV == "cpu" and shape[1] > 16 and os.environ.get("RCMVS_EMU_FULL", "0") != "1":
+        pytest.skip("a minute on the kernel emulation: RCMVS_EMU_FULL=1 (always run on the GPU)")
+    from rc_mvsnet_amd.casmvsnet import CostRegNet
+    Dt, Ht, Wt = shape
+    g = torch.Generator().manual_seed(Dt * 100 + Wt)
+    net = CostRegNet(8, 8)
+    with torch.no_grad():
+        for prm in net.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * (0.2 if prm.dim() > 1 else 0.5))
+        net.conv11.bn.running_var.copy_(0.5 + torch.rand(8, generator=g))
+        net.conv11.bn.running_mean.copy_(0.3 * torch.randn(8, generator=g))
+        net.conv11.bn.weight.copy_(0.5 + torch.rand(8, generator=g))
+    net = net.to(DEV).eval()
+    t = torch.randn(1, 16, Dt, Ht, Wt, generator=g) * torch.exp(0.7 * torch.randn(1, 16, Dt, Ht, Wt, generator=g))
+    r0 = torch.randn(1, 8, 2 * Dt, 2 * Ht, 2 * Wt, generator=g) * torch.exp(0.7 * torch.randn(1, 8, 2 * Dt, 2 * Ht, 2 * Wt, generator=g))
+    with torch.no_grad():
+        bn = net.conv11.bn
+        sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).cpu().double()
+        sh = bn.bias.cpu().double() - bn.running_mean.cpu().double() * sc
+        mid = torch.nn.functional.conv_transpose3d(t.double(), net.conv11.conv.weight.cpu().double(), padding=1, stride=2, output_padding=1)
+        mid = torch.relu(mid * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+        x8 = mid + r0.double()
+        ref = torch.nn.functional.conv3d(x8, net.prob.weight.cpu().double(), padding=1)[:, 0]
+        plan = net.hip_plan()
+        tcl, rcl = gpu(t.permute(0, 2, 3, 4, 1)), gpu(r0.permute(0, 2, 3, 4, 1))
+        tmax, rmax = hip.absmax(tcl), hip.absmax(rcl)
+        coef = plan["conv11_coef"].cpu().double()
+        assert float(mid.abs().max()) <= float(coef[0]) * float(t.abs().max()) + float(coef[1])        # the derived bound holds
+        got = hip.conv11_prob(tcl, tmax, plan["conv11"][0], plan["conv11"][1], plan["conv11"][2], rcl, rmax, plan["conv11_coef"], plan["prob"],
+                              zchunk=zchunk).cpu().double()
+        # the two launches it replaces: fp16-pair transposed conv, then the prob conv as an fp32 convolution
+        x8_h = hip.deconv3d(tcl, *plan["conv11"], residual=rcl, relu=True, x_absmax=tmax)
+        two = hip.conv3d(x8_h, plan["prob"]).cpu().double()[..., 0]
+        try:
+            hip.force_direct_conv(64)               # the fp32 FMA-chain kernels for both layers
+            f32 = hip.conv3d(hip.deconv3d(tcl, *plan["conv11"], residual=rcl, relu=True), plan["prob"]).cpu().double()[..., 0]
+        finally:
+            hip.force_direct_conv(0)
+        if Dt == 4:                 # eight planes: the head in the same launch = softmax / soft-argmin / confidence over the logits above, bit for bit
+            planes = gpu(torch.stack((400.0 + 50.0 * torch.rand(1, 2 * Ht, 2 * Wt, generator=g), 1.0 + torch.rand(1, 2 * Ht, 2 * Wt, generator=g)), dim=-1))
+            d1, c1 = hip.conv11_prob(tcl, tmax, plan["conv11"][0], plan["conv11"][1], plan["conv11"][2], rcl, rmax, plan["conv11_coef"], plan["prob"], planes=planes)
+            d2, c2 = hip.softmax_head(gpu(got.float()), planes)
+            assert torch.equal(d1, d2) and torch.equal(c1, c2)
+    mag = float(ref.abs().max())
+    e_f, e_2, e_32 = (float((a - ref).abs().max()) for a in (got, two, f32))
+    print(f"conv11+prob {shape} zchunk {zchunk}: max error vs fp64 / max|logit|: fused {e_f / mag:.2e}, two launches {e_2 / mag:.2e}, fp32 kernels {e_32 / mag:.2e}")
+    assert e_f <= 2.0 * e_32 + 1e-7 * mag and e_f < 3e-6 * mag, (e_f, e_32, mag)
+
+
 @pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 16), (32, 32), (32, 16), (64, 32)])
 @pytest.mark.parametrize("shape", [(3, 11, 21), (2, 37, 70), (1, 8, 32)])
 def test_conv3d_x3_planar_vs_fp64(hip, Ci, Co, shape):
