@@ -21,6 +21,7 @@
 // bound of the stored outputs (one atomic max per block) for the next layer.
 #include "common.h"
 #include "x3_pieces.h"
+#include <atomic>
 #include <type_traits>
 
 namespace rcmvs {
@@ -420,11 +421,11 @@ static int deep_launch_t(const float* x, const float* wimg, const float* scale, 
                          const DeepDims& dm_in, int dev, const float* xmax, float* ymax, hipStream_t st) {
     using C = Deep<CI, CO, K>;
     constexpr int MAXDEV = 64;
-    static bool raised[MAXDEV];                    // per device: dynamic-LDS limit of this instantiation (benign race: same value)
-    if (C::LDS > 64 * 1024 && !raised[dev]) {
+    static std::atomic<bool> raised[MAXDEV];                    // per device: dynamic-LDS limit of this instantiation
+    if (C::LDS > 64 * 1024 && !raised[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)conv3d_deep_kernel<CI, CO, K>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
             return fail(-1, "conv3d_deep: cannot raise the dynamic LDS limit to %d bytes", C::LDS);
-        raised[dev] = true;
+        raised[dev].store(true, std::memory_order_release);
     }
     DeepDims dm = dm_in;
     dm.tiles_h = (dm.Hg + C::TH - 1) / C::TH; dm.tiles_w = (dm.Wg + C::TW - 1) / C::TW;

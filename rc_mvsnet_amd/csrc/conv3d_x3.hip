@@ -54,6 +54,7 @@
 // kept to the bare split (22 VALU per float4) and table-driven addressing.
 #include "common.h"
 #include "x3_pieces.h"
+#include <atomic>
 #include <cstdlib>
 
 #ifndef X3_ABLATION
@@ -927,7 +928,7 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
     // chunked split (cost in half steps: steps + 1.5 per item start, a block of a balanced launch starts ceil(steps / Dt) + 1 items at most)
     dm.bal = 0;
     {
-        constexpr int mode = 2;                                             // by the cost model (0 / 1 = off / forced were A/B settings, tools/dev/x3_balance_ab.py)
+        constexpr int mode = 2;                                             // by the cost model (0 / 1 = off / forced were A/B settings of round 4: profiles/HISTORY.md)
         const long long T = (long long)dm.B * dm.ntiles * dm.Dt;
         const long long spb = (T + n_blk - 1) / n_blk + 1;                   // steps of the longest block
         const long long ipb = (spb + dm.Dt - 1) / dm.Dt + 1;                 // item starts of a block, at most
@@ -939,8 +940,8 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
             const size_t ldsb = (size_t)C::LDSB + (size_t)dm.itemcap * 16 + (size_t)dm.stepcap * 4 + 64;
             if (ldsb <= 160 * 1024) {
                 const int grid_b = (int)(T < n_blk ? T : n_blk);
-                static bool attr_set_b[64];
-                if (!attr_set_b[dev]) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b[dev] = true; }
+                static std::atomic<bool> attr_set_b[64];
+                if (!attr_set_b[dev].load(std::memory_order_acquire)) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set_b[dev].store(true, std::memory_order_release); }
                 hipLaunchKernelGGL((conv3d_x3_kernel<CI, CO, K, NP>), dim3((unsigned)grid_b), dim3(512), ldsb, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, res, y, dm, xmax, ymax);
                 return launch_status("conv3d_x3");
             }
@@ -962,8 +963,8 @@ static int x3_launch_t(const float* x, const float* wimg, const float* scale, co
     if (lds > 160 * 1024) return fail(-1, "conv3d_x3: the schedule of a block does not fit the LDS (%zu bytes)", lds);
     if (dm.zchunk >= 32768 || dm.itemcap >= 32768) return fail(-1, "conv3d_x3: schedule descriptor fields overflow");
     dim3 grid((unsigned)grid_n);
-    static bool attr_set[64];
-    if (!attr_set[dev]) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[dev] = true; }
+    static std::atomic<bool> attr_set[64];
+    if (!attr_set[dev].load(std::memory_order_acquire)) { (void)hipFuncSetAttribute((const void*)conv3d_x3_kernel<CI, CO, K, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[dev].store(true, std::memory_order_release); }
     hipLaunchKernelGGL((conv3d_x3_kernel<CI, CO, K, NP>), grid, dim3(512), lds, st, x, reinterpret_cast<const x3_u32x4*>(wimg), scale, shift, res, y, dm, xmax, ymax);
     return launch_status("conv3d_x3");
 }
@@ -986,9 +987,9 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
         if ((long long)B * D * H * W * so * Co * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_x3: output tensor too large for 32-bit offsets");
     }
     // per-device facts (a process may drive several GPUs, e.g. nn.DataParallel replicas): CU count, and whether the kernel's
-    // dynamic-LDS limit has been raised on that device.  Races are benign (the same values are written).
+    // dynamic-LDS limit has been raised on that device (atomics: the library is re-entrant).
     constexpr int MAXDEV = 64;
-    static int cu_of[MAXDEV];
+    static std::atomic<int> cu_of[MAXDEV];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return fail(-1, "conv3d_x3: cannot query the device");
     if (cu_of[dev] == 0) {

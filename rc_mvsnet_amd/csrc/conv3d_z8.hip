@@ -20,6 +20,7 @@
 // (A first form with wave = (n-tile, K half), 4 x 32 tiles and the halves meeting through LDS one tick later measured 96 - 100 us: removed.)
 #include "common.h"
 #include "x3_pieces.h"
+#include <atomic>
 
 namespace rcmvs {
 
@@ -307,11 +308,11 @@ static int z8_launch_t(const float* x, const float* wimg, const float* scale, co
                        const float* xmax, float* ymax, hipStream_t st) {
     using C = Z8<CIN, COUT>;
     constexpr int MAXDEV = 64;
-    static bool raised[MAXDEV];
-    if (C::LDS > 64 * 1024 && !raised[dev]) {
+    static std::atomic<bool> raised[MAXDEV];
+    if (C::LDS > 64 * 1024 && !raised[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)conv3d_z8_kernel<CIN, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
             return fail(-1, "conv3d_z8: cannot raise the dynamic LDS limit to %d bytes", C::LDS);
-        raised[dev] = true;
+        raised[dev].store(true, std::memory_order_release);
     }
     const long long T = (long long)dm.B * dm.ntiles * dm.D;
     const int blocks = (int)(T < n_cu ? T : n_cu);
@@ -325,7 +326,7 @@ int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, cons
     if (!xmax) return fail(-1, "conv3d_z8: the fp16-pair form needs a bound of max|x|");
     if ((long long)B * D * H * W * (Ci > Co ? Ci : Co) * 4 >= 0x7ffffff0LL) return fail(-1, "conv3d_z8: tensor too large for 32-bit offsets");
     constexpr int MAXDEV = 64;
-    static int cu_of[MAXDEV];
+    static std::atomic<int> cu_of[MAXDEV];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return fail(-1, "conv3d_z8: cannot query the device");
     if (cu_of[dev] == 0) {
@@ -338,7 +339,7 @@ int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, cons
     const int ty = Co == 16 ? Z8<16, 16>::TY : (Ci == 8 ? Z8<8, 8>::TY : Z8<16, 8>::TY);      // (32 -> 8: as 16 -> 8)
     dm.tiles_x = (W + 31) / 32;
     dm.ntiles = dm.tiles_x * ((H + ty - 1) / ty);
-    const int n_blk = max_blocks > 0 ? max_blocks : cu_of[dev];
+    const int n_blk = max_blocks > 0 ? max_blocks : cu_of[dev].load();
     if (((long long)B * dm.ntiles * D + n_blk - 1) / n_blk + 2LL * (((long long)B * dm.ntiles * D + n_blk - 1) / n_blk / D + 3) >= 65536)
         return 1;        // too many steps per block for the 16-bit stream arithmetic: not taken (conv3d_x3_launch goes on to the split kernel)
     if (Ci == 8 && Co == 8) return z8_launch_t<8, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);

@@ -173,7 +173,7 @@ __device__ static inline float bilinear_up(const float* __restrict__ p, int hp, 
     // scenes against 7 %).  The map is 80-330 KB, the kernel is bound by its stores; the loads cost nothing measurable.
     // Round 4 (profiles/r4_two_streams_ab.txt): a one-lane agent-scope acquire at the top of EVERY inference kernel with plain loads
     // here does NOT remove the corruption (84 of 90 rounds) and costs 18 % on one stream: the stale data is not in the reader's vector
-    // L1, the mechanism stays unexplained, and the multi-stream mode stays off (rc_mvsnet_amd/scene_pipeline.py).
+    // L1, the mechanism stays unexplained, and the binding refuses a second stream per process (ops._stream(); profiles/r6_two_streams.txt).
     float top = lx0 * ld_agent(p + y0 * wp + x0) + lx1 * ld_agent(p + y0 * wp + x1);
     float bot = lx0 * ld_agent(p + y1 * wp + x0) + lx1 * ld_agent(p + y1 * wp + x1);
     return ly0 * top + ly1 * bot;

@@ -15,6 +15,7 @@ so that a rank owns every depth map its fusion needs.
 """
 import argparse
 import os
+import sys
 import time
 
 import torch
@@ -142,14 +143,18 @@ def main(argv=None):
     args = ap.parse_args(argv)
     nproc = args.gpus * args.procs_per_gpu
     if nproc > 1 and not launched():
-        import sys
         raise SystemExit(launch_ranks("rc_mvsnet_amd.eval_driver", nproc, sys.argv[1:] if argv is None else argv, module=True))
 
     from .casmvsnet import CascadeMVSNet_eval
     rank, local, world = rank_env()
-    if world != nproc:
-        raise SystemExit(f"eval_driver: --gpus {args.gpus} x --procs-per-gpu {args.procs_per_gpu} = {nproc} ranks, but WORLD_SIZE={world} "
-                         f"(launch torch.distributed.run with --nproc-per-node {nproc}, or drop WORLD_SIZE and let the driver start them)")
+    # Under an external launcher the launcher owns the rank layout: `torch.distributed.run --nproc-per-node 8 -m rc_mvsnet_amd.eval_driver --outdir out`
+    # (no --gpus) and multi-node launches (WORLD_SIZE = nodes x local ranks) shard by (rank, world) as they are.  Only an
+    # EXPLICIT --gpus / --procs-per-gpu is checked, and against the ranks of THIS node (LOCAL_WORLD_SIZE), not the job.
+    explicit = any(a.split("=")[0] in ("--gpus", "--procs-per-gpu") for a in (sys.argv[1:] if argv is None else argv))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if launched() and explicit and local_world != nproc:
+        raise SystemExit(f"eval_driver: --gpus {args.gpus} x --procs-per-gpu {args.procs_per_gpu} = {nproc} ranks per node, but the launcher started "
+                         f"{local_world} (launch torch.distributed.run with --nproc-per-node {nproc}, drop the two flags, or drop the launcher and let the driver start the ranks)")
     device = torch.device("cpu")
     if torch.cuda.is_available():
         index = device_index(local, args.procs_per_gpu)

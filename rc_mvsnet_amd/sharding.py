@@ -50,7 +50,28 @@ def free_port():
         return sk.getsockname()[1]
 
 
-RENDEZVOUS_TIMEOUT_S = 120      # init_process_group timeout of the drivers (bench.py, eval_driver): fail readably instead of hanging for 30 minutes
+# init_process_group's timeout is also the default timeout of every later collective and barrier of the group (gloo and NCCL / RCCL alike): ranks that
+# skew by more than this -- one of them building the HIP library for the first time, a slow warm-up, a long CPU baseline on rank 0 -- abort the run
+# mid-way.  So the drivers (bench.py, eval_driver) first check that the rendezvous port ANSWERS within RENDEZVOUS_TIMEOUT_S (a readable failure instead of
+# a 30-minute hang when MASTER_ADDR / MASTER_PORT are wrong), then create the group with PyTorch's long default.
+RENDEZVOUS_TIMEOUT_S = 120
+GROUP_TIMEOUT_S = 1800
+
+
+def _wait_for_master(timeout_s):
+    """Ranks other than 0: poll MASTER_ADDR:MASTER_PORT until the store of rank 0 listens (True) or the time is up (False)."""
+    import time
+    addr, port = os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")
+    if not addr or not port or os.environ.get("RANK", "0") == "0":
+        return True
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        try:
+            with socket.create_connection((addr, int(port)), timeout=2.0):
+                return True
+        except OSError:
+            time.sleep(0.2)
+    return False
 
 
 def init_process_group(backend):
@@ -58,7 +79,9 @@ def init_process_group(backend):
     import datetime
     import torch.distributed as dist
     try:
-        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
+        if not _wait_for_master(RENDEZVOUS_TIMEOUT_S):
+            raise TimeoutError("the rendezvous port does not answer")
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=GROUP_TIMEOUT_S))
     except Exception as e:
         raise SystemExit(f"rank {os.environ.get('RANK', '?')} of {os.environ.get('WORLD_SIZE', '?')}: {backend} rendezvous on "
                          f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')} failed within {RENDEZVOUS_TIMEOUT_S} s: "

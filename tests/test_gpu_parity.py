@@ -1134,6 +1134,9 @@ def test_cascade_fp16_pair_form_on_extreme_activation_ranges(hip, gain):
         assert float(dd.mean()) / rng < 1e-5 and float(stable.float().mean()) >= 0.99
     else:
         assert float(stable.float().mean()) >= 0.97 and float(dd[stable].mean()) / rng < 1e-5
+        # ... and the WHOLE map stays bounded (the flips are a plane or two on ~1.5 % of the pixels): a regression that moves many pixels by
+        # millimetres must not pass as "unstable pixels"
+        assert float(dd.mean()) / rng < 5e-5 and float(dd.max()) < 12.0
 
 
 def test_cascade_config5_arithmetic_vs_reference_golden(hip):
