@@ -635,7 +635,7 @@ def main(argv=None):
 
     per_stage_ms, achieved = k1_summary(events)
     traffic, traffic_file = None, None  # HBM bytes per scene from the committed PMC profile (FETCH_SIZE x2 + WRITE_SIZE)
-    for name in ("r5_k1_traffic.json", "r4_k1_traffic.json"):
+    for name in ("r6_k1_traffic.json", "r5_k1_traffic.json", "r4_k1_traffic.json"):
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["bytes_per_scene"]
             traffic_file = name
