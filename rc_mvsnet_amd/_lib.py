@@ -51,6 +51,7 @@ SIGNATURES = {
     "rcmvs_fuse_view": [_p, _i, _p, _p, _p, _p, _f, _i, _d, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "rcmvs_compact_points": [_p, _p, _p, _p, _p, _p, _ll, _p],
     "rcmvs_prepare_image": [_p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "rcmvs_resize_rgb_cl": [_p, _p, _i, _i, _i, _i, _i, _p],
     "rcmvs_conv1x1_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_conv1x1_mfma_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_fpn_out_fused": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

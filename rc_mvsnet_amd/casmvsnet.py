@@ -692,8 +692,7 @@ class DepthNet(nn.Module):
             if self.train_variant:
                 if imgs is None:
                     raise RcmvsError("DepthNet (train variant): imgs (B,V,3,H,W) are needed for volume_feature_no_ref")
-                small = F.interpolate(imgs.float().reshape(B * V, *imgs.shape[2:]), (h, w), mode="bilinear", align_corners=False)
-                small_cl = ops.to_channels_last(small.contiguous()).view(B, V, h, w, 3)
+                small_cl = ops.resize_rgb_cl(imgs.float().reshape(B * V, *imgs.shape[2:]).contiguous(), (h, w)).view(B, V, h, w, 3)
         if _hip_inference(self, *features, depth_values):
             f_cl = torch.stack([ops.to_channels_last(f.contiguous().float()) for f in features], dim=1)
             var = ops.warp_variance(f_cl, rot, trans, planes, D)
@@ -830,8 +829,7 @@ class _CascadeBase(nn.Module):
                 depth, conf = ops.depth_head(x8, plan["prob"], planes, x_absmax=vmax[CostRegNet.BOUND_ROWS - 1] if vmax is not None and HEAD_PAIR else None)
             out = {"depth": depth, "photometric_confidence": conf}
             if self.TRAIN_VARIANT:
-                small = F.interpolate(imgs.reshape(B * V, 3, H, W), (h, w), mode="bilinear", align_corners=False)
-                small_cl = ops.to_channels_last(small.contiguous()).view(B, V, h, w, 3)
+                small_cl = ops.resize_rgb_cl(imgs.reshape(B * V, 3, H, W).contiguous(), (h, w)).view(B, V, h, w, 3)
                 # module is in eval mode on this path -> the reference's in-place pow_ quirk applies
                 out["volume_feature_no_ref"] = ops.warp_noref(f_cl, small_cl, rot, trans, planes, D, square_first=True)
             outputs[key] = out
@@ -865,8 +863,7 @@ class _CascadeBase(nn.Module):
                 planes = ops.hypothesis_planes(prev, depth_values, (H, W), scale, D, self.depth_interals_ratio[s])
                 small_cl = None
                 if self.TRAIN_VARIANT:
-                    small = F.interpolate(imgs.reshape(B * V, 3, H, W), (h, w), mode="bilinear", align_corners=False)
-                    small_cl = ops.to_channels_last(small.contiguous()).view(B, V, h, w, 3)
+                    small_cl = ops.resize_rgb_cl(imgs.reshape(B * V, 3, H, W).contiguous(), (h, w)).view(B, V, h, w, 3)
             res = ops.WarpVarianceFn.apply(f_cl, rot, trans, planes, D, small_cl)
             var, noref = res if self.TRAIN_VARIANT else (res, None)
             cr = self._cr(s)

@@ -20,9 +20,41 @@ __global__ __launch_bounds__(256) void prepare_image_kernel(const unsigned char*
     out[2 * h * w + p] = ip::prepared_pixel(src, H, W, h, w, y, x, 2, m2, s2);
 }
 
+// The train variant's small images (models/casmvsnet.py:60-62,148-150: F.interpolate(imgs, (h, w), mode="bilinear", align_corners=False), then the
+// channels-last view the warp kernels read): (N, 3, H, W) planar -> (N, h, w, 3), ATen's upsample_bilinear2d arithmetic (source index
+// max(scale (dst + 0.5) - 0.5, 0) with scale = H / h in fp32, the two row blends before the column blend, no contraction) so that the result
+// equals torch's on the same GPU.  One thread per output pixel.
+__global__ __launch_bounds__(256) void resize_rgb_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int h, int w) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= h * w) return;
+    const int n = blockIdx.y;
+    const int oy = p / w, ox = p - oy * w;
+    const float rh = (float)H / (float)h, rw = (float)W / (float)w;
+    const float h1r = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.0f), w1r = fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.0f);
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = h1 < H - 1 ? 1 : 0, w1p = w1 < W - 1 ? 1 : 0;
+    const float h1l = h1r - (float)h1, w1l = w1r - (float)w1;
+    const float h0l = 1.0f - h1l, w0l = 1.0f - w1l;
+    const float* xp = x + (long long)n * 3 * H * W;
+    float* yp = y + ((long long)n * h * w + p) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* pc = xp + (long long)c * H * W + (long long)h1 * W + w1;
+        yp[c] = h0l * (w0l * pc[0] + w1l * pc[w1p]) + h1l * (w0l * pc[(long long)h1p * W] + w1l * pc[(long long)h1p * W + w1p]);
+    }
+}
+
 }  // namespace rcmvs
 
 using namespace rcmvs;
+
+extern "C" int rcmvs_resize_rgb_cl(const float* x, float* y, int N, int H, int W, int h, int w, void* stream) {
+    RCMVS_REQUIRE(x && y, "resize_rgb_cl: null pointer");
+    RCMVS_REQUIRE(N > 0 && H > 0 && W > 0 && h > 0 && w > 0 && (long long)h * w < (1ll << 30) && N <= 65535, "resize_rgb_cl: bad dims N=%d %dx%d -> %dx%d", N, H, W, h, w);
+    hipLaunchKernelGGL(resize_rgb_cl_kernel, dim3((h * w + 255) / 256, N), dim3(256), 0, as_stream(stream), x, y, H, W, h, w);
+    return launch_status("resize_rgb_cl");
+}
 
 extern "C" int rcmvs_prepare_image(const unsigned char* src, float* out, int H, int W, int h, int w, const float* mean_host,
                                    const float* std_host, void* stream) {

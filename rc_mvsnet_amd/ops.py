@@ -375,6 +375,17 @@ def conv2d_s2d(x, w_packed, scale=None, shift=None, relu=False):
 
 
 # ------------------------------------------------------------------------------- 2-D feature pyramid
+def resize_rgb_cl(x, hw):
+    """(N,3,H,W) -> (N,h,w,3): F.interpolate(x, hw, mode="bilinear", align_corners=False) + the channels-last view, one launch (no gradient)."""
+    N, C, H, W = x.shape
+    if C != 3:
+        raise _lib.RcmvsError("resize_rgb_cl: expects RGB images (N,3,H,W)")
+    h, w = int(hw[0]), int(hw[1])
+    y = torch.empty((N, h, w, 3), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_resize_rgb_cl(_chk(x, "x"), _chk(y, "y"), N, H, W, h, w, _stream()), "resize_rgb_cl")
+    return y
+
+
 def rgb_to_nhwc4(x):
     """(N,3,H,W) -> (N,H,W,4), zero 4th channel."""
     N, _, H, W = x.shape

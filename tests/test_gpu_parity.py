@@ -258,6 +258,19 @@ def test_warp_variance_window_form(hip):
         hip.warp_variance(feats, rot, trans, planes, 8, variant=5)
 
 
+@pytest.mark.parametrize("N,H,W,h,w", [(3, 64, 96, 16, 24), (2, 64, 96, 32, 48), (1, 20, 28, 20, 28), (2, 37, 53, 9, 13), (1, 16, 16, 40, 24)])
+def test_resize_rgb_cl_is_torch_bilinear(hip, N, H, W, h, w):
+    """The train variant's small images (models/casmvsnet.py:60-62: F.interpolate(..., mode="bilinear", align_corners=False)) fused with the
+    channels-last transpose: ATen's arithmetic, so equal to torch on the same device up to the last bit or two (integer and ragged scales,
+    identity, up-sampling)."""
+    g = torch.Generator().manual_seed(H + w)
+    x = gpu(torch.randn(N, 3, H, W, generator=g))
+    ref = torch.nn.functional.interpolate(x, (h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    got = hip.resize_rgb_cl(x, (h, w))
+    assert got.shape == (N, h, w, 3)
+    assert float((got - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------ K2/K3
 @pytest.mark.parametrize("Ci,Co,mode", [(8, 16, "s2"), (16, 16, "s1"), (16, 32, "s2"), (32, 32, "s1"), (32, 64, "s2"),
                                         (64, 64, "s1"), (64, 32, "t2"), (32, 16, "t2")])
