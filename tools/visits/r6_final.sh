@@ -59,4 +59,5 @@ print(json.dumps({"source": "round 6 (tools/visits/r6_final.sh): rocprofv3 --ker
                             "bytes of wide coalesced reads), counters in KB, averages per launch", "per_kernel": per, "bytes_per_scene": tot,
                   "algorithmic_bytes_per_scene": 457441280}, indent=1))
 PY
+rm -rf gpurun_out/${tag}_pmc gpurun_out/${tag}_prof        # (raw counter / trace files: tens of MB; the summaries above are what is kept)
 exit 0
