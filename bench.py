@@ -656,7 +656,9 @@ def main(argv=None):
                 "algorithmic_bytes_per_scene": sum(bytes_stage),
                 "per_stage_us": [round(m * 1e3, 2) for m in per_stage_ms],
                 "per_stage_GBs": [round(b / (m * 1e-3) / 1e9, 1) if m > 0 else 0.0 for b, m in zip(bytes_stage, per_stage_ms)],
-                "timing": f"HIP events on the launch stream around every K1 launch, separate untimed pass of {nprobe} scenes right after the timed region"}
+                "timing": f"HIP events carrying each K1 kernel's own start / stop timestamps (hipExtLaunchKernelGGL through rcmvs_warp_variance_timed_fwd: the "
+                          f"duration rocprofv3 reports; event records AROUND a launch add 3-6 us of marker packets), separate untimed pass of {nprobe} scenes "
+                          "right after the timed region"}
     try:        # the window path depends on the geometry only (homographies, plane table): count stage 1's tiles on it with blank feature maps
         if V != 3:
             raise RuntimeError("stage 1 runs the plane-pipelined gather form at this view count (profiles/r6_k1_views.txt)")

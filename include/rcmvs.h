@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 105          /* 0.1.5 -- 105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl.  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
+#define RCMVS_VERSION 105          /* 0.1.5 -- 105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl, rcmvs_warp_variance_timed_fwd.  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
                                       the FMA-contracted forms are opted into with RCMVS_K1_FAST_BLEND of rcmvs_warp_variance_hint_fwd; the plane-pipelined form
                                       (variant 7) takes 2, 3, 4 or 6 source views.
                                       103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5-7; rcmvs_warp_variance_fwd is FMA-contracted for V = 3, C = 8;
@@ -98,6 +98,13 @@ int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const fl
 int rcmvs_warp_variance_hint_fwd(const float* feats, const float* rot, const float* trans,
                                  const float* planes, float* var,
                                  int B, int V, int C, int D, int h, int w, int hint, void* stream);
+
+/* rcmvs_warp_variance_hint_fwd whose kernel leaves its own start / stop timestamps in two caller-owned hipEvent_t (hipExtLaunchKernelGGL; either may be
+ * NULL): the launch duration a profiler reports, without the marker packets that event records around a launch add.  For measurement (bench.py's
+ * roofline object); the results are those of the hint entry. */
+int rcmvs_warp_variance_timed_fwd(const float* feats, const float* rot, const float* trans,
+                                  const float* planes, float* var,
+                                  int B, int V, int C, int D, int h, int w, int hint, void* start_event, void* stop_event, void* stream);
 
 /* The window-form kernel (csrc/k1_win.h) with its tile statistics: variant 5 = source windows loaded
  * ahead of the coordinate phase, 6 = after the fit test.  stats (device pointer, two unsigned, caller-zeroed, NULL = none):

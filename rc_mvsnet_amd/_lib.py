@@ -31,6 +31,7 @@ SIGNATURES = {
     "rcmvs_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_debug_warp_variance_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_warp_variance_hint_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "rcmvs_warp_variance_timed_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "rcmvs_debug_warp_variance_win_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     "rcmvs_absmax_fwd": [_p, _ll, _i, _p, _p],
     "rcmvs_conv3d_scaled_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],

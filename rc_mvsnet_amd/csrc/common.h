@@ -1,6 +1,7 @@
 // Shared helpers for librcmvs_hip.so (gfx950 only; wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdarg>
 #include "../../include/rcmvs.h"
@@ -21,6 +22,12 @@ inline int launch_status(const char* what) {
     if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
     return 0;
 }
+
+// A launch whose start / stop timestamps go to two caller-owned events (hipExtLaunchKernelGGL: the dispatch's own timestamps, what rocprofv3 reports as
+// the kernel's duration -- event records around a launch add the marker packets' ~2-3 us each); both events NULL = a plain launch.
+#define RCMVS_LAUNCH_TIMED(kernel, grid, block, lds, st, ev0, ev1, ...) do { \
+        if ((ev0) || (ev1)) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev0, ev1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__); } while (0)
 
 #define RCMVS_REQUIRE(cond, ...) do { if (!(cond)) return ::rcmvs::fail(-1, __VA_ARGS__); } while (0)
 

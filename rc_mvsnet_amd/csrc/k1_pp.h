@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void warp_variance_pp_kernel(
 
 template <int C, int DKB, int NVT>
 static int k1_pp_launch_one(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
-                            int B, int V, int D, int h, int w, hipStream_t st) {
+                            int B, int V, int D, int h, int w, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     constexpr int PIX = 256 / (C / 4), TW = PIX / 4;
     const int txp = (w + TW - 1) / TW, typ = (h + 3) / 4;
     dim3 grid(txp * typ, (D + DKB - 1) / DKB, B);
-    hipLaunchKernelGGL((warp_variance_pp_kernel<C, DKB, NVT>), grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, txp);
+    RCMVS_LAUNCH_TIMED((warp_variance_pp_kernel<C, DKB, NVT>), grid, dim3(256), 0, st, ev0, ev1, feats, rot, trans, planes, var, V, D, h, w, txp);
     return launch_status("warp_variance_fwd (plane-pipelined form)");
 }
 

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void warp_variance_win_kernel(
 // host side: launch one instantiation
 template <int C, int DKB, int NVT, int WP, int WR, int MODE>
 static int k1_win_launch_one(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
-                             int B, int V, int D, int h, int w, unsigned* stats, hipStream_t st) {
+                             int B, int V, int D, int h, int w, unsigned* stats, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     using W = K1Win<C, DKB, NVT, WP, WR>;
     const int txp = (w + W::TW - 1) / W::TW, typ = (h + W::TH - 1) / W::TH;
     dim3 grid(txp * typ, (D + DKB - 1) / DKB, B);
@@ -293,7 +293,7 @@ static int k1_win_launch_one(const float* feats, const float* rot, const float* 
             raised[dev].store(true, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, stats);
+    RCMVS_LAUNCH_TIMED(kern, grid, dim3(256), lds, st, ev0, ev1, feats, rot, trans, planes, var, V, D, h, w, txp, stats);
     return launch_status("warp_variance_fwd (window form)");
 }
 

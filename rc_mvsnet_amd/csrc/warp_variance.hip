@@ -487,7 +487,8 @@ extern "C" {
 // coordinate chain per lane, compiler IEEE division: what variant 0 is held bit-identical to), 3 = store-only ablation,
 // 5 / 6 = the LDS-window form (k1_win.h), 7 = the plane-pipelined gather form (k1_pp.h); k1_production_variant() picks 0, 5 or 7
 static int k1_launch(const float* feats, const float* rot, const float* trans, const float* planes, float* var,
-                     int B, int V, int C, int D, int h, int w, int variant, hipStream_t st, unsigned* stats = nullptr) {
+                     int B, int V, int C, int D, int h, int w, int variant, hipStream_t st, unsigned* stats = nullptr,
+                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     RCMVS_REQUIRE(feats && rot && trans && planes && var, "warp_variance_fwd: null pointer");
     RCMVS_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "warp_variance_fwd: bad sizes B=%d D=%d h=%d w=%d", B, D, h, w);
     RCMVS_REQUIRE(V >= 2 && V - 1 <= RCMVS_MAX_SRC_VIEWS, "warp_variance_fwd: V=%d unsupported", V);
@@ -500,9 +501,9 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
         RCMVS_REQUIRE(nsrc == 2 || nsrc == 3 || nsrc == 4 || nsrc == 6, "warp_variance_fwd: the plane-pipelined form is built for 2, 3, 4 or 6 source views (got V=%d)", V);
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
 #define RCMVS_K1PP(NN) do { \
-            if (C == 32) return k1_pp_launch_one<32, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st); \
-            if (C == 16) return k1_pp_launch_one<16, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st); \
-            return k1_pp_launch_one<8, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st); } while (0)
+            if (C == 32) return k1_pp_launch_one<32, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st, ev0, ev1); \
+            if (C == 16) return k1_pp_launch_one<16, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st, ev0, ev1); \
+            return k1_pp_launch_one<8, 8, NN>(feats, rot, trans, planes, var, B, V, D, h, w, st, ev0, ev1); } while (0)
         if (nsrc == 2) RCMVS_K1PP(2);
         if (nsrc == 3) RCMVS_K1PP(3);
         if (nsrc == 4) RCMVS_K1PP(4);
@@ -513,8 +514,8 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
         // window form (k1_win.h): 5 = source windows loaded ahead of the coordinate phase, 6 = after the fit test
         RCMVS_REQUIRE(V == 3, "warp_variance_fwd: the window form is built for two source views (got V=%d)", V);
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
-#define RCMVS_K1WIN(CC, DD, PP, RR) (variant == 5 ? k1_win_launch_one<CC, DD, 2, PP, RR, 1>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st) : \
-                                                    k1_win_launch_one<CC, DD, 2, PP, RR, 2>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st))
+#define RCMVS_K1WIN(CC, DD, PP, RR) (variant == 5 ? k1_win_launch_one<CC, DD, 2, PP, RR, 1>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st, ev0, ev1) : \
+                                                    k1_win_launch_one<CC, DD, 2, PP, RR, 2>(feats, rot, trans, planes, var, B, V, D, h, w, stats, st, ev0, ev1))
         if (C == 32) return RCMVS_K1WIN(32, 4, 16, 8);
         if (C == 16) return RCMVS_K1WIN(16, 4, 32, 8);
         return RCMVS_K1WIN(8, 4, 64, 8);
@@ -535,8 +536,8 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
         const int txp = (w + TWp - 1) / TWp, typ = (h + 3) / 4;
         RCMVS_REQUIRE((long long)V * h * w * C * 4 < 0x7fffffffLL, "warp_variance_fwd: feature block too large for 32-bit offsets");
         dim3 gridp(txp * typ, (D + dkb - 1) / dkb, B);
-#define RCMVS_K1TP(CC, DD, FF, NN) hipLaunchKernelGGL((warp_variance_tp_kernel<CC, DD, FF, NN>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp)
-#define RCMVS_K1MV(CC, DD, FF) hipLaunchKernelGGL((warp_variance_mv_kernel<CC, DD, FF>), gridp, dim3(256), lds, st, feats, rot, trans, planes, var, V, D, h, w, txp, VC)
+#define RCMVS_K1TP(CC, DD, FF, NN) RCMVS_LAUNCH_TIMED((warp_variance_tp_kernel<CC, DD, FF, NN>), gridp, dim3(256), lds, st, ev0, ev1, feats, rot, trans, planes, var, V, D, h, w, txp)
+#define RCMVS_K1MV(CC, DD, FF) RCMVS_LAUNCH_TIMED((warp_variance_mv_kernel<CC, DD, FF>), gridp, dim3(256), lds, st, ev0, ev1, feats, rot, trans, planes, var, V, D, h, w, txp, VC)
 #define RCMVS_K1TP_N(CC, DD, FF) do { if (nvt == 2) RCMVS_K1TP(CC, DD, FF, 2); else if (nvt == 4) RCMVS_K1TP(CC, DD, FF, 4); else RCMVS_K1MV(CC, DD, FF); } while (0)
 #define RCMVS_K1TP_F(CC, DD) do { if (fastm) RCMVS_K1TP_N(CC, DD, true); else RCMVS_K1TP_N(CC, DD, false); } while (0)
 #define RCMVS_K1TP_6(CC, DD) do { if (fastm) RCMVS_K1TP(CC, DD, true, 6); else RCMVS_K1TP(CC, DD, false, 6); } while (0)
@@ -560,7 +561,7 @@ static int k1_launch(const float* feats, const float* rot, const float* trans, c
     const int TW = 256 / C, TH = 4;
     const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y, (D + DK - 1) / DK, B);
-#define RCMVS_K1_LAUNCH(CC, VV) hipLaunchKernelGGL((warp_variance_ref_kernel<CC, VV>), grid, dim3(256), 0, st, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y)
+#define RCMVS_K1_LAUNCH(CC, VV) RCMVS_LAUNCH_TIMED((warp_variance_ref_kernel<CC, VV>), grid, dim3(256), 0, st, ev0, ev1, feats, rot, trans, planes, var, V, D, h, w, tiles_x, tiles_y)
 #define RCMVS_K1_VARIANTS(CC) do { if (variant == 2) RCMVS_K1_LAUNCH(CC, false); else RCMVS_K1_LAUNCH(CC, true); } while (0)
     switch (C) {
         case 8:  RCMVS_K1_VARIANTS(8); break;
@@ -603,6 +604,13 @@ int rcmvs_warp_variance_hint_fwd(const float* feats, const float* rot, const flo
                                  const float* planes, float* var,
                                  int B, int V, int C, int D, int h, int w, int hint, void* stream) {
     return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, k1_production_variant(V, C, h, w, hint), as_stream(stream));
+}
+
+int rcmvs_warp_variance_timed_fwd(const float* feats, const float* rot, const float* trans,
+                                  const float* planes, float* var,
+                                  int B, int V, int C, int D, int h, int w, int hint, void* start_event, void* stop_event, void* stream) {
+    return k1_launch(feats, rot, trans, planes, var, B, V, C, D, h, w, k1_production_variant(V, C, h, w, hint), as_stream(stream), nullptr,
+                     reinterpret_cast<hipEvent_t>(start_event), reinterpret_cast<hipEvent_t>(stop_event));
 }
 
 int rcmvs_debug_warp_variance_fwd(const float* feats, const float* rot, const float* trans,

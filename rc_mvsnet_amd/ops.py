@@ -140,17 +140,23 @@ def warp_variance(feats, rot, trans, planes, ndepth, variant=None, uniform_plane
                                                              _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, int(variant),
                                                              _stream()), "debug_warp_variance_fwd")
         return var
-    ev = None
+    hint = K1_FAST_BLEND | (K1_UNIFORM_PLANES if uniform_planes else 0)
     if K1_EVENTS is not None:
+        # the kernel's own start / stop timestamps (hipExtLaunchKernelGGL through rcmvs_warp_variance_timed_fwd): what rocprofv3 reports as the launch's
+        # duration.  Event RECORDS around the launch measure 3-6 us more per launch (two marker packets).  A torch event owns its hipEvent_t only after a
+        # first record, so both are recorded once here and then overwritten by the launch.
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    _lib.check(_lib.load().rcmvs_warp_variance_hint_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
-                                                        _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w,
-                                                        K1_FAST_BLEND | (K1_UNIFORM_PLANES if uniform_planes else 0), _stream()),
-               "warp_variance_hint_fwd")
-    if ev is not None:
         ev[1].record()
+        _lib.check(_lib.load().rcmvs_warp_variance_timed_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                             _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, hint,
+                                                             ctypes.c_void_p(ev[0].cuda_event), ctypes.c_void_p(ev[1].cuda_event), _stream()),
+                   "warp_variance_timed_fwd")
         K1_EVENTS.append(ev)
+        return var
+    _lib.check(_lib.load().rcmvs_warp_variance_hint_fwd(_chk(feats, "feats"), _chk(rot, "rot"), _chk(trans, "trans"),
+                                                        _chk(planes, "planes"), _chk(var, "var"), B, V, C, ndepth, h, w, hint, _stream()),
+               "warp_variance_hint_fwd")
     return var
 
 

@@ -26,6 +26,7 @@
 #define __shared__ static
 
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
@@ -122,6 +123,9 @@ template <class T> inline T lane_value(const WaveView& w, int l, T own) {
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
     ::shim::run_grid(dim3(grid), dim3(block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
+// (the kernel's start / stop events of hipExtLaunchKernelGGL are not modelled: a plain launch)
+#define hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev0, ev1, flags, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__)
 
 inline void __syncthreads() { ::shim::yield(::shim::AT_BLOCK); }
 inline int __syncthreads_count(int pred) {

@@ -132,6 +132,34 @@ def test_warp_variance_vs_oracle(hip, B, V, C, D, h, w, uniform):
     assert torch.equal(vv, var), want
 
 
+def test_warp_variance_timed_entry(hip):
+    """rcmvs_warp_variance_timed_fwd (bench.py's roofline probe): the hinted call with the kernel's own start / stop timestamps in two caller-owned
+    events -- same results bit for bit, a positive duration that is no longer than event records around the same launch."""
+    if DEV == "cpu":
+        pytest.skip("events are not modelled on the kernel emulation")
+    from rc_mvsnet_amd import synthetic
+    feats = gpu(torch.randn(1, 3, 128, 160, 32))
+    rot, trans = hip.compose_homography(gpu(synthetic.proj_matrices(1, 3, 512, 640)["stage1"]))
+    planes = hip.hypothesis_planes(None, gpu(synthetic.depth_values(1)), (512, 640), 4, 48, 4)
+    want = hip.warp_variance(feats, rot, trans, planes, 48, uniform_planes=True)
+    rec = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    torch.cuda.synchronize()
+    rec[0].record()
+    hip.warp_variance(feats, rot, trans, planes, 48, uniform_planes=True)
+    rec[1].record()
+    torch.cuda.synchronize()
+    try:
+        hip.K1_EVENTS = []
+        got = hip.warp_variance(feats, rot, trans, planes, 48, uniform_planes=True)
+        torch.cuda.synchronize()
+        (e0, e1), = hip.K1_EVENTS
+    finally:
+        hip.K1_EVENTS = None
+    own, around = e0.elapsed_time(e1) * 1e3, rec[0].elapsed_time(rec[1]) * 1e3
+    print(f"K1 stage-1 launch: {own:.1f} us by its own timestamps, {around:.1f} us between event records around it")
+    assert torch.equal(got, want) and 5.0 < own <= around + 1.0
+
+
 def test_warp_variance_golden_fixture(hip):
     """homo_warping fixture from the reference (incl. out-of-bounds / negative / zero depths):
     with V=2 and a zero reference map, var = w^2/2 - (w/2)^2 = w^2/4  ->  |w| = 2*sqrt(var)."""
