@@ -107,12 +107,13 @@ __global__ __launch_bounds__(256, 2) void conv11_prob_kernel(
         ls[i] = has ? cell * 32 + c4 * 8 : -1;
     }
     x3_u32x4 pf[CP_NLD];
-    auto fetch = [&](int z) {
+    auto fetch_to = [&](x3_u32x4 (&dst)[CP_NLD], int z) {
         const bool zin = z >= 0 && z < Dt;
         const int zoff = zin ? z * iplane_bytes : 0;
 #pragma unroll
-        for (int i = 0; i < CP_NLD; ++i) pf[i] = __builtin_amdgcn_raw_buffer_load_b128(trs, zin ? goff[i] : OOB, zoff, 0);
+        for (int i = 0; i < CP_NLD; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(trs, zin ? goff[i] : OOB, zoff, 0);
     };
+    auto fetch = [&](int z) { fetch_to(pf, z); };
     // ---- weights: the 9 live fragments of the transposed conv (K step j = (kd, r), m-tile mt = (pd, ph): kd <= pd and r <= ph), two pieces each;
     // the three rotations of the prob conv's fragment
     x3_u32x4 A11[4][4];                                         // (high pieces: registers; low pieces and the prob conv's fragments: LDS, read per use)
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv11_prob_kernel(
     const x3_byte* const wll = wl + lane * 16;
     float* const lg = reinterpret_cast<float*>(wl + CP_WFRAG * 1024 + wave * (FUSE_D * CP_LGW));      // (FUSE_D) this wave's logits [plane][3 rows x 28]
     const int sf = max(s0, 0);                                  // first step that exists
+    x3_u32x4 pf1[CP_NLD];                                       // (prologue only: both input planes of the first step fly together -- one round trip, not two)
     fetch(sf);
+    fetch_to(pf1, sf + 1);
     float bt = tmax_lane, br = rmax_lane;
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) { bt = fmaxf(bt, __shfl_xor(bt, m)); br = fmaxf(br, __shfl_xor(br, m)); }
@@ -139,20 +142,20 @@ __global__ __launch_bounds__(256, 2) void conv11_prob_kernel(
     const float ts_scale = x3_pow2_scale(bt, tinv);
     const float xs8 = x3_pow2_scale(br + (c1 * bt + c2), x8inv);
     const float unscale11 = tinv * whdr11, unscalep = x8inv * whdrp;
-    auto stash = [&](int slot) {
+    auto stash_from = [&](const x3_u32x4 (&src)[CP_NLD], int slot) {
 #pragma unroll
         for (int i = 0; i < CP_NLD; ++i) {
             x3_u32x2 h, l;
-            x3_split4h(__builtin_bit_cast(x3_f32x4, pf[i]) * ts_scale, h, l);
+            x3_split4h(__builtin_bit_cast(x3_f32x4, src[i]) * ts_scale, h, l);
             if (ls[i] >= 0) {
                 *reinterpret_cast<x3_u32x2*>(ib + slot * CP_IBUF + ls[i]) = h;
                 *reinterpret_cast<x3_u32x2*>(ib + slot * CP_IBUF + CP_IPIECE + ls[i]) = l;
             }
         }
     };
+    auto stash = [&](int slot) { stash_from(pf, slot); };
     stash(sf & 1);
-    fetch(sf + 1);
-    stash((sf + 1) & 1);
+    stash_from(pf1, (sf + 1) & 1);
     // ---- transposed conv: lane geometry.  B fragment of K step (kd, r): 8 channels (half kk & 1) of cell (row cr + r, column n + c), c = kk >> 1
     const int g4 = kq;                                          // D fragment: rows 4 g4 .. 4 g4 + 3 of an m-tile = (pw = g4 >> 1, co0 = 4 (g4 & 1))
     const int pw = g4 >> 1, co0 = (g4 & 1) * 4;
