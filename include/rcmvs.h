@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 105          /* 0.1.5 -- 105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl, rcmvs_warp_variance_timed_fwd.  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
+#define RCMVS_VERSION 105          /* 0.1.5 -- 105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl, rcmvs_warp_variance_timed_fwd, rcmvs_conv2d_pair_fwd (+ pack, floats).  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
                                       the FMA-contracted forms are opted into with RCMVS_K1_FAST_BLEND of rcmvs_warp_variance_hint_fwd; the plane-pipelined form
                                       (variant 7) takes 2, 3, 4 or 6 source views.
                                       103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5-7; rcmvs_warp_variance_fwd is FMA-contracted for V = 3, C = 8;
@@ -488,6 +488,15 @@ int rcmvs_compact_points(const unsigned char* mask, const float* xyz, const unsi
  * 127-145 (same in datasets/tanks.py): src = decoded image (H,W,3) uint8 on the device -> out (3,h,w) fp32 =
  * (bilinear_resize(src / 255) - mean[c]) / std[c] with cv2.resize's INTER_LINEAR coordinate rule (a copy when the size is
  * unchanged).  mean_host / std_host: HOST arrays of 3 floats. */
+/* Two consecutive 3x3 stride-1 Conv2d blocks (conv + BatchNorm(eval) + ReLU, twice) of FeatureNet's trunk in one launch (csrc/conv2d_pair.hip): replaces
+ *   x = self.conv1[1](x); x = self.conv1[2](x)        (models/modules.py:372-379,413-424; 16 -> 16 -> 16 channels)
+ * exact split-bf16 matrix-core arithmetic like the planar kernels it replaces; the intermediate map stays in LDS.
+ *   rcmvs_pack_conv2d_pair: wa, wb (16,16,3,3) Conv2d weights of the two layers -> image of rcmvs_conv2d_pair_weight_floats() floats;
+ *   x, y (N,H,W,16) channels-last; scale / shift: the folded BatchNorm of each layer (16 floats each).  C must be 16. */
+long long rcmvs_conv2d_pair_weight_floats(void);
+int rcmvs_pack_conv2d_pair(const float* wa, const float* wb, float* image, void* stream);
+int rcmvs_conv2d_pair_fwd(const float* x, const float* image, const float* scale_a, const float* shift_a, const float* scale_b, const float* shift_b,
+                          float* y, int N, int H, int W, int C, void* stream);
 /* The train variant's small images: F.interpolate(imgs, (h, w), mode="bilinear", align_corners=False) (models/casmvsnet.py:60-62,148-150) fused with
  * the channels-last transpose the warp kernels want: x (N,3,H,W) planar -> y (N,h,w,3); ATen's upsample_bilinear2d arithmetic. */
 int rcmvs_resize_rgb_cl(const float* x, float* y, int N, int H, int W, int h, int w, void* stream);

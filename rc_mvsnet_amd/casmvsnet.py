@@ -26,6 +26,7 @@ HEAD_PAIR = os.environ.get("RCMVS_HEAD_PAIR", "1") != "0"       # ... and the de
 # the last transposed layer + the prob conv (+ the head, D = 8) in one pass (csrc/conv11_prob.hip): 1 = at the cascade's last stage (D = 8: 50 against 70 us on
 # a DTU scene; at the other stages the two launches are as fast, profiles/r6_conv11_prob.txt), 2 = at every stage, 0 = never (the 8-channel volume in memory)
 CONV11_PROB = int(os.environ.get("RCMVS_CONV11_PROB", "1"))
+CONV_PAIR = os.environ.get("RCMVS_CONV_PAIR", "1") != "0"       # FeatureNet's conv1.1 -> conv1.2 as one launch (csrc/conv2d_pair.hip); 0 = two launches of the planar kernel
 DEEP_PAIR = os.environ.get("RCMVS_DEEP_PAIR", "1") != "0"       # ... its deep levels (conv5-7) included (csrc/conv3d_deep.hip); 0 = fp32 MFMAs there
 
 import torch
@@ -253,6 +254,10 @@ class FeatureNet(nn.Module):
                     plan[n] = ("s2d_mfma3d", ops.pack_conv3d_weight(w3)) + _bn_fold(m.bn)
                     continue
                 plan[n] = (ops.pack_conv2d_weight(w, pad_in_to=pad_to),) + _bn_fold(m.bn) + (m.stride,)
+            # conv1.1 -> conv1.2 (16 -> 16 -> 16, stride 1) as ONE launch with the map between them in LDS (csrc/conv2d_pair.hip)
+            m11, m12 = mods[3], mods[4]
+            if CONV_PAIR and all(tuple(m.conv.weight.shape) == (16, 16, 3, 3) and m.stride == 1 for m in (m11, m12)):
+                plan["pair1"] = (ops.pack_conv2d_pair(m11.conv.weight, m12.conv.weight),) + _bn_fold(m11.bn) + _bn_fold(m12.bn)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
             if unet:
                 for n in ("out2", "out3")[:self.num_stage - 1]:           # 1x1, Co = Ci: the middle tap of a one-plane 3-D kernel
@@ -309,7 +314,10 @@ class FeatureNet(nn.Module):
         else:
             c00 = cbr(ops.rgb_to_nhwc4(x.contiguous().float()), "conv0.0")
         c0 = cbr(c00, "conv0.1")
-        c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
+        if "pair1" in p and not ops._CONV_IMPL:
+            c1 = ops.conv2d_pair(cbr(c0, "conv1.0"), *p["pair1"])
+        else:
+            c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = cbr(cbr(cbr(c1, "conv2.0"), "conv2.1"), "conv2.2")
         # A thunk takes an optional activation-bound vector (ops.ABSMAX_FLOATS floats, zero-filled): the output conv then leaves (max|f|)^2
         # there -- the bound of the variance volume built from the map, which the fp16-pair cost regularisation needs -- in its epilogue

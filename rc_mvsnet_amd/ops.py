@@ -381,6 +381,26 @@ def conv2d_s2d(x, w_packed, scale=None, shift=None, relu=False):
 
 
 # ------------------------------------------------------------------------------- 2-D feature pyramid
+def pack_conv2d_pair(wa, wb):
+    """Two (16,16,3,3) Conv2d weights -> the fragment image of conv2d_pair (csrc/conv2d_pair.hip)."""
+    if tuple(wa.shape) != (16, 16, 3, 3) or tuple(wb.shape) != (16, 16, 3, 3):
+        raise _lib.RcmvsError("pack_conv2d_pair: built for two 16 -> 16 3x3 layers")
+    lib = _lib.load()
+    img = torch.empty(int(lib.rcmvs_conv2d_pair_weight_floats()), device=wa.device, dtype=torch.float32)
+    _lib.check(lib.rcmvs_pack_conv2d_pair(_chk(wa.detach().float().contiguous(), "wa"), _chk(wb.detach().float().contiguous(), "wb"), _chk(img, "image"), _stream()),
+               "pack_conv2d_pair")
+    return img
+
+
+def conv2d_pair(x, image, scale_a, shift_a, scale_b, shift_b):
+    """x (N,H,W,16) -> relu(bn_b(conv_b(relu(bn_a(conv_a(x)))))) (N,H,W,16): two 3x3 Conv2d blocks in one launch, the map between them in LDS."""
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().rcmvs_conv2d_pair_fwd(_chk(x, "x"), _chk(image, "image"), _chk(scale_a, "scale_a"), _chk(shift_a, "shift_a"),
+                                                 _chk(scale_b, "scale_b"), _chk(shift_b, "shift_b"), _chk(y, "y"), N, H, W, C, _stream()), "conv2d_pair_fwd")
+    return y
+
+
 def resize_rgb_cl(x, hw):
     """(N,3,H,W) -> (N,h,w,3): F.interpolate(x, hw, mode="bilinear", align_corners=False) + the channels-last view, one launch (no gradient)."""
     N, C, H, W = x.shape

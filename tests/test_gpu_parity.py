@@ -286,6 +286,33 @@ def test_warp_variance_window_form(hip):
         hip.warp_variance(feats, rot, trans, planes, 8, variant=5)
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 8, 30), (2, 19, 47), (3, 32, 64), (1, 5, 3)])
+def test_conv2d_pair_vs_fp64(hip, N, H, W):
+    """FeatureNet's conv1.1 -> conv1.2 (two 16 -> 16 3x3 Conv2d blocks: conv + BatchNorm(eval) + ReLU, models/modules.py:372-379) in one launch
+    (csrc/conv2d_pair.hip, the map between them in LDS) against an fp64 evaluation, next to the two launches of the planar split-bf16 kernel it
+    replaces: ragged tiles, maps smaller than a tile, the second layer's zero padding of the INTERMEDIATE map at the image border."""
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, 16, H, W, generator=g) * torch.exp(0.5 * torch.randn(N, 16, H, W, generator=g))
+    wa, wb = (torch.randn(16, 16, 3, 3, generator=g) / 12.0 for _ in range(2))
+    sa, sb = (0.5 + torch.rand(16, generator=g) for _ in range(2))
+    ha, hb = (0.2 * torch.randn(16, generator=g) for _ in range(2))
+    f = torch.nn.functional
+    mid = torch.relu(f.conv2d(x.double(), wa.double(), padding=1) * sa.double().view(1, -1, 1, 1) + ha.double().view(1, -1, 1, 1))
+    ref = torch.relu(f.conv2d(mid, wb.double(), padding=1) * sb.double().view(1, -1, 1, 1) + hb.double().view(1, -1, 1, 1))
+    xcl = gpu(x.permute(0, 2, 3, 1))
+    img = hip.pack_conv2d_pair(gpu(wa), gpu(wb))
+    got = hip.conv2d_pair(xcl, img, gpu(sa), gpu(ha), gpu(sb), gpu(hb)).cpu().permute(0, 3, 1, 2).double()
+    # the two launches it replaces (each layer as a one-plane volume on the planar kernel)
+    w3 = lambda w: torch.cat((torch.zeros_like(w).unsqueeze(2), w.unsqueeze(2), torch.zeros_like(w).unsqueeze(2)), dim=2)
+    pa, pb = hip.pack_conv3d_weight(gpu(w3(wa))), hip.pack_conv3d_weight(gpu(w3(wb)))
+    t = hip.conv3d(xcl.unsqueeze(1), pa, gpu(sa), gpu(ha), relu=True)
+    two = hip.conv3d(t, pb, gpu(sb), gpu(hb), relu=True).squeeze(1).cpu().permute(0, 3, 1, 2).double()
+    mag = float(ref.abs().max())
+    e_f, e_2 = float((got - ref).abs().max()), float((two - ref).abs().max())
+    print(f"conv2d pair {N}x{H}x{W}: max error vs fp64 / max: fused {e_f / mag:.2e}, two launches {e_2 / mag:.2e}")
+    assert e_f <= 2.0 * e_2 + 2e-7 * mag and e_f < 2e-6 * mag
+
+
 @pytest.mark.parametrize("N,H,W,h,w", [(3, 64, 96, 16, 24), (2, 64, 96, 32, 48), (1, 20, 28, 20, 28), (2, 37, 53, 9, 13), (1, 16, 16, 40, 24)])
 def test_resize_rgb_cl_is_torch_bilinear(hip, N, H, W, h, w):
     """The train variant's small images (models/casmvsnet.py:60-62: F.interpolate(..., mode="bilinear", align_corners=False)) fused with the
