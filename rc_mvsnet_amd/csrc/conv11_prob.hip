@@ -187,12 +187,20 @@ __global__ __launch_bounds__(256, 2) void conv11_prob_kernel(
     for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
         for (int j = 0; j < CP_NJ; ++j) pacc[rr][j] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
+    // both plane buffers start as zeros: voxels of the halo tile that lie outside the image (the prob conv's zero padding) are never written
+    for (int o = tid * 16; o < 2 * CP_XBUF; o += 256 * 16) *reinterpret_cast<x3_u32x4*>(xb + o) = (x3_u32x4){0u, 0u, 0u, 0u};
     __syncthreads();
 
     // vmcnt counts loads AND stores, in order: a wait for a load also waits for every store issued before it, and a logit store's acknowledgement
     // takes microseconds under the skip volume's read stream (the first form of this kernel -- stores at the end of a step, the next step's loads
     // behind them -- lost 15 - 25 us per launch to that: profiles/r6_conv11_prob.txt).  So the loads of step s + 1 (skip values, input plane s + 3)
     // are requested at the END of step s, in front of the prob conv's stores of step s: nothing waits for a store but the next request point.
+    // The row of a (n-tile, m-tile) pair is the same for the whole wave (halo row 4 wave + 2 tt + ph - 1), the column and the channel quad are the lane's
+    // and the same for every pair: the lane part of every address below is ONE register computed once, the rest is scalar arithmetic (the first form
+    // recomputed rows, bounds and offsets per lane, pair and step: 700 VALU instructions per wave and step against 90 MFMAs, profiles/r6_final_pmc.txt)
+    const int rq_lane = (colok && !(CP_ABL & 1)) ? (ow * 8 + co0) * 4 : OOB;          // skip values: byte offset inside a row of the skip volume
+    const bool wr_lane = colok && hc >= 0 && hc < CP_HWU && !(CP_ABL & 32);             // this lane's column of the halo tile lies inside the image: it is written
+    const int xo_lane = hc * 16 + co0 * 2;                                              // its byte offset inside a row of the LDS plane
     x3_u32x4 rq[2][4];
     auto request = [&](int s, int need) {                       // need = 0: nothing (out-of-range offsets: no traffic)
 #pragma unroll
@@ -200,9 +208,9 @@ __global__ __launch_bounds__(256, 2) void conv11_prob_kernel(
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int pd = mt >> 1, ph = mt & 1;
-                const int hr = 2 * (2 * wave + tt) + ph - 1, oh = h0 - 1 + hr;
-                const bool ok = colok && hr >= 0 && hr < CP_HH && oh >= 0 && oh < H && ((need >> pd) & 1) && !(CP_ABL & 1);
-                rq[tt][mt] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ok ? ((oh * W + ow) * 8 + co0) * 4 : OOB, need ? (2 * s + pd) * (H * W * 32) : 0, 0);
+                const int hr = 2 * (2 * wave + tt) + ph - 1, oh = h0 - 1 + hr;                     // (scalar)
+                const bool rowok = hr >= 0 && hr < CP_HH && oh >= 0 && oh < H && ((need >> pd) & 1);
+                rq[tt][mt] = __builtin_amdgcn_raw_buffer_load_b128(rrs, rowok ? rq_lane : OOB, rowok ? ((2 * s + pd) * H + oh) * (W * 32) : 0, 0);
             }
         if (!(CP_ABL & 16)) fetch(need ? s + 2 : -1);
     };
@@ -248,18 +256,17 @@ __global__ __launch_bounds__(256, 2) void conv11_prob_kernel(
             for (int mt = 0; mt < 4; ++mt) {
                 const int pd = mt >> 1, ph = mt & 1;
                 if (!((need >> pd) & 1)) continue;
-                const int hr = 2 * (2 * wave + tt) + ph - 1, oh = h0 - 1 + hr;
-                const bool inside = colok && oh >= 0 && oh < H;
-                x3_f32x4 v = acc[tt][mt] * sc11 + sh11;
-                v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
+                const int hr = 2 * (2 * wave + tt) + ph - 1, oh = h0 - 1 + hr;                     // (scalar)
+                if (!(hr >= 0 && hr < CP_HH && oh >= 0 && oh < H)) continue;                      // a row outside the halo tile, or outside the image:
+                x3_f32x4 v = acc[tt][mt] * sc11 + sh11;                                            // there the planes keep the zeros of the prologue
+                v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});                 // (the prob conv's zero padding)
                 v += __builtin_bit_cast(x3_f32x4, rq[tt][mt]);
-                if (!inside) v = (x3_f32x4){0.f, 0.f, 0.f, 0.f};          // the prob conv's zero padding
                 x3_u32x2 h, l;
                 x3_split4h(v * xs8, h, l);
-                if (hr >= 0 && hr < CP_HH && hc >= 0 && hc < CP_HWU && !(CP_ABL & 32)) {
-                    const int o = pd * CP_XBUF + (hr * CP_HW + hc) * 16 + co0 * 2;
-                    *reinterpret_cast<x3_u32x2*>(xb + o) = h;
-                    *reinterpret_cast<x3_u32x2*>(xb + CP_XPIECE + o) = l;
+                if (wr_lane) {
+                    x3_byte* q = xb + (pd * CP_XBUF + hr * (CP_HW * 16)) + xo_lane;
+                    *reinterpret_cast<x3_u32x2*>(q) = h;
+                    *reinterpret_cast<x3_u32x2*>(q + CP_XPIECE) = l;
                 }
             }
         if (!(CP_ABL & 16)) stash(s & 1);                       // plane s + 2 over plane s (every wave is past the step's MFMAs: the barrier above)
