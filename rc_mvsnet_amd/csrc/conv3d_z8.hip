@@ -9,8 +9,10 @@
 // pieces), each stages its share of the next input plane (split into fp16 pieces on the way into a two-slot LDS ring), one barrier per
 // input plane.  A SIMD hosts two such waves: while one waits for LDS or memory the other issues MFMAs.
 // Work is a STREAM of planes: a block takes a contiguous range of the flattened (tile, z) steps; an item (tile, z range of n planes) needs
-// n + 2 input planes = n + 2 ticks (the ring, the register queue and the loads run on across item boundaries: no latency is exposed when
-// the block moves to its next tile).  Tick t: park stream plane t + 1 (requested two ticks earlier), request stream plane t + 3, feed
+// the n + 2 input planes around it -- minus the planes outside the volume (round 6: the zero planes z = -1 and z = D are never fed; the tick
+// that feeds plane D - 1 stores the last TWO output planes), so a whole tile costs D ticks and only a cut inside a tile costs two extra
+// (the ring, the register queue and the loads run on across item boundaries: no latency is exposed when the block moves to its next tile).
+// Tick t: park stream plane t + 1 (requested two ticks earlier), request stream plane t + 3, feed
 // stream plane t to the three rolling accumulators (kd = 0, 1, 2: output planes t, t - 1, t - 2 of the item) and store the one it completes.
 // Measured on the way (16 -> 8 at 32 x 256 x 320; profiles/r4_z8.txt): three planes read per output plane instead of rolling accumulators
 // 74.3 us (LDS bandwidth is not the bound); a cursor object instead of the closed-form stream plan 72.2; with every memory, LDS and MFMA
@@ -61,17 +63,19 @@ struct Z8Dims {
 };
 
 // The block's stream in closed form: its steps [lo, hi) of the flattened (tile, z) sequence fall into items -- a first one (tile0, planes zb0 ..
-// zb0 + nz0 - 1), full tiles, a tail -- and item k contributes nz_k + 2 stream planes.  Stream position s -> (tile, plane of the item ip, zb, nz)
-// costs a dozen scalar instructions (a cursor object with its 64-bit divisions inlined four times per loop body was most of a tick's
-// 700 instructions: 37 of 75 us with every memory, LDS and MFMA instruction switched off).
-struct Z8Plan { int nticks, L0, tile0, zb0, nz0, last, nz_last, Dp2; unsigned inv; };
-__device__ __forceinline__ bool z8_entry(const Z8Plan& p, int D, int s, int& tile, int& ip, int& zb, int& nz) {
+// zb0 + nz0 - 1), full tiles, a tail.  Item-local input plane ip stands for input plane zb - 1 + ip; an item feeds ip = a0 .. a1 - 1 with
+// a0 = 1 when it starts at the volume's first plane (zb = 0) and a1 = nz + 1 when it ends at its last (zb + nz = D), else 0 / nz + 2: a full
+// tile is D stream planes (ip = 1 .. D), a tail nz + 1 (ip = 1 .. nz + 1).  Stream position s -> (tile, ip, zb, nz) costs a dozen scalar
+// instructions (a cursor object with its 64-bit divisions inlined four times per loop body was most of a tick's 700 instructions: 37 of
+// 75 us with every memory, LDS and MFMA instruction switched off).
+struct Z8Plan { int nticks, L0, a00, tile0, zb0, nz0, last, nz_last, D; unsigned inv; };
+__device__ __forceinline__ bool z8_entry(const Z8Plan& p, int s, int& tile, int& ip, int& zb, int& nz) {
     if (s >= p.nticks) return false;
-    if (s < p.L0) { tile = p.tile0; ip = s; zb = p.zb0; nz = p.nz0; return true; }
+    if (s < p.L0) { tile = p.tile0; ip = s + p.a00; zb = p.zb0; nz = p.nz0; return true; }
     const int x = s - p.L0;
-    const int k1 = (int)__umulhi((unsigned)x, p.inv);          // x / (D + 2), exact for x < 2^16 (host-checked)
-    tile = p.tile0 + 1 + k1; ip = x - k1 * p.Dp2; zb = 0;
-    nz = (1 + k1 == p.last) ? p.nz_last : D;
+    const int k1 = p.D == 1 ? x : (int)__umulhi((unsigned)x, p.inv);      // x / D, exact for x < 2^16 (host-checked; D = 1 has no 32-bit reciprocal)
+    tile = p.tile0 + 1 + k1; ip = x - k1 * p.D + 1; zb = 0;
+    nz = (1 + k1 == p.last) ? p.nz_last : p.D;
     return true;
 }
 
@@ -101,9 +105,10 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
         const int R = S - pl.nz0, full = R / dm.D, tail = R % dm.D;
         const int nitems = 1 + full + (tail > 0);
         pl.last = nitems - 1; pl.nz_last = tail > 0 ? tail : dm.D;
-        pl.L0 = pl.nz0 + 2; pl.Dp2 = dm.D + 2;
-        pl.inv = (unsigned)(0x100000000ull / (unsigned)pl.Dp2) + 1u;
-        pl.nticks = S + 2 * nitems;
+        pl.a00 = pl.zb0 == 0 ? 1 : 0;
+        pl.L0 = pl.nz0 + 2 - pl.a00 - (pl.zb0 + pl.nz0 == dm.D ? 1 : 0); pl.D = dm.D;
+        pl.inv = (unsigned)(0x100000000ull / (unsigned)dm.D) + 1u;
+        pl.nticks = pl.L0 + full * dm.D + (tail > 0 ? tail + 1 : 0);
     }
 
     // ---- scales, weights (register-stationary), this lane's B-fragment offsets inside a slice
@@ -140,11 +145,13 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     int loff[NLD], hyx[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int e = tid + i * 512, v = e / C::Q4, c4 = e % C::Q4;
+        // (a thread whose last share lies past the end of the plane repeats its previous one -- the same load, the same pieces to the same LDS
+        // address -- so that stash() is straight-line code: 1 - 2 us per launch against exec-masked stores)
+        static_assert(NLD * 512 - C::TYP * C::TXP * C::Q4 <= 512 && C::TYP * C::TXP * C::Q4 >= 512, "the repeated share exists");
+        const int e0 = tid + i * 512, e = e0 >= C::TYP * C::TXP * C::Q4 ? e0 - 512 : e0, v = e / C::Q4, c4 = e % C::Q4;
         const int hy = v / C::TXP, hx = v % C::TXP;
-        const bool has = e < C::TYP * C::TXP * C::Q4;
-        loff[i] = has ? hy * C::ROWB + hx * C::VB + ((c4 * 8) ^ z8_swz<CIN>(hx)) : -1;
-        hyx[i] = has ? (hy << 20) | (hx << 8) | c4 : -1;
+        loff[i] = hy * C::ROWB + hx * C::VB + ((c4 * 8) ^ z8_swz<CIN>(hx));
+        hyx[i] = (hy << 20) | (hx << 8) | c4;
     }
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)((long long)dm.B * dm.D * dm.H * dm.W * CIN * 4), 0x00020000);
     const int zstride = dm.H * dm.W * CIN * 4;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     int f_tile = -1;
     auto fetch = [&](x3_f32x4 (&q)[NLD], int sf) {
         int tile, ip, zb, nz;
-        const bool valid = z8_entry(pl, dm.D, sf, tile, ip, zb, nz);
+        const bool valid = z8_entry(pl, sf, tile, ip, zb, nz);
         bool zin = false;
         int zoff = 0;
         if (valid) {
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
                 for (int i = 0; i < NLD; ++i) {
                     const int hy = hyx[i] >> 20, hx = (hyx[i] >> 8) & 0xfff, c4 = hyx[i] & 0xff;
                     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                    goff[i] = (hyx[i] >= 0 && gy >= 0 && gy < dm.H && gx >= 0 && gx < dm.W) ? base + ((hy * dm.W + hx) * CIN + c4 * 4) * 4 : OOB;
+                    goff[i] = (gy >= 0 && gy < dm.H && gx >= 0 && gx < dm.W) ? base + ((hy * dm.W + hx) * CIN + c4 * 4) * 4 : OOB;
                 }
             }
             const int z = zb - 1 + ip;
@@ -184,10 +191,8 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
         for (int i = 0; i < NLD; ++i) {
             x3_u32x2 h, l;
             x3_split4h(q[i] * xs_scale, h, l);
-            if (loff[i] >= 0) {
-                *reinterpret_cast<x3_u32x2*>(sb + loff[i]) = h;
-                *reinterpret_cast<x3_u32x2*>(sb + C::PLB + loff[i]) = l;
-            }
+            *reinterpret_cast<x3_u32x2*>(sb + loff[i]) = h;
+            *reinterpret_cast<x3_u32x2*>(sb + C::PLB + loff[i]) = l;
         }
     };
 
@@ -215,15 +220,13 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
         stash(q, (t + 1) & 1);
         fetch(q, t + 1 + QD);
         int ctile, ip, czb, cnz;                           // ip = plane of the item (0 .. nz + 1): input plane zb - 1 + ip
-        z8_entry(pl, dm.D, t, ctile, ip, czb, cnz);        // (t < nticks: the loop's own bound)
+        z8_entry(pl, t, ctile, ip, czb, cnz);              // (t < nticks: the loop's own bound)
         {
-            if (ip == 0) {
+            if (ip == (czb == 0 ? 1 : 0)) {                // first plane of the item: empty accumulators, where this lane's voxels of output plane zb go
 #pragma unroll
                 for (int i = 0; i < C::NTW; ++i)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) acc[i][c] = (x3_f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            if (ip == 2) {                                 // first output plane of the item: where this lane's voxels go
                 const int b = ctile / dm.ntiles, tl = ctile % dm.ntiles;
 #pragma unroll
                 for (int i = 0; i < C::NTW; ++i) {
@@ -275,6 +278,15 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
                     const bool in = ob[i] != OOB;
                     vmax = in ? x3_absmax4(vmax, v) : vmax;
                     ob[i] = in ? ob[i] + ostep : OOB;
+                }
+            }
+            if (ip == cnz && czb + cnz == dm.D) {          // the item ends at the volume's last plane: plane D (zeros) is not fed, output plane D - 1 is complete as well
+#pragma unroll
+                for (int i = 0; i < C::NTW; ++i) {
+                    x3_f32x4 v = acc[i][1] * sc + sh;
+                    if (dm.relu) v = __builtin_elementwise_max(v, (x3_f32x4){0.f, 0.f, 0.f, 0.f});
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(x3_u32x4, v), yrs, ob[i], 0, 0);
+                    vmax = ob[i] != OOB ? x3_absmax4(vmax, v) : vmax;
                 }
             }
 #pragma unroll
@@ -340,7 +352,7 @@ int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, cons
     dm.tiles_x = (W + 31) / 32;
     dm.ntiles = dm.tiles_x * ((H + ty - 1) / ty);
     const int n_blk = max_blocks > 0 ? max_blocks : cu_of[dev].load();
-    if (((long long)B * dm.ntiles * D + n_blk - 1) / n_blk + 2LL * (((long long)B * dm.ntiles * D + n_blk - 1) / n_blk / D + 3) >= 65536)
+    if (((long long)B * dm.ntiles * D + n_blk - 1) / n_blk + 2 >= 65536)
         return 1;        // too many steps per block for the 16-bit stream arithmetic: not taken (conv3d_x3_launch goes on to the split kernel)
     if (Ci == 8 && Co == 8) return z8_launch_t<8, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);
     if (Ci == 16 && Co == 8) return z8_launch_t<16, 8>(x, wimg, scale, shift, y, dm, n_blk, dev, xmax, ymax, st);

@@ -658,6 +658,39 @@ def test_conv3d_x3_item_schedule_is_bit_exact(hip, Ci, Co, kind):
         assert torch.equal(y, base), (blocks, float((y - base).abs().max()))
 
 
+@pytest.mark.parametrize("Ci", [8, 16, 32])
+@pytest.mark.parametrize("shape", [(1, 1, 9, 35), (1, 2, 17, 40), (2, 5, 9, 70), (1, 11, 20, 33)])
+def test_conv0_stream_cuts_are_bit_exact(hip, Ci, shape):
+    """conv0's z-streaming kernel (csrc/conv3d_z8.hip, fp16-pair form) cuts the flattened (tile, z) sequence into one range per block and
+    never feeds the planes outside the volume (a whole tile is D ticks; the tick of plane D - 1 stores two output planes).  Whatever the
+    block count -- 1: every tile whole; 3 / 7: cuts inside tiles, items that start or end at either face of the volume, one-plane items;
+    default: one step per block on these sizes -- every output voxel sees the same arithmetic: results are bit-identical, and they are
+    the fp64 convolution to the pair form's accuracy."""
+    if DEV == "cpu" and (Ci == 32 or shape[1] > 5) and os.environ.get("RCMVS_EMU_FULL", "0") != "1":
+        pytest.skip("a minute on the kernel emulation: RCMVS_EMU_FULL=1 (always run on the GPU)")
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(Ci + D)
+    x = torch.randn(B, Ci, D, H, W, generator=g) * torch.exp(torch.randn(B, Ci, D, H, W, generator=g))
+    w = torch.randn(8, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+    scale, shift = gpu(0.5 + torch.rand(8, generator=g)), gpu(0.1 * torch.randn(8, generator=g))
+    ref = torch.relu(torch.nn.functional.conv3d(x.double(), w.double(), padding=1) * scale.cpu().double().view(1, -1, 1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1, 1))
+    xcl = gpu(x.permute(0, 2, 3, 4, 1))
+    wp = hip.pack_conv3d_weight(gpu(w))
+    xmax = hip.absmax(xcl)
+    ymax = torch.zeros(hip.ABSMAX_FLOATS, device=xcl.device)
+    base = hip.conv3d(xcl, wp, scale, shift, relu=True, x_absmax=xmax, y_absmax=ymax)
+    assert float(ymax.max()) == float(base.abs().max())
+    err = float((base.cpu().permute(0, 4, 1, 2, 3).double() - ref).abs().max())
+    assert err < 3e-6 * float(ref.abs().max()), err
+    for blocks in (1, 3, 7):
+        try:
+            hip.force_direct_conv(blocks << 8)          # bits 8-15 of the debug selector: cap on the block count
+            y = hip.conv3d(xcl, wp, scale, shift, relu=True, x_absmax=xmax)
+        finally:
+            hip.force_direct_conv(0)
+        assert torch.equal(y, base), (blocks, float((y - base).abs().max()))
+
+
 def test_prob_conv_z_chunk_does_not_change_the_result(hip):
     """The marching prob conv picks its z chunk per launch (grid fill); a block stages chunk + 2 planes, every output voxel still sums
     the same three planes in the same order: any chunk length (debug selector bits 16-23) must give bit-identical logits."""

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from rc_mvsnet_amd import _lib, ops, synthetic
 from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+if os.environ.get("RCMVS_LIB"):          # a variant build (tools/dev/build_*_variants.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["RCMVS_LIB"])
 _lib.load()
 dev = "cuda:0"
 V, H, W = int(os.environ.get("V", 3)), int(os.environ.get("H", 512)), int(os.environ.get("W", 640))
@@ -16,8 +18,9 @@ scene = (i.to(dev), {k: v.to(dev) for k, v in p.items()}, d.to(dev))
 N = 20
 with torch.no_grad():
     for _ in range(5):
-        m(*scene)
+        out = m(*scene)
     torch.cuda.synchronize()
+    print("lib", os.environ.get("RCMVS_LIB", "product"), "depth checksum %.10e" % float(out["depth"].double().sum()))
     ev = []
     ops.CONV_EVENTS = ev
     for _ in range(N):
