@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 105          /* 0.1.5 -- 105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl, rcmvs_warp_variance_timed_fwd, rcmvs_conv2d_pair_fwd (+ pack, floats).  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
+#define RCMVS_VERSION 106          /* 0.1.6 -- 106: + rcmvs_conv2d_stem_fwd (+ pack, floats).  105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl, rcmvs_warp_variance_timed_fwd, rcmvs_conv2d_pair_fwd (+ pack, floats).  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
                                       the FMA-contracted forms are opted into with RCMVS_K1_FAST_BLEND of rcmvs_warp_variance_hint_fwd; the plane-pipelined form
                                       (variant 7) takes 2, 3, 4 or 6 source views.
                                       103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5-7; rcmvs_warp_variance_fwd is FMA-contracted for V = 3, C = 8;
@@ -497,6 +497,19 @@ long long rcmvs_conv2d_pair_weight_floats(void);
 int rcmvs_pack_conv2d_pair(const float* wa, const float* wb, float* image, void* stream);
 int rcmvs_conv2d_pair_fwd(const float* x, const float* image, const float* scale_a, const float* shift_a, const float* scale_b, const float* shift_b,
                           float* y, int N, int H, int W, int C, void* stream);
+
+/* FeatureNet's first block in one launch (csrc/conv2d_stem.hip): replaces
+ *   conv0 = self.conv0(x)        (models/modules.py:372-373,413-415: Conv2d(3, 8, 3, 1) -> Conv2d(8, 8, 3, 1), each conv + BatchNorm(eval) + ReLU)
+ * x (N,3,H,W) planar images as the reference hands them over -> y (N,H,W,8) channels-last.  First layer: fp32 FMA chain in the tap order of
+ * rcmvs_conv2d_fwd (w_a_packed = that layer's weight from rcmvs_pack_conv2d_weight with the input channels padded to 4); second layer: exact
+ * split-bf16 matrix-core arithmetic like the planar kernel it replaces (image_b from rcmvs_pack_conv2d_stem: (8,8,3,3) Conv2d weight ->
+ * rcmvs_conv2d_stem_weight_floats() floats); the 8-channel map between the two layers stays in LDS.  scale / shift: the folded BatchNorm of
+ * each layer (8 floats each). */
+long long rcmvs_conv2d_stem_weight_floats(void);
+int rcmvs_pack_conv2d_stem(const float* wb, float* image, void* stream);
+int rcmvs_conv2d_stem_fwd(const float* x, const float* w_a_packed, const float* scale_a, const float* shift_a, const float* image_b, const float* scale_b,
+                          const float* shift_b, float* y, int N, int H, int W, void* stream);
+
 /* The train variant's small images: F.interpolate(imgs, (h, w), mode="bilinear", align_corners=False) (models/casmvsnet.py:60-62,148-150) fused with
  * the channels-last transpose the warp kernels want: x (N,3,H,W) planar -> y (N,h,w,3); ATen's upsample_bilinear2d arithmetic. */
 int rcmvs_resize_rgb_cl(const float* x, float* y, int N, int H, int W, int h, int w, void* stream);

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librcmvs_hip.so")
-REQUIRED_VERSION = 105      # RCMVS_VERSION of include/rcmvs.h this binding was written against (105: rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd)
+REQUIRED_VERSION = 106      # RCMVS_VERSION of include/rcmvs.h this binding was written against (106: rcmvs_conv2d_stem_fwd)
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rcmvs.h")
 
@@ -56,6 +56,9 @@ SIGNATURES = {
     "rcmvs_conv2d_pair_weight_floats": [],
     "rcmvs_pack_conv2d_pair": [_p, _p, _p, _p],
     "rcmvs_conv2d_pair_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_conv2d_stem_weight_floats": [],
+    "rcmvs_pack_conv2d_stem": [_p, _p, _p],
+    "rcmvs_conv2d_stem_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "rcmvs_conv1x1_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_conv1x1_mfma_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "rcmvs_fpn_out_fused": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -104,7 +107,7 @@ SIGNATURES = {
     "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
 }
 _RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll, "rcmvs_nerf_workspace_floats": _ll, "rcmvs_nerf_train_workspace_floats": _ll, "rcmvs_nerf_bwd_workspace_floats": _ll,
-             "rcmvs_packed_weight_floats": _ll, "rcmvs_fpn_folded_mfma_floats": _ll, "rcmvs_conv2d_pair_weight_floats": _ll}
+             "rcmvs_packed_weight_floats": _ll, "rcmvs_fpn_folded_mfma_floats": _ll, "rcmvs_conv2d_pair_weight_floats": _ll, "rcmvs_conv2d_stem_weight_floats": _ll}
 
 _lib = None
 
@@ -152,10 +155,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RcmvsError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("RCMVS_LIB") or LIB_PATH       # RCMVS_LIB: another build of the same ABI (developer A/B of kernel variants, tools/dev/build_variant.sh)
+    if not os.path.exists(path):
+        raise RcmvsError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes

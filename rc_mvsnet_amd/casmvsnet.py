@@ -26,6 +26,7 @@ HEAD_PAIR = os.environ.get("RCMVS_HEAD_PAIR", "1") != "0"       # ... and the de
 # the last transposed layer + the prob conv (+ the head, D = 8) in one pass (csrc/conv11_prob.hip): 1 = at the cascade's last stage (D = 8: 50 against 70 us on
 # a DTU scene; at the other stages the two launches are as fast, profiles/r6_conv11_prob.txt), 2 = at every stage, 0 = never (the 8-channel volume in memory)
 CONV11_PROB = int(os.environ.get("RCMVS_CONV11_PROB", "1"))
+CONV_STEM = os.environ.get("RCMVS_CONV_STEM", "1") != "0"       # FeatureNet's conv0.0 -> conv0.1 as one launch (csrc/conv2d_stem.hip); 0 = the tile kernel + the planar kernel
 CONV_PAIR = os.environ.get("RCMVS_CONV_PAIR", "1") != "0"       # FeatureNet's conv1.1 -> conv1.2 as one launch (csrc/conv2d_pair.hip); 0 = two launches of the planar kernel
 DEEP_PAIR = os.environ.get("RCMVS_DEEP_PAIR", "1") != "0"       # ... its deep levels (conv5-7) included (csrc/conv3d_deep.hip); 0 = fp32 MFMAs there
 
@@ -258,6 +259,10 @@ class FeatureNet(nn.Module):
             m11, m12 = mods[3], mods[4]
             if CONV_PAIR and all(tuple(m.conv.weight.shape) == (16, 16, 3, 3) and m.stride == 1 for m in (m11, m12)):
                 plan["pair1"] = (ops.pack_conv2d_pair(m11.conv.weight, m12.conv.weight),) + _bn_fold(m11.bn) + _bn_fold(m12.bn)
+            # conv0.0 -> conv0.1 (3 -> 8 -> 8, stride 1) as ONE launch from the planar images (csrc/conv2d_stem.hip)
+            m00, m01 = mods[0], mods[1]
+            if CONV_STEM and tuple(m00.conv.weight.shape) == (8, 3, 3, 3) and tuple(m01.conv.weight.shape) == (8, 8, 3, 3) and m00.stride == 1 and m01.stride == 1:
+                plan["stem"] = (plan["conv0.0"][0],) + _bn_fold(m00.bn) + (ops.pack_conv2d_stem(m01.conv.weight),) + _bn_fold(m01.bn)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
             if unet:
                 for n in ("out2", "out3")[:self.num_stage - 1]:           # 1x1, Co = Ci: the middle tap of a one-plane 3-D kernel
@@ -307,13 +312,18 @@ class FeatureNet(nn.Module):
             return ops.conv2d(t, w, sc, sh, stride=stride, relu=True)
 
         w00 = p["conv0.0"][0] if len(p["conv0.0"]) == 4 else None
-        # the planar first layer is built for the reference's 3 -> 8, k = 3, stride 1 (base_channels = 8); other widths take the NHWC4 path
-        if w00 is not None and w00.ci == 4 and w00.co == 8 and w00.k == 3 and p["conv0.0"][3] == 1 and not ops._CONV_IMPL:
-            w, sc, sh, _ = p["conv0.0"]                              # the first layer reads the planar images itself (no NHWC4 pass)
-            c00 = ops.conv2d_rgb(x.contiguous().float(), w, sc, sh, relu=True)
+        if "stem" in p and not ops._CONV_IMPL:
+            c0 = ops.conv2d_stem(x.contiguous().float(), *p["stem"])
         else:
-            c00 = cbr(ops.rgb_to_nhwc4(x.contiguous().float()), "conv0.0")
-        c0 = cbr(c00, "conv0.1")
+            c0 = None
+        # the planar first layer is built for the reference's 3 -> 8, k = 3, stride 1 (base_channels = 8); other widths take the NHWC4 path
+        if c0 is not None:
+            pass
+        elif w00 is not None and w00.ci == 4 and w00.co == 8 and w00.k == 3 and p["conv0.0"][3] == 1 and not ops._CONV_IMPL:
+            w, sc, sh, _ = p["conv0.0"]                              # the first layer reads the planar images itself (no NHWC4 pass)
+            c0 = cbr(ops.conv2d_rgb(x.contiguous().float(), w, sc, sh, relu=True), "conv0.1")
+        else:
+            c0 = cbr(cbr(ops.rgb_to_nhwc4(x.contiguous().float()), "conv0.0"), "conv0.1")
         if "pair1" in p and not ops._CONV_IMPL:
             c1 = ops.conv2d_pair(cbr(c0, "conv1.0"), *p["pair1"])
         else:

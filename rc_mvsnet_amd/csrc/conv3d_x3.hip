@@ -134,7 +134,10 @@ struct X3 {
     static constexpr int MT = MT_ALL / MSPLIT;                           // m-tiles per consumer wave
     static constexpr int KSW = (KSTEPS + KSPLIT - 1) / KSPLIT;          // K steps per consumer wave
     static constexpr int TX = ((x3_unit(KIND) && CIN >= 32) || (KIND == X3_S2 && CIN >= 16) || NCW == 6) ? 16 : 32;
-    static constexpr int TY = (MAP == X3_XT) ? 8 : ((KIND == X3_S2 || NCW == 6) ? 2 : 4);      // (TY = 6 on the two-piece form, whose smaller ring leaves the LDS for it: halo 1.59x -> 1.42x, 32 -> 8 89.0 -> 85.1 us, 16 -> 8 116.4 -> 115.0: not worth a third tile geometry)
+#ifndef X3_P1_TY32
+#define X3_P1_TY32 8
+#endif
+    static constexpr int TY = (MAP == X3_XT) ? 8 : ((KIND == X3_P1 && CIN == 32 && NCW == 4) ? X3_P1_TY32 : ((KIND == X3_S2 || NCW == 6) ? 2 : 4));      // (TY = 6 on the two-piece form, whose smaller ring leaves the LDS for it: halo 1.59x -> 1.42x, 32 -> 8 89.0 -> 85.1 us, 16 -> 8 116.4 -> 115.0: not worth a third tile geometry)
     static constexpr int CS = (MAP == X3_XT || KIND == X3_S2) ? 2 : 1;   // voxels between neighbouring columns
     static constexpr int RS = (MAP == X3_YT || KIND == X3_S2) ? 2 : 1;   // halo rows between neighbouring tile rows
     static constexpr int TYP = x3_unit(KIND) ? TY + 2 : (KIND == X3_S2 ? 2 * TY + 1 : TY + 1);

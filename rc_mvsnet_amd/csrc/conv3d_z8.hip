@@ -23,6 +23,7 @@
 #include "common.h"
 #include "x3_pieces.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace rcmvs {
 
@@ -312,8 +313,12 @@ __global__ __launch_bounds__(512) void conv3d_z8_kernel(
     }
 }
 
-// (16 -> 16, conv2, runs on this kernel too -- the plain M = co map is in the template -- but does not gain: 24.4 against 24.2 us; it stays on the split kernel)
-bool conv3d_z8_supported(int Ci, int Co, int kind) { return kind == 0 && Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32); }
+bool conv3d_z8_supported(int Ci, int Co, int kind) {
+    // conv2 (16 -> 16) runs here too since the planes outside the volume are no longer fed (same-box, us per launch at stages 1 / 2 / 3: 20.3 / 27.4 / 28.0
+    // against 20.0 / 30.0 / 31.6 on the split kernel); RCMVS_Z8_CONV2=0 sends it back (A/B, and the test of the split kernel's 16 -> 16 pair form)
+    static const bool conv2 = [] { const char* e = getenv("RCMVS_Z8_CONV2"); return !e || e[0] != '0'; }();
+    return kind == 0 && ((Co == 8 && (Ci == 8 || Ci == 16 || Ci == 32)) || (conv2 && Ci == 16 && Co == 16));
+}
 
 template <int CIN, int COUT>
 static int z8_launch_t(const float* x, const float* wimg, const float* scale, const float* shift, float* y, const Z8Dims& dm, int n_cu, int dev,

@@ -477,6 +477,28 @@ def conv2d_rgb(x, w_packed, scale=None, shift=None, relu=False):
     return y
 
 
+def pack_conv2d_stem(wb):
+    """The (8,8,3,3) Conv2d weight of FeatureNet's conv0.1 -> the fragment image of conv2d_stem (csrc/conv2d_stem.hip)."""
+    if tuple(wb.shape) != (8, 8, 3, 3):
+        raise _lib.RcmvsError("pack_conv2d_stem: built for an 8 -> 8 3x3 second layer")
+    lib = _lib.load()
+    img = torch.empty(int(lib.rcmvs_conv2d_stem_weight_floats()), device=wb.device, dtype=torch.float32)
+    _lib.check(lib.rcmvs_pack_conv2d_stem(_chk(wb.detach().float().contiguous(), "wb"), _chk(img, "image"), _stream()), "pack_conv2d_stem")
+    return img
+
+
+def conv2d_stem(x, w_a_packed, scale_a, shift_a, image_b, scale_b, shift_b):
+    """FeatureNet's conv0 block in one launch: x (N,3,H,W) planar -> (N,H,W,8) channels-last = relu(bn_b(conv_b(relu(bn_a(conv_a(x)))))).
+    w_a_packed: the 3 -> 8 3x3 weight packed with pad_in_to=4 (pack_conv2d_weight); image_b: pack_conv2d_stem."""
+    N, C, H, W = x.shape
+    if C != 3 or w_a_packed.ci != 4 or w_a_packed.co != 8 or w_a_packed.k != 3:
+        raise _lib.RcmvsError(f"conv2d_stem: expected a (N,3,H,W) input and a 3 -> 8 3x3 weight packed to 4 input channels (got {tuple(x.shape)}, {w_a_packed.ci} -> {w_a_packed.co}, k={w_a_packed.k})")
+    y = torch.empty((N, H, W, 8), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcmvs_conv2d_stem_fwd(_chk(x, "x"), _chk(w_a_packed.blob, "w_a"), _chk(scale_a, "scale_a"), _chk(shift_a, "shift_a"), _chk(image_b, "image_b"),
+                                                 _chk(scale_b, "scale_b"), _chk(shift_b, "shift_b"), _chk(y, "y"), N, H, W, _stream()), "conv2d_stem_fwd")
+    return y
+
+
 def fpn_out_fused(lat, up, w_inner_packed, b_inner, w_out_packed):
     """conv3x3(up2(up) + conv1x1(lat) + bias): lat (N,H,W,8), up (N,H/2,W/2,32) -> (N,H,W,8), the 32-channel merge never stored."""
     N, H, W, CL = lat.shape

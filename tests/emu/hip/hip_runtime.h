@@ -358,6 +358,16 @@ inline emu_v2u __builtin_amdgcn_raw_buffer_load_b64_emu(__amdgpu_buffer_rsrc_t r
     return v;
 }
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b128_emu((r), (v), (s), (a))
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32_emu(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned long long)(unsigned)soffset;
+    unsigned v = 0u;
+    if (off < r.num_records && off + 4u <= r.num_records) std::memcpy(&v, r.base + off, 4);
+    return v;
+}
+#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) __builtin_amdgcn_raw_buffer_load_b32_emu((r), (v), (s), (a))
+// v_med3_f32 on non-NaN operands: the median of three
+inline float __builtin_amdgcn_fmed3f_emu(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
+#define __builtin_amdgcn_fmed3f(a, b, c) __builtin_amdgcn_fmed3f_emu((a), (b), (c))
 // raw buffer stores drop out-of-range lanes
 inline void __builtin_amdgcn_raw_buffer_store_b128_emu(emu_v4u v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     const unsigned off = (unsigned)voffset + (unsigned)soffset;

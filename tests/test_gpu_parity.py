@@ -286,6 +286,34 @@ def test_warp_variance_window_form(hip):
         hip.warp_variance(feats, rot, trans, planes, 8, variant=5)
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 28, 60), (1, 37, 53), (3, 9, 11), (3, 64, 96), (3, 512, 640)])
+def test_conv2d_stem_vs_fp64(hip, N, H, W):
+    """FeatureNet's conv0 block (Conv2d(3, 8) -> Conv2d(8, 8), each conv + BatchNorm(eval) + ReLU, models/modules.py:372-373) in one launch from the
+    planar images (csrc/conv2d_stem.hip, the 8-channel map between the layers in LDS) against an fp64 evaluation, next to the two launches it
+    replaces (the first layer on the tile kernel, the second on the planar split-bf16 kernel): exact tile multiples, ragged tiles, maps smaller
+    than a tile, the second layer's zero padding of the INTERMEDIATE map at the image border; more tiles than resident blocks (the blocks are
+    persistent: 60 tiles on the emulation's 24 resident blocks, a DTU scene's 2 442 on the GPU's 1 024)."""
+    if DEV == "cpu" and H > 100:
+        pytest.skip("GPU only: minutes on the kernel emulation")
+    g = torch.Generator().manual_seed(H * 5 + W)
+    x = torch.randn(N, 3, H, W, generator=g) * torch.exp(0.5 * torch.randn(N, 3, H, W, generator=g))
+    wa, wb = torch.randn(8, 3, 3, 3, generator=g) / 5.0, torch.randn(8, 8, 3, 3, generator=g) / 8.0
+    sa, sb = (0.5 + torch.rand(8, generator=g) for _ in range(2))
+    ha, hb = (0.2 * torch.randn(8, generator=g) for _ in range(2))
+    f = torch.nn.functional
+    mid = torch.relu(f.conv2d(x.double(), wa.double(), padding=1) * sa.double().view(1, -1, 1, 1) + ha.double().view(1, -1, 1, 1))
+    ref = torch.relu(f.conv2d(mid, wb.double(), padding=1) * sb.double().view(1, -1, 1, 1) + hb.double().view(1, -1, 1, 1))
+    pa = hip.pack_conv2d_weight(gpu(wa), pad_in_to=4)
+    got = hip.conv2d_stem(gpu(x), pa, gpu(sa), gpu(ha), hip.pack_conv2d_stem(gpu(wb)), gpu(sb), gpu(hb)).cpu().permute(0, 3, 1, 2).double()
+    w3 = lambda w: torch.cat((torch.zeros_like(w).unsqueeze(2), w.unsqueeze(2), torch.zeros_like(w).unsqueeze(2)), dim=2)
+    t = hip.conv2d_rgb(gpu(x), pa, gpu(sa), gpu(ha), relu=True)
+    two = hip.conv3d(t.unsqueeze(1), hip.pack_conv3d_weight(gpu(w3(wb))), gpu(sb), gpu(hb), relu=True).squeeze(1).cpu().permute(0, 3, 1, 2).double()
+    mag = float(ref.abs().max())
+    e_f, e_2 = float((got - ref).abs().max()), float((two - ref).abs().max())
+    print(f"conv2d stem {N}x{H}x{W}: max error vs fp64 / max: fused {e_f / mag:.2e}, two launches {e_2 / mag:.2e}")
+    assert e_f <= 2.0 * e_2 + 2e-7 * mag and e_f < 2e-6 * mag
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 8, 30), (2, 19, 47), (3, 32, 64), (1, 5, 3)])
 def test_conv2d_pair_vs_fp64(hip, N, H, W):
     """FeatureNet's conv1.1 -> conv1.2 (two 16 -> 16 3x3 Conv2d blocks: conv + BatchNorm(eval) + ReLU, models/modules.py:372-379) in one launch
@@ -465,9 +493,9 @@ def test_conv3d_x3h_marching_forms_of_the_layers_that_moved_to_the_tile_kernel(h
     import subprocess, sys
     if DEV == "cpu":
         pytest.skip("GPU only: a child pytest process on the kernel emulation would take minutes")
-    env = dict(os.environ, RCMVS_DEEP3="0", RCMVS_DEEP4="0", RCMVS_DEEP9="0")
+    env = dict(os.environ, RCMVS_DEEP3="0", RCMVS_DEEP4="0", RCMVS_DEEP9="0", RCMVS_Z8_CONV2="0")      # (+ conv2, 16 -> 16, which runs on the z-streaming kernel of csrc/conv3d_z8.hip since round 6)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
-                        "test_conv3d_x3h_vs_fp64 and (32-32-s1 or 32-16-t2 or 16-32-s2)"], env=env, capture_output=True, text=True, timeout=900)
+                        "test_conv3d_x3h_vs_fp64 and (32-32-s1 or 32-16-t2 or 16-32-s2 or 16-16-s1)"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
