@@ -853,6 +853,10 @@ int conv3d_deep_launch(const float* x, const float* wimg, const float* scale, co
 
 // conv3d_z8.hip: conv0 of stages 2 / 3 (Cin = 16 / 8 -> 8) and conv2 (16 -> 16), stride 1, no skip tensor, without the producer / consumer split; same image
 bool conv3d_z8_supported(int Ci, int Co, int kind);
+// conv3d_zs2.hip: conv1 (8 -> 16, stride 2) of a B = 1 inference scene on the same z-streaming scheme
+bool conv3d_zs2_supported(int Ci, int Co, int kind);
+int conv3d_zs2_launch(const float* x, const float* wimg, const float* scale, const float* shift, float* y,
+                      int B, int D, int H, int W, int relu, hipStream_t st, int max_blocks, const float* xmax, float* ymax);
 int conv3d_z8_launch(const float* x, const float* wimg, const float* scale, const float* shift, float* y,
                      int B, int D, int H, int W, int Ci, int Co, int relu, hipStream_t st, int max_blocks, const float* xmax, float* ymax);
 
@@ -980,6 +984,10 @@ int conv3d_x3_launch(const float* x, const float* wimg, const float* scale, cons
     if (xmax && !res && !s2d && conv3d_z8_supported(Ci, Co, kind)) {
         const int rc = conv3d_z8_launch(x, wimg, scale, shift, y, B, D, H, W, Ci, Co, relu, st, max_blocks, xmax, ymax);
         if (rc != 1) return rc;        // (1 = not taken: volumes with more than 64 k steps per block stay on the split kernel)
+    }
+    if (xmax && !res && !s2d && conv3d_zs2_supported(Ci, Co, kind)) {
+        const int rc = conv3d_zs2_launch(x, wimg, scale, shift, y, B, D, H, W, relu, st, max_blocks, xmax, ymax);
+        if (rc != 1) return rc;
     }
     const int ysq = (s2d >> 1) & 1;            // `s2d` carries two flags: bit 0 = space-to-depth view of the input, bit 1 = square the output bound
     s2d &= 1;

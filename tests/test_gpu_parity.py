@@ -493,9 +493,9 @@ def test_conv3d_x3h_marching_forms_of_the_layers_that_moved_to_the_tile_kernel(h
     import subprocess, sys
     if DEV == "cpu":
         pytest.skip("GPU only: a child pytest process on the kernel emulation would take minutes")
-    env = dict(os.environ, RCMVS_DEEP3="0", RCMVS_DEEP4="0", RCMVS_DEEP9="0", RCMVS_Z8_CONV2="0")      # (+ conv2, 16 -> 16, which runs on the z-streaming kernel of csrc/conv3d_z8.hip since round 6)
+    env = dict(os.environ, RCMVS_DEEP3="0", RCMVS_DEEP4="0", RCMVS_DEEP9="0", RCMVS_Z8_CONV2="0", RCMVS_ZS2="0")      # (+ conv2, 16 -> 16, and conv1, 8 -> 16 stride 2, which run on the z-streaming kernels of csrc/conv3d_z8.hip / conv3d_zs2.hip since round 6)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
-                        "test_conv3d_x3h_vs_fp64 and (32-32-s1 or 32-16-t2 or 16-32-s2 or 16-16-s1)"], env=env, capture_output=True, text=True, timeout=900)
+                        "test_conv3d_x3h_vs_fp64 and (32-32-s1 or 32-16-t2 or 16-32-s2 or 16-16-s1 or 8-16-s2)"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -714,6 +714,39 @@ def test_conv0_stream_cuts_are_bit_exact(hip, Ci, shape):
         try:
             hip.force_direct_conv(blocks << 8)          # bits 8-15 of the debug selector: cap on the block count
             y = hip.conv3d(xcl, wp, scale, shift, relu=True, x_absmax=xmax)
+        finally:
+            hip.force_direct_conv(0)
+        assert torch.equal(y, base), (blocks, float((y - base).abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 9, 35), (1, 2, 17, 40), (2, 5, 9, 70), (1, 8, 20, 33), (1, 11, 33, 130)])
+def test_conv1_stream_cuts_are_bit_exact(hip, shape):
+    """conv1 (8 -> 16, stride 2) on its z-streaming kernel (csrc/conv3d_zs2.hip, fp16-pair form): a tick is an output plane = an input-plane pair, an item
+    that starts inside a tile opens with a lead tick, planes outside the volume (z = -1; z = D for odd D) are never requested.  Whatever the block count
+    -- 1: whole tiles; 3 / 7: cuts inside tiles; default -- every output voxel sees the same arithmetic: results are bit-identical, equal to the split
+    kernel's (RCMVS_ZS2=0 is a child-process switch: here the fp64 convolution stands in, to the pair form's accuracy); even and odd depths, one-plane
+    volumes, ragged tiles, batch 2."""
+    if DEV == "cpu" and shape[1] * shape[3] > 300 and os.environ.get("RCMVS_EMU_FULL", "0") != "1":
+        pytest.skip("a minute on the kernel emulation: RCMVS_EMU_FULL=1 (always run on the GPU)")
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * 31 + W)
+    x = torch.randn(B, 8, D, H, W, generator=g) * torch.exp(torch.randn(B, 8, D, H, W, generator=g))
+    w = torch.randn(16, 8, 3, 3, 3, generator=g) / (8 * 27) ** 0.5
+    scale, shift = gpu(0.5 + torch.rand(16, generator=g)), gpu(0.1 * torch.randn(16, generator=g))
+    ref = torch.relu(torch.nn.functional.conv3d(x.double(), w.double(), padding=1, stride=2) * scale.cpu().double().view(1, -1, 1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1, 1))
+    xcl = gpu(x.permute(0, 2, 3, 4, 1))
+    wp = hip.pack_conv3d_weight(gpu(w))
+    xmax = hip.absmax(xcl)
+    ymax = torch.zeros(hip.ABSMAX_FLOATS, device=xcl.device)
+    base = hip.conv3d(xcl, wp, scale, shift, stride=2, relu=True, x_absmax=xmax, y_absmax=ymax)
+    assert tuple(base.shape) == (B, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 16)
+    assert float(ymax.max()) == float(base.abs().max())
+    err = float((base.cpu().permute(0, 4, 1, 2, 3).double() - ref).abs().max())
+    assert err < 3e-6 * float(ref.abs().max()), err
+    for blocks in (1, 3, 7):
+        try:
+            hip.force_direct_conv(blocks << 8)          # bits 8-15 of the debug selector: cap on the block count
+            y = hip.conv3d(xcl, wp, scale, shift, stride=2, relu=True, x_absmax=xmax)
         finally:
             hip.force_direct_conv(0)
         assert torch.equal(y, base), (blocks, float((y - base).abs().max()))

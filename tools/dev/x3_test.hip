@@ -2,6 +2,8 @@
 // volumes, then HIP-event timings at the config-2 layer shapes.   hipcc --offload-arch=gfx950 -O3 tools/dev/x3_test.hip -o x3_test
 // -DX3_ABLATION=1 adds the phase-ablation switches (X3_DBG=<mask>; the switches themselves slow the MFMA loop: compare within that build only)
 #include "../../rc_mvsnet_amd/csrc/conv3d_x3.hip"
+#include "../../rc_mvsnet_amd/csrc/conv3d_deep.hip"      // (conv3d_x3_launch hands the deep-level and Cout = 8 / conv2 shapes on to these two)
+#include "../../rc_mvsnet_amd/csrc/conv3d_z8.hip"
 #include <vector>
 #include <random>
 #include <cmath>
