@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RCMVS_VERSION 106          /* 0.1.6 -- 106: + rcmvs_conv2d_stem_fwd (+ pack, floats).  105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl, rcmvs_warp_variance_timed_fwd, rcmvs_conv2d_pair_fwd (+ pack, floats).  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
+#define RCMVS_VERSION 106          /* 0.1.6 -- 106: + rcmvs_conv2d_stem_fwd, rcmvs_conv2d_tile_fwd (+ pack, floats each).  105: + rcmvs_conv11_prob_fwd, rcmvs_softmax_head_fwd, rcmvs_resize_rgb_cl, rcmvs_warp_variance_timed_fwd, rcmvs_conv2d_pair_fwd (+ pack, floats).  104: rcmvs_warp_variance_fwd is the exact kernel again for every V and C (bit-identical to the reference-order variant 2);
                                       the FMA-contracted forms are opted into with RCMVS_K1_FAST_BLEND of rcmvs_warp_variance_hint_fwd; the plane-pipelined form
                                       (variant 7) takes 2, 3, 4 or 6 source views.
                                       103: + rcmvs_warp_variance_hint_fwd, rcmvs_debug_warp_variance_win_fwd; rcmvs_debug_warp_variance_fwd takes variants 0-3, 5-7; rcmvs_warp_variance_fwd is FMA-contracted for V = 3, C = 8;
@@ -509,6 +509,18 @@ long long rcmvs_conv2d_stem_weight_floats(void);
 int rcmvs_pack_conv2d_stem(const float* wb, float* image, void* stream);
 int rcmvs_conv2d_stem_fwd(const float* x, const float* w_a_packed, const float* scale_a, const float* shift_a, const float* image_b, const float* scale_b,
                           const float* shift_b, float* y, int N, int H, int W, void* stream);
+
+/* FeatureNet's two 32 -> 16 3x3 layers at half resolution as tile kernels (csrc/conv2d_tile.hip): replaces
+ *   x = self.conv1[0](conv0)                  (s2d = 1: models/modules.py:374,416 -- Conv2d(8, 16, 5, stride=2, padding=2) + BatchNorm(eval) + ReLU as a 3x3 layer on the
+ *                                              space-to-depth view: x is the (N,2H,2W,8) map, the weight the (16,32,3,3) re-indexed one, tap k = 2t + parity)
+ *   out = self.out2(intra_feat)               (s2d = 0: models/modules.py:437,452 -- Conv2d(32, 16, 3, padding=1, bias=False); x (N,H,W,32))
+ * y (N,H,W,16) channels-last; exact split-bf16 matrix-core arithmetic like the planar kernel they replace.  scale / shift: folded BatchNorm (16 floats each) or
+ * NULL; ysq_absmax (RCMVS_ABSMAX_FLOATS floats, zero-filled) or NULL: receives (max|y|)^2, the bound of the variance volume built from y.
+ *   rcmvs_pack_conv2d_tile: w (16,32,3,3) -> image of rcmvs_conv2d_tile_weight_floats() floats. */
+long long rcmvs_conv2d_tile_weight_floats(void);
+int rcmvs_pack_conv2d_tile(const float* w, float* image, void* stream);
+int rcmvs_conv2d_tile_fwd(const float* x, const float* image, const float* scale, const float* shift, float* y, int N, int H, int W, int s2d, int relu,
+                          float* ysq_absmax, void* stream);
 
 /* The train variant's small images: F.interpolate(imgs, (h, w), mode="bilinear", align_corners=False) (models/casmvsnet.py:60-62,148-150) fused with
  * the channels-last transpose the warp kernels want: x (N,3,H,W) planar -> y (N,h,w,3); ATen's upsample_bilinear2d arithmetic. */

@@ -56,6 +56,9 @@ SIGNATURES = {
     "rcmvs_conv2d_pair_weight_floats": [],
     "rcmvs_pack_conv2d_pair": [_p, _p, _p, _p],
     "rcmvs_conv2d_pair_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "rcmvs_conv2d_tile_weight_floats": [],
+    "rcmvs_pack_conv2d_tile": [_p, _p, _p],
+    "rcmvs_conv2d_tile_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "rcmvs_conv2d_stem_weight_floats": [],
     "rcmvs_pack_conv2d_stem": [_p, _p, _p],
     "rcmvs_conv2d_stem_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
@@ -107,7 +110,7 @@ SIGNATURES = {
     "rcmvs_composite_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
 }
 _RESTYPES = {"rcmvs_last_error_string": ctypes.c_char_p, "rcmvs_nerf_weight_floats": _ll, "rcmvs_nerf_workspace_floats": _ll, "rcmvs_nerf_train_workspace_floats": _ll, "rcmvs_nerf_bwd_workspace_floats": _ll,
-             "rcmvs_packed_weight_floats": _ll, "rcmvs_fpn_folded_mfma_floats": _ll, "rcmvs_conv2d_pair_weight_floats": _ll, "rcmvs_conv2d_stem_weight_floats": _ll}
+             "rcmvs_packed_weight_floats": _ll, "rcmvs_fpn_folded_mfma_floats": _ll, "rcmvs_conv2d_pair_weight_floats": _ll, "rcmvs_conv2d_stem_weight_floats": _ll, "rcmvs_conv2d_tile_weight_floats": _ll}
 
 _lib = None
 

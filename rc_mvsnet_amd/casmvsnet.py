@@ -26,6 +26,7 @@ HEAD_PAIR = os.environ.get("RCMVS_HEAD_PAIR", "1") != "0"       # ... and the de
 # the last transposed layer + the prob conv (+ the head, D = 8) in one pass (csrc/conv11_prob.hip): 1 = at the cascade's last stage (D = 8: 50 against 70 us on
 # a DTU scene; at the other stages the two launches are as fast, profiles/r6_conv11_prob.txt), 2 = at every stage, 0 = never (the 8-channel volume in memory)
 CONV11_PROB = int(os.environ.get("RCMVS_CONV11_PROB", "1"))
+CONV_TILE = os.environ.get("RCMVS_CONV_TILE", "1") != "0"       # FeatureNet's conv1.0 (5x5 stride 2 as space-to-depth) and out2 (32 -> 16) on the tile kernel of csrc/conv2d_tile.hip; 0 = the planar kernel
 CONV_STEM = os.environ.get("RCMVS_CONV_STEM", "1") != "0"       # FeatureNet's conv0.0 -> conv0.1 as one launch (csrc/conv2d_stem.hip); 0 = the tile kernel + the planar kernel
 CONV_PAIR = os.environ.get("RCMVS_CONV_PAIR", "1") != "0"       # FeatureNet's conv1.1 -> conv1.2 as one launch (csrc/conv2d_pair.hip); 0 = two launches of the planar kernel
 DEEP_PAIR = os.environ.get("RCMVS_DEEP_PAIR", "1") != "0"       # ... its deep levels (conv5-7) included (csrc/conv3d_deep.hip); 0 = fp32 MFMAs there
@@ -263,6 +264,9 @@ class FeatureNet(nn.Module):
             m00, m01 = mods[0], mods[1]
             if CONV_STEM and tuple(m00.conv.weight.shape) == (8, 3, 3, 3) and tuple(m01.conv.weight.shape) == (8, 8, 3, 3) and m00.stride == 1 and m01.stride == 1:
                 plan["stem"] = (plan["conv0.0"][0],) + _bn_fold(m00.bn) + (ops.pack_conv2d_stem(m01.conv.weight),) + _bn_fold(m01.bn)
+            m10 = mods[2]
+            if CONV_TILE and tuple(m10.conv.weight.shape) == (16, 8, 5, 5) and m10.stride == 2:
+                plan["tile10"] = (ops.pack_conv2d_tile(self._w5s2(m10.conv.weight.detach()).contiguous()),) + _bn_fold(m10.bn)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
             if unet:
                 for n in ("out2", "out3")[:self.num_stage - 1]:           # 1x1, Co = Ci: the middle tap of a one-plane 3-D kernel
@@ -273,6 +277,8 @@ class FeatureNet(nn.Module):
                     w3 = self.out2.weight.detach().new_zeros(16, 32, 3, 3, 3)
                     w3[:, :, 1] = self.out2.weight.detach()
                     plan["out2"] = ("mfma3d", ops.pack_conv3d_weight(w3))
+                    if CONV_TILE:
+                        plan["out2t"] = ops.pack_conv2d_tile(self.out2.weight)
                 else:
                     plan["out2"] = ops.pack_conv2d_weight(self.out2.weight)
             if self.num_stage == 3 and not unet:
@@ -324,10 +330,14 @@ class FeatureNet(nn.Module):
             c0 = cbr(ops.conv2d_rgb(x.contiguous().float(), w, sc, sh, relu=True), "conv0.1")
         else:
             c0 = cbr(cbr(ops.rgb_to_nhwc4(x.contiguous().float()), "conv0.0"), "conv0.1")
-        if "pair1" in p and not ops._CONV_IMPL:
-            c1 = ops.conv2d_pair(cbr(c0, "conv1.0"), *p["pair1"])
+        if "tile10" in p and not ops._CONV_IMPL and c0.shape[1] % 2 == 0 and c0.shape[2] % 2 == 0:
+            c10 = ops.conv2d_tile(c0, p["tile10"][0], p["tile10"][1], p["tile10"][2], relu=True, s2d=True)
         else:
-            c1 = cbr(cbr(cbr(c0, "conv1.0"), "conv1.1"), "conv1.2")
+            c10 = cbr(c0, "conv1.0")
+        if "pair1" in p and not ops._CONV_IMPL:
+            c1 = ops.conv2d_pair(c10, *p["pair1"])
+        else:
+            c1 = cbr(cbr(c10, "conv1.1"), "conv1.2")
         c2 = cbr(cbr(cbr(c1, "conv2.0"), "conv2.1"), "conv2.2")
         # A thunk takes an optional activation-bound vector (ops.ABSMAX_FLOATS floats, zero-filled): the output conv then leaves (max|f|)^2
         # there -- the bound of the variance volume built from the map, which the fp16-pair cost regularisation needs -- in its epilogue
@@ -354,6 +364,8 @@ class FeatureNet(nn.Module):
             if isinstance(p["out2"], tuple):
                 def out2(bound=None, t=intra):
                     keep = bound is not None and not ops._CONV_IMPL
+                    if "out2t" in p and not ops._CONV_IMPL:
+                        return ops.conv2d_tile(t, p["out2t"], ysq_absmax=bound), keep
                     return ops.conv3d(t.unsqueeze(1), p["out2"][1], y_absmax=bound if keep else None, y_absmax_square=keep).squeeze(1), keep
                 out["stage2"] = out2
             else:

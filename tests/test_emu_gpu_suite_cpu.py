@@ -60,7 +60,7 @@ def reuse(module, name, slow=False):
 
 FAST = {
     GP: ["test_layout_roundtrip", "test_compose_homography", "test_hypothesis_planes_vs_golden", "test_hypothesis_planes_stage1_exact",
-         "test_warp_variance_vs_oracle", "test_resize_rgb_cl_is_torch_bilinear", "test_conv2d_pair_vs_fp64", "test_conv2d_stem_vs_fp64", "test_warp_variance_golden_fixture", "test_warp_variance_backward_vs_oracle_autograd",
+         "test_warp_variance_vs_oracle", "test_resize_rgb_cl_is_torch_bilinear", "test_conv2d_pair_vs_fp64", "test_conv2d_stem_vs_fp64", "test_conv2d_tile_vs_fp64", "test_warp_variance_golden_fixture", "test_warp_variance_backward_vs_oracle_autograd",
          "test_conv3d_vs_oracle", "test_conv3d_x3_item_schedule_is_bit_exact", "test_conv3d_x3_planar_vs_fp64", "test_conv3d_x3h_vs_fp64", "test_conv0_stream_cuts_are_bit_exact", "test_conv1_stream_cuts_are_bit_exact", "test_conv11_prob_vs_fp64", "test_prob_conv_marching_kernel", "test_prob_conv_z_chunk_does_not_change_the_result", "test_conv2d_s2d_is_the_5x5_stride2_layer", "test_conv3d_lds_halo_kernel", "test_deconv3d_vs_oracle", "test_conv3d_golden_and_linearity",
          "test_costreg_vs_golden", "test_conv2d_vs_torch_cpu", "test_depth_head_vs_oracle", "test_depth_head_forms_are_bit_identical", "test_depth_head_matrix_core_form_vs_fp32_form", "test_depth_head_golden",
          "test_fpn_out_fused_is_bit_identical", "test_fpn_out_folded_matches_the_unfused_path", "test_conv1x1_matrix_core_form", "test_feature_output_convs_keep_the_variance_bound", "test_first_layer_reads_the_planar_images_itself", "test_standalone_blocks_vs_reference_golden",

@@ -286,6 +286,42 @@ def test_warp_variance_window_form(hip):
         hip.warp_variance(feats, rot, trans, planes, 8, variant=5)
 
 
+@pytest.mark.parametrize("s2d", [False, True])
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 19, 47), (3, 40, 64), (1, 5, 3)])
+def test_conv2d_tile_vs_fp64(hip, N, H, W, s2d):
+    """FeatureNet's two 32 -> 16 3x3 layers on the tile kernel (csrc/conv2d_tile.hip): the FPN output conv out2 (plain conv, with the bound of the variance
+    volume kept in the epilogue) and conv1.0 -- a 5x5 stride-2 Conv2d(8, 16) + BatchNorm + ReLU read through the space-to-depth view of its input
+    (models/modules.py:374,437) -- against an fp64 evaluation, next to the planar split-bf16 kernel they ran on: exact tile multiples, ragged tiles, maps
+    smaller than a tile."""
+    from rc_mvsnet_amd.casmvsnet import FeatureNet
+    g = torch.Generator().manual_seed(H * 3 + W + int(s2d))
+    f = torch.nn.functional
+    if s2d:
+        x = torch.randn(N, 8, 2 * H, 2 * W, generator=g) * torch.exp(0.5 * torch.randn(N, 8, 2 * H, 2 * W, generator=g))
+        w5 = torch.randn(16, 8, 5, 5, generator=g) / (8 * 25) ** 0.5
+        sc, sh = 0.5 + torch.rand(16, generator=g), 0.2 * torch.randn(16, generator=g)
+        ref = torch.relu(f.conv2d(x.double(), w5.double(), stride=2, padding=2) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+        w = FeatureNet._w5s2(w5)
+        xcl = gpu(x.permute(0, 2, 3, 1))
+        got_t = hip.conv2d_tile(xcl, hip.pack_conv2d_tile(gpu(w)), gpu(sc), gpu(sh), relu=True, s2d=True)
+        old = hip.conv2d_s2d(xcl, hip.pack_conv3d_weight(gpu(FeatureNet._w3(w).contiguous())), gpu(sc), gpu(sh), relu=True)
+    else:
+        x = torch.randn(N, 32, H, W, generator=g) * torch.exp(0.5 * torch.randn(N, 32, H, W, generator=g))
+        w = torch.randn(16, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
+        ref = f.conv2d(x.double(), w.double(), padding=1)
+        xcl = gpu(x.permute(0, 2, 3, 1))
+        bound = torch.zeros(hip.ABSMAX_FLOATS, device=xcl.device)
+        got_t = hip.conv2d_tile(xcl, hip.pack_conv2d_tile(gpu(w)), ysq_absmax=bound)
+        assert float(bound.max()) == float(got_t.abs().max() ** 2)
+        old = hip.conv3d(xcl.unsqueeze(1), hip.pack_conv3d_weight(gpu(FeatureNet._w3(w).contiguous()))).squeeze(1)
+    assert tuple(got_t.shape) == (N, H, W, 16)
+    got, two = got_t.cpu().permute(0, 3, 1, 2).double(), old.cpu().permute(0, 3, 1, 2).double()
+    mag = float(ref.abs().max())
+    e_t, e_o = float((got - ref).abs().max()), float((two - ref).abs().max())
+    print(f"conv2d tile s2d={s2d} {N}x{H}x{W}: max error vs fp64 / max: tile kernel {e_t / mag:.2e}, planar kernel {e_o / mag:.2e}")
+    assert e_t <= 2.0 * e_o + 2e-7 * mag and e_t < 2e-6 * mag
+
+
 @pytest.mark.parametrize("N,H,W", [(2, 28, 60), (1, 37, 53), (3, 9, 11), (3, 64, 96), (3, 512, 640)])
 def test_conv2d_stem_vs_fp64(hip, N, H, W):
     """FeatureNet's conv0 block (Conv2d(3, 8) -> Conv2d(8, 8), each conv + BatchNorm(eval) + ReLU, models/modules.py:372-373) in one launch from the
