@@ -33,7 +33,10 @@ struct Z8 {
     // ("XT": an n-tile is 32 columns of one row), (shift along y, co) for Cin = 16 ("YT": 16 columns of two rows); Cout = 16: M = co ("PL": 16 columns of one row)
     static constexpr bool XT = COUT == 8 && CIN == 8, YT = COUT == 8 && CIN >= 16, PL = COUT == 16;
     static constexpr bool ALO = CIN == 32;           // Cin = 32: 36 k-steps x two pieces are 288 registers -- the low pieces of the weights live in LDS (36 KB, read per use)
-    static constexpr int NTW = YT ? 1 : 2;           // n-tiles per wave (two where the weights leave the registers: a tick of 27 - 45 MFMAs per wave is mostly barrier)
+#ifndef Z8_PL_NTW
+#define Z8_PL_NTW 1         // (conv2, us per launch at stages 1 / 2 / 3: 18.4 / 26.2 / 25.7 with one n-tile per wave = 4 x 32 tiles, 20.4 / 27.5 / 28.7 with two)
+#endif
+    static constexpr int NTW = YT ? 1 : (PL ? Z8_PL_NTW : 2);           // n-tiles per wave (XT with one: 52.2 against 47.3 us at stage 3) (two where the weights leave the registers: a tick of 27 - 45 MFMAs per wave is mostly barrier)
     static constexpr int NTT = 8 * NTW;              // n-tiles per tick
     static constexpr int TY = PL ? NTT / 2 : NTT, TX = 32;      // XT: a row per n-tile; YT: row pairs, two side by side; PL: rows, two side by side
     static constexpr int RSTEP = PL ? 4 : 8;         // tile rows between the two n-tiles of a wave
