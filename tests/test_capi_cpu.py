@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_error_string(lib):
     from rc_mvsnet_amd import _lib
-    assert lib.rcmvs_version() == _lib.REQUIRED_VERSION == 105
+    assert lib.rcmvs_version() == _lib.REQUIRED_VERSION == 106
     # bad arguments are rejected on the host before any launch (no GPU needed)
     rc = lib.rcmvs_conv3d_fwd(None, None, None, None, None, None, 1, 1, 1, 1, 8, 8, 1, 0, None)
     assert rc < 0

@@ -730,7 +730,7 @@ def test_conv0_stream_cuts_are_bit_exact(hip, Ci, shape):
     block count -- 1: every tile whole; 3 / 7: cuts inside tiles, items that start or end at either face of the volume, one-plane items;
     default: one step per block on these sizes -- every output voxel sees the same arithmetic: results are bit-identical, and they are
     the fp64 convolution to the pair form's accuracy."""
-    if DEV == "cpu" and (Ci == 32 or shape[1] > 5) and os.environ.get("RCMVS_EMU_FULL", "0") != "1":
+    if DEV == "cpu" and (Ci == 32 or shape[1] > 2) and os.environ.get("RCMVS_EMU_FULL", "0") != "1":
         pytest.skip("a minute on the kernel emulation: RCMVS_EMU_FULL=1 (always run on the GPU)")
     B, D, H, W = shape
     g = torch.Generator().manual_seed(Ci + D)
