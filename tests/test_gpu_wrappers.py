@@ -180,7 +180,13 @@ def test_eval_driver_two_worker_processes_per_gpu_write_the_same_files(tmp_path)
     names = sorted(os.path.relpath(os.path.join(d, f), one) for d, _, fs in os.walk(one) for f in fs)
     assert len(names) == 12                                              # 6 items x (depth_est, confidence)
     for n in names:
-        assert open(os.path.join(one, n), "rb").read() == open(os.path.join(two, n), "rb").read(), n
+        a, b = open(os.path.join(one, n), "rb").read(), open(os.path.join(two, n), "rb").read()
+        if a != b:                                                       # (say how different: a wrong pixel and a truncated file are different bugs)
+            import numpy as np
+            from rc_mvsnet_amd import data_io
+            x, y = data_io.read_pfm(os.path.join(one, n))[0], data_io.read_pfm(os.path.join(two, n))[0]
+            d = np.abs(np.asarray(x, dtype=np.float64) - np.asarray(y, dtype=np.float64)) if np.shape(x) == np.shape(y) else None
+            raise AssertionError(f"{n}: {len(a)} vs {len(b)} bytes" + ("" if d is None else f", {int((d > 0).sum())} of {d.size} values differ, max {float(d.max()):.3e}"))
 
 
 def test_a_second_stream_is_refused(monkeypatch):
