@@ -510,16 +510,17 @@ int rcmvs_pack_conv2d_stem(const float* wb, float* image, void* stream);
 int rcmvs_conv2d_stem_fwd(const float* x, const float* w_a_packed, const float* scale_a, const float* shift_a, const float* image_b, const float* scale_b,
                           const float* shift_b, float* y, int N, int H, int W, void* stream);
 
-/* FeatureNet's two 32 -> 16 3x3 layers at half resolution as tile kernels (csrc/conv2d_tile.hip): replaces
+/* FeatureNet's 32-channel 3x3 layers as tile kernels (csrc/conv2d_tile.hip; Co = 16 or 32): replaces
+ *   x = self.conv2[1](x); x = self.conv2[2](x)   (Co = 32, s2d = 0, one call per layer: models/modules.py:376-377,418-419 -- Conv2d(32, 32, 3, 1) + BatchNorm(eval) + ReLU)
  *   x = self.conv1[0](conv0)                  (s2d = 1: models/modules.py:374,416 -- Conv2d(8, 16, 5, stride=2, padding=2) + BatchNorm(eval) + ReLU as a 3x3 layer on the
  *                                              space-to-depth view: x is the (N,2H,2W,8) map, the weight the (16,32,3,3) re-indexed one, tap k = 2t + parity)
  *   out = self.out2(intra_feat)               (s2d = 0: models/modules.py:437,452 -- Conv2d(32, 16, 3, padding=1, bias=False); x (N,H,W,32))
- * y (N,H,W,16) channels-last; exact split-bf16 matrix-core arithmetic like the planar kernel they replace.  scale / shift: folded BatchNorm (16 floats each) or
+ * y (N,H,W,Co) channels-last; exact split-bf16 matrix-core arithmetic like the planar kernel they replace.  scale / shift: folded BatchNorm (Co floats each) or
  * NULL; ysq_absmax (RCMVS_ABSMAX_FLOATS floats, zero-filled) or NULL: receives (max|y|)^2, the bound of the variance volume built from y.
- *   rcmvs_pack_conv2d_tile: w (16,32,3,3) -> image of rcmvs_conv2d_tile_weight_floats() floats. */
-long long rcmvs_conv2d_tile_weight_floats(void);
-int rcmvs_pack_conv2d_tile(const float* w, float* image, void* stream);
-int rcmvs_conv2d_tile_fwd(const float* x, const float* image, const float* scale, const float* shift, float* y, int N, int H, int W, int s2d, int relu,
+ *   rcmvs_pack_conv2d_tile: w (Co,32,3,3) -> image of rcmvs_conv2d_tile_weight_floats(Co) floats. */
+long long rcmvs_conv2d_tile_weight_floats(int Co);
+int rcmvs_pack_conv2d_tile(const float* w, float* image, int Co, void* stream);
+int rcmvs_conv2d_tile_fwd(const float* x, const float* image, const float* scale, const float* shift, float* y, int N, int H, int W, int Co, int s2d, int relu,
                           float* ysq_absmax, void* stream);
 
 /* The train variant's small images: F.interpolate(imgs, (h, w), mode="bilinear", align_corners=False) (models/casmvsnet.py:60-62,148-150) fused with

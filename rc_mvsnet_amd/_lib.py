@@ -56,9 +56,9 @@ SIGNATURES = {
     "rcmvs_conv2d_pair_weight_floats": [],
     "rcmvs_pack_conv2d_pair": [_p, _p, _p, _p],
     "rcmvs_conv2d_pair_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "rcmvs_conv2d_tile_weight_floats": [],
-    "rcmvs_pack_conv2d_tile": [_p, _p, _p],
-    "rcmvs_conv2d_tile_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "rcmvs_conv2d_tile_weight_floats": [_i],
+    "rcmvs_pack_conv2d_tile": [_p, _p, _i, _p],
+    "rcmvs_conv2d_tile_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "rcmvs_conv2d_stem_weight_floats": [],
     "rcmvs_pack_conv2d_stem": [_p, _p, _p],
     "rcmvs_conv2d_stem_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],

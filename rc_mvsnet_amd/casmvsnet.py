@@ -267,6 +267,9 @@ class FeatureNet(nn.Module):
             m10 = mods[2]
             if CONV_TILE and tuple(m10.conv.weight.shape) == (16, 8, 5, 5) and m10.stride == 2:
                 plan["tile10"] = (ops.pack_conv2d_tile(self._w5s2(m10.conv.weight.detach()).contiguous()),) + _bn_fold(m10.bn)
+            for n, m in (("conv2.1", mods[6]), ("conv2.2", mods[7])):           # 32 -> 32 at quarter resolution: the eight-wave form of the tile kernel
+                if CONV_TILE and tuple(m.conv.weight.shape) == (32, 32, 3, 3) and m.stride == 1:
+                    plan["tile:" + n] = (ops.pack_conv2d_tile(m.conv.weight),) + _bn_fold(m.bn)
             plan["out1"] = ops.pack_conv2d_weight(self.out1.weight)
             if unet:
                 for n in ("out2", "out3")[:self.num_stage - 1]:           # 1x1, Co = Ci: the middle tap of a one-plane 3-D kernel
@@ -303,6 +306,9 @@ class FeatureNet(nn.Module):
         p = self.hip_plan()
 
         def cbr(t, n):
+            if "tile:" + n in p and not ops._CONV_IMPL:
+                img, sc, sh = p["tile:" + n]
+                return ops.conv2d_tile(t, img, sc, sh, relu=True)
             if p[n][0] == "mfma3d":
                 _, w3, sc, sh = p[n]
                 return ops.conv3d(t.unsqueeze(1), w3, sc, sh, relu=True).squeeze(1)

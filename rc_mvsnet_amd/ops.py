@@ -478,25 +478,28 @@ def conv2d_rgb(x, w_packed, scale=None, shift=None, relu=False):
 
 
 def pack_conv2d_tile(w):
-    """A (16,32,3,3) Conv2d weight -> the fragment image of conv2d_tile (csrc/conv2d_tile.hip)."""
-    if tuple(w.shape) != (16, 32, 3, 3):
-        raise _lib.RcmvsError("pack_conv2d_tile: built for a 32 -> 16 3x3 layer")
+    """A (Co,32,3,3) Conv2d weight, Co = 16 or 32 -> the fragment image of conv2d_tile (csrc/conv2d_tile.hip)."""
+    Co = w.shape[0]
+    if Co not in (16, 32) or tuple(w.shape) != (Co, 32, 3, 3):
+        raise _lib.RcmvsError("pack_conv2d_tile: built for 32 -> 16 and 32 -> 32 3x3 layers")
     lib = _lib.load()
-    img = torch.empty(int(lib.rcmvs_conv2d_tile_weight_floats()), device=w.device, dtype=torch.float32)
-    _lib.check(lib.rcmvs_pack_conv2d_tile(_chk(w.detach().float().contiguous(), "w"), _chk(img, "image"), _stream()), "pack_conv2d_tile")
+    img = torch.empty(int(lib.rcmvs_conv2d_tile_weight_floats(Co)), device=w.device, dtype=torch.float32)
+    _lib.check(lib.rcmvs_pack_conv2d_tile(_chk(w.detach().float().contiguous(), "w"), _chk(img, "image"), Co, _stream()), "pack_conv2d_tile")
     return img
 
 
 def conv2d_tile(x, image, scale=None, shift=None, relu=False, s2d=False, ysq_absmax=None):
-    """32 -> 16 3x3 conv on a tile kernel: x (N,H,W,32) -> (N,H,W,16), or (s2d=True) x (N,2H,2W,8) read through its space-to-depth view (a 5x5 stride-2
-    layer as a 3x3 one, weight re-indexed as FeatureNet._w5s2 does).  ysq_absmax: zero-filled bound vector that receives (max|y|)^2."""
+    """32 -> Co 3x3 conv on a tile kernel (Co = 16 or 32, read off the image's size): x (N,H,W,32) -> (N,H,W,Co), or (s2d=True, Co = 16) x (N,2H,2W,8) read through
+    its space-to-depth view (a 5x5 stride-2 layer as a 3x3 one, weight re-indexed as FeatureNet._w5s2 does).  ysq_absmax: zero-filled bound vector that receives (max|y|)^2."""
     N, Hx, Wx, C = x.shape
-    if C != (8 if s2d else 32) or (s2d and (Hx % 2 or Wx % 2)):
-        raise _lib.RcmvsError(f"conv2d_tile: unexpected input {tuple(x.shape)} (s2d={s2d})")
+    lib = _lib.load()
+    Co = {int(lib.rcmvs_conv2d_tile_weight_floats(c)): c for c in (16, 32)}.get(image.numel())
+    if Co is None or C != (8 if s2d else 32) or (s2d and (Hx % 2 or Wx % 2 or Co != 16)):
+        raise _lib.RcmvsError(f"conv2d_tile: unexpected input {tuple(x.shape)} (s2d={s2d}) or image of {image.numel()} floats")
     H, W = (Hx // 2, Wx // 2) if s2d else (Hx, Wx)
-    y = torch.empty((N, H, W, 16), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().rcmvs_conv2d_tile_fwd(_chk(x, "x"), _chk(image, "image"), _opt(scale, "scale"), _opt(shift, "shift"), _chk(y, "y"), N, H, W, int(s2d), int(relu),
-                                                 _opt(ysq_absmax, "ysq_absmax"), _stream()), "conv2d_tile_fwd")
+    y = torch.empty((N, H, W, Co), device=x.device, dtype=torch.float32)
+    _lib.check(lib.rcmvs_conv2d_tile_fwd(_chk(x, "x"), _chk(image, "image"), _opt(scale, "scale"), _opt(shift, "shift"), _chk(y, "y"), N, H, W, Co, int(s2d), int(relu),
+                                         _opt(ysq_absmax, "ysq_absmax"), _stream()), "conv2d_tile_fwd")
     return y
 
 

@@ -286,7 +286,7 @@ def test_warp_variance_window_form(hip):
         hip.warp_variance(feats, rot, trans, planes, 8, variant=5)
 
 
-@pytest.mark.parametrize("s2d", [False, True])
+@pytest.mark.parametrize("s2d", [False, True, 32])
 @pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 19, 47), (3, 40, 64), (1, 5, 3)])
 def test_conv2d_tile_vs_fp64(hip, N, H, W, s2d):
     """FeatureNet's two 32 -> 16 3x3 layers on the tile kernel (csrc/conv2d_tile.hip): the FPN output conv out2 (plain conv, with the bound of the variance
@@ -296,7 +296,15 @@ def test_conv2d_tile_vs_fp64(hip, N, H, W, s2d):
     from rc_mvsnet_amd.casmvsnet import FeatureNet
     g = torch.Generator().manual_seed(H * 3 + W + int(s2d))
     f = torch.nn.functional
-    if s2d:
+    if s2d == 32:                                                         # 32 -> 32 (conv2.1 / conv2.2): the eight-wave form, BatchNorm + ReLU
+        x = torch.randn(N, 32, H, W, generator=g) * torch.exp(0.5 * torch.randn(N, 32, H, W, generator=g))
+        w = torch.randn(32, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
+        sc, sh = 0.5 + torch.rand(32, generator=g), 0.2 * torch.randn(32, generator=g)
+        ref = torch.relu(f.conv2d(x.double(), w.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+        xcl = gpu(x.permute(0, 2, 3, 1))
+        got_t = hip.conv2d_tile(xcl, hip.pack_conv2d_tile(gpu(w)), gpu(sc), gpu(sh), relu=True)
+        old = hip.conv3d(xcl.unsqueeze(1), hip.pack_conv3d_weight(gpu(FeatureNet._w3(w).contiguous())), gpu(sc), gpu(sh), relu=True).squeeze(1)
+    elif s2d:
         x = torch.randn(N, 8, 2 * H, 2 * W, generator=g) * torch.exp(0.5 * torch.randn(N, 8, 2 * H, 2 * W, generator=g))
         w5 = torch.randn(16, 8, 5, 5, generator=g) / (8 * 25) ** 0.5
         sc, sh = 0.5 + torch.rand(16, generator=g), 0.2 * torch.randn(16, generator=g)
@@ -314,7 +322,7 @@ def test_conv2d_tile_vs_fp64(hip, N, H, W, s2d):
         got_t = hip.conv2d_tile(xcl, hip.pack_conv2d_tile(gpu(w)), ysq_absmax=bound)
         assert float(bound.max()) == float(got_t.abs().max() ** 2)
         old = hip.conv3d(xcl.unsqueeze(1), hip.pack_conv3d_weight(gpu(FeatureNet._w3(w).contiguous()))).squeeze(1)
-    assert tuple(got_t.shape) == (N, H, W, 16)
+    assert tuple(got_t.shape) == (N, H, W, 32 if s2d == 32 else 16)
     got, two = got_t.cpu().permute(0, 3, 1, 2).double(), old.cpu().permute(0, 3, 1, 2).double()
     mag = float(ref.abs().max())
     e_t, e_o = float((got - ref).abs().max()), float((two - ref).abs().max())
