@@ -43,7 +43,7 @@ __host__ __device__ inline void dp_class_tap(int p, int i, int& kd, int& kh, int
     kd = pd ? 2 * id : 1; kh = ph ? 2 * ih : 1; kw = pw ? 2 * iw : 1;
 }
 
-template <int CIN, int COUT, int KIND>
+template <int CIN, int COUT, int KIND, int MS = 1>
 struct Deep {
     // cell tile: 4 x 8 cells of one (b, d) plane, n-tile t = rows 2t, 2t + 1.  (NT = 4, 8 x 8 cells, for the 32 -> 32 layer -- 8x the cells, a quarter of
     // the weights -- measured 9.0 / 20.9 us per launch against 8.9 / 17.3, and NT = 1, 2 x 8 cells, 11.9 / 24.7: 32 cells is the sweet spot between the
@@ -64,8 +64,13 @@ struct Deep {
     static constexpr int UNITS = NVOX * (CIN / 8);      // 8-channel units of the halo (32 B in, 16 + 16 B out)
     static constexpr int NLD = (UNITS + 511) / 512;
     static constexpr int PF = KIND == DP_T2 ? 6 : 8;    // k-steps of weight prefetch per ring (8 registers per step)
-    static constexpr int KP = KIND == DP_T2 ? 1 : 8 / MT;      // convolutions: wave = (m-tile, one of KP parts of the K range); the parts meet through LDS
-    static constexpr int PARTB = KIND == DP_T2 ? 0 : (KP - 1) * MT * NT * 1024;
+    // MS = 2 (64 output channels, conv5 / conv6, when twice the tiles still fit one round of blocks: 60 tiles at stage 1): the m-tiles of a tile are cut over two blocks -- each
+    // streams its share of the weight image only (the vector L1's 64 B/clk is the floor of these launches) and halves its K ranges once more: 9.0 / 10.2 us against 10.2 / 12.8;
+    // with 160 tiles (stages 2 / 3) the 320 blocks are a second round: 13.5 / 15.4 against 10.5 / 13.0
+    static constexpr int MSPLIT = (KIND != DP_T2 && MT == 4) ? MS : 1;
+    static constexpr int MB = MT / MSPLIT;                     // m-tiles per block
+    static constexpr int KP = KIND == DP_T2 ? 1 : 8 / MB;      // convolutions: wave = (m-tile, one of KP parts of the K range); the parts meet through LDS
+    static constexpr int PARTB = KIND == DP_T2 ? 0 : (KP - 1) * MB * NT * 1024;
     static constexpr int LDS = 2 * PLANE + PARTB + 64;
     static constexpr long long IMG_HALFS = 8 + (long long)KSTEPS * 2 * MT * 512;
     static_assert((CIN % 32 == 0 || (CIN == 16 && KIND != DP_T2)) && COUT % 16 == 0 && (KIND == DP_T2 ? (MT == 2 || MT == 1) : (MT == 4 || MT == 2)), "wave layout");
@@ -125,11 +130,11 @@ __device__ __forceinline__ int dp_t2_segments(int wave, int (&cls)[3]) {
     return g == 0 ? 1 : (g == 1 ? 3 : 2);
 }
 
-template <int CIN, int COUT, int KIND>
+template <int CIN, int COUT, int KIND, int MS = 1>
 __global__ __launch_bounds__(512) void conv3d_deep_kernel(
     const float* __restrict__ x, const x3_u32x4* __restrict__ wimg, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ res, float* __restrict__ y, DeepDims dm, const float* __restrict__ xmax, float* __restrict__ ymax) {
-    using C = Deep<CIN, COUT, KIND>;
+    using C = Deep<CIN, COUT, KIND, MS>;
     constexpr int MT = C::MT, NT = C::NT, PF = C::PF, VS = C::VS, PLANE = C::PLANE, HALVES = C::HALVES;
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) x3_byte smem[];
@@ -156,8 +161,9 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
     int seg_cls[3] = {0, 0, 0}, nseg = 1, mt0;
     if constexpr (KIND == DP_T2 && MT == 1) { seg_cls[0] = wave; mt0 = 0; }                 // 16 output channels: a wave per parity class (1 - 8 taps: the MFMAs are nothing here)
     else if constexpr (KIND == DP_T2) { nseg = dp_t2_segments(wave, seg_cls); mt0 = wave & 1; }
-    else mt0 = wave % MT;
-    const int kp = KIND == DP_T2 ? 0 : wave / MT;                    // which part of the K range (convolutions)
+    else mt0 = blockIdx.y * C::MB + wave % C::MB;
+    const int kp = KIND == DP_T2 ? 0 : wave / C::MB;                 // which part of the K range (convolutions)
+    const int mtl = KIND == DP_T2 ? 0 : wave % C::MB;                // (m-tile inside the block's share)
     auto seg_range = [&](int sg, int& j0, int& nsteps) {
         if constexpr (KIND == DP_T2) {
             const int cls = seg_cls[sg], nt = dp_ntaps(cls);
@@ -327,14 +333,14 @@ __global__ __launch_bounds__(512) void conv3d_deep_kernel(
             finisher = kp == 0;
             if (!finisher) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) *reinterpret_cast<x3_f32x4*>(part + ((((kp - 1) * MT + mt0) * NT + t) * 64 + lane) * 16) = tot[t];
+                for (int t = 0; t < NT; ++t) *reinterpret_cast<x3_f32x4*>(part + ((((kp - 1) * C::MB + mtl) * NT + t) * 64 + lane) * 16) = tot[t];
             }
             __syncthreads();
             if (finisher) {
 #pragma unroll
                 for (int q = 0; q < C::KP - 1; ++q)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) tot[t] += *reinterpret_cast<const x3_f32x4*>(part + (((q * MT + mt0) * NT + t) * 64 + lane) * 16);
+                    for (int t = 0; t < NT; ++t) tot[t] += *reinterpret_cast<const x3_f32x4*>(part + (((q * C::MB + mtl) * NT + t) * 64 + lane) * 16);
             }
         }
         if (finisher) {
@@ -416,24 +422,39 @@ int conv3d_deep_pack(const float* w, float* img, int Co, int Ci, int kind, int t
     return fail(-1, "conv3d_deep_pack: unsupported Ci=%d Co=%d kind=%d", Ci, Co, kind);
 }
 
+template <int CI, int CO, int K, int MS>
+static int deep_launch_ms(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
+                          const DeepDims& dm, long long blocks, int dev, const float* xmax, float* ymax, hipStream_t st) {
+    using C = Deep<CI, CO, K, MS>;
+    constexpr int MAXDEV = 64;
+    static std::atomic<bool> raised[MAXDEV];                    // per device: dynamic-LDS limit of this instantiation
+    if (C::LDS > 64 * 1024 && !raised[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)conv3d_deep_kernel<CI, CO, K, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+            return fail(-1, "conv3d_deep: cannot raise the dynamic LDS limit to %d bytes", C::LDS);
+        raised[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((conv3d_deep_kernel<CI, CO, K, MS>), dim3((unsigned)blocks, C::MSPLIT), dim3(512), C::LDS, st, x, reinterpret_cast<const x3_u32x4*>(wimg),
+                       scale, shift, res, y, dm, xmax, ymax);
+    return launch_status("conv3d_deep");
+}
+
 template <int CI, int CO, int K>
 static int deep_launch_t(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
                          const DeepDims& dm_in, int dev, const float* xmax, float* ymax, hipStream_t st) {
     using C = Deep<CI, CO, K>;
-    constexpr int MAXDEV = 64;
-    static std::atomic<bool> raised[MAXDEV];                    // per device: dynamic-LDS limit of this instantiation
-    if (C::LDS > 64 * 1024 && !raised[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)conv3d_deep_kernel<CI, CO, K>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
-            return fail(-1, "conv3d_deep: cannot raise the dynamic LDS limit to %d bytes", C::LDS);
-        raised[dev].store(true, std::memory_order_release);
-    }
     DeepDims dm = dm_in;
     dm.tiles_h = (dm.Hg + C::TH - 1) / C::TH; dm.tiles_w = (dm.Wg + C::TW - 1) / C::TW;
     const long long blocks = (long long)dm.B * dm.Dg * dm.tiles_h * dm.tiles_w;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return fail(-1, "conv3d_deep: bad grid");
-    hipLaunchKernelGGL((conv3d_deep_kernel<CI, CO, K>), dim3((unsigned)blocks), dim3(512), C::LDS, st, x, reinterpret_cast<const x3_u32x4*>(wimg),
-                       scale, shift, res, y, dm, xmax, ymax);
-    return launch_status("conv3d_deep");
+    if constexpr (K != DP_T2 && CO == 64) {                      // two blocks per tile while they fit one round (one block per CU: 512 threads, > 80 KB of LDS)
+        static std::atomic<int> cu_of[64];
+        if (cu_of[dev] == 0) {
+            hipDeviceProp_t prop;
+            cu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        if (2 * blocks <= cu_of[dev].load()) return deep_launch_ms<CI, CO, K, 2>(x, wimg, scale, shift, res, y, dm, blocks, dev, xmax, ymax, st);
+    }
+    return deep_launch_ms<CI, CO, K, 1>(x, wimg, scale, shift, res, y, dm, blocks, dev, xmax, ymax, st);
 }
 
 int conv3d_deep_launch(const float* x, const float* wimg, const float* scale, const float* shift, const float* res, float* y,
