@@ -77,7 +77,7 @@ FAST = {
     GD: ["test_tanks_loader_items_match_reference"],          # the DTU twin asserts `.is_cuda`; tests/test_dataset_cpu.py covers it
 }
 SLOW = {
-    GP: ["test_train_variant_volume_feature", "test_warp_variance_variants_agree", "test_feature_net_vs_oracle",
+    GP: ["test_train_variant_volume_feature", "test_warp_variance_variants_agree", "test_feature_net_vs_oracle", "test_feature_net_fused_kernels_match_the_one_layer_launches",
          "test_cascade_batch_two_equals_two_singles", "test_conv3d_x3_vs_fp64", "test_conv3d_x3_strided_vs_fp64",
          "test_cascade_on_the_unet_pyramid_vs_reference_golden"],
     GR: ["test_neural_volume_vs_golden", "test_render_forward_vs_reference_golden", "test_render_forward_five_view_extension_vs_reference_golden"],

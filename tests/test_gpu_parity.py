@@ -976,6 +976,35 @@ def test_feature_net_vs_oracle(hip):
             assert float(e.max()) < 5e-5 * max(1.0, float(ref[k].abs().max()))
 
 
+def test_feature_net_fused_kernels_match_the_one_layer_launches(hip, monkeypatch):
+    """FeatureNet with its fused / tile kernels (conv0.0 -> conv0.1, conv1.0 and out2, conv1.1 -> conv1.2, conv2.1 / conv2.2: csrc/conv2d_stem.hip, conv2d_tile.hip,
+    conv2d_pair.hip) against the same network with every one of them switched off (RCMVS_CONV_STEM / _TILE / _PAIR = 0: the one-layer launches they replace), on image
+    sizes that are ragged against every tile shape (14 x 30, 8 x 32, 8 x 30 pixels; sizes are multiples of 4 as the pyramid requires) and batches of 1 - 3 images:
+    the three stage maps agree to fp32 rounding (the exact split-bf16 arithmetic on both sides; the first layer an fp32 FMA chain on both)."""
+    from rc_mvsnet_amd import synthetic, casmvsnet
+    from rc_mvsnet_amd.casmvsnet import CascadeMVSNet_eval
+    m = CascadeMVSNet_eval()
+    m.load_state_dict(synthetic.cascade_state_dict(0), strict=True)
+    m = m.to(DEV).eval()
+    sizes = ((1, 36, 52), (3, 64, 100), (2, 92, 124)) if DEV != "cpu" else ((1, 36, 52),)
+    for (N, H, W) in sizes:
+        imgs = gpu(synthetic.images(1, N, H, W, 3)[0])
+        outs = []
+        for on in (True, False):
+            for name in ("CONV_STEM", "CONV_TILE", "CONV_PAIR"):
+                monkeypatch.setattr(casmvsnet, name, on)
+            m.feature._plan = None                          # (the switches are read when the plan is built)
+            with torch.no_grad():
+                outs.append({k: v.clone() for k, v in m.feature.forward_cl(imgs).items()})
+        m.feature._plan = None
+        assert ("stem" in m.feature.hip_plan()) == bool(casmvsnet.CONV_STEM)
+        for k in outs[0]:
+            a, b = outs[0][k], outs[1][k]
+            err = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+            assert a.shape == b.shape and err < 2e-6, (N, H, W, k, err)
+    m.feature._plan = None
+
+
 def _golden_state(g, prefix):
     return {k[len(prefix):]: torch.as_tensor(np.asarray(v)) for k, v in g.items() if k.startswith(prefix)}
 
